@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of exact cosine top-100 over a 10M x 768 fp16 corpus (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of 64 synthetic queries: the whole corpus
+(row-sharded over the N ranks; total rows FIXED, so scaling is strong) is scanned once, per-shard
+top-k lists are all-gathered over RCCL and merged.  Corpus, queries and outputs are resident in HBM
+when the timed region starts.  Two batches are kept in flight (vf_index_search_begin / _end), as a
+serving loop would.  Rank 0 prints ONE JSON line.
+
+roofline: live HIP-event timing of the dominant kernel (k_scan main launch) inside the library,
+on the stream it runs on (vf_index_profile); algorithmic bytes = rows scanned x (d*2 + 4).
+cpu_baseline: the CPU oracle (oracle/vf_oracle.c, a port of the reference's CPU path) timed on a
+bounded sample on this box's host cores, scaled to the full corpus -- reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+GEN_CHUNK = 125_000    # rows per generator call; shard boundaries are multiples of it at 1/2/4/8 GPUs
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--opt", action="append", default=[], help="index option name=value (tuning)")
+    return ap.parse_args()
+
+
+def make_shard(torch, lo, hi, d, device):
+    """Rows [lo, hi) of the synthetic corpus: N(0,1) -> fp16, seeded per global GEN_CHUNK so the corpus
+    does not depend on the number of ranks."""
+    out = torch.empty((hi - lo, d), dtype=torch.float16, device=device)
+    c0 = lo // GEN_CHUNK
+    c1 = (hi + GEN_CHUNK - 1) // GEN_CHUNK
+    g = torch.Generator(device=device)
+    for c in range(c0, c1):
+        g.manual_seed(1234 + c)
+        a, b = c * GEN_CHUNK, (c + 1) * GEN_CHUNK
+        blk = torch.randn((GEN_CHUNK, d), generator=g, device=device, dtype=torch.float32).to(torch.float16)
+        s, e = max(a, lo), min(b, hi)
+        out[s - lo:e - lo] = blk[s - a:e - a]
+        del blk
+    return out
+
+
+def cpu_baseline(args):
+    import numpy as np
+    from oracle import canonical as oracle  # the checker / baseline leg: allowed to use the oracle
+    n = min(args.cpu_sample_rows, args.rows)
+    rng = np.random.default_rng(1234)
+    corpus = np.empty((n, args.dim), dtype=np.float16)
+    for i in range(0, n, 100_000):
+        m = min(100_000, n - i)
+        corpus[i:i + m] = rng.standard_normal((m, args.dim), dtype=np.float32).astype(np.float16)
+    q = np.random.default_rng(4321).standard_normal((args.batch, args.dim)).astype(np.float32)
+    oracle.search(corpus[:20_000], q, args.k)  # warm the thread pool
+    best = 1e30
+    t_all = time.time()
+    reps = 0
+    while reps < 2 or (time.time() - t_all < 10.0 and reps < 8):
+        t0 = time.time()
+        oracle.search(corpus, q, args.k)
+        best = min(best, time.time() - t0)
+        reps += 1
+    t_full = best * (args.rows / n)
+    return {
+        "value": round(args.batch / t_full, 3), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+        "sample": f"oracle/vf_oracle.c exact cosine top-{args.k}, {args.batch} queries x {n} of the {args.rows} "
+                  f"rows (fp16, d={args.dim}), best of {reps} runs = {best:.3f}s, scaled x{args.rows / n:.1f} to the full corpus",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import veritasfi_amd as vf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    lo, hi = vf.shard_bounds(args.rows, world, rank)
+    corpus = make_shard(torch, lo, hi, args.dim, device)
+    gq = torch.Generator(device=device)
+    gq.manual_seed(4321)
+    qpool = [torch.randn((args.batch, args.dim), generator=gq, device=device, dtype=torch.float32) for _ in range(4)]
+    index = vf.DenseIndex(corpus, id_offset=lo)
+    for o in args.opt:
+        name, val = o.split("=")
+        index.set_option(name, int(val))
+    nslots = index.slots
+    out_ids = [torch.empty((args.batch, args.k), dtype=torch.int64, device=device) for _ in range(nslots)]
+    out_sc = [torch.empty((args.batch, args.k), dtype=torch.float32, device=device) for _ in range(nslots)]
+    if world > 1:
+        g_ids = torch.empty((world * args.batch, args.k), dtype=torch.int64, device=device)
+        g_sc = torch.empty((world * args.batch, args.k), dtype=torch.float32, device=device)
+    merged = [None]
+
+    def finish(slot):
+        index.search_end(slot)
+        if world > 1:  # the exchange step: all-gather of per-shard top-k over xGMI, then the merge kernel
+            dist.all_gather_into_tensor(g_ids, out_ids[slot])
+            dist.all_gather_into_tensor(g_sc, out_sc[slot])
+            merged[0] = vf.merge_topk_device(g_ids.view(world, args.batch, args.k), g_sc.view(world, args.batch, args.k), args.k)
+        else:
+            merged[0] = (out_ids[slot], out_sc[slot])
+
+    def run(steps):
+        pending = []
+        for i in range(steps):
+            slot = i % nslots
+            if len(pending) == nslots:
+                finish(pending.pop(0))
+            index.search_begin(slot, qpool[i % len(qpool)], args.k, out_ids[slot], out_sc[slot])
+            pending.append(slot)
+        while pending:
+            finish(pending.pop(0))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    index.set_option("profile", 1)  # resets the HIP-event accumulators
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = index.profile()
+    stats = index.stats()
+    index.set_option("profile", 0)
+
+    if rank == 0:
+        qps = args.steps * args.batch / elapsed
+        roof = None
+        if prof["scan_launches"] > 0:
+            avg_ms = prof["scan_ms_total"] / prof["scan_launches"]
+            gbs = prof["scan_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "vf::k_scan<main>",
+                    "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": prof["scan_bytes_per_launch"],
+                    "pipeline_ms_per_batch": round(prof["pipeline_ms_total"] / prof["scan_launches"], 4)}
+        line = {
+            "metric": "queries/sec top-100 over 10Mx768 corpus", "value": round(qps, 1), "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.rows}x{args.dim} fp16 corpus, batch-{args.batch} queries, exact cosine "
+                                   f"top-{args.k}, row-sharded over {world} GPU(s) + RCCL all-gather of per-shard top-k",
+                       "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
+                       "rows_per_gpu": hi - lo, "in_flight_batches": nslots},
+            "roofline": roof,
+            "search_stats": {"candidates_per_query": round(stats["candidates"] / max(1, stats["n_queries"]), 1),
+                             "exact_reruns_last_batch": stats["exact_reruns"], "path": stats["path"]},
+            "rerank_p50_ms": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    index.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * veritasfi_hip.h -- C ABI of libveritasfi_hip.so (MI355X / gfx950, hand-written HIP).
+ *
+ * Drop-in boundary for VeritasFi's dense-retrieval hot path.  The
+ * reference is pure Python and delegates this path to third-party objects; each entry point
+ * below names the reference call it stands behind (paths relative to the reference root).
+ * Plain pointers and sizes only -- no torch / numpy types cross this boundary.  The Python
+ * classes in veritasfi_amd/ bind it with ctypes (INTEGRATION.md shows the reference-side stub).
+ *
+ * Conventions
+ *   - every function returns VF_OK (0) or a negative VF_E* code; nothing aborts or throws across
+ *     the ABI; vf_last_error() gives a thread-local message for the last failure.
+ *   - "host" pointers are caller-owned host memory; "device" pointers (suffix _device / d_*) are
+ *     HBM pointers on the index's GPU (e.g. torch tensor .data_ptr()); the library never frees them.
+ *   - ranking contract: descending cosine, ties broken by LOWER id first; k > N pads ids with -1
+ *     and scores with -FLT_MAX (faiss contract, src/utils/faissRetriever.py:37).
+ *   - scores are the CANONICAL fp32 cosine (DESIGN.md "Canonical score"): bit-identical to the CPU
+ *     oracle in oracle/vf_oracle.c, independent of sharding, batch size and kernel path.
+ *   - zero-norm rows / queries score 0 (sklearn divides by 1: experiments/retriever/step3_mul.py:275).
+ *   - a handle may be used from several threads (per-handle mutex); handles are per process.
+ */
+#ifndef VERITASFI_HIP_H
+#define VERITASFI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_VERSION 100 /* 0.1.0 */
+
+enum {
+    VF_OK = 0,
+    VF_EINVAL = -1,       /* bad argument */
+    VF_ENOMEM = -2,       /* host or device allocation failed */
+    VF_EHIP = -3,         /* a HIP runtime call failed (message has the HIP error string) */
+    VF_EUNSUPPORTED = -4, /* valid request this build does not implement (e.g. fp8 corpus) */
+    VF_EINTERNAL = -5
+};
+
+enum { VF_DTYPE_F32 = 0, VF_DTYPE_F16 = 1, VF_DTYPE_FP8_E4M3 = 2 };
+
+typedef struct vf_index vf_index;
+
+/* counters of the last search on a handle (for tests / benches; not part of the reference surface) */
+typedef struct vf_search_stats {
+    int64_t path;            /* 0 = small-N exact dense, 1 = fused MFMA scan, 2 = chunked exact */
+    int64_t n_queries;
+    int64_t candidates;      /* total candidates appended by the fused scan (all queries) */
+    int64_t max_candidates;  /* largest per-query candidate count */
+    int64_t uncertified;     /* queries whose fused result failed the exactness certificate */
+    int64_t overflowed;      /* queries whose candidate buffer overflowed */
+    int64_t exact_reruns;    /* queries recomputed by the chunked exact path */
+    int64_t reserved[9];
+} vf_search_stats;
+
+int vf_version(void);
+const char* vf_last_error(void);
+int vf_device_count(int32_t* out);
+
+/* ---- dense index: replaces faiss.IndexFlatIP + normalize_L2 ---------------------------------
+ * src/utils/faissRetriever.py:11-26 (FaissRetriever.__init__): rows [n,d] row-major of `dtype`,
+ * copied to device `device_id`.  Rows are stored as given (fp16 rows are the corpus; fp32 rows keep
+ * an fp32 copy for exact scoring plus an fp16 scan copy); per-row norms are computed on the GPU.
+ * `id_offset` is added to every returned id (row-sharding across ranks). */
+int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
+                    int32_t device_id, int64_t id_offset);
+
+/* Same, rows already resident in HBM on `device_id`.  The index BORROWS d_rows (no copy for fp16
+ * with d % 64 == 0); the caller keeps it alive until vf_index_destroy. */
+int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
+                           int32_t device_id, int64_t id_offset);
+
+/* src/utils/faissRetriever.py:34-38 (FaissRetriever.invoke after embed_query): queries [nq,d] fp32,
+ * NOT normalised (the library normalises, like faiss.normalize_L2 at :35); out_ids [nq,k] int64,
+ * out_scores [nq,k] fp32, best first.  Synchronous; host buffers. */
+int vf_index_search(vf_index* idx, const float* queries, int32_t nq, int32_t k, int64_t* out_ids,
+                    float* out_scores);
+
+/* Same with device buffers; work is enqueued on `stream` (a hipStream_t, NULL = default stream) and
+ * the call returns after the results are final in d_ids / d_scores (it synchronises the stream once,
+ * to read the 64-byte certificate word; see DESIGN.md "Exactness certificate"). */
+int vf_index_search_device(vf_index* idx, const float* d_queries, int32_t nq, int32_t k,
+                           int64_t* d_ids, float* d_scores, void* stream);
+
+/* Pipelined form for throughput: _begin enqueues batch work into slot (0 <= slot < vf_index_slots)
+ * and returns immediately; _end waits for that slot, certifies, repairs if needed.  Outputs are valid
+ * after _end.  Slots run on internal streams ordered after `stream` at _begin time. */
+int vf_index_slots(vf_index* idx, int32_t* out);
+int vf_index_search_begin(vf_index* idx, int32_t slot, const float* d_queries, int32_t nq, int32_t k,
+                          int64_t* d_ids, float* d_scores, void* stream);
+int vf_index_search_end(vf_index* idx, int32_t slot);
+
+int vf_index_info(vf_index* idx, int64_t* n, int32_t* d, int32_t* dtype, int32_t* device_id);
+int vf_index_stats(vf_index* idx, vf_search_stats* out);
+/* tuning knobs, by name ("force_path", "sample_rows", "margin", "cap", "waves" ...); tests use
+ * force_path to exercise every path on the same data.  Unknown name -> VF_EINVAL. */
+int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
+/* Live kernel timing with HIP events on the stream the kernels run on (bench.py roofline):
+ * after vf_index_set_option(idx, "profile", 1) every fused search records events around its main
+ * k_scan launch and around the whole per-batch pipeline; this returns the accumulated totals
+ * (milliseconds, launches) since the option was set.  bytes_per_launch = algorithmic bytes the main
+ * k_scan launch reads (rows scanned x (d*2 + 4)). */
+int vf_index_profile(vf_index* idx, double* scan_ms_total, int64_t* scan_launches, double* pipeline_ms_total,
+                     int64_t* scan_bytes_per_launch);
+int vf_index_destroy(vf_index* idx);
+
+/* ---- small dense cosine ------------------------------------------------------------------------
+ * src/utils/ensembleRetriever.py:275-279 (compute_similarity_mtx after the embed loop):
+ * x [n,d] fp32 host -> out [n,n] fp32 host, canonical cosine of every row pair. */
+int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out, int32_t device_id);
+
+/* experiments/retriever/step3_mul.py:275 (similarities_matrix = cosine_similarity(E, C)):
+ * a [na,d], b [nb,d] fp32 host -> out [na,nb] fp32 host. */
+int vf_cosine_scores(const float* a, int32_t na, const float* b, int64_t nb, int32_t d, float* out,
+                     int32_t device_id);
+
+/* ---- multi-GPU merge: after the RCCL all-gather of per-shard top-k -----------------
+ * d_ids_parts / d_score_parts [nparts, nq, k] (global ids, -1 padded) on the current device ->
+ * d_ids / d_scores [nq, k].  Asynchronous on `stream`. */
+int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts, int32_t nparts,
+                         int32_t nq, int32_t k, int64_t* d_ids, float* d_scores, int32_t device_id,
+                         void* stream);
+
+/* src/utils/vllmManager.py:443-457 (rank_chunk score fusion): scores = rerank + time_score,
+ * order = argsort descending (ties lower index first).  Host buffers, n <= 4096. */
+int vf_fuse_rank(const float* rerank_scores, const float* time_scores, int32_t n, float* out_scores,
+                 int64_t* out_order, int32_t device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VERITASFI_HIP_H */

@@ -1,0 +1,334 @@
+"""GPU parity tests: the HIP path through the C ABI vs the CPU oracle, bit for bit.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -q
+Bar (BASELINE.json north_star): ids and rank order identical to the CPU path, scores within 1e-3 --
+here scores are required to be BIT-identical to the canonical oracle, which is stronger.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import golden_inputs as GI
+from conftest import assert_ranked, assert_topk_equiv, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def vf():
+    import veritasfi_amd as m
+    from veritasfi_amd import _ffi
+    _ffi.lib()  # raises if the HIP library is missing: no fallback
+    n = _ffi.c_i32(0)
+    _ffi.check(_ffi.lib().vf_device_count(n), "vf_device_count")
+    assert n.value >= 1, "no GPU visible"
+    return m
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _assert_exact(oracle, corpus, queries, k, ids, scores, id_offset=0):
+    oi, os_ = oracle.search(corpus, queries, k, id_offset=id_offset)
+    bad = np.nonzero((oi != ids).any(axis=1))[0]
+    assert bad.size == 0, f"ids differ for queries {bad[:8].tolist()} (first: got {ids[bad[0]][:8]}, want {oi[bad[0]][:8]})"
+    assert np.array_equal(_bits(os_), _bits(scores)), float(np.max(np.abs(os_ - scores)))
+    for q in range(ids.shape[0]):
+        assert_ranked(ids[q], scores[q])
+
+
+def _data(seed, n, d, nq, dtype):
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((n, d)).astype(np.float32)
+    if dtype == np.float16:
+        c = c.astype(np.float16)
+    q = np.random.default_rng(seed + 1).standard_normal((nq, d)).astype(np.float32)
+    return c, q
+
+
+# ---- small-N exact dense path ---------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,nq,k,dtype", [
+    (1000, 768, 4, 10, np.float32),
+    (7, 32, 2, 10, np.float32),         # k > n: -1 / -FLT_MAX padding
+    (150, 768, 1, 3, np.float16),
+    (513, 100, 9, 40, np.float32),      # d not a multiple of 16
+    (64, 1, 3, 5, np.float32),          # d = 1
+    (16384, 256, 70, 100, np.float16),  # largest small-path corpus, two query batches
+    (2048, 1024, 3, 2048, np.float32),  # the reference's k = 2048 (ensembleRetriever.py:66), all rows ranked
+])
+def test_small_path_bit_exact(vf, oracle, n, d, nq, k, dtype):
+    c, q = _data(11, n, d, nq, dtype)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, k)
+        assert ix.stats()["path"] == 0
+    _assert_exact(oracle, c, q, k, ids, sc)
+    if k > n:
+        assert np.all(ids[:, n:] == -1) and np.all(sc[:, n:] == -FLT_MAX)
+
+
+def test_empty_and_degenerate(vf, oracle):
+    c, q = _data(12, 100, 64, 3, np.float32)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q[:0], 5)
+        assert ids.shape == (0, 5)
+        ids, sc = ix.search(q, 0)
+        assert ids.shape == (3, 0)
+    with vf.DenseIndex(np.zeros((0, 64), np.float32)) as ix:  # empty corpus
+        ids, sc = ix.search(q, 4)
+        assert np.all(ids == -1) and np.all(sc == -FLT_MAX)
+    # zero rows and zero queries score 0 (sklearn divides by 1)
+    c2 = c.copy()
+    c2[[3, 50]] = 0
+    q2 = q.copy()
+    q2[1] = 0
+    with vf.DenseIndex(c2) as ix:
+        ids, sc = ix.search(q2, 100)
+    _assert_exact(oracle, c2, q2, 100, ids, sc)
+    assert np.all(sc[1] == 0.0) and ids[1].tolist() == list(range(100))
+
+
+# ---- golden vectors produced by the real reference ----------------------------------------------
+@pytest.mark.parametrize("ci", range(len(GI.G2_CASES)))
+def test_golden_step3_batch(vf, oracle, ci):
+    g = load_golden(f"g2_step3_batch_case{ci}.npz")
+    chunks, evid, k = GI.g2_inputs(ci)
+    assert str(g["input_sha"]) == GI.sha(chunks, evid)
+    from veritasfi_amd.retrieval import top_chunks_from_embeddings
+    ids, sims = top_chunks_from_embeddings(evid, chunks, k)
+    kk = chunks.shape[0] if k == -1 else k
+    for e in range(evid.shape[0]):
+        assert_topk_equiv(g["ids"][e], g["sims"][e], ids[e], sims[e])
+    clear = g["min_gap"] > 1e-5
+    assert np.array_equal(ids[clear], g["ids"][clear])
+    _assert_exact(oracle, chunks, evid, kk, ids, sims)
+
+
+def test_golden_continuous_and_ties(vf, oracle):
+    g = load_golden("g1_continuous_select_top_chunks.npz")
+    chunks, evid = GI.g1_inputs()
+    from veritasfi_amd.retrieval import top_chunks_from_embeddings
+    for k in (3, 8):
+        ids, sims = top_chunks_from_embeddings(evid, chunks, k)
+        assert_topk_equiv(g[f"ids_k{k}"], g["sim_row"][g[f"ids_k{k}"]], ids[0], sims[0])
+    chunks, evid, groups = GI.g4_inputs()
+    ids, sims = top_chunks_from_embeddings(evid, chunks, -1)
+    _assert_exact(oracle, chunks, evid, chunks.shape[0], ids, sims)
+    g3 = load_golden("g3_cosine_fp16_inputs.npz")
+    corpus, queries = GI.g3_inputs()
+    sim = vf.cosine_scores(queries, corpus.astype(np.float32))
+    assert np.max(np.abs(sim - g3["sim"])) <= 1e-6
+    assert np.array_equal(_bits(sim), _bits(oracle.cosine(queries, corpus.astype(np.float32))))
+
+
+# ---- fused MFMA scan path -------------------------------------------------------------------------
+FUSED_CASES = [
+    # n, d, nq, k, dtype
+    (50_000, 768, 64, 100, np.float16),   # C2 shape, scaled down
+    (40_000, 768, 5, 10, np.float16),     # one 32-query tile
+    (30_000, 768, 70, 100, np.float16),   # two batches (64 + 6)
+    (60_000, 1024, 64, 100, np.float16),  # bge-large dim
+    (33_000, 384, 17, 50, np.float16),    # 6 segments -> G = 2/3
+    (25_000, 100, 8, 20, np.float16),     # d padded to 128, scan copy
+    (45_000, 768, 64, 100, np.float32),   # fp32 corpus: fp16 scan copy + fp32 exact rows
+    (70_000, 768, 3, 1000, np.float16),   # large k (k' = 1250)
+    (20_000, 768, 2, 2048, np.float16),   # the reference's k = 2048
+]
+
+
+@pytest.mark.parametrize("n,d,nq,k,dtype", FUSED_CASES)
+def test_fused_path_bit_exact(vf, oracle, n, d, nq, k, dtype):
+    c, q = _data(21, n, d, nq, dtype)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, k)
+        st = ix.stats()
+    print("fused stats", (n, d, nq, k), st)
+    assert st["path"] == 1
+    _assert_exact(oracle, c, q, k, ids, sc)
+    # on i.i.d. data the certificate should hold without repairs
+    assert st["overflowed"] == 0 and st["exact_reruns"] <= max(1, nq // 16), st
+
+
+def test_paths_agree_and_options(vf, oracle):
+    c, q = _data(22, 40_000, 768, 33, np.float16)
+    with vf.DenseIndex(c) as ix:
+        a = ix.search(q, 100)
+        ix.set_option("force_path", 2)  # chunked exact
+        b = ix.search(q, 100)
+        assert ix.stats()["path"] == 2
+        ix.set_option("force_path", 1)
+        for name, val in (("scan_g", 1), ("scan_g", 3), ("scan_g", 4), ("sample_rows", 4), ("sample_rows", 64),
+                          ("refresh_every", 16), ("waves", 64), ("waves", 1024), ("margin", 8), ("cap", 2048)):
+            ix.set_option(name, val)
+            r = ix.search(q, 100)
+            print("option", name, val, ix.stats())
+            assert np.array_equal(r[0], a[0]) and np.array_equal(_bits(r[1]), _bits(a[1])), (name, val)
+        with pytest.raises(RuntimeError):
+            ix.set_option("no_such_option", 1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1]))
+    _assert_exact(oracle, c, q, 100, *a)
+
+
+def test_certificate_repairs_on_hostile_data(vf, oracle):
+    """Duplicates straddling the k / k' boundary and a corpus sorted by score (candidate flood)
+    must still come out exact: the certificate fails or the buffer overflows and the exact path repairs."""
+    rng = np.random.default_rng(23)
+    n, d = 30_000, 256
+    q = rng.standard_normal((4, d)).astype(np.float32)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    # 400 verbatim copies of one vector close to query 0 -> a tie group wider than k' - k
+    hot = (q[0] + 0.05 * rng.standard_normal(d)).astype(np.float32)
+    base[rng.choice(n, 400, replace=False)] = hot
+    c = base.astype(np.float16)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, 100)
+        st = ix.stats()
+    print("duplicate stats", st)
+    _assert_exact(oracle, c, q, 100, ids, sc)
+    assert st["uncertified"] >= 1 and st["exact_reruns"] >= 1
+    # ascending-by-score order for query 1: every later row beats the threshold
+    sims = oracle.cosine(q[1:2], c.astype(np.float32))[0]
+    c_sorted = c[np.argsort(sims, kind="stable")]
+    with vf.DenseIndex(c_sorted) as ix:
+        ids, sc = ix.search(q, 100)
+        st = ix.stats()
+    print("sorted-corpus stats", st)
+    _assert_exact(oracle, c_sorted, q, 100, ids, sc)
+
+
+def test_sharding_invariance_and_merge(vf, oracle):
+    """Per-shard search + merge == unsharded search, bit for bit, uneven shards."""
+    import torch
+    c, q = _data(24, 90_000, 768, 16, np.float16)
+    k = 100
+    full_i, full_s = oracle.search(c, q, k)
+    bounds = [0, 20_000, 20_500, 61_000, 90_000]  # includes a small-path shard (500 rows)
+    parts_i, parts_s = [], []
+    qd = torch.from_numpy(q).cuda()
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        with vf.DenseIndex(c[a:b], id_offset=a) as ix:
+            i, s = ix.search_device(qd, k)
+            parts_i.append(i.clone())
+            parts_s.append(s.clone())
+    mi, ms = vf.merge_topk_device(torch.stack(parts_i).contiguous(), torch.stack(parts_s).contiguous(), k)
+    torch.cuda.synchronize()
+    assert np.array_equal(mi.cpu().numpy(), full_i)
+    assert np.array_equal(_bits(ms.cpu().numpy()), _bits(full_s))
+    omi, oms = oracle.merge_topk(torch.stack(parts_i).cpu().numpy(), torch.stack(parts_s).cpu().numpy(), k)
+    assert np.array_equal(omi, full_i) and np.array_equal(_bits(oms), _bits(full_s))
+
+
+def test_device_and_pipelined_api(vf, oracle):
+    import torch
+    c, q = _data(25, 48_000, 768, 64, np.float16)
+    cd = torch.from_numpy(c).cuda()  # corpus already in HBM: borrowed, no copy
+    qd = torch.from_numpy(q).cuda()
+    with vf.DenseIndex(cd) as ix:
+        i0, s0 = ix.search_device(qd, 100)
+        assert ix.slots >= 2
+        outs = []
+        for step in range(6):  # two slots in flight
+            slot = step % 2
+            if step >= 2:
+                ix.search_end(slot)
+            outs.append(ix.search_begin(slot, qd, 100))
+        ix.search_end(0)
+        ix.search_end(1)
+        torch.cuda.synchronize()
+        for i, s in outs:
+            assert torch.equal(i, i0) and torch.equal(s, s0)
+        with pytest.raises(RuntimeError):
+            ix.search_end(0)  # nothing pending
+    _assert_exact(oracle, c, q, 100, i0.cpu().numpy(), s0.cpu().numpy())
+
+
+def test_threads_share_one_index(vf, oracle):
+    """The reference shares one retriever between request threads without a lock."""
+    c, q = _data(26, 36_000, 768, 8, np.float16)
+    want = oracle.search(c, q, 50)
+    errs = []
+    with vf.DenseIndex(c) as ix:
+        def work(t):
+            try:
+                for _ in range(3):
+                    ids, sc = ix.search(q[t % 8:t % 8 + 1], 50)
+                    assert np.array_equal(ids[0], want[0][t % 8]) and np.array_equal(_bits(sc[0]), _bits(want[1][t % 8]))
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    assert not errs, errs
+
+
+def test_small_dense_ops(vf, oracle):
+    from oracle import ref_numpy as R
+    rng = np.random.default_rng(27)
+    x = rng.standard_normal((155, 1024)).astype(np.float32)  # n ~ retrieved chunks (stress_test.py:153)
+    m = vf.cosine_matrix(x)
+    assert np.array_equal(_bits(m), _bits(oracle.cosine(x, x)))
+    assert np.max(np.abs(m - R.similarity_matrix(x))) <= 1e-6
+    assert np.all(np.abs(np.diag(m) - 1.0) <= 1e-6)
+    rer = rng.standard_normal(155).astype(np.float32)
+    rer[10] = rer[20]  # exact tie
+    t = R.time_scores(rng.integers(-500, 500, 155)).astype(np.float32)
+    t[10] = t[20]
+    scores, order = vf.fuse_rank(rer, t)
+    assert np.array_equal(_bits(scores), _bits(rer + t))
+    assert np.array_equal(order, R.fuse_and_rank(rer, t))
+
+
+def test_drop_in_classes(vf, oracle):
+    """FaissRetriever / compute_similarity_mtx / select_top_chunks with the reference's call shapes."""
+    rng = np.random.default_rng(28)
+    table = rng.standard_normal((3000, 128)).astype(np.float32)
+
+    class FakeEmb:  # stands in for HuggingFaceEmbeddings (ragManager.py:50)
+        def embed_query(self, text):
+            return table[int(text)].tolist()
+
+        def embed_documents(self, texts):
+            return [table[int(t)].tolist() for t in texts]
+
+    fr = vf.FaissRetriever(table[:2500].tolist(), FakeEmb())  # list-of-lists, as chroma returns them
+    I, D = fr.invoke(["2600", "2700", "17"], 2048)  # (indices, distances), ensembleRetriever.py:66
+    assert I.dtype == np.int64 and D.dtype == np.float32 and I.shape == (3, 2048)
+    _assert_exact(oracle, table[:2500], table[[2600, 2700, 17]], 2048, I, D)
+    assert I[2, 0] == 17 and abs(D[2, 0] - 1.0) < 1e-6
+    mtx = vf.compute_similarity_mtx(FakeEmb(), [str(i) for i in range(40)])
+    assert tuple(mtx.shape) == (40, 40)
+    assert bool((mtx[3, [1, 2, 3]] > 0.9).any())  # vllmManager.py:476 usage
+    assert np.array_equal(_bits(mtx.numpy()), _bits(oracle.cosine(table[:40], table[:40])))
+
+
+def test_errors_are_reported_not_fatal(vf):
+    from veritasfi_amd import _ffi
+    with pytest.raises(RuntimeError, match="fp8"):
+        h = _ffi.vp()
+        x = np.zeros((4, 16), np.uint8)
+        import ctypes
+        _ffi.check(_ffi.lib().vf_index_create(ctypes.byref(h), x.ctypes.data, 4, 16, _ffi.VF_DTYPE_FP8_E4M3, 0, 0), "create")
+    with pytest.raises(RuntimeError):
+        vf.DenseIndex(np.zeros((4, 16), np.float32), device_id=99)
+    with vf.DenseIndex(np.ones((4, 16), np.float32)) as ix:
+        with pytest.raises(ValueError):
+            ix.search(np.ones((1, 8), np.float32), 1)
+
+
+# ---- BASELINE configs[1] at full size: 1M x 768 fp16, B = 64, k = 100 ----------------------------
+def test_c2_full_size_bit_exact(vf, oracle):
+    n, d, nq, k = 1_000_000, 768, 64, 100
+    rng = np.random.default_rng(1234)
+    c = np.empty((n, d), dtype=np.float16)
+    for i in range(0, n, 100_000):  # chunked to bound host memory
+        c[i:i + 100_000] = rng.standard_normal((100_000, d), dtype=np.float32).astype(np.float16)
+    q = np.random.default_rng(4321).standard_normal((nq, d)).astype(np.float32)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, k)
+        st = ix.stats()
+    print("C2 stats", st)
+    assert st["path"] == 1 and st["overflowed"] == 0
+    _assert_exact(oracle, c, q, k, ids, sc)

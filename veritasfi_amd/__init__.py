@@ -1,0 +1,22 @@
+"""veritasfi_amd -- MI355X-native (gfx950) embedding / retrieval / re-rank hot path for VeritasFi.
+
+Host code is Python; all compute is hand-written HIP behind a C ABI (``include/veritasfi_hip.h``,
+``libveritasfi_hip.so``), bound with ctypes.  There is no CPU fallback: importing this package is
+cheap and GPU-free, but every operation raises if the HIP library is not built or no GPU is present.
+
+Drop-in names (same signatures as the reference):
+
+* ``FaissRetriever``                     -- ``src/utils/faissRetriever.py``
+* ``select_top_chunks(_batch)``, ``get_embeddings``, ``last_token_pool``
+                                         -- ``experiments/retriever/step3_mul.py`` / ``continuous_retrieval.py``
+* ``compute_similarity_mtx``, ``fuse_and_rank``, ``time_scores``
+                                         -- ``src/utils/ensembleRetriever.py:265-281``, ``src/utils/vllmManager.py:443-457``
+* ``ShardedRetriever``                   -- row-sharded multi-GPU search
+"""
+from .index import DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device  # noqa: F401
+from .faiss_retriever import FaissRetriever  # noqa: F401
+from .retrieval import get_embeddings, last_token_pool, select_top_chunks, select_top_chunks_batch  # noqa: F401
+from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_rank, time_scores  # noqa: F401
+from .sharded import ShardedRetriever, shard_bounds  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,87 @@
+"""ctypes binding of ``libveritasfi_hip.so`` (C ABI: ``include/veritasfi_hip.h``).
+
+There is NO fallback: if the library is missing or fails to load, every entry point raises.  Build it
+with ``python -m veritasfi_amd.build`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libveritasfi_hip.so")
+
+VF_OK = 0
+VF_DTYPE_F32, VF_DTYPE_F16, VF_DTYPE_FP8_E4M3 = 0, 1, 2
+
+c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+p_i32, p_i64, p_f32 = ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.POINTER(c_f32)
+vp = ctypes.c_void_p
+
+
+class SearchStats(ctypes.Structure):
+    _fields_ = [
+        ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
+        ("uncertified", c_i64), ("overflowed", c_i64), ("exact_reruns", c_i64), ("reserved", c_i64 * 9),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/veritasfi_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "vf_version": (ctypes.c_int, []),
+    "vf_last_error": (ctypes.c_char_p, []),
+    "vf_device_count": (ctypes.c_int, [p_i32]),
+    "vf_index_create": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, c_i32, c_i64]),
+    "vf_index_create_device": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, c_i32, c_i64]),
+    "vf_index_search": (ctypes.c_int, [vp, vp, c_i32, c_i32, vp, vp]),
+    "vf_index_search_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, vp, vp, vp]),
+    "vf_index_slots": (ctypes.c_int, [vp, p_i32]),
+    "vf_index_search_begin": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i32, vp, vp, vp]),
+    "vf_index_search_end": (ctypes.c_int, [vp, c_i32]),
+    "vf_index_info": (ctypes.c_int, [vp, p_i64, p_i32, p_i32, p_i32]),
+    "vf_index_stats": (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
+    "vf_index_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, c_i64]),
+    "vf_index_profile": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), p_i64, ctypes.POINTER(ctypes.c_double), p_i64]),
+    "vf_index_destroy": (ctypes.c_int, [vp]),
+    "vf_cosine_matrix": (ctypes.c_int, [vp, c_i32, c_i32, vp, c_i32]),
+    "vf_cosine_scores": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32]),
+    "vf_merge_topk_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
+    "vf_fuse_rank": (ctypes.c_int, [vp, vp, c_i32, vp, vp, c_i32]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is not built -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `python -m veritasfi_amd.build` "
+                        "(hipcc --offload-arch=gfx950). veritasfi_amd has no CPU fallback.")
+                L = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)  # AttributeError if the ABI and this table drift apart
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().vf_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map a VF_E* code to RuntimeError(vf_last_error()), as SURVEY 8b prescribes."""
+    if rc != VF_OK:
+        raise RuntimeError(f"{what or 'veritasfi_hip'} failed (rc={rc}): {last_error()}")

@@ -1,0 +1,669 @@
+// vf_api.hip -- the C ABI of libveritasfi_hip.so (include/veritasfi_hip.h): handle management,
+// path selection and stream orchestration around the kernels in vf_kernels.hip.
+//
+// Reference surface replaced: faiss.IndexFlatIP build + search behind FaissRetriever
+// (src/utils/faissRetriever.py:11-38), sklearn.cosine_similarity + argsort
+// (experiments/retriever/step3_mul.py:233-289), compute_similarity_mtx
+// (src/utils/ensembleRetriever.py:275-279), rank_chunk fusion (src/utils/vllmManager.py:454-457).
+#include "../../include/veritasfi_hip.h"
+#include "vf_internal.h"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace vf;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define VF_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(VF_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                                     ":" + std::to_string(__LINE__) + ")");                            \
+    } while (0)
+
+#define VF_TRY(expr)             \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != VF_OK) return _rc; \
+    } while (0)
+
+extern "C" int vf_version(void) { return VF_VERSION; }
+extern "C" const char* vf_last_error(void) { return g_err.c_str(); }
+
+extern "C" int vf_device_count(int32_t* out) {
+    if (!out) return fail(VF_EINVAL, "vf_device_count: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out = 0; return fail(VF_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *out = n;
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kSlots = 2;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return VF_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return fail(VF_ENOMEM, std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
+        bytes = need;
+        return VF_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
+    bool timed = false;
+    DevBuf qn, qimg, s0, cnt, tau, hist, cand, flags, counts;   // fused-path state
+    DevBuf dense_s, cn_tmp, parts_ids, parts_sc, run_ids, run_sc, qsel; // exact-path scratch
+    int* h_flags = nullptr;      // pinned, [max batches * 64]
+    u32* h_counts = nullptr;     // pinned
+    size_t h_cap = 0;
+    // pending call
+    bool pending = false;
+    const float* d_queries = nullptr;
+    int nq = 0, k = 0, path = 0;
+    int64_t* d_ids = nullptr;
+    float* d_scores = nullptr;
+    hipStream_t user_stream = nullptr;
+};
+
+}  // namespace
+
+struct vf_index {
+    int device = 0;
+    int64_t n = 0;
+    int d = 0, dp = 0, dtype = 0;
+    int64_t id_offset = 0;
+    int n_cu = 256;
+    bool owns_rows = false;
+    void* rows_orig = nullptr;        // as given (fp32 or fp16), [n][d]
+    _Float16* rows_scan = nullptr;    // fp16 [n][dp]; may alias rows_orig
+    bool owns_scan = false;
+    float* norm = nullptr;            // canonical norms [n]
+    float* inv_scan = nullptr;        // [n]
+    float* cn_cache = nullptr;        // canonical normalised rows when n <= kSmallN
+    std::mutex mu;
+    Slot slots[kSlots];
+    // options
+    int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
+            refresh_every = 128;
+    vf_search_stats stats{};
+    bool profile = false;
+    double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
+    int64_t prof_launches = 0, prof_bytes = 0;
+};
+
+static int ensure_pinned(Slot& s, size_t nq_total) {
+    if (nq_total <= s.h_cap) return VF_OK;
+    if (s.h_flags) (void)hipHostFree(s.h_flags);
+    if (s.h_counts) (void)hipHostFree(s.h_counts);
+    s.h_flags = nullptr; s.h_counts = nullptr; s.h_cap = 0;
+    size_t cap = std::max<size_t>(nq_total, 256);
+    VF_HIP(hipHostMalloc((void**)&s.h_flags, cap * sizeof(int), hipHostMallocDefault));
+    VF_HIP(hipHostMalloc((void**)&s.h_counts, cap * sizeof(u32), hipHostMallocDefault));
+    s.h_cap = cap;
+    return VF_OK;
+}
+
+static int build_common(vf_index* ix) {
+    hipDeviceProp_t prop;
+    VF_HIP(hipGetDeviceProperties(&prop, ix->device));
+    ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    VF_HIP(scan_configure());
+    const int is_half = ix->dtype == VF_DTYPE_F16;
+    ix->dp = (ix->d + 63) / 64 * 64;
+    const size_t npad = (size_t)ix->n + 64;
+    VF_HIP(hipMalloc((void**)&ix->norm, npad * sizeof(float)));
+    VF_HIP(hipMalloc((void**)&ix->inv_scan, npad * sizeof(float)));
+    VF_HIP(hipMemset(ix->norm, 0, npad * sizeof(float)));
+    VF_HIP(hipMemset(ix->inv_scan, 0, npad * sizeof(float)));
+    const bool need_scan = ix->n > kSmallN;  // small corpora never run the fused scan
+    _Float16* scan_out = nullptr;
+    if (need_scan) {
+        if (is_half && ix->dp == ix->d && ((uintptr_t)ix->rows_orig % 16) == 0) {
+            ix->rows_scan = (_Float16*)ix->rows_orig;
+            ix->owns_scan = false;
+        } else {
+            VF_HIP(hipMalloc((void**)&ix->rows_scan, (size_t)ix->n * ix->dp * sizeof(_Float16)));
+            ix->owns_scan = true;
+            scan_out = ix->rows_scan;
+        }
+    }
+    VF_HIP(launch_prep_rows(ix->rows_orig, is_half, ix->n, ix->d, ix->dp, scan_out, ix->norm, ix->inv_scan, nullptr));
+    if (ix->n > 0 && ix->n <= kSmallN) {
+        VF_HIP(hipMalloc((void**)&ix->cn_cache, (size_t)ix->n * ix->d * sizeof(float)));
+        VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, 0, ix->n, ix->d, ix->norm, ix->cn_cache, nullptr));
+    }
+    for (int i = 0; i < kSlots; ++i) {
+        VF_HIP(hipStreamCreateWithFlags(&ix->slots[i].stream, hipStreamNonBlocking));
+        VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_in, hipEventDisableTiming));
+        VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_done, hipEventDisableTiming));
+        for (int e = 0; e < 4; ++e) VF_HIP(hipEventCreate(&ix->slots[i].ev_t[e]));
+    }
+    VF_HIP(hipDeviceSynchronize());
+    return VF_OK;
+}
+
+static void destroy_index(vf_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < kSlots; ++i) {
+        Slot& s = ix->slots[i];
+        DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.cand, &s.flags, &s.counts, &s.dense_s,
+                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel};
+        for (DevBuf* b : bufs) b->release();
+        if (s.h_flags) (void)hipHostFree(s.h_flags);
+        if (s.h_counts) (void)hipHostFree(s.h_counts);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        for (int e = 0; e < 4; ++e) if (s.ev_t[e]) (void)hipEventDestroy(s.ev_t[e]);
+    }
+    if (ix->owns_scan && ix->rows_scan) (void)hipFree(ix->rows_scan);
+    if (ix->owns_rows && ix->rows_orig) (void)hipFree(ix->rows_orig);
+    if (ix->norm) (void)hipFree(ix->norm);
+    if (ix->inv_scan) (void)hipFree(ix->inv_scan);
+    if (ix->cn_cache) (void)hipFree(ix->cn_cache);
+    delete ix;
+}
+
+static int create_impl(vf_index** out, const void* rows, bool rows_on_device, int64_t n, int32_t d, int32_t dtype,
+                       int32_t device_id, int64_t id_offset) {
+    if (!out) return fail(VF_EINVAL, "vf_index_create: null out");
+    *out = nullptr;
+    if (n < 0 || d <= 0 || (n > 0 && !rows)) return fail(VF_EINVAL, "vf_index_create: bad rows/n/d");
+    if (dtype == VF_DTYPE_FP8_E4M3) return fail(VF_EUNSUPPORTED, "vf_index_create: fp8 corpus not implemented in this build");
+    if (dtype != VF_DTYPE_F32 && dtype != VF_DTYPE_F16) return fail(VF_EINVAL, "vf_index_create: unknown dtype");
+    if (n >= (int64_t)0xFFFFFFFFll) return fail(VF_EUNSUPPORTED, "vf_index_create: more than 2^32-1 rows per shard");
+    int ndev = 0;
+    VF_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(VF_EINVAL, "vf_index_create: bad device_id");
+    VF_HIP(hipSetDevice(device_id));
+    vf_index* ix = new (std::nothrow) vf_index();
+    if (!ix) return fail(VF_ENOMEM, "vf_index_create: host allocation failed");
+    ix->device = device_id; ix->n = n; ix->d = d; ix->dtype = dtype; ix->id_offset = id_offset;
+    const size_t esz = dtype == VF_DTYPE_F16 ? 2 : 4;
+    int rc = VF_OK;
+    if (rows_on_device) {
+        ix->rows_orig = const_cast<void*>(rows);
+        ix->owns_rows = false;
+    } else if (n > 0) {
+        hipError_t e = hipMalloc(&ix->rows_orig, (size_t)n * d * esz);
+        if (e != hipSuccess) rc = fail(VF_ENOMEM, std::string("hipMalloc(corpus): ") + hipGetErrorString(e));
+        else {
+            ix->owns_rows = true;
+            e = hipMemcpy(ix->rows_orig, rows, (size_t)n * d * esz, hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = fail(VF_EHIP, std::string("hipMemcpy(corpus): ") + hipGetErrorString(e));
+        }
+    }
+    if (rc == VF_OK) rc = build_common(ix);
+    if (rc != VF_OK) { std::string keep = g_err; destroy_index(ix); g_err = keep; return rc; }
+    *out = ix;
+    return VF_OK;
+}
+
+extern "C" int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
+                               int32_t device_id, int64_t id_offset) {
+    return create_impl(out, rows, false, n, d, dtype, device_id, id_offset);
+}
+
+extern "C" int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
+                                      int32_t device_id, int64_t id_offset) {
+    return create_impl(out, d_rows, true, n, d, dtype, device_id, id_offset);
+}
+
+extern "C" int vf_index_destroy(vf_index* ix) {
+    if (!ix) return VF_OK;
+    destroy_index(ix);
+    return VF_OK;
+}
+
+extern "C" int vf_index_info(vf_index* ix, int64_t* n, int32_t* d, int32_t* dtype, int32_t* device_id) {
+    if (!ix) return fail(VF_EINVAL, "vf_index_info: null handle");
+    if (n) *n = ix->n;
+    if (d) *d = ix->d;
+    if (dtype) *dtype = ix->dtype;
+    if (device_id) *device_id = ix->device;
+    return VF_OK;
+}
+
+extern "C" int vf_index_stats(vf_index* ix, vf_search_stats* out) {
+    if (!ix || !out) return fail(VF_EINVAL, "vf_index_stats: null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    *out = ix->stats;
+    return VF_OK;
+}
+
+extern "C" int vf_index_profile(vf_index* ix, double* scan_ms_total, int64_t* scan_launches, double* pipeline_ms_total,
+                                int64_t* scan_bytes_per_launch) {
+    if (!ix) return fail(VF_EINVAL, "vf_index_profile: null handle");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (scan_ms_total) *scan_ms_total = ix->prof_scan_ms;
+    if (scan_launches) *scan_launches = ix->prof_launches;
+    if (pipeline_ms_total) *pipeline_ms_total = ix->prof_pipe_ms;
+    if (scan_bytes_per_launch) *scan_bytes_per_launch = ix->prof_bytes;
+    return VF_OK;
+}
+
+extern "C" int vf_index_slots(vf_index* ix, int32_t* out) {
+    if (!ix || !out) return fail(VF_EINVAL, "vf_index_slots: null argument");
+    *out = kSlots;
+    return VF_OK;
+}
+
+extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value) {
+    if (!ix || !name) return fail(VF_EINVAL, "vf_index_set_option: null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    const std::string s(name);
+    if (s == "force_path") ix->force_path = value;
+    else if (s == "sample_rows") ix->sample_rows = value;
+    else if (s == "margin") ix->margin = value;
+    else if (s == "cap") ix->cap_opt = value;
+    else if (s == "waves") ix->waves_opt = value;
+    else if (s == "scan_g") ix->scan_g = value;
+    else if (s == "refresh_every") ix->refresh_every = value;
+    else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
+    else return fail(VF_EINVAL, "vf_index_set_option: unknown option " + s);
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact path: canonical dense scores chunk by chunk + LDS sort + running merge.
+// qn_dev: [nq][d] canonical normalised queries on device.  Writes [nq][k] at out_ids/out_scores.
+// ------------------------------------------------------------------------------------------------
+static int exact_search(vf_index* ix, Slot& s, const float* qn_dev, int nq, int k, int64_t* out_ids,
+                        float* out_scores, hipStream_t st) {
+    const int is_half = ix->dtype == VF_DTYPE_F16;
+    const int64_t chunk = kSmallN;
+    const int64_t nchunks = ix->n == 0 ? 1 : (ix->n + chunk - 1) / chunk;
+    if (nchunks > 1 && (int64_t)k * 2 * 8 > 160 * 1024)
+        return fail(VF_EUNSUPPORTED, "exact chunked search supports k <= 10240 when n > 16384");
+    VF_TRY(s.dense_s.ensure((size_t)nq * chunk * sizeof(float)));
+    if (nchunks == 1) {
+        const float* cn = ix->cn_cache;
+        if (!cn && ix->n > 0) {
+            VF_TRY(s.cn_tmp.ensure((size_t)chunk * ix->d * sizeof(float)));
+            VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, 0, ix->n, ix->d, ix->norm, s.cn_tmp.as<float>(), st));
+            cn = s.cn_tmp.as<float>();
+        }
+        VF_HIP(launch_dense_dot16(qn_dev, nq, cn, ix->n, ix->d, s.dense_s.as<float>(), chunk, st));
+        VF_HIP(launch_sort_rows(s.dense_s.as<float>(), chunk, nq, (int)ix->n, k, ix->id_offset, (long long*)out_ids,
+                                out_scores, k, st));
+        return VF_OK;
+    }
+    VF_TRY(s.cn_tmp.ensure((size_t)chunk * ix->d * sizeof(float)));
+    const size_t part = (size_t)nq * k;
+    VF_TRY(s.parts_ids.ensure(2 * part * sizeof(long long)));
+    VF_TRY(s.parts_sc.ensure(2 * part * sizeof(float)));
+    VF_TRY(s.run_ids.ensure(part * sizeof(long long)));
+    VF_TRY(s.run_sc.ensure(part * sizeof(float)));
+    long long* pid = s.parts_ids.as<long long>();
+    float* psc = s.parts_sc.as<float>();
+    VF_HIP(hipMemsetAsync(pid, 0xFF, part * sizeof(long long), st));  // running part = all -1
+    VF_HIP(hipMemsetAsync(psc, 0, part * sizeof(float), st));
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int64_t r0 = c * chunk, nr = std::min(chunk, ix->n - r0);
+        VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, r0, nr, ix->d, ix->norm, s.cn_tmp.as<float>(), st));
+        VF_HIP(launch_dense_dot16(qn_dev, nq, s.cn_tmp.as<float>(), nr, ix->d, s.dense_s.as<float>(), chunk, st));
+        VF_HIP(launch_sort_rows(s.dense_s.as<float>(), chunk, nq, (int)nr, k, ix->id_offset + r0, pid + part, psc + part,
+                                k, st));
+        VF_HIP(launch_merge_topk(pid, psc, 2, nq, k, s.run_ids.as<long long>(), s.run_sc.as<float>(), st));
+        VF_HIP(hipMemcpyAsync(pid, s.run_ids.p, part * sizeof(long long), hipMemcpyDeviceToDevice, st));
+        VF_HIP(hipMemcpyAsync(psc, s.run_sc.p, part * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    VF_HIP(hipMemcpyAsync(out_ids, s.run_ids.p, part * sizeof(long long), hipMemcpyDeviceToDevice, st));
+    VF_HIP(hipMemcpyAsync(out_scores, s.run_sc.p, part * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// path selection + fused pipeline
+// ------------------------------------------------------------------------------------------------
+struct FusedPlan {
+    int kprime, cap, total_waves, grid, samp;
+    float eps;
+};
+
+static int qn_tile_for(int nq_batch) { return nq_batch <= kQueryTile ? kQueryTile : kMaxBatch; }
+
+static bool fused_possible(const vf_index* ix, int k) {
+    if (ix->n <= 1024 || k > kMaxKFused || k <= 0) return false;
+    if (scan_lds_bytes(ix->dp, kQueryTile) > 160 * 1024) return false;
+    return true;
+}
+
+static int batch_limit(const vf_index* ix) {
+    // 64 queries need dp * 64 * 2 bytes of LDS; fall back to 32-query passes for wide rows
+    return scan_lds_bytes(ix->dp, kMaxBatch) <= 160 * 1024 ? kMaxBatch : kQueryTile;
+}
+
+static FusedPlan make_plan(const vf_index* ix, int k) {
+    FusedPlan p;
+    const int margin = ix->margin >= 0 ? (int)ix->margin : std::max(32, k / 4);
+    p.kprime = k + margin;
+    int cap = kMaxCap;
+    while (cap < 4 * p.kprime && cap < 16384) cap <<= 1;
+    if (ix->cap_opt > 0) { cap = 1; while (cap < ix->cap_opt) cap <<= 1; cap = std::min(cap, 16384); }
+    while (cap < 2 * p.kprime) cap <<= 1;
+    p.cap = cap;
+    int64_t wgs = std::min<int64_t>(ix->n_cu, std::max<int64_t>(1, ix->n / 512));
+    if (ix->waves_opt > 0) wgs = std::max<int64_t>(1, ix->waves_opt / (kScanThreads / 64));
+    p.grid = (int)wgs;
+    p.total_waves = p.grid * (kScanThreads / 64);
+    p.samp = (int)std::max<int64_t>(1, ix->sample_rows);
+    // |approx - canonical| bound (DESIGN.md "Exactness certificate"): fp16 query rounding 2^-12,
+    // fp16 corpus rounding 2^-12 when the corpus was fp32, fp16 subnormal floor, two fp32 dot products.
+    const double u16 = 1.0 / 4096.0;
+    p.eps = (float)(u16 * (ix->dtype == VF_DTYPE_F32 ? 2.0 : 1.0) + sqrt((double)ix->d) * ldexp(1.0, -24) +
+                    2.0 * ix->d * ldexp(1.0, -24) + 1e-6);
+    return p;
+}
+
+static int select_path(const vf_index* ix, int k) {
+    if (ix->force_path >= 0) {
+        if (ix->force_path == 1 && !fused_possible(ix, k)) return -1;
+        return (int)ix->force_path;
+    }
+    if (ix->n <= kSmallN) return 0;
+    return fused_possible(ix, k) ? 1 : 2;
+}
+
+static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq, int k, int64_t* d_ids,
+                      float* d_scores, hipStream_t user) {
+    Slot& s = ix->slots[slot_id];
+    if (s.pending) return fail(VF_EINVAL, "vf_index_search_begin: slot already has a pending search");
+    const int path = select_path(ix, k);
+    if (path < 0) return fail(VF_EUNSUPPORTED, "forced fused path is not possible for this n / k / d");
+    VF_HIP(hipEventRecord(s.ev_in, user));
+    VF_HIP(hipStreamWaitEvent(s.stream, s.ev_in, 0));
+    hipStream_t st = s.stream;
+    const int bl = batch_limit(ix);
+    VF_TRY(s.qn.ensure((size_t)std::max(nq, 1) * ix->d * sizeof(float)));
+    VF_TRY(s.qimg.ensure(scan_lds_bytes(ix->dp, kMaxBatch)));
+    VF_TRY(ensure_pinned(s, (size_t)nq));
+    s.pending = true; s.d_queries = d_queries; s.nq = nq; s.k = k; s.d_ids = d_ids; s.d_scores = d_scores;
+    s.path = path; s.user_stream = user;
+    if (nq == 0 || k == 0) { VF_HIP(hipEventRecord(s.ev_done, st)); return VF_OK; }
+
+    if (path != 1) {
+        for (int b0 = 0; b0 < nq; b0 += bl) {
+            const int nb = std::min(bl, nq - b0);
+            VF_HIP(launch_prep_queries(d_queries + (size_t)b0 * ix->d, nb, ix->d, ix->dp, qn_tile_for(nb),
+                                       s.qn.as<float>() + (size_t)b0 * ix->d, s.qimg.as<_Float16>(), st));
+            VF_TRY(exact_search(ix, s, s.qn.as<float>() + (size_t)b0 * ix->d, nb, k, d_ids + (size_t)b0 * k,
+                                d_scores + (size_t)b0 * k, st));
+        }
+        VF_HIP(hipEventRecord(s.ev_done, st));
+        return VF_OK;
+    }
+
+    const FusedPlan p = make_plan(ix, k);
+    VF_TRY(s.s0.ensure((size_t)kMaxBatch * p.total_waves * p.samp * sizeof(float)));
+    VF_TRY(s.cnt.ensure(kMaxBatch * sizeof(u32)));
+    VF_TRY(s.tau.ensure(kMaxBatch * sizeof(int)));
+    VF_TRY(s.hist.ensure((size_t)kMaxBatch * kHistBins * sizeof(u32)));
+    VF_TRY(s.cand.ensure((size_t)kMaxBatch * p.cap * sizeof(u64)));
+    VF_TRY(s.flags.ensure((size_t)std::max(nq, 1) * sizeof(int)));
+    VF_TRY(s.counts.ensure((size_t)std::max(nq, 1) * sizeof(u32)));
+    s.timed = ix->profile;
+    if (s.timed) VF_HIP(hipEventRecord(s.ev_t[2], st));
+    for (int b0 = 0; b0 < nq; b0 += bl) {
+        const int nb = std::min(bl, nq - b0);
+        const int qt = qn_tile_for(nb);
+        float* qn_b = s.qn.as<float>() + (size_t)b0 * ix->d;
+        VF_HIP(launch_prep_queries(d_queries + (size_t)b0 * ix->d, nb, ix->d, ix->dp, qt, qn_b, s.qimg.as<_Float16>(), st));
+        ScanArgs a{};
+        a.rows = (const char*)ix->rows_scan; a.inv_scan = ix->inv_scan; a.qimg = s.qimg.as<_Float16>();
+        a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * 2; a.total_waves = p.total_waves; a.samp = p.samp;
+        a.s0 = s.s0.as<float>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>(); a.hist = s.hist.as<u32>();
+        a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
+        a.refresh_every = (int)std::max<int64_t>(1, ix->refresh_every); a.nq = nb;
+        // sample slots no wave writes (a wave range shorter than samp) must read as empty: 0xFF bytes
+        // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
+        if (ix->n / p.total_waves < p.samp)
+            VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qt * p.total_waves * p.samp * sizeof(float), st));
+        VF_HIP(launch_scan(a, kModeSample, qt, p.grid, (int)ix->scan_g, st));
+        VF_HIP(launch_sel0(a, qt, st));
+        if (s.timed && b0 == 0) VF_HIP(hipEventRecord(s.ev_t[0], st));
+        VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, st));
+        if (s.timed && b0 == 0) {
+            VF_HIP(hipEventRecord(s.ev_t[1], st));
+            const int64_t per_wave = ix->n / p.total_waves;
+            const int64_t sampled = std::min<int64_t>(ix->n, (int64_t)p.total_waves * std::min<int64_t>(p.samp, per_wave));
+            ix->prof_bytes = (ix->n - sampled) * ((int64_t)ix->d * 2 + 4);
+        }
+        FinalArgs f{};
+        f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.rows_orig = ix->rows_orig;
+        f.orig_is_half = ix->dtype == VF_DTYPE_F16; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
+        f.d = ix->d; f.k = k; f.kprime = p.kprime; f.eps = p.eps; f.n_rows = ix->n; f.id_offset = ix->id_offset;
+        f.out_ids = (long long*)(d_ids + (size_t)b0 * k); f.out_scores = d_scores + (size_t)b0 * k;
+        f.flags = s.flags.as<int>() + b0; f.cand_count_out = s.counts.as<u32>() + b0;
+        VF_HIP(launch_final(f, nb, st));
+    }
+    if (s.timed) VF_HIP(hipEventRecord(s.ev_t[3], st));
+    VF_HIP(hipMemcpyAsync(s.h_flags, s.flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+    VF_HIP(hipMemcpyAsync(s.h_counts, s.counts.p, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, st));
+    VF_HIP(hipEventRecord(s.ev_done, st));
+    return VF_OK;
+}
+
+static int end_impl(vf_index* ix, int slot_id) {
+    Slot& s = ix->slots[slot_id];
+    if (!s.pending) return fail(VF_EINVAL, "vf_index_search_end: slot has no pending search");
+    s.pending = false;
+    VF_HIP(hipEventSynchronize(s.ev_done));
+    vf_search_stats stt{};
+    stt.path = s.path; stt.n_queries = s.nq;
+    if (s.path == 1 && s.nq > 0 && s.k > 0) {
+        if (s.timed) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.ev_t[0], s.ev_t[1]) == hipSuccess) { ix->prof_scan_ms += ms; ++ix->prof_launches; }
+            if (hipEventElapsedTime(&ms, s.ev_t[2], s.ev_t[3]) == hipSuccess) ix->prof_pipe_ms += ms;
+            s.timed = false;
+        }
+        std::vector<int> redo;
+        for (int q = 0; q < s.nq; ++q) {
+            stt.candidates += s.h_counts[q];
+            stt.max_candidates = std::max<int64_t>(stt.max_candidates, s.h_counts[q]);
+            if (s.h_flags[q] == 1) ++stt.uncertified;
+            if (s.h_flags[q] == 2) ++stt.overflowed;
+            if (s.h_flags[q] != 0) redo.push_back(q);
+        }
+        if (!redo.empty()) {
+            // repair: exact chunked search for the flagged queries only (still on the GPU)
+            const int m = (int)redo.size();
+            hipStream_t st = s.stream;
+            VF_TRY(s.qsel.ensure((size_t)m * ix->d * sizeof(float) + (size_t)m * s.k * (sizeof(long long) + sizeof(float))));
+            float* qsel = s.qsel.as<float>();
+            long long* rid = (long long*)(qsel + (size_t)m * ix->d);
+            float* rsc = (float*)(rid + (size_t)m * s.k);
+            for (int i = 0; i < m; ++i)
+                VF_HIP(hipMemcpyAsync(qsel + (size_t)i * ix->d, s.qn.as<float>() + (size_t)redo[i] * ix->d,
+                                      (size_t)ix->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+            for (int i0 = 0; i0 < m; i0 += kMaxBatch) {
+                const int nb = std::min(kMaxBatch, m - i0);
+                VF_TRY(exact_search(ix, s, qsel + (size_t)i0 * ix->d, nb, s.k, (int64_t*)(rid + (size_t)i0 * s.k),
+                                    rsc + (size_t)i0 * s.k, st));
+            }
+            for (int i = 0; i < m; ++i) {
+                VF_HIP(hipMemcpyAsync(s.d_ids + (size_t)redo[i] * s.k, rid + (size_t)i * s.k, (size_t)s.k * sizeof(long long),
+                                      hipMemcpyDeviceToDevice, st));
+                VF_HIP(hipMemcpyAsync(s.d_scores + (size_t)redo[i] * s.k, rsc + (size_t)i * s.k, (size_t)s.k * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+            }
+            VF_HIP(hipEventRecord(s.ev_done, st));
+            VF_HIP(hipEventSynchronize(s.ev_done));
+            stt.exact_reruns = m;
+        }
+    }
+    // later work on the caller's stream sees the results
+    VF_HIP(hipStreamWaitEvent(s.user_stream, s.ev_done, 0));
+    ix->stats = stt;
+    return VF_OK;
+}
+
+static int check_search_args(vf_index* ix, const void* q, int nq, int k, const void* ids, const void* sc) {
+    if (!ix) return fail(VF_EINVAL, "search: null handle");
+    if (nq < 0 || k < 0) return fail(VF_EINVAL, "search: negative nq / k");
+    if (nq > 0 && k > 0 && (!q || !ids || !sc)) return fail(VF_EINVAL, "search: null buffer");
+    return VF_OK;
+}
+
+extern "C" int vf_index_search_begin(vf_index* ix, int32_t slot, const float* d_queries, int32_t nq, int32_t k,
+                                     int64_t* d_ids, float* d_scores, void* stream) {
+    VF_TRY(check_search_args(ix, d_queries, nq, k, d_ids, d_scores));
+    if (slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_search_begin: bad slot");
+    std::lock_guard<std::mutex> g(ix->mu);
+    VF_HIP(hipSetDevice(ix->device));
+    int rc = begin_impl(ix, slot, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
+    if (rc != VF_OK) ix->slots[slot].pending = false;
+    return rc;
+}
+
+extern "C" int vf_index_search_end(vf_index* ix, int32_t slot) {
+    if (!ix) return fail(VF_EINVAL, "vf_index_search_end: null handle");
+    if (slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_search_end: bad slot");
+    std::lock_guard<std::mutex> g(ix->mu);
+    VF_HIP(hipSetDevice(ix->device));
+    return end_impl(ix, slot);
+}
+
+extern "C" int vf_index_search_device(vf_index* ix, const float* d_queries, int32_t nq, int32_t k, int64_t* d_ids,
+                                      float* d_scores, void* stream) {
+    VF_TRY(check_search_args(ix, d_queries, nq, k, d_ids, d_scores));
+    std::lock_guard<std::mutex> g(ix->mu);
+    VF_HIP(hipSetDevice(ix->device));
+    if (ix->slots[0].pending) return fail(VF_EINVAL, "vf_index_search_device: slot 0 busy (begin without end)");
+    int rc = begin_impl(ix, 0, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
+    if (rc != VF_OK) { ix->slots[0].pending = false; return rc; }
+    return end_impl(ix, 0);
+}
+
+extern "C" int vf_index_search(vf_index* ix, const float* queries, int32_t nq, int32_t k, int64_t* out_ids,
+                               float* out_scores) {
+    VF_TRY(check_search_args(ix, queries, nq, k, out_ids, out_scores));
+    if (nq == 0 || k == 0) return VF_OK;
+    VF_HIP(hipSetDevice(ix->device));
+    float* dq = nullptr; int64_t* di = nullptr; float* ds = nullptr;
+    int rc = VF_OK;
+    auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (di) (void)hipFree(di); if (ds) (void)hipFree(ds); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&dq, (size_t)nq * ix->d * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc((void**)&di, (size_t)nq * k * sizeof(int64_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&ds, (size_t)nq * k * sizeof(float))) != hipSuccess) {
+        cleanup();
+        return fail(VF_ENOMEM, std::string("hipMalloc(search buffers): ") + hipGetErrorString(e));
+    }
+    e = hipMemcpy(dq, queries, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cleanup(); return fail(VF_EHIP, std::string("hipMemcpy(queries): ") + hipGetErrorString(e)); }
+    rc = vf_index_search_device(ix, dq, nq, k, di, ds, nullptr);
+    if (rc == VF_OK) {
+        e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess) e = hipMemcpy(out_ids, di, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(out_scores, ds, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(VF_EHIP, std::string("copy results: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small dense cosine (compute_similarity_mtx / cosine_similarity restatements)
+// ------------------------------------------------------------------------------------------------
+extern "C" int vf_cosine_scores(const float* a, int32_t na, const float* b, int64_t nb, int32_t d, float* out,
+                                int32_t device_id) {
+    if (na < 0 || nb < 0 || d <= 0) return fail(VF_EINVAL, "vf_cosine_scores: bad sizes");
+    if (na == 0 || nb == 0) return VF_OK;
+    if (!a || !b || !out) return fail(VF_EINVAL, "vf_cosine_scores: null buffer");
+    VF_HIP(hipSetDevice(device_id));
+    DevBuf da, db, an, bn, na_norm, nb_norm, tmp, dout;
+    int rc = VF_OK;
+    auto done = [&](int code) {
+        DevBuf* bufs[] = {&da, &db, &an, &bn, &na_norm, &nb_norm, &tmp, &dout};
+        for (DevBuf* x : bufs) x->release();
+        return code;
+    };
+#define VF_CS(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return done(fail(VF_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+#define VF_CT(expr) do { rc = (expr); if (rc != VF_OK) return done(rc); } while (0)
+    VF_CT(da.ensure((size_t)na * d * 4)); VF_CT(db.ensure((size_t)nb * d * 4));
+    VF_CT(an.ensure((size_t)na * d * 4)); VF_CT(bn.ensure((size_t)nb * d * 4));
+    VF_CT(na_norm.ensure((size_t)na * 4)); VF_CT(nb_norm.ensure((size_t)nb * 4));
+    VF_CT(tmp.ensure((size_t)std::max<int64_t>(na, nb) * 4)); VF_CT(dout.ensure((size_t)na * nb * 4));
+    VF_CS(hipMemcpy(da.p, a, (size_t)na * d * 4, hipMemcpyHostToDevice));
+    VF_CS(hipMemcpy(db.p, b, (size_t)nb * d * 4, hipMemcpyHostToDevice));
+    VF_CS(launch_prep_rows(da.p, 0, na, d, d, nullptr, na_norm.as<float>(), tmp.as<float>(), nullptr));
+    VF_CS(launch_prep_rows(db.p, 0, nb, d, d, nullptr, nb_norm.as<float>(), tmp.as<float>(), nullptr));
+    VF_CS(launch_normalize_rows(da.p, 0, 0, na, d, na_norm.as<float>(), an.as<float>(), nullptr));
+    VF_CS(launch_normalize_rows(db.p, 0, 0, nb, d, nb_norm.as<float>(), bn.as<float>(), nullptr));
+    VF_CS(launch_dense_dot16(an.as<float>(), na, bn.as<float>(), nb, d, dout.as<float>(), nb, nullptr));
+    VF_CS(hipMemcpy(out, dout.p, (size_t)na * nb * 4, hipMemcpyDeviceToHost));
+#undef VF_CS
+#undef VF_CT
+    return done(VF_OK);
+}
+
+extern "C" int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out, int32_t device_id) {
+    return vf_cosine_scores(x, n, x, n, d, out, device_id);
+}
+
+extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts, int32_t nparts, int32_t nq,
+                                    int32_t k, int64_t* d_ids, float* d_scores, int32_t device_id, void* stream) {
+    if (nparts <= 0 || nq < 0 || k < 0) return fail(VF_EINVAL, "vf_merge_topk_device: bad sizes");
+    if (nq == 0 || k == 0) return VF_OK;
+    if (!d_ids_parts || !d_score_parts || !d_ids || !d_scores) return fail(VF_EINVAL, "vf_merge_topk_device: null buffer");
+    if ((size_t)nparts * k > 16384) return fail(VF_EUNSUPPORTED, "vf_merge_topk_device: nparts * k > 16384");
+    VF_HIP(hipSetDevice(device_id));
+    VF_HIP(scan_configure());
+    VF_HIP(launch_merge_topk((const long long*)d_ids_parts, d_score_parts, nparts, nq, k, (long long*)d_ids, d_scores,
+                             (hipStream_t)stream));
+    return VF_OK;
+}
+
+extern "C" int vf_fuse_rank(const float* rerank_scores, const float* time_scores, int32_t n, float* out_scores,
+                            int64_t* out_order, int32_t device_id) {
+    if (n < 0 || n > 4096) return fail(VF_EINVAL, "vf_fuse_rank: n must be in [0, 4096]");
+    if (n == 0) return VF_OK;
+    if (!rerank_scores || !time_scores || !out_scores || !out_order) return fail(VF_EINVAL, "vf_fuse_rank: null buffer");
+    VF_HIP(hipSetDevice(device_id));
+    DevBuf a, b, o, ord;
+    auto done = [&](int code) { a.release(); b.release(); o.release(); ord.release(); return code; };
+    int rc;
+    if ((rc = a.ensure(n * 4)) || (rc = b.ensure(n * 4)) || (rc = o.ensure(n * 4)) || (rc = ord.ensure(n * 8))) return done(rc);
+    hipError_t e = hipMemcpy(a.p, rerank_scores, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b.p, time_scores, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_fuse_rank(a.as<float>(), b.as<float>(), n, o.as<float>(), ord.as<long long>(), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_scores, o.p, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_order, ord.p, n * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(fail(VF_EHIP, std::string("vf_fuse_rank: ") + hipGetErrorString(e)));
+    return done(VF_OK);
+}

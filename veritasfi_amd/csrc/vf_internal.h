@@ -1,0 +1,84 @@
+// vf_internal.h -- shared between the kernel TU (vf_kernels.hip) and the C-ABI TU (vf_api.hip).
+// gfx950 only.  Not part of the public ABI (that is include/veritasfi_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vf {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- fixed design constants ------------------------------------------------------
+constexpr int kQueryTile = 32;        // queries per MFMA N-tile (v_mfma_f32_32x32x16_f16)
+constexpr int kMaxBatch = 64;         // queries per scan pass (2 N-tiles); larger nq loops
+constexpr int kRowTile = 32;          // corpus rows per MFMA M-tile
+constexpr int kScanThreads = 512;     // 8 waves per workgroup, one workgroup per CU
+constexpr int kHistBins = 2048;       // threshold histogram over cosine in [-1, 1]
+constexpr int kSmallN = 16384;        // <= this many rows: exact dense path (LDS sort)
+constexpr int kMaxCap = 8192;         // candidate slots per query in the fused path (u64 each)
+constexpr int kMaxKFused = 2048;      // largest k the fused path serves (k' <= 4096 <= cap/2)
+
+enum ScanMode { kModeSample = 0, kModeMain = 1 };
+
+// Arguments of the fused scan kernel (k_scan).  Plain struct passed by value.
+struct ScanArgs {
+    const char* rows;        // fp16 scan copy, row-major, row_bytes per row (dp * 2)
+    const float* inv_scan;   // [n] 1 / (canonical norm * row scale): approx score = acc * inv_scan
+    const _Float16* qimg;    // query image [dp/8][QN][8] fp16 (normalised queries, zero padded)
+    long long n;             // rows in this shard
+    int dp;                  // padded dim, multiple of 64
+    long long row_bytes;
+    int total_waves;         // TW: rows are split evenly over TW waves
+    int samp;                // sample rows at the head of each wave's range
+    // sample mode output
+    float* s0;               // [QN][TW * samp] approx scores of the sample rows (-inf = empty)
+    // main mode state (all zeroed / seeded per batch)
+    u32* cnt;                // [QN] candidates appended
+    int* tau_bin;            // [QN] current threshold bin (monotone non-decreasing)
+    u32* hist;               // [QN][kHistBins] counts of appended candidates per bin
+    u64* cand;               // [QN][cap] (orderkey(approx) << 32) | local row
+    int cap;
+    int kprime;              // k + margin: the threshold keeps >= kprime rows above it
+    int refresh_every;       // recompute tau when a query's count crosses a multiple of this
+    int nq;                  // real queries (<= QN); padded queries never pass
+};
+
+struct FinalArgs {
+    const u32* cnt; const u64* cand; int cap;
+    const void* rows_orig; int orig_is_half; long long orig_row_elems;  // exact rows for rescoring
+    const float* norm;       // canonical norms [n]
+    const float* qn;         // canonical normalised queries [nq][d] fp32
+    int d; int k; int kprime; float eps;
+    long long n_rows;        // rows in the shard (certificate is moot when all were re-scored)
+    long long id_offset;
+    long long* out_ids; float* out_scores;   // [nq][k]
+    int* flags;              // [nq] 0 = certified exact, 1 = uncertified, 2 = overflow
+    u32* cand_count_out;     // [nq] copy of cnt for stats
+};
+
+// ---- launchers (defined in vf_kernels.hip) -----------------------------------------------------
+hipError_t launch_prep_rows(const void* rows, int is_half, long long n, int d, int dp,
+                            _Float16* scan /*may be null when rows are used in place*/,
+                            float* norm, float* inv_scan, hipStream_t s);
+hipError_t launch_prep_queries(const float* q, int nq, int d, int dp, int qn_tile /*32 or 64*/,
+                               float* qn, _Float16* qimg, hipStream_t s);
+hipError_t launch_normalize_rows(const void* rows, int is_half, long long row0, long long nrows, int d,
+                                 const float* norm, float* out, hipStream_t s);
+hipError_t launch_dense_dot16(const float* qn, int nq, const float* cn, long long nrows, int d,
+                              float* out, long long out_stride, hipStream_t s);
+hipError_t launch_sort_rows(const float* scores, long long score_stride, int nq, int n, int k,
+                            long long id_base, long long* out_ids, float* out_scores, int out_stride,
+                            hipStream_t s);
+hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int want_g /*0 = auto*/,
+                       hipStream_t s);
+hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
+hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s);
+hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,
+                             int k, long long* ids, float* scores, hipStream_t s);
+hipError_t launch_fuse_rank(const float* a, const float* b, int n, float* out, long long* order,
+                            hipStream_t s);
+size_t scan_lds_bytes(int dp, int qn_tile);
+hipError_t scan_configure();   // sets max dynamic LDS on the scan kernels (once per process/device)
+
+}  // namespace vf

@@ -1,0 +1,191 @@
+"""DenseIndex -- Python handle over ``vf_index_*`` (exact cosine top-k on one MI355X).
+
+Stands where ``faiss.IndexFlatIP`` + ``faiss.normalize_L2`` stand in the reference
+(``src/utils/faissRetriever.py:18-24,35-37``).  NumPy in / NumPy out for the drop-in classes; torch
+CUDA tensors in / out (zero copy, device pointers through the C ABI) for the serving and multi-GPU
+paths.  PyTorch is plumbing here: device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class DenseIndex:
+    def __init__(self, rows, device_id: int = 0, id_offset: int = 0):
+        """rows: [n, d] float32 / float16 ndarray (copied to HBM) or a CUDA torch tensor (borrowed)."""
+        L = _ffi.lib()
+        self._h = _ffi.vp()
+        self._keepalive = None
+        self.device_id = int(device_id)
+        if _is_torch_tensor(rows):
+            import torch
+            if not rows.is_cuda:
+                rows = rows.cpu().numpy()
+            else:
+                if rows.dim() != 2 or not rows.is_contiguous():
+                    raise ValueError("rows must be a contiguous [n, d] tensor")
+                if rows.dtype == torch.float16:
+                    dt = _ffi.VF_DTYPE_F16
+                elif rows.dtype == torch.float32:
+                    dt = _ffi.VF_DTYPE_F32
+                else:
+                    raise TypeError(f"unsupported corpus dtype {rows.dtype}")
+                self.device_id = rows.device.index if rows.device.index is not None else self.device_id
+                self._keepalive = rows
+                self.n, self.d = int(rows.shape[0]), int(rows.shape[1])
+                _ffi.check(L.vf_index_create_device(ctypes.byref(self._h), rows.data_ptr(), self.n, self.d, dt,
+                                                    self.device_id, int(id_offset)), "vf_index_create_device")
+                self.id_offset = int(id_offset)
+                return
+        rows = np.asarray(rows)
+        if rows.ndim != 2:
+            raise ValueError("rows must be [n, d]")
+        if rows.dtype == np.float16:
+            dt = _ffi.VF_DTYPE_F16
+        else:
+            rows = rows.astype(np.float32, copy=False)  # faissRetriever.py:21  x = embeddings.astype('float32')
+            dt = _ffi.VF_DTYPE_F32
+        rows = np.ascontiguousarray(rows)
+        self.n, self.d = int(rows.shape[0]), int(rows.shape[1])
+        self.id_offset = int(id_offset)
+        _ffi.check(L.vf_index_create(ctypes.byref(self._h), rows.ctypes.data, self.n, self.d, dt, self.device_id,
+                                     self.id_offset), "vf_index_create")
+
+    # -- host buffers ------------------------------------------------------------------------------
+    def search(self, queries, k: int):
+        """queries [nq, d] -> (ids int64 [nq, k], scores float32 [nq, k]); ids first, as
+        FaissRetriever.invoke returns them (faissRetriever.py:38)."""
+        q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"queries must be [nq, {self.d}], got {q.shape}")
+        k = int(k)
+        ids = np.empty((q.shape[0], k), dtype=np.int64)
+        scores = np.empty((q.shape[0], k), dtype=np.float32)
+        _ffi.check(_ffi.lib().vf_index_search(self._h, q.ctypes.data, q.shape[0], k, ids.ctypes.data,
+                                              scores.ctypes.data), "vf_index_search")
+        return ids, scores
+
+    # -- device buffers (torch CUDA tensors) ---------------------------------------------------------
+    def _dev_args(self, queries, k, out_ids, out_scores):
+        import torch
+        if not (queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()):
+            raise ValueError("queries must be a contiguous float32 CUDA tensor")
+        nq = int(queries.shape[0])
+        if out_ids is None:
+            out_ids = torch.empty((nq, k), dtype=torch.int64, device=queries.device)
+        if out_scores is None:
+            out_scores = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+        stream = torch.cuda.current_stream(queries.device).cuda_stream
+        return nq, out_ids, out_scores, stream
+
+    def search_device(self, queries, k: int, out_ids=None, out_scores=None):
+        nq, out_ids, out_scores, stream = self._dev_args(queries, int(k), out_ids, out_scores)
+        _ffi.check(_ffi.lib().vf_index_search_device(self._h, queries.data_ptr(), nq, int(k), out_ids.data_ptr(),
+                                                     out_scores.data_ptr(), stream), "vf_index_search_device")
+        return out_ids, out_scores
+
+    def search_begin(self, slot: int, queries, k: int, out_ids=None, out_scores=None):
+        """Enqueue a batch into `slot` and return at once; results are valid after search_end(slot).
+        The caller keeps `queries` alive until then."""
+        nq, out_ids, out_scores, stream = self._dev_args(queries, int(k), out_ids, out_scores)
+        _ffi.check(_ffi.lib().vf_index_search_begin(self._h, int(slot), queries.data_ptr(), nq, int(k),
+                                                    out_ids.data_ptr(), out_scores.data_ptr(), stream),
+                   "vf_index_search_begin")
+        return out_ids, out_scores
+
+    def search_end(self, slot: int):
+        _ffi.check(_ffi.lib().vf_index_search_end(self._h, int(slot)), "vf_index_search_end")
+
+    @property
+    def slots(self) -> int:
+        out = _ffi.c_i32(0)
+        _ffi.check(_ffi.lib().vf_index_slots(self._h, ctypes.byref(out)), "vf_index_slots")
+        return int(out.value)
+
+    # -- misc --------------------------------------------------------------------------------------
+    def stats(self) -> dict:
+        st = _ffi.SearchStats()
+        _ffi.check(_ffi.lib().vf_index_stats(self._h, ctypes.byref(st)), "vf_index_stats")
+        return st.as_dict()
+
+    def profile(self) -> dict:
+        """HIP-event totals since set_option("profile", 1): main k_scan ms / launches, pipeline ms."""
+        ms, n, pipe, nbytes = ctypes.c_double(0), _ffi.c_i64(0), ctypes.c_double(0), _ffi.c_i64(0)
+        _ffi.check(_ffi.lib().vf_index_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(pipe),
+                                               ctypes.byref(nbytes)), "vf_index_profile")
+        return {"scan_ms_total": ms.value, "scan_launches": int(n.value), "pipeline_ms_total": pipe.value,
+                "scan_bytes_per_launch": int(nbytes.value)}
+
+    def set_option(self, name: str, value: int) -> None:
+        _ffi.check(_ffi.lib().vf_index_set_option(self._h, name.encode(), int(value)), "vf_index_set_option")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _ffi.lib().vf_index_destroy(self._h)
+            self._h = _ffi.vp()
+        self._keepalive = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def cosine_scores(a, b, device_id: int = 0) -> np.ndarray:
+    """Canonical cosine matrix [na, nb] (step3_mul.py:275 ``cosine_similarity(E, C)``)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("cosine_scores: a [na, d], b [nb, d]")
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float32)
+    _ffi.check(_ffi.lib().vf_cosine_scores(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], a.shape[1],
+                                           out.ctypes.data, int(device_id)), "vf_cosine_scores")
+    return out
+
+
+def cosine_matrix(x, device_id: int = 0) -> np.ndarray:
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+    out = np.empty((x.shape[0], x.shape[0]), dtype=np.float32)
+    _ffi.check(_ffi.lib().vf_cosine_matrix(x.ctypes.data, x.shape[0], x.shape[1], out.ctypes.data, int(device_id)),
+               "vf_cosine_matrix")
+    return out
+
+
+def merge_topk_device(ids_parts, score_parts, k: int):
+    """[G, nq, k] CUDA tensors (parts in ascending id-range order) -> ([nq, k], [nq, k])."""
+    import torch
+    g, nq, kk = ids_parts.shape
+    assert kk == k and ids_parts.is_contiguous() and score_parts.is_contiguous()
+    ids = torch.empty((nq, k), dtype=torch.int64, device=ids_parts.device)
+    sc = torch.empty((nq, k), dtype=torch.float32, device=ids_parts.device)
+    dev = ids_parts.device.index or 0
+    _ffi.check(_ffi.lib().vf_merge_topk_device(ids_parts.data_ptr(), score_parts.data_ptr(), g, nq, k, ids.data_ptr(),
+                                               sc.data_ptr(), dev, torch.cuda.current_stream(ids_parts.device).cuda_stream),
+               "vf_merge_topk_device")
+    return ids, sc
+
+
+def fuse_rank(rerank_scores, time_scores, device_id: int = 0):
+    a = np.ascontiguousarray(np.asarray(rerank_scores, dtype=np.float32))
+    b = np.ascontiguousarray(np.asarray(time_scores, dtype=np.float32))
+    assert a.shape == b.shape and a.ndim == 1
+    out = np.empty_like(a)
+    order = np.empty(a.shape[0], dtype=np.int64)
+    _ffi.check(_ffi.lib().vf_fuse_rank(a.ctypes.data, b.ctypes.data, a.shape[0], out.ctypes.data, order.ctypes.data,
+                                       int(device_id)), "vf_fuse_rank")
+    return out, order
