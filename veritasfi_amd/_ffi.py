@@ -67,6 +67,13 @@ def lib():
                     raise RuntimeError(
                         f"{LIB_PATH} is missing: build it with `python -m veritasfi_amd.build` "
                         "(hipcc --offload-arch=gfx950). veritasfi_amd has no CPU fallback.")
+                # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as
+                # /opt/rocm's).  Load torch FIRST so our library binds to that copy; the other order
+                # leaves torch unable to see the GPU, and device pointers / streams are shared anyway.
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
                 L = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)  # AttributeError if the ABI and this table drift apart

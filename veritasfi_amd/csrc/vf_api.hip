@@ -79,7 +79,7 @@ struct DevBuf {
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_scan = nullptr;  // ev_scan: after this slot's main k_scan
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
     DevBuf qn, qimg, s0, cnt, tau, hist, cand, flags, counts;   // fused-path state
@@ -167,6 +167,7 @@ static int build_common(vf_index* ix) {
         VF_HIP(hipStreamCreateWithFlags(&ix->slots[i].stream, hipStreamNonBlocking));
         VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_in, hipEventDisableTiming));
         VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_done, hipEventDisableTiming));
+        VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_scan, hipEventDisableTiming));
         for (int e = 0; e < 4; ++e) VF_HIP(hipEventCreate(&ix->slots[i].ev_t[e]));
     }
     VF_HIP(hipDeviceSynchronize());
@@ -187,6 +188,7 @@ static void destroy_index(vf_index* ix) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_scan) (void)hipEventDestroy(s.ev_scan);
         for (int e = 0; e < 4; ++e) if (s.ev_t[e]) (void)hipEventDestroy(s.ev_t[e]);
     }
     if (ix->owns_scan && ix->rows_scan) (void)hipFree(ix->rows_scan);
@@ -454,8 +456,14 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qt * p.total_waves * p.samp * sizeof(float), st));
         VF_HIP(launch_scan(a, kModeSample, qt, p.grid, (int)ix->scan_g, st));
         VF_HIP(launch_sel0(a, qt, st));
+        // Main scans of different slots cannot share a CU (one 96 KB+ LDS workgroup each), so they run
+        // back to back anyway; ordering them explicitly keeps queueing time out of the timed bracket
+        // while this slot's prep / sample / seed kernels still overlap the other slot's scan.
+        for (int o = 0; o < kSlots; ++o)
+            if (o != slot_id) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
         if (s.timed && b0 == 0) VF_HIP(hipEventRecord(s.ev_t[0], st));
         VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, st));
+        VF_HIP(hipEventRecord(s.ev_scan, st));
         if (s.timed && b0 == 0) {
             VF_HIP(hipEventRecord(s.ev_t[1], st));
             const int64_t per_wave = ix->n / p.total_waves;
