@@ -68,7 +68,7 @@ int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int3
                     int32_t device_id, int64_t id_offset);
 
 /* Same, rows already resident in HBM on `device_id`.  The index BORROWS d_rows (no copy for fp16
- * with d % 64 == 0); the caller keeps it alive until vf_index_destroy. */
+ * with d % 128 == 0); the caller keeps it alive until vf_index_destroy. */
 int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
                            int32_t device_id, int64_t id_offset);
 
@@ -104,6 +104,9 @@ int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
  * k_scan launch reads (rows scanned x (d*2 + 4)). */
 int vf_index_profile(vf_index* idx, double* scan_ms_total, int64_t* scan_launches, double* pipeline_ms_total,
                      int64_t* scan_bytes_per_launch);
+/* Debug aid (not part of the reference surface): wall-clock stamps of the last main scan of `slot`
+ * when option "debug" has bit 7 set; returns the number of 64-bit words copied (>= 0) or VF_E*. */
+int vf_index_debug_read(vf_index* idx, int32_t slot, unsigned long long* out, int64_t n_words);
 int vf_index_destroy(vf_index* idx);
 
 /* ---- small dense cosine ------------------------------------------------------------------------

@@ -31,7 +31,9 @@
  *                 acc[l] += acc[l+8] (l<8); acc[l] += acc[l+4] (l<4);
  *                 acc[l] += acc[l+2] (l<2); result = acc[0] + acc[1].
  *   norm(x)     : n = (float)sqrt((double)dot16(x,x,d));  n == 0 -> 1.
- *   xn[j]       : x[j] / n   (IEEE fp32 division)
+ *   xn[j]       : x[j] * inv,  inv = (float)(1.0 / (double)n)   -- faiss's own form
+ *                 (fvec_renorm_L2: inv_nr = 1.0 / sqrtf(nr); x[i] *= inv_nr); sklearn divides
+ *                 instead, which differs in the last bit only (goldens are compared at 2e-6)
  *   cos(q,c)    : dot16(qn, cn, d)
  *   ranking     : descending score, ties broken by LOWER id first.
  *
@@ -70,8 +72,8 @@ static inline float canon_norm(const float* x, int d) {
 }
 
 static inline void canon_normalize(const float* x, int d, float* out) {
-    const float n = canon_norm(x, d);
-    for (int j = 0; j < d; ++j) out[j] = x[j] / n;
+    const float inv = (float)(1.0 / (double)canon_norm(x, d));
+    for (int j = 0; j < d; ++j) out[j] = x[j] * inv;
 }
 
 static inline void half_row_to_float(const uint16_t* h, int d, float* out) {

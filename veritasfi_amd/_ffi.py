@@ -46,6 +46,7 @@ SIGNATURES = {
     "vf_index_stats": (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
     "vf_index_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, c_i64]),
     "vf_index_profile": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), p_i64, ctypes.POINTER(ctypes.c_double), p_i64]),
+    "vf_index_debug_read": (ctypes.c_int, [vp, c_i32, vp, c_i64]),
     "vf_index_destroy": (ctypes.c_int, [vp]),
     "vf_cosine_matrix": (ctypes.c_int, [vp, c_i32, c_i32, vp, c_i32]),
     "vf_cosine_scores": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32]),

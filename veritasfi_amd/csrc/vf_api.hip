@@ -82,10 +82,13 @@ struct Slot {
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_scan = nullptr;  // ev_scan: after this slot's main k_scan
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
-    DevBuf qn, qimg, s0, cnt, tau, hist, cand, flags, counts;   // fused-path state
+    DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
+    DevBuf dbg;
     DevBuf dense_s, cn_tmp, parts_ids, parts_sc, run_ids, run_sc, qsel; // exact-path scratch
     int* h_flags = nullptr;      // pinned, [max batches * 64]
     u32* h_counts = nullptr;     // pinned
+    int* d_flags = nullptr;      // device views of the two above
+    u32* d_counts = nullptr;
     size_t h_cap = 0;
     // pending call
     bool pending = false;
@@ -115,21 +118,24 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128;
+            refresh_every = 32, debug = 0;
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
     int64_t prof_launches = 0, prof_bytes = 0;
 };
 
+// flags / candidate counts are written by k_final straight into host-mapped pinned memory
 static int ensure_pinned(Slot& s, size_t nq_total) {
     if (nq_total <= s.h_cap) return VF_OK;
     if (s.h_flags) (void)hipHostFree(s.h_flags);
     if (s.h_counts) (void)hipHostFree(s.h_counts);
     s.h_flags = nullptr; s.h_counts = nullptr; s.h_cap = 0;
     size_t cap = std::max<size_t>(nq_total, 256);
-    VF_HIP(hipHostMalloc((void**)&s.h_flags, cap * sizeof(int), hipHostMallocDefault));
-    VF_HIP(hipHostMalloc((void**)&s.h_counts, cap * sizeof(u32), hipHostMallocDefault));
+    VF_HIP(hipHostMalloc((void**)&s.h_flags, cap * sizeof(int), hipHostMallocMapped));
+    VF_HIP(hipHostMalloc((void**)&s.h_counts, cap * sizeof(u32), hipHostMallocMapped));
+    VF_HIP(hipHostGetDevicePointer((void**)&s.d_flags, s.h_flags, 0));
+    VF_HIP(hipHostGetDevicePointer((void**)&s.d_counts, s.h_counts, 0));
     s.h_cap = cap;
     return VF_OK;
 }
@@ -140,7 +146,7 @@ static int build_common(vf_index* ix) {
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     VF_HIP(scan_configure());
     const int is_half = ix->dtype == VF_DTYPE_F16;
-    ix->dp = (ix->d + 63) / 64 * 64;
+    ix->dp = (ix->d + 127) / 128 * 128;  // whole 128-element (256 B) segments pairs: see pick_G
     const size_t npad = (size_t)ix->n + 64;
     VF_HIP(hipMalloc((void**)&ix->norm, npad * sizeof(float)));
     VF_HIP(hipMalloc((void**)&ix->inv_scan, npad * sizeof(float)));
@@ -180,8 +186,8 @@ static void destroy_index(vf_index* ix) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = ix->slots[i];
-        DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.cand, &s.flags, &s.counts, &s.dense_s,
-                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel};
+        DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.hist_coarse, &s.cand, &s.flags, &s.counts, &s.dense_s,
+                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg};
         for (DevBuf* b : bufs) b->release();
         if (s.h_flags) (void)hipHostFree(s.h_flags);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
@@ -277,6 +283,18 @@ extern "C" int vf_index_profile(vf_index* ix, double* scan_ms_total, int64_t* sc
     return VF_OK;
 }
 
+// debug: copy the wall-clock stamps of slot's last main scan (option debug bit 7) to host
+extern "C" int vf_index_debug_read(vf_index* ix, int32_t slot, unsigned long long* out, int64_t n_words) {
+    if (!ix || !out || slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_debug_read: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    Slot& s = ix->slots[slot];
+    const size_t bytes = std::min<size_t>(s.dbg.bytes, (size_t)n_words * 8);
+    VF_HIP(hipSetDevice(ix->device));
+    VF_HIP(hipDeviceSynchronize());
+    if (bytes) VF_HIP(hipMemcpy(out, s.dbg.p, bytes, hipMemcpyDeviceToHost));
+    return (int)(bytes / 8);
+}
+
 extern "C" int vf_index_slots(vf_index* ix, int32_t* out) {
     if (!ix || !out) return fail(VF_EINVAL, "vf_index_slots: null argument");
     *out = kSlots;
@@ -294,6 +312,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "waves") ix->waves_opt = value;
     else if (s == "scan_g") ix->scan_g = value;
     else if (s == "refresh_every") ix->refresh_every = value;
+    else if (s == "debug") ix->debug = value;
     else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
     else return fail(VF_EINVAL, "vf_index_set_option: unknown option " + s);
     return VF_OK;
@@ -371,8 +390,9 @@ static int batch_limit(const vf_index* ix) {
 
 static FusedPlan make_plan(const vf_index* ix, int k) {
     FusedPlan p;
-    const int margin = ix->margin >= 0 ? (int)ix->margin : std::max(32, k / 4);
-    p.kprime = k + margin;
+    // k' = k + margin, rounded up to a multiple of 32 (whole re-score rounds of 32 row groups)
+    const int margin = ix->margin >= 0 ? (int)ix->margin : std::max(24, k / 4);
+    p.kprime = ix->margin >= 0 ? k + margin : (k + margin + 31) / 32 * 32;
     int cap = kMaxCap;
     while (cap < 4 * p.kprime && cap < 16384) cap <<= 1;
     if (ix->cap_opt > 0) { cap = 1; while (cap < ix->cap_opt) cap <<= 1; cap = std::min(cap, 16384); }
@@ -431,12 +451,11 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
 
     const FusedPlan p = make_plan(ix, k);
     VF_TRY(s.s0.ensure((size_t)kMaxBatch * p.total_waves * p.samp * sizeof(float)));
-    VF_TRY(s.cnt.ensure(kMaxBatch * sizeof(u32)));
+    VF_TRY(s.cnt.ensure((size_t)kMaxBatch * kCntStride * sizeof(u32)));
     VF_TRY(s.tau.ensure(kMaxBatch * sizeof(int)));
     VF_TRY(s.hist.ensure((size_t)kMaxBatch * kHistBins * sizeof(u32)));
+    VF_TRY(s.hist_coarse.ensure((size_t)kMaxBatch * 64 * sizeof(u32)));
     VF_TRY(s.cand.ensure((size_t)kMaxBatch * p.cap * sizeof(u64)));
-    VF_TRY(s.flags.ensure((size_t)std::max(nq, 1) * sizeof(int)));
-    VF_TRY(s.counts.ensure((size_t)std::max(nq, 1) * sizeof(u32)));
     s.timed = ix->profile;
     if (s.timed) VF_HIP(hipEventRecord(s.ev_t[2], st));
     for (int b0 = 0; b0 < nq; b0 += bl) {
@@ -449,7 +468,10 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * 2; a.total_waves = p.total_waves; a.samp = p.samp;
         a.s0 = s.s0.as<float>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>(); a.hist = s.hist.as<u32>();
         a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
-        a.refresh_every = (int)std::max<int64_t>(1, ix->refresh_every); a.nq = nb;
+        a.hist_coarse = s.hist_coarse.as<u32>(); a.stage_cap = scan_stage_cap(ix->dp, qt);
+        a.dbg = nullptr;
+        if (ix->debug & 128) { VF_TRY(s.dbg.ensure((size_t)p.total_waves * 4 * sizeof(u64))); a.dbg = s.dbg.as<u64>(); }
+        a.refresh_every = (int)std::min<int64_t>(64, std::max<int64_t>(1, ix->refresh_every)); a.nq = nb; a.debug = (int)ix->debug;
         // sample slots no wave writes (a wave range shorter than samp) must read as empty: 0xFF bytes
         // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
         if (ix->n / p.total_waves < p.samp)
@@ -471,16 +493,16 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             ix->prof_bytes = (ix->n - sampled) * ((int64_t)ix->d * 2 + 4);
         }
         FinalArgs f{};
-        f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.rows_orig = ix->rows_orig;
+        f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.tau_bin = a.tau_bin; f.rows_orig = ix->rows_orig;
         f.orig_is_half = ix->dtype == VF_DTYPE_F16; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
         f.d = ix->d; f.k = k; f.kprime = p.kprime; f.eps = p.eps; f.n_rows = ix->n; f.id_offset = ix->id_offset;
         f.out_ids = (long long*)(d_ids + (size_t)b0 * k); f.out_scores = d_scores + (size_t)b0 * k;
-        f.flags = s.flags.as<int>() + b0; f.cand_count_out = s.counts.as<u32>() + b0;
+        f.flags = s.d_flags + b0; f.cand_count_out = s.d_counts + b0;
+        f.dbg = nullptr;
+        if (ix->debug & 256) { VF_TRY(s.dbg.ensure((size_t)std::max(p.total_waves * 4, 64 * 8) * sizeof(u64))); f.dbg = s.dbg.as<u64>(); }
         VF_HIP(launch_final(f, nb, st));
     }
     if (s.timed) VF_HIP(hipEventRecord(s.ev_t[3], st));
-    VF_HIP(hipMemcpyAsync(s.h_flags, s.flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
-    VF_HIP(hipMemcpyAsync(s.h_counts, s.counts.p, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, st));
     VF_HIP(hipEventRecord(s.ev_done, st));
     return VF_OK;
 }

@@ -17,6 +17,7 @@ constexpr int kScanThreads = 512;     // 8 waves per workgroup, one workgroup pe
 constexpr int kHistBins = 2048;       // threshold histogram over cosine in [-1, 1]
 constexpr int kSmallN = 16384;        // <= this many rows: exact dense path (LDS sort)
 constexpr int kMaxCap = 8192;         // candidate slots per query in the fused path (u64 each)
+constexpr int kCntStride = 32;        // u32 elements between per-query counters: one 128-B line each
 constexpr int kMaxKFused = 2048;      // largest k the fused path serves (k' <= 4096 <= cap/2)
 
 enum ScanMode { kModeSample = 0, kModeMain = 1 };
@@ -34,18 +35,23 @@ struct ScanArgs {
     // sample mode output
     float* s0;               // [QN][TW * samp] approx scores of the sample rows (-inf = empty)
     // main mode state (all zeroed / seeded per batch)
-    u32* cnt;                // [QN] candidates appended
+    u32* cnt;                // [QN * kCntStride] candidates appended (one counter per 128-B line)
     int* tau_bin;            // [QN] current threshold bin (monotone non-decreasing)
     u32* hist;               // [QN][kHistBins] counts of appended candidates per bin
+    u32* hist_coarse;        // [QN][64] the same counts per 32 fine bins
+    int stage_cap;           // LDS candidate-stage entries per workgroup (main mode)
     u64* cand;               // [QN][cap] (orderkey(approx) << 32) | local row
     int cap;
     int kprime;              // k + margin: the threshold keeps >= kprime rows above it
     int refresh_every;       // recompute tau when a query's count crosses a multiple of this
     int nq;                  // real queries (<= QN); padded queries never pass
+    unsigned long long* dbg; // optional [grid][8 waves][4] wall-clock stamps (debug bit 7), else null
+    int debug;               // bit 0: timing experiment -- seed tau so that nothing passes (results invalid)
 };
 
 struct FinalArgs {
     const u32* cnt; const u64* cand; int cap;
+    const int* tau_bin;      // final thresholds of the scan (validity check)
     const void* rows_orig; int orig_is_half; long long orig_row_elems;  // exact rows for rescoring
     const float* norm;       // canonical norms [n]
     const float* qn;         // canonical normalised queries [nq][d] fp32
@@ -55,6 +61,7 @@ struct FinalArgs {
     long long* out_ids; float* out_scores;   // [nq][k]
     int* flags;              // [nq] 0 = certified exact, 1 = uncertified, 2 = overflow
     u32* cand_count_out;     // [nq] copy of cnt for stats
+    unsigned long long* dbg; // optional [nq][8] wall-clock stamps of the phases (debug), else null
 };
 
 // ---- launchers (defined in vf_kernels.hip) -----------------------------------------------------
@@ -79,6 +86,7 @@ hipError_t launch_merge_topk(const long long* ids_parts, const float* score_part
 hipError_t launch_fuse_rank(const float* a, const float* b, int n, float* out, long long* order,
                             hipStream_t s);
 size_t scan_lds_bytes(int dp, int qn_tile);
+int scan_stage_cap(int dp, int qn_tile);
 hipError_t scan_configure();   // sets max dynamic LDS on the scan kernels (once per process/device)
 
 }  // namespace vf

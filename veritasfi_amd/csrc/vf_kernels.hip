@@ -43,7 +43,8 @@ __device__ __forceinline__ float group16_tree(float acc) {
     return acc;
 }
 
-__device__ __forceinline__ float canon_div(float x, float n) { return (float)((double)x / (double)n); }
+// canonical inverse norm: (float)(1.0 / (double)n), as faiss's fvec_renorm_L2 computes it
+__device__ __forceinline__ float canon_inv(float n) { return (float)(1.0 / (double)n); }
 __device__ __forceinline__ float canon_norm_from_sumsq(float s) {
     const float n = (float)sqrt((double)s);
     return n == 0.0f ? 1.0f : n;
@@ -139,23 +140,27 @@ hipError_t launch_prep_rows(const void* rows, int is_half, long long n, int d, i
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep_queries(const float* q, int nq, int d, int dp, int QN, float* qn,
                                                        _Float16* qimg) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* xs = (float*)smem_raw;  // the query row, staged once
     __shared__ float s_norm;
     const int slot = blockIdx.x;
     const int tid = threadIdx.x;
     if (slot < nq) {
         const float* x = q + (long long)slot * d;
+        for (int j = tid; j < d; j += 256) xs[j] = x[j];
+        __syncthreads();
         if (tid < 16) {
             float acc = 0.0f;
-            for (int j = tid; j < d; j += 16) acc = __builtin_fmaf(x[j], x[j], acc);
+            for (int j = tid; j < d; j += 16) acc = __builtin_fmaf(xs[j], xs[j], acc);
             acc = group16_tree(acc);
             if (tid == 0) s_norm = canon_norm_from_sumsq(acc);
         }
         __syncthreads();
-        const float nm = s_norm;
+        const float inv = canon_inv(s_norm);
         for (int j = tid; j < dp; j += 256) {
             float v = 0.0f;
             if (j < d) {
-                v = canon_div(x[j], nm);
+                v = xs[j] * inv;
                 qn[(long long)slot * d + j] = v;
             }
             qimg[((long long)(j >> 3) * QN + slot) * 8 + (j & 7)] = (_Float16)v;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void k_prep_queries(const float* q, int nq, in
 
 hipError_t launch_prep_queries(const float* q, int nq, int d, int dp, int qn_tile, float* qn, _Float16* qimg,
                                hipStream_t s) {
-    hipLaunchKernelGGL(k_prep_queries, dim3(qn_tile), dim3(256), 0, s, q, nq, d, dp, qn_tile, qn, qimg);
+    hipLaunchKernelGGL(k_prep_queries, dim3(qn_tile), dim3(256), (size_t)d * sizeof(float), s, q, nq, d, dp, qn_tile, qn, qimg);
     return hipGetLastError();
 }
 
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void k_normalize_rows(const void* rows, int is
     const long long total = nrows * (long long)d;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / d;
-        out[i] = canon_div(load_elem(rows, is_half, (row0 + r) * (long long)d + (i - r * d)), norm[row0 + r]);
+        out[i] = load_elem(rows, is_half, (row0 + r) * (long long)d + (i - r * d)) * canon_inv(norm[row0 + r]);
     }
 }
 
@@ -374,71 +379,86 @@ __device__ __forceinline__ void compute_superstep(f16v (&acc)[NT], const h8 (&bu
             }
 }
 
-// Recompute tau for query q from its histogram: the largest bin b with sum(hist[b..]) >= kprime.
-// All 64 lanes cooperate (lane owns bins [32*lane, 32*lane+32)); returns -1 if fewer than kprime
-// are counted.  Two passes so no per-lane array is live (this is a rare path; keep it out of the
-// hot loop's register budget).  Counts only grow between the passes, which keeps the bound valid:
-// the second pass can only reach kprime at the same or a higher bin than the first would have.
-__device__ __attribute__((noinline)) int wave_tau_from_hist(const u32* hist_q, int kprime, int lane) {
-    u32 sum = 0;
-#pragma unroll 1
-    for (int i = 0; i < 32; ++i)
-        sum += __hip_atomic_load(hist_q + lane * 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u32 suf = sum;
-#pragma unroll 1
+// Recompute tau for query q: the largest fine bin b with sum(fine[b..]) >= kprime, found in two
+// round trips through a two-level histogram (64 coarse bins of 32 fine bins): lane l reads coarse[l],
+// a suffix scan finds the coarse bin L where the count crosses kprime, then lanes 0..31 read the 32
+// fine bins of L.  Returns -1 if fewer than kprime are counted.  Coarse and fine counters are bumped
+// by separate relaxed atomics, so a reader can see them out of step; that can only make tau LESS
+// tight or -- rarely -- too tight, and a too-tight tau is caught a posteriori by k_final (it checks
+// that >= kprime candidates sit at or above the final tau), which then takes the exact path.
+__device__ __forceinline__ int wave_tau_two_level(const u32* coarse_q, const u32* fine_q, int kprime,
+                                                            int lane) {
+    const u32 c = __hip_atomic_load(coarse_q + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 suf = c;
+#pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const u32 v = __shfl_down(suf, off);
         if (lane + off < 64) suf += v;
     }
-    const u32 above = suf - sum;
-    int best = -1;
-    if (above < (u32)kprime && suf >= (u32)kprime) {
-        u32 run = above;
-#pragma unroll 1
-        for (int i = 31; i >= 0; --i) {
-            run += __hip_atomic_load(hist_q + lane * 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (run >= (u32)kprime) { best = lane * 32 + i; break; }
-        }
+    const u32 above = suf - c;
+    const unsigned long long cross = __ballot(above < (u32)kprime && suf >= (u32)kprime);
+    if (cross == 0ull) return -1;
+    const int L = __ffsll((long long)cross) - 1;
+    const u32 aboveL = (u32)__shfl((int)above, L);
+    const u32 f = lane < 32 ? __hip_atomic_load(fine_q + L * 32 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    u32 sf = f;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const u32 v = __shfl_down(sf, off);
+        if (lane + off < 32) sf += v;
     }
-#pragma unroll 1
-    for (int off = 32; off; off >>= 1) best = max(best, __shfl_xor(best, off));
-    return best;
+    const unsigned long long ok = __ballot(lane < 32 && aboveL + sf >= (u32)kprime);
+    if (ok == 0ull) return -1;
+    return L * 32 + (63 - __clzll((long long)ok));
 }
+
+// ---- LDS control block of k_scan (right after the query image) ---------------------------------
+//   +0   u32 stage_cnt     candidates staged by this workgroup (main mode)
+//   +4   u32 next_tile     next unclaimed tile of the workgroup's row range
+//   +16  int tau_lds[64]   the workgroup's copy of the per-query threshold bins
+//   +272 uint4 entries[stage_cap]
+constexpr int kCtlBytes = 272;
+
+template <int NT>
+__device__ __forceinline__ constexpr int QN_of() { return NT * kQueryTile; }
 
 // Per-tile values the epilogue needs, fetched BEFORE the next prefetch is issued so that waiting for
 // them (vmcnt is in-order) never drains the prefetch: lane r (and r+32) holds 1/norm of tile row r.
+// Every 8th tile (staggered over the 8 waves) a wave also re-reads the GLOBAL thresholds and folds
+// them into the workgroup's LDS copy; the filter itself only ever reads the LDS copy, so the global
+// tau lines -- which atomicMax keeps evicting from L2 -- are off the per-tile path.
 template <int NT>
 struct EpiRegs {
     float inv_lane;
-    int tau[NT];
+    int tau_g[NT];
+    bool sync_tau;
 };
 
 template <int NT, int MODE>
-__device__ __forceinline__ void epi_prefetch(EpiRegs<NT>& e, const ScanArgs& a, long long t0, int lane) {
+__device__ __forceinline__ void epi_prefetch(EpiRegs<NT>& e, const ScanArgs& a, long long t0, int lane, bool sync_tau) {
     e.inv_lane = a.inv_scan[t0 + (lane & 31)];  // inv_scan is padded by 64 entries past n
-    if (MODE == kModeMain) {
+    e.sync_tau = sync_tau;
+    if (MODE == kModeMain && sync_tau) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            e.tau[nt] = __hip_atomic_load(a.tau_bin + nt * kQueryTile + (lane & 31), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
+            e.tau_g[nt] = __hip_atomic_load(a.tau_bin + nt * kQueryTile + (lane & 31), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 template <int NT, int MODE>
 __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&acc)[NT], const EpiRegs<NT>& e,
-                                              long long t0, long long lo, long long hi, long long gw, int lane) {
+                                              long long t0, long long hi, long long s0_slot, int lane, char* ctl) {
     const int r31 = lane & 31, h = lane >> 5;
-    // inverse norms of this lane's 16 rows (reg -> row (reg&3) + 8*(reg>>2) + 4*h) via readlane
-    float inv[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
+    // 1/norm of this lane's row for accumulator register `reg` (row (reg&3) + 8*(reg>>2) + 4*h): two
+    // readlanes of the per-tile inv_lane and a select, recomputed at each use to keep registers free
+    auto inv_of = [&](int reg) {
         const int r0 = (reg & 3) + 8 * (reg >> 2);
         const float lo_half = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.inv_lane), r0));
         const float hi_half = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.inv_lane), r0 + 4));
-        inv[reg] = h ? hi_half : lo_half;
-    }
+        return h ? hi_half : lo_half;
+    };
     if (MODE == kModeSample) {
-        const long long slot0 = gw * (long long)a.samp + (t0 - lo);
         const long long s0_stride = (long long)a.total_waves * a.samp;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -446,173 +466,286 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (t0 + rr < hi) a.s0[(long long)q * s0_stride + slot0 + rr] = acc[nt][reg] * inv[reg];
+                if (t0 + rr < hi) a.s0[(long long)q * s0_stride + s0_slot + rr] = acc[nt][reg] * inv_of(reg);
             }
         }
         return;
     }
     // ---- main mode: threshold filter ----
+    int* tau_lds = (int*)(ctl + 16);
+    if (e.sync_tau && lane < 32) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) atomicMax(tau_lds + nt * kQueryTile + lane, e.tau_g[nt]);
+    }
+    // bit (nt * 16 + reg) of `mask` = "this lane's score for (query nt*32 + r31, row reg) passes"
     float tb[NT];
-    bool any = false;
+    u32 mask = 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int q = nt * kQueryTile + r31;
-        const int t = e.tau[nt];
+        const int t = tau_lds[q];
         tb[nt] = q < a.nq ? (t <= 0 ? -INFINITY : (float)t) : INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const float x = bin_x(acc[nt][reg] * inv[reg]);
-            any |= (t0 + rr < hi) && (x >= tb[nt]);
+            const float x = bin_x(acc[nt][reg] * inv_of(reg));
+            mask |= ((t0 + rr < hi) && (x >= tb[nt])) ? (1u << (nt * 16 + reg)) : 0u;
         }
+        __builtin_amdgcn_sched_barrier(0);  // one N-tile at a time: keeps the live set small
     }
-    if (__ballot(any) == 0ull) return;
+    if (__ballot(mask != 0u) == 0ull) return;
 
-    // ---- rare path: append candidates, bump histogram, maybe refresh tau ----
+    // ---- rare path: stage candidates in LDS; once per block of `refresh_every` staged entries ONE
+    // wave refreshes one tau and publishes that block to the global histograms.
+    // No global memory operation is issued per candidate: vmcnt retires in order, so even a no-return
+    // atomic here would hold up the consumption of the corpus stage already in flight.  The
+    // workgroup flushes its stage to the global lists once, at the end.
+    if (a.debug & 4) return;  // timing experiment: filter only
+    u32* stage_cnt = (u32*)ctl;
+    uint4* stage_ent = (uint4*)(ctl + kCtlBytes);
+    const u32 c = (u32)__popc(mask);
+    const u32 R = (u32)a.refresh_every;  // 1..64
+    u32 slot = 0;
+    bool need = false;
+    if (c > 0) {
+        slot = atomicAdd(stage_cnt, c);  // LDS atomic (wave-aggregated by the compiler)
+        need = (slot / R) != ((slot + c) / R);
+    }
+    const u32 slot_end = slot + c;
+    if (a.debug & 8) return;  // timing experiment: claim slots, write nothing (flush skips w != 1)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int q = nt * kQueryTile + r31;
-        int c = 0;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const float x = bin_x(acc[nt][reg] * inv[reg]);
-            c += ((t0 + rr < hi) && (x >= tb[nt])) ? 1 : 0;
-        }
-        bool need = false;
-        if (c > 0) {
-            u32 slot = atomicAdd(a.cnt + q, (u32)c);
-            need = (slot / (u32)a.refresh_every) != ((slot + (u32)c) / (u32)a.refresh_every);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
+            if (mask & (1u << (nt * 16 + reg))) {
                 const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const float sc = acc[nt][reg] * inv[reg];
-                const float x = bin_x(sc);
-                if ((t0 + rr < hi) && (x >= tb[nt])) {
-                    if (slot < (u32)a.cap)
-                        a.cand[(long long)q * a.cap + slot] = ((u64)orderkey(sc) << 32) | (u64)(u32)(t0 + rr);
-                    ++slot;
-                    atomicAdd(a.hist + (long long)q * kHistBins + bin_of_x(x), 1u);
+                const float sc = acc[nt][reg] * inv_of(reg);
+                const u32 bin = (u32)bin_of_x(bin_x(sc));
+                const u32 key = orderkey(sc), row = (u32)(t0 + rr);
+                if (slot < (u32)a.stage_cap) {
+                    stage_ent[slot] = make_uint4(row, key, (u32)q | (bin << 8), 1u);  // w = 1: entry written
+                } else {  // stage full (hostile data): append straight to the global list
+                    const u32 gs = atomicAdd(a.cnt + q * kCntStride, 1u);
+                    if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)key << 32) | (u64)row;
+                    atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
+                    atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
                 }
+                ++slot;
             }
         }
-        unsigned long long m = __ballot(need);
-        while (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int qq = nt * kQueryTile + (leader & 31);
-            const int nb = wave_tau_from_hist(a.hist + (long long)qq * kHistBins, a.kprime, lane);
-            if (lane == 0 && nb > 0) atomicMax(a.tau_bin + qq, nb);
+    }
+    if (a.debug & 2) return;  // timing experiment: never publish / refresh
+    const unsigned long long m = __ballot(need);
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const u32 blk = (u32)__shfl((int)slot_end, leader) / R - 1u;  // the block this wave completed
+        // (1) refresh one tau from what is published so far (two dependent L2 reads)
+        const u32 lm = (u32)__shfl((int)mask, leader);
+        const int qq = ((lm & 0xFFFFu) ? 0 : kQueryTile) + (leader & 31);
+        const int nb = wave_tau_two_level(a.hist_coarse + qq * 64, a.hist + (long long)qq * kHistBins, a.kprime, lane);
+        if (lane == 0 && nb > 0) {
+            atomicMax(a.tau_bin + qq, nb);
+            atomicMax(tau_lds + qq, nb);
+        }
+        // (2) publish the completed block: lane i takes entry blk*R + i, fire-and-forget atomics.
+        //     Entries other waves claimed but have not written yet read w == 0 (the stage is zeroed at
+        //     kernel start) and are skipped: the histogram then under-counts, which only makes tau
+        //     less tight.
+        const u32 idx = blk * R + (u32)lane;
+        if ((u32)lane < R && idx < (u32)a.stage_cap) {
+            const uint4 en = stage_ent[idx];
+            if (en.w == 1u) {
+                const u32 q = en.z & 0xFFu, bin = en.z >> 8;
+                if (q < (u32)QN_of<NT>() && bin < (u32)kHistBins) {
+                    atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
+                    atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
+                }
+            }
         }
     }
 }
 
+// k_scan: see the block comment above.  One workgroup (8 waves) per CU; the workgroup owns the row
+// range [n*wg/grid, n*(wg+1)/grid); its first 8*samp rows are the sample part, the rest the main part.
+// Waves claim 32-row tiles of the part dynamically from an LDS counter: a wave that stalls (tau
+// refresh, unlucky memory channel) simply takes fewer tiles, so the workgroup finishes together.
 template <int NT, int G, int MODE>
 __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QN = NT * kQueryTile;
+    constexpr int WAVES = kScanThreads / 64;
     const int tid = threadIdx.x;
-    {   // query image -> LDS, verbatim
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const long long grid = gridDim.x;
+    const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
+    const long long swg = (long long)a.samp * WAVES;
+    const long long Rs = (Ra + swg < Rb) ? Ra + swg : Rb;
+    const long long lo = MODE == kModeSample ? Ra : Rs;
+    const long long hi = MODE == kModeSample ? Rs : Rb;
+    const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);  // per workgroup: < 2^31 / 32 rows
+    const int SS = (a.dp >> 6) / G;
+    char* ctl = smem + (size_t)a.dp * QN * 2;
+    u32* next_tile = (u32*)(ctl + 4);
+
+    // Two register stages (A0, A1), one flat sequence of supersteps over (tile, ss).  The prefetch of
+    // the next step is issued UNCONDITIONALLY before the current one is consumed (past the end it
+    // re-reads the last step: harmless), so the compiler's counted vmcnt waits never cover the stage
+    // in flight.
+    h8 A0[4 * G], A1[4 * G];
+    EpiRegs<NT> epi;
+    int cur_tile = wid, claimed = 0x7fffffff, tiles_done = 0;
+    const bool active = cur_tile < ntiles;
+    // row index of this lane in `tile`, clamped into the part (32-bit: a shard has < 2^32 rows)
+    const u32 lo32 = (u32)lo + (u32)r31, hi32m1 = (u32)(hi - 1);
+    auto rowof = [&](int tile) {
+        const u32 r = lo32 + (u32)tile * kRowTile;
+        return (long long)(r < hi32m1 ? r : hi32m1);
+    };
+    // first corpus stage goes out before the query image is staged, so HBM latency overlaps the fill
+    if (active) issue_loads<G>(A0, a.rows, a.row_bytes, rowof(cur_tile), 0, h);
+    {   // query image -> LDS, verbatim; control block + candidate stage zeroed; tau copied
         const uint4* src = (const uint4*)a.qimg;
         uint4* dst = (uint4*)smem;
         const int nvec = (a.dp >> 3) * QN;
+#pragma unroll 4
         for (int i = tid; i < nvec; i += kScanThreads) dst[i] = src[i];
+        uint4* z = (uint4*)ctl;
+        const int nz = (MODE == kModeMain) ? (kCtlBytes / 16 + a.stage_cap) : 1;
+        for (int i = tid; i < nz; i += kScanThreads) z[i] = make_uint4(0u, (i == 0) ? (u32)WAVES : 0u, 0u, 0u);
     }
     __syncthreads();
-    const int lane = tid & 63, wid = tid >> 6;
-    const int r31 = lane & 31, h = lane >> 5;
-    const long long gw = (long long)blockIdx.x * (kScanThreads / 64) + wid;
-    if (gw >= a.total_waves) return;
-    const long long ra = a.n * gw / a.total_waves, rb = a.n * (gw + 1) / a.total_waves;
-    const long long rs = (ra + a.samp < rb) ? ra + a.samp : rb;
-    const long long lo = MODE == kModeSample ? ra : rs;
-    const long long hi = MODE == kModeSample ? rs : rb;
-    if (lo >= hi) return;
-    const int SS = (a.dp >> 6) / G;
-    const long long ntiles = (hi - lo + kRowTile - 1) / kRowTile;
-    const long long total = ntiles * SS;
+    if (MODE == kModeMain && tid < QN) ((int*)(ctl + 16))[tid] = a.tau_bin[tid];
+    __syncthreads();
     const char* lds_lane = smem + ((4 * h) * QN + r31) * 16;
+    unsigned long long* dbg = (MODE == kModeMain && (a.debug & 128) && a.dbg && lane == 0)
+                                  ? a.dbg + ((long long)blockIdx.x * WAVES + wid) * 4 : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
 
-    f16v acc[NT];
+    if (active) {
+        f16v acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
-
-    // Two register stages (A0, A1), one flat sequence of supersteps over (tile, ss).  The prefetch of
-    // step it+1 is issued UNCONDITIONALLY before step it is consumed (past the end it re-reads the last
-    // step: harmless), so the compiler's counted vmcnt waits never cover the stage in flight.
-    h8 A0[4 * G], A1[4 * G];
-    EpiRegs<NT> epi;
-    TileCursor cur = {lo, 0}, nxt;
-    const long long last_t0 = lo + (ntiles - 1) * kRowTile;
-    auto advance = [&](const TileCursor& c) {
-        TileCursor o;
-        if (c.ss + 1 == SS) { o.t0 = c.t0 + kRowTile; o.ss = 0; } else { o.t0 = c.t0; o.ss = c.ss + 1; }
-        if (o.t0 > last_t0) { o.t0 = last_t0; o.ss = SS - 1; }
-        return o;
-    };
-    auto rowof = [&](const TileCursor& c) {
-        const long long r = c.t0 + r31;
-        return r < hi ? r : hi - 1;
-    };
-#define VF_SCAN_STEP(CURBUF, NXTBUF)                                                       \
-    {                                                                                      \
-        const bool last_ss = (cur.ss + 1 == SS);                                           \
-        if (last_ss) epi_prefetch<NT, MODE>(epi, a, cur.t0, lane);                         \
-        nxt = advance(cur);                                                                \
-        issue_loads<G>(NXTBUF, a.rows, a.row_bytes, rowof(nxt), nxt.ss, h);                \
-        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ABOVE the MFMAs */         \
-        compute_superstep<NT, G>(acc, CURBUF, lds_lane, cur.ss);                           \
-        if (last_ss) {                                                                     \
-            tile_epilogue<NT, MODE>(a, acc, epi, cur.t0, lo, hi, gw, lane);                \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                              \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;          \
-        }                                                                                  \
-        cur = nxt;                                                                         \
+            for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+        // SS is even (launch_scan picks G so): a tile is SS/2 pairs (A0 then A1) and always starts in A0.
+        const int pairs = SS >> 1;
+        while (true) {
+            const long long t0 = lo + (long long)cur_tile * kRowTile;
+            {   // one claim per wave (LDS atomic); the result is consumed at the tile's end
+                int v_ = 0;
+                if (lane == 0) v_ = (int)atomicAdd(next_tile, 1u);
+                claimed = __builtin_amdgcn_readfirstlane(v_);
+            }
+            const long long myrow = rowof(cur_tile);
+            for (int p = 0; p + 1 < pairs; ++p) {
+                issue_loads<G>(A1, a.rows, a.row_bytes, myrow, 2 * p + 1, h);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs
+                compute_superstep<NT, G>(acc, A0, lds_lane, 2 * p);
+                issue_loads<G>(A0, a.rows, a.row_bytes, myrow, 2 * p + 2, h);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_superstep<NT, G>(acc, A1, lds_lane, 2 * p + 1);
+            }
+            issue_loads<G>(A1, a.rows, a.row_bytes, myrow, SS - 1, h);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_superstep<NT, G>(acc, A0, lds_lane, SS - 2);
+            // last superstep of the tile: epilogue operands first, then the next tile's first stage
+            const bool more = claimed < ntiles;
+            epi_prefetch<NT, MODE>(epi, a, t0, lane, ((tiles_done & (WAVES - 1)) == wid));
+            issue_loads<G>(A0, a.rows, a.row_bytes, rowof(more ? claimed : cur_tile), 0, h);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_superstep<NT, G>(acc, A1, lds_lane, SS - 1);
+            tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, (long long)blockIdx.x * swg + (t0 - lo), lane, ctl);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+            ++tiles_done;
+            if (!more) break;
+            cur_tile = claimed;
+        }
     }
-    issue_loads<G>(A0, a.rows, a.row_bytes, rowof(cur), cur.ss, h);
-    long long it = 0;
-    for (; it + 1 < total; it += 2) {
-        VF_SCAN_STEP(A0, A1)
-        VF_SCAN_STEP(A1, A0)
+    if (dbg) { dbg[1] = wall_clock64(); }
+    if (MODE == kModeMain) {
+        // Flush the staged candidates to the per-query global lists, once per workgroup: rank the
+        // entries per query in LDS, claim one contiguous range per non-empty query with ONE returning
+        // global atomic (counters sit on separate 128-B lines), then write the entries.
+        __syncthreads();
+        if (dbg) dbg[2] = wall_clock64();
+        const u32 staged = (a.debug & 16) ? 0u : *(const u32*)ctl;  // bit 4: timing experiment, no flush
+        const u32 nst = staged < (u32)a.stage_cap ? staged : (u32)a.stage_cap;
+        uint4* ent = (uint4*)(ctl + kCtlBytes);
+        u32* qcnt = (u32*)smem;         // the query image is dead now: reuse its first bytes
+        u32* qbase = qcnt + QN;
+        if (tid < QN) qcnt[tid] = 0u;
+        __syncthreads();
+        for (u32 i = tid; i < nst; i += kScanThreads) {
+            const uint4 e = ent[i];
+            const u32 q = e.z & 0xFFu;
+            if (e.w != 1u || q >= (u32)QN) continue;  // never index global memory with an unwritten entry
+            ent[i].w = 2u + atomicAdd(qcnt + q, 1u);  // local rank, tagged
+        }
+        __syncthreads();
+        if (tid < QN) {
+            const u32 c = qcnt[tid];
+            qbase[tid] = c ? atomicAdd(a.cnt + tid * kCntStride, c) : 0u;
+        }
+        __syncthreads();
+        for (u32 i = tid; i < nst; i += kScanThreads) {
+            const uint4 e = ent[i];
+            if (e.w < 2u) continue;
+            const u32 q = e.z & 0xFFu;
+            const u32 gs = qbase[q] + (e.w - 2u);
+            if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)e.y << 32) | (u64)e.x;
+        }
+        if (dbg) dbg[3] = wall_clock64();
     }
-    if (it < total) VF_SCAN_STEP(A0, A1)
-#undef VF_SCAN_STEP
 }
 
-size_t scan_lds_bytes(int dp, int qn_tile) { return (size_t)dp * qn_tile * 2; }
+// dynamic LDS of k_scan: query image + (main mode) candidate stage
+size_t scan_lds_bytes(int dp, int qn_tile) { return (size_t)dp * qn_tile * 2 + kCtlBytes; }
+int scan_stage_cap(int dp, int qn_tile) {
+    const size_t used = scan_lds_bytes(dp, qn_tile);
+    const size_t freeb = used < 160 * 1024 ? 160 * 1024 - used : 0;
+    const size_t area = freeb < 32 * 1024 ? freeb : 32 * 1024;
+    return (int)(area / 16);
+}
 
 template <int NT, int G, int MODE>
 static hipError_t launch_scan_inst(const ScanArgs& a, int grid, hipStream_t s) {
-    const size_t lds = scan_lds_bytes(a.dp, NT * kQueryTile);
+    size_t lds = scan_lds_bytes(a.dp, NT * kQueryTile);
+    if (MODE == kModeMain) lds += (size_t)a.stage_cap * 16;
     hipLaunchKernelGGL((k_scan<NT, G, MODE>), dim3(grid), dim3(kScanThreads), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NT, int G>
-static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, hipStream_t s) {
-    return mode == kModeSample ? launch_scan_inst<NT, G, kModeSample>(a, grid, s)
-                               : launch_scan_inst<NT, G, kModeMain>(a, grid, s);
-}
-
-// Segments (128 B of each row) per pipeline stage.  G=2 keeps the main-mode kernel spill-free
-// (251 VGPRs at NT=2); larger G puts more bytes in flight per wave but spills on this compiler.
-static int pick_G(int dp, int want) {
-    const int segs = dp >> 6;
-    if (want >= 1 && want <= 4 && segs % want == 0) return want;
-    if (segs % 2 == 0) return 2;
-    if (segs % 3 == 0) return 3;
-    return 1;
+// Segments (128 B of each row) per pipeline stage; the superstep count dp/64/G must be even (the
+// tile loop alternates two register stages).  Main mode: G=2 keeps the kernel spill-free with its
+// filter epilogue (234 VGPRs at NT=2).  Sample mode is latency-bound (a workgroup has only 128 rows):
+// the deepest spill-free G (4) puts a third of a 32-row tile in flight per stage.
+static int pick_G(int dp, int want, int mode) {
+    const int segs = dp >> 6;  // dp is a multiple of 128, so segs is even
+    auto ok = [&](int g) { return g >= 1 && segs % g == 0 && ((segs / g) & 1) == 0; };
+    if (mode == kModeSample) {
+        for (int g : {4, 3, 2}) if (ok(g)) return g;
+        return 1;
+    }
+    if (want >= 1 && want <= 4 && ok(want)) return want;
+    if (ok(2)) return 2;
+    if (ok(3)) return 3;
+    return 1;  // segs even => always ok
 }
 
 hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int want_g, hipStream_t s) {
-    const int G = pick_G(a.dp, want_g);
+    const int G = pick_G(a.dp, want_g, mode);
     const int NT = qn_tile / kQueryTile;
-#define VF_CASE(NTV, GV) \
-    if (NT == NTV && G == GV) return launch_scan_mode<NTV, GV>(a, mode, grid, s);
-    VF_CASE(1, 1) VF_CASE(1, 2) VF_CASE(1, 3) VF_CASE(1, 4)
-    VF_CASE(2, 1) VF_CASE(2, 2) VF_CASE(2, 3) VF_CASE(2, 4)
+#define VF_CASE(NTV, GV, MODEV) \
+    if (NT == NTV && G == GV && mode == MODEV) return launch_scan_inst<NTV, GV, MODEV>(a, grid, s);
+    VF_CASE(1, 1, kModeMain) VF_CASE(1, 2, kModeMain) VF_CASE(1, 3, kModeMain) VF_CASE(1, 4, kModeMain)
+    VF_CASE(2, 1, kModeMain) VF_CASE(2, 2, kModeMain) VF_CASE(2, 3, kModeMain) VF_CASE(2, 4, kModeMain)
+    VF_CASE(1, 1, kModeSample) VF_CASE(1, 2, kModeSample) VF_CASE(1, 3, kModeSample) VF_CASE(1, 4, kModeSample)
+    VF_CASE(2, 1, kModeSample) VF_CASE(2, 2, kModeSample) VF_CASE(2, 3, kModeSample) VF_CASE(2, 4, kModeSample)
 #undef VF_CASE
     return hipErrorInvalidValue;
 }
@@ -625,9 +758,36 @@ static hipError_t configure_one() {
 
 // ------------------------------------------------------------------------------------------------
 // k_sel0: per query, seed the threshold from the sample scores: LDS histogram -> tau bin with
-// >= kprime sample rows at or above it -> emit those rows as the first candidates.
+// >= kprime sample rows at or above it -> emit those rows as the first candidates, publish the
+// fine / coarse histograms the main scan keeps counting into.
 // ------------------------------------------------------------------------------------------------
-template <int QN>
+__device__ __forceinline__ int wave_tau_from_lds(const u32* lh, int kprime, int lane) {
+    u32 hv[32];
+    u32 sum = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { hv[i] = lh[lane * 32 + i]; sum += hv[i]; }
+    u32 suf = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 v = __shfl_down(suf, off);
+        if (lane + off < 64) suf += v;
+    }
+    const u32 above = suf - sum;
+    int best = -1;
+    if (above < (u32)kprime && suf >= (u32)kprime) {
+        u32 run = above;
+        bool found = false;
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            run += hv[i];
+            if (!found && run >= (u32)kprime) { best = lane * 32 + i; found = true; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) best = max(best, __shfl_xor(best, off));
+    return best;
+}
+
 __global__ __launch_bounds__(1024) void k_sel0(ScanArgs a) {
     __shared__ u32 lh[kHistBins];
     __shared__ u32 lcnt;
@@ -638,88 +798,229 @@ __global__ __launch_bounds__(1024) void k_sel0(ScanArgs a) {
     __syncthreads();
     const long long len = (long long)a.total_waves * a.samp;
     const float* s = a.s0 + (long long)q * len;
+    const long long swg = (long long)a.samp * (kScanThreads / 64), grid = a.total_waves / (kScanThreads / 64);
+    constexpr int kKeep = 32;  // sample scores per thread kept in registers between the two phases
+    float v[kKeep];
+    const bool in_regs = len <= (long long)kKeep * 1024;
     if (q < a.nq) {
-        for (long long i = tid; i < len; i += 1024) {
-            const float v = s[i];
-            if (v > -INFINITY) atomicAdd(&lh[bin_of_x(bin_x(v))], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const int nb = wave_tau_from_hist(lh, a.kprime, tid);
-        if (tid == 0) sbin = nb > 0 ? nb : 0;
-    }
-    __syncthreads();
-    const int tb = sbin;
-    if (q < a.nq) {
-        for (long long i = tid; i < len; i += 1024) {
-            const float v = s[i];
-            if (v > -INFINITY && bin_of_x(bin_x(v)) >= tb) {
-                const u32 slot = atomicAdd(&lcnt, 1u);
-                const long long w = i / a.samp;
-                const long long row = a.n * w / a.total_waves + (i - w * a.samp);
-                if (slot < (u32)a.cap) a.cand[(long long)q * a.cap + slot] = ((u64)orderkey(v) << 32) | (u64)(u32)row;
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < kKeep; ++u) {
+                const long long i = tid + (long long)u * 1024;
+                const float x = s[i < len ? i : len - 1];
+                v[u] = i < len ? x : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < kKeep; ++u)
+                if (v[u] > -INFINITY) atomicAdd(&lh[bin_of_x(bin_x(v[u]))], 1u);
+        } else {
+            for (long long i = tid; i < len; i += 1024) {
+                const float x = s[i];
+                if (x > -INFINITY) atomicAdd(&lh[bin_of_x(bin_x(x))], 1u);
             }
         }
     }
     __syncthreads();
+    if (tid < 64) {
+        const int nb = wave_tau_from_lds(lh, a.kprime, tid);
+        if (tid == 0) sbin = nb > 0 ? nb : 0;
+    }
+    __syncthreads();
+    const int tb = sbin;
+    auto emit = [&](float x, long long i) {
+        if (x > -INFINITY && bin_of_x(bin_x(x)) >= tb) {
+            const u32 slot = atomicAdd(&lcnt, 1u);
+            const long long wg = i / swg;
+            const long long row = a.n * wg / grid + (i - wg * swg);
+            if (slot < (u32)a.cap) a.cand[(long long)q * a.cap + slot] = ((u64)orderkey(x) << 32) | (u64)(u32)row;
+        }
+    };
+    if (q < a.nq) {
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < kKeep; ++u) emit(v[u], tid + (long long)u * 1024);
+        } else {
+            for (long long i = tid; i < len; i += 1024) emit(s[i], i);
+        }
+    }
+    __syncthreads();
     for (int b = tid; b < kHistBins; b += 1024) a.hist[(long long)q * kHistBins + b] = (q < a.nq && b >= tb) ? lh[b] : 0u;
+    if (tid < 64) {
+        u32 c = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int b = tid * 32 + i;
+            c += (q < a.nq && b >= tb) ? lh[b] : 0u;
+        }
+        a.hist_coarse[q * 64 + tid] = c;
+    }
     if (tid == 0) {
-        a.cnt[q] = lcnt;
-        a.tau_bin[q] = q < a.nq ? tb : kHistBins;
+        a.cnt[q * kCntStride] = lcnt;
+        a.tau_bin[q] = (q < a.nq && !(a.debug & 1)) ? tb : kHistBins;
     }
 }
 
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s) {
-    if (qn_tile == 32) hipLaunchKernelGGL(k_sel0<32>, dim3(32), dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL(k_sel0<64>, dim3(64), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_sel0, dim3(qn_tile), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_final: per query.  Sort the candidates by approximate score, re-score the best k' with the
-// CANONICAL fp32 arithmetic (bit-identical to oracle/vf_oracle.c), sort by (canonical desc, id asc),
+// k_final: per query.  Rank the candidates by approximate score, re-score the best k' with the
+// CANONICAL fp32 arithmetic (bit-identical to oracle/vf_oracle.c), rank by (canonical desc, id asc),
 // write k results and the exactness certificate:
 //   every row not re-scored has approx <= A (A = approx of the k'-th candidate), hence canonical
 //   <= A + eps; if canonical_k > A + eps no such row can enter the top k  =>  result is exact.
+// Ranking is by counting (rank = number of larger keys; keys are unique): O(n^2 / threads) compares
+// against LDS-broadcast keys but NO barriers inside, which beats a bitonic network at n ~ 1-2k
+// (a 1024-thread bitonic sort of 2048 keys costs 66 barriers, ~100 us measured).  n > 4096 (hostile
+// data) falls back to the bitonic sort.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_final(FinalArgs a) {
+constexpr int kFinalThreads = 512;
+constexpr int kRankMaxN = 4096;
+
+// out[r] = the key of rank r (descending) for every r < limit; keys[0..n) unique, in LDS.
+__device__ __forceinline__ void rank_select_desc(const u64* keys, int n, u64* out, int limit, int tid) {
+    for (int i0 = tid; i0 < n; i0 += 4 * kFinalThreads) {
+        u64 mine[4];
+        int rank[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kFinalThreads;
+            mine[u] = i < n ? keys[i] : 0ull;
+            rank[u] = 0;
+        }
+        // 16 keys per batch are read (same address in every lane: LDS broadcast) before any compare,
+        // so the loop runs at LDS throughput instead of one LDS latency per key
+        int j = 0;
+        for (; j + 16 <= n; j += 16) {
+            u64 kj[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) kj[t] = keys[j + t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rank[u] += kj[t] > mine[u] ? 1 : 0;
+        }
+        for (; j < n; ++j) {
+            const u64 kj = keys[j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += kj > mine[u] ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * kFinalThreads < n && rank[u] < limit) out[rank[u]] = mine[u];
+    }
+}
+
+// Canonical cosine of one corpus row against the (already normalised) query, by one 16-lane group:
+// lane l owns partial sum l (elements l, l+16, ...), then the fixed tree.  All of a batch's loads are
+// issued UNCONDITIONALLY (index clamped, value masked afterwards) with the dtype a template
+// parameter: a per-element runtime condition around a load makes hipcc branch around each one and
+// wait vmcnt(0) per element -- 48 serialized round trips per row, 18 us measured.
+template <bool IS_HALF>
+__device__ __forceinline__ float rescore_row(const void* rows, long long base, int d, const float* qv, float nm,
+                                             int l) {
+    float acc = 0.0f;
+    const float inv = canon_inv(nm);
+    for (int j0 = l; j0 < d; j0 += 16 * 48) {
+        float cv[48];
+#pragma unroll
+        for (int u = 0; u < 48; ++u) {
+            const int j = j0 + 16 * u;
+            const long long idx = base + (j < d ? j : d - 1);
+            cv[u] = IS_HALF ? (float)((const _Float16*)rows)[idx] : ((const float*)rows)[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 48; ++u) {
+            const int j = j0 + 16 * u;
+            const float qq = qv[j < d ? j : d - 1];
+            const float t = __builtin_fmaf(qq, cv[u] * inv, acc);
+            acc = j < d ? t : acc;
+        }
+    }
+    return group16_tree(acc);
+}
+
+__global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    u64* ck = (u64*)smem_raw;
+    u64* ck = (u64*)smem_raw;                 // [cap] candidate keys
+    u64* top = ck + a.cap;                    // [4096] ranked approx keys, then ranked canonical keys
+    u64* rk = ck;                             // re-scored keys (unordered): reuses ck once `top` is built
+    float* qs = (float*)(top + 4096);         // [d] this query's canonical normalised vector
     const int q = blockIdx.x, tid = threadIdx.x;
-    const u32 n_raw = a.cnt[q];
+    unsigned long long* dbg = (a.dbg && tid == 0) ? a.dbg + (long long)q * 8 : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
+    const u32 n_raw = a.cnt[q * kCntStride];
     const int n = n_raw < (u32)a.cap ? (int)n_raw : a.cap;
-    const int P = next_pow2(n > 1 ? n : 1);
-    const u64* cq = a.cand + (long long)q * a.cap;
-    for (int i = tid; i < P; i += 1024) ck[i] = i < n ? cq[i] : 0ull;
-    __syncthreads();
-    bitonic_sort_desc(ck, P, tid, 1024);
     const int m = n < a.kprime ? n : a.kprime;
-    const int KP = next_pow2(m > 1 ? m : 1);
-    // the re-scored keys live behind the first kprime sorted candidates (cap >= 2 * kprime)
-    u64* rk = ck + (a.cap >> 1);
-    const float approx_floor = m > 0 ? unorderkey((u32)(ck[m - 1] >> 32)) : -INFINITY;
+    const u64* cq = a.cand + (long long)q * a.cap;
+    // Pre-filter by the scan's final threshold: if at least k' candidates sit at or above tau (i.e. tau
+    // is a valid bound -- normally it is, and tight), nothing below it can be among the best k', so only
+    // the survivors (typically 1.2-2 x k') are ranked instead of every candidate the scan ever kept.
+    u64* sel = (u64*)(qs + ((a.d + 1) & ~1));  // [4096] + counter, when the LDS budget allows (see launch_final)
+    u32& s_nsel = *(u32*)(sel + 4096);
+    const bool can_sel = (size_t)a.cap * 8 + 2 * 4096 * 8 + ((size_t)a.d + 1) * 4 + 16 <= 160 * 1024;
+    bool ranked = false;
+    if (can_sel && n > a.kprime) {
+        if (tid == 0) s_nsel = 0u;
+        __syncthreads();
+        const int tbin = a.tau_bin[q];
+        for (int i = tid; i < n; i += kFinalThreads) {
+            const u64 kv = cq[i];
+            if (bin_of_x(bin_x(unorderkey((u32)(kv >> 32)))) >= tbin) {
+                const u32 sl = atomicAdd(&s_nsel, 1u);
+                if (sl < 4096u) sel[sl] = kv;
+            }
+        }
+        __syncthreads();
+        const int ns = (int)s_nsel;
+        if (ns >= a.kprime && ns <= 4096) {
+            rank_select_desc(sel, ns, top, m, tid);
+            ranked = true;
+        }
+    }
+    if (ranked) {
+    } else if (n <= kRankMaxN) {
+        for (int i = tid; i < n; i += kFinalThreads) ck[i] = cq[i];
+        __syncthreads();
+        rank_select_desc(ck, n, top, m, tid);
+    } else {
+        const int P = next_pow2(n);
+        for (int i = tid; i < P; i += kFinalThreads) ck[i] = i < n ? cq[i] : 0ull;
+        __syncthreads();
+        bitonic_sort_desc(ck, P, tid, kFinalThreads);
+        for (int i = tid; i < m; i += kFinalThreads) top[i] = ck[i];
+    }
     __syncthreads();
+    if (dbg) dbg[1] = wall_clock64();
+    const float approx_floor = m > 0 ? unorderkey((u32)(top[m - 1] >> 32)) : -INFINITY;
+    // canonical re-score: one 16-lane group per row, all of a row's loads in flight at once
     const int g = tid >> 4, l = tid & 15;
-    const float* qv = a.qn + (long long)q * a.d;
-    for (int i = g; i < m; i += 64) {
-        const u32 row = (u32)ck[i];
-        const float nm = a.norm[row];
-        const long long base = (long long)row * a.orig_row_elems;
-        float acc = 0.0f;
-        for (int j = l; j < a.d; j += 16)
-            acc = __builtin_fmaf(qv[j], canon_div(load_elem(a.rows_orig, a.orig_is_half, base + j), nm), acc);
-        acc = group16_tree(acc);
+    // the query vector is staged in LDS when it fits next to the candidate keys (it does unless cap = 16384)
+    const bool q_in_lds = (size_t)a.cap * 8 + 4096 * 8 + (size_t)a.d * 4 <= 160 * 1024;
+    if (q_in_lds) {
+        for (int j = tid; j < a.d; j += kFinalThreads) qs[j] = a.qn[(long long)q * a.d + j];
+        __syncthreads();
+    }
+    const float* qv = q_in_lds ? qs : a.qn + (long long)q * a.d;
+    for (int i = g; i < m; i += kFinalThreads / 16) {
+        const u32 row = (u32)top[i];
+        const float acc = a.orig_is_half
+                              ? rescore_row<true>(a.rows_orig, (long long)row * a.orig_row_elems, a.d, qv, a.norm[row], l)
+                              : rescore_row<false>(a.rows_orig, (long long)row * a.orig_row_elems, a.d, qv, a.norm[row], l);
         if (l == 0) rk[i] = ((u64)orderkey(acc) << 32) | (u64)(0xFFFFFFFFu - row);
     }
-    for (int i = m + tid; i < KP; i += 1024) rk[i] = 0ull;
     __syncthreads();
-    bitonic_sort_desc(rk, KP, tid, 1024);
-    for (int i = tid; i < a.k; i += 1024) {
+    if (dbg) dbg[2] = wall_clock64();
+    rank_select_desc(rk, m, top, m, tid);  // top now holds the canonical ranking
+    __syncthreads();
+    if (dbg) dbg[3] = wall_clock64();
+    for (int i = tid; i < a.k; i += kFinalThreads) {
         long long id = -1;
         float sc = -FLT_MAX;
         if (i < m) {
-            const u64 kv = rk[i];
+            const u64 kv = top[i];
             id = a.id_offset + (long long)(0xFFFFFFFFu - (u32)kv);
             sc = unorderkey((u32)(kv >> 32));
         }
@@ -730,20 +1031,29 @@ __global__ __launch_bounds__(1024) void k_final(FinalArgs a) {
         int flag = 0;
         if (n_raw > (u32)a.cap) flag = 2;
         else if ((long long)m < a.n_rows) {  // some row was not re-scored: need the certificate
+            // (1) the final tau must be a valid bound: >= kprime candidates at or above it
+            const int tbin = a.tau_bin[q];
+            if (tbin > 0 && (m < a.kprime || bin_of_x(bin_x(approx_floor)) < tbin)) flag = 1;
+            // (2) the k-th canonical score must clear every row that was not re-scored
             if (a.k > m) flag = 1;
-            else {
-                const float ck_k = unorderkey((u32)(rk[a.k - 1] >> 32));
+            else if (flag == 0) {
+                const float ck_k = unorderkey((u32)(top[a.k - 1] >> 32));
                 if (!(ck_k > approx_floor + a.eps)) flag = 1;
             }
         }
+        // flags / counts live in host-mapped pinned memory: no device-to-host copy kernel needed
         a.flags[q] = flag;
         a.cand_count_out[q] = n_raw;
+        if (dbg) dbg[4] = wall_clock64();
     }
 }
 
 hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_final, dim3(nq), dim3(1024), (size_t)a.cap * 8, s, a);
+    size_t lds = (size_t)a.cap * 8 + 4096 * 8;
+    if (lds + (size_t)a.d * 4 <= 160 * 1024) lds += ((size_t)a.d + 1) * 4;       // query vector
+    if (lds + 4096 * 8 + 16 <= 160 * 1024) lds += 4096 * 8 + 16;                  // pre-filter survivors + counter
+    hipLaunchKernelGGL(k_final, dim3(nq), dim3(kFinalThreads), lds, s, a);
     return hipGetLastError();
 }
 
