@@ -131,6 +131,50 @@ int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts,
 int vf_fuse_rank(const float* rerank_scores, const float* time_scores, int32_t n, float* out_scores,
                  int64_t* out_order, int32_t device_id);
 
+/* ---- encoder forward: embedding model and cross-encoder re-ranker -----------------------------
+ * Stands where the reference calls third-party model objects:
+ *   HuggingFaceEmbeddings(...).embed_query / embed_documents   src/utils/ragManager.py:50,
+ *       src/utils/faissRetriever.py:33, src/load_data.py:99,124 (the embed loop)
+ *   get_embeddings' model(**inputs) + pooling                   experiments/retriever/step3_mul.py:191-209,
+ *       continuous_retrieval.py:127-152
+ *   reranker.compute_score(pairs, batch_size=8)                  src/utils/vllmManager.py:450-452
+ * BERT-family post-LN encoder (BERT / XLM-R), fp16 weights, fp32 accumulate.  Tokenisation stays in
+ * Python (the reference's tokenizers are third-party too); this boundary takes token ids. */
+typedef struct vf_encoder vf_encoder;
+typedef struct vf_encoder_config {
+    int32_t vocab, hidden, layers, heads, ffn, max_pos, type_vocab;
+    int32_t roberta_pad_idx; /* -1: BERT positions 0..t-1; >= 0: cumsum(mask)*mask + pad_idx (RoBERTa / XLM-R) */
+    int32_t pooling;         /* 0 CLS, 1 unmasked mean (continuous_retrieval.py:148), 2 last token (step3_mul.py:181-188) */
+    int32_t normalize;       /* 1: L2-normalise the pooled vector (bge models) */
+    int32_t head;            /* 0: embeddings [b, hidden]; 1: RobertaClassificationHead -> one logit per sequence */
+    float ln_eps;
+} vf_encoder_config;
+
+/* Weight blobs (host), in this order.  fp16: word[vocab,H] pos[max_pos,H] type[type_vocab,H], then per
+ * layer Wqkv[3H,H] (q rows, k rows, v rows) Wo[H,H] W1[F,H] W2[H,F], then (head==1) dense[H,H] out_proj[H].
+ * fp32: emb_ln_gamma[H] emb_ln_beta[H], then per layer bqkv[3H] bo[H] ln1_gamma[H] ln1_beta[H] b1[F] b2[H]
+ * ln2_gamma[H] ln2_beta[H], then (head==1) dense_bias[H] out_proj_bias[1].  nn.Linear layout [out,in]. */
+int vf_encoder_weight_sizes(const vf_encoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
+int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg, const void* w_fp16, int64_t n_fp16,
+                      const float* w_fp32, int64_t n_fp32, int32_t device_id);
+/* ids / mask / type_ids (may be NULL) [b, t] int32 host, t % 32 == 0, t <= 512 (pad with mask 0);
+ * t_valid = columns the tokenizer produced (<= t; the rest is alignment padding the caller added: the
+ * unmasked-mean and last-token poolings count only the first t_valid columns);
+ * out [b, hidden] (head 0) or [b] (head 1) fp32 host. */
+int vf_encoder_forward(vf_encoder* enc, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                       int32_t b, int32_t t, int32_t t_valid, float* out);
+/* last_hidden_state [b, t, hidden] fp32 host (callers that pool themselves: step3_mul.py:203-207) */
+int vf_encoder_forward_hidden(vf_encoder* enc, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                              int32_t b, int32_t t, float* out_hidden);
+int vf_encoder_info(vf_encoder* enc, vf_encoder_config* out);
+int vf_encoder_destroy(vf_encoder* enc);
+/* re-ranker = encoder with head == 1 */
+int vf_reranker_create(vf_encoder** out, const vf_encoder_config* cfg, const void* w_fp16, int64_t n_fp16,
+                       const float* w_fp32, int64_t n_fp32, int32_t device_id);
+int vf_reranker_score(vf_encoder* rr, const int32_t* ids, const int32_t* mask, const int32_t* type_ids, int32_t b,
+                      int32_t t, float* out_scores);
+int vf_reranker_destroy(vf_encoder* rr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,188 @@
+"""GPU parity of the HIP encoder forward (embedding model + cross-encoder re-ranker) against the same
+architecture in plain PyTorch fp32 on the CPU (HF BertModel / XLMRobertaForSequenceClassification with
+seeded random weights: no checkpoints exist in this pipeline).  Floating-point path: fp16 weights and
+activations with fp32 accumulation, so the bar is a tolerance, written in each test."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vf():
+    import veritasfi_amd as m
+    from veritasfi_amd import _ffi
+    _ffi.lib()
+    return m
+
+
+def _hf_bert(hidden, layers, heads, ffn, vocab=1000, seed=0):
+    import torch
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(seed)
+    cfg = BertConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ffn,
+                     vocab_size=vocab, max_position_embeddings=512)
+    m = BertModel(cfg, add_pooling_layer=False).eval()
+    m = m.half().float()  # both sides see the same fp16-representable weights
+    return m
+
+
+def _hf_xlmr_cls(hidden, layers, heads, ffn, vocab=1200, seed=1):
+    import torch
+    from transformers import XLMRobertaConfig, XLMRobertaForSequenceClassification
+    torch.manual_seed(seed)
+    cfg = XLMRobertaConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                           intermediate_size=ffn, vocab_size=vocab, max_position_embeddings=514, type_vocab_size=1,
+                           num_labels=1, pad_token_id=1)
+    m = XLMRobertaForSequenceClassification(cfg).eval()
+    for p in m.parameters():  # random-init heads are tiny; give the logits some spread
+        if p.dim() == 1:
+            p.data.add_(0.05 * torch.randn_like(p))
+    return m.half().float()
+
+
+def _batch(rng, b, t, vocab, pad_id=0, ragged=True):
+    ids = rng.integers(5, vocab, size=(b, t)).astype(np.int64)
+    mask = np.ones((b, t), dtype=np.int64)
+    if ragged:
+        for i in range(b):
+            n = int(rng.integers(max(2, t // 4), t + 1)) if i else t
+            mask[i, n:] = 0
+            ids[i, n:] = pad_id
+    return ids, mask
+
+
+@pytest.mark.parametrize("name,hidden,layers,heads,ffn,b,t", [
+    ("tiny", 128, 2, 2, 512, 3, 48),
+    ("small-odd-t", 256, 3, 4, 1024, 5, 100),
+    ("bge-base-shape", 768, 12, 12, 3072, 4, 128),
+])
+def test_embedding_encoder_matches_torch_fp32(vf, name, hidden, layers, heads, ffn, b, t):
+    import torch
+    model = _hf_bert(hidden, layers, heads, ffn)
+    rng = np.random.default_rng(3)
+    ids, mask = _batch(rng, b, t, 1000)
+    with torch.no_grad():
+        ref_h = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state.numpy()
+    ref = ref_h[:, 0]
+    ref = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    enc = vf.HipEncoder.from_hf(model, pooling=0, normalize=True)
+    got = enc.forward(ids, mask)
+    hs = enc.hidden_states(ids, mask)
+    enc.close()
+    assert got.shape == (b, hidden) and hs.shape == (b, t, hidden)
+    cos = np.sum(got * ref, axis=1)
+    err = np.abs(got - ref).max()
+    herr = np.abs(hs - ref_h)[mask.astype(bool)]
+    print(name, "cos", cos.min(), "max|d emb|", err, "hidden mean/max err", herr.mean(), herr.max())
+    # tolerance: fp16 activations through `layers` post-LN blocks; LN outputs are O(1)
+    assert cos.min() > 0.9995 and err < 4e-3
+    assert herr.mean() < 6e-3 and herr.max() < 8e-2
+
+
+def test_pooling_variants(vf):
+    import torch
+    from veritasfi_amd.retrieval import get_embeddings
+    model = _hf_bert(128, 2, 2, 512)
+    rng = np.random.default_rng(4)
+    ids, mask = _batch(rng, 4, 64, 1000)
+    with torch.no_grad():
+        h = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state
+    cfg, w16, w32 = vf.pack_hf_weights(model, pooling=1, normalize=False)   # unmasked mean (continuous_retrieval.py:148)
+    e = vf.HipEncoder(cfg, w16, w32)
+    # padded columns: the reference averages over whatever the tokenizer padded to; here T = 64 exactly
+    assert np.abs(e.forward(ids, mask) - h.mean(dim=1).numpy()).max() < 2e-2
+    e.close()
+    cfg["pooling"] = 2                                                      # last_token_pool (step3_mul.py:181-188)
+    e = vf.HipEncoder(cfg, w16, w32)
+    lens = mask.sum(1) - 1
+    want = h[torch.arange(4), torch.from_numpy(lens)].numpy()              # right padding branch
+    assert np.abs(e.forward(ids, mask) - want).max() < 3e-2
+    full = np.ones_like(mask)
+    with torch.no_grad():
+        h2 = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(full)).last_hidden_state
+    assert np.abs(e.forward(ids, full) - h2[:, -1].numpy()).max() < 3e-2   # "left padding" branch: [:, -1]
+    # the reference-shaped get_embeddings running its own pooling on HipModel's hidden states
+    class Tok:
+        def __call__(self, texts, padding=True, truncation=True, return_tensors="pt", max_length=None):
+            rows = [ids[int(x)] for x in texts]
+            m = [mask[int(x)] for x in texts]
+            return {"input_ids": torch.from_numpy(np.stack(rows)), "attention_mask": torch.from_numpy(np.stack(m))}
+    emb = get_embeddings(["0", "1", "2", "3"], vf.HipModel(e), Tok(), "cpu", batch_size=2, pooling="last_token")
+    assert emb.shape == (4, 128) and np.abs(emb - want).max() < 3e-2
+    e.close()
+
+
+@pytest.mark.parametrize("hidden,layers,heads,ffn,b,t", [(128, 2, 2, 512, 6, 64), (768, 12, 12, 3072, 8, 256)])
+def test_reranker_matches_torch_fp32(vf, hidden, layers, heads, ffn, b, t):
+    import torch
+    model = _hf_xlmr_cls(hidden, layers, heads, ffn)
+    rng = np.random.default_rng(5)
+    ids, mask = _batch(rng, b, t, 1200, pad_id=1)
+    with torch.no_grad():
+        ref = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits.view(-1).numpy()
+    rr = vf.HipEncoder.from_hf(model)
+    got = rr.forward(ids, mask)
+    rr.close()
+    print("reranker logits", ref[:4], got[:4], np.abs(ref - got).max())
+    assert got.shape == (b,)
+    assert np.abs(ref - got).max() < 2e-2 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(np.argsort(-ref), np.argsort(-got)) or np.abs(ref - got).max() < np.min(np.diff(np.sort(ref)))
+
+
+def test_drop_in_embedder_and_reranker_objects(vf):
+    """HipEmbeddings / HipReranker carry the reference's method names and feed FaissRetriever / rank fusion."""
+    import torch
+    rng = np.random.default_rng(6)
+
+    class Tok:  # whitespace-hash tokenizer with the HF call signature (no tokenizer files offline)
+        def __call__(self, a, b=None, padding=True, truncation=True, max_length=64, return_tensors="np"):
+            a = [a] if isinstance(a, str) else list(a)
+            b = [None] * len(a) if b is None else list(b)
+            rows = []
+            for x, y in zip(a, b):
+                toks = [2] + [5 + (hash(w) % 900) for w in x.split()] + [3]
+                if y is not None:
+                    toks += [5 + (hash(w) % 900) for w in y.split()] + [3]
+                rows.append(toks[:max_length])
+            t = max(len(r) for r in rows)
+            ids = np.ones((len(rows), t), np.int64)
+            mask = np.zeros((len(rows), t), np.int64)
+            for i, r in enumerate(rows):
+                ids[i, :len(r)] = r
+                mask[i, :len(r)] = 1
+            return {"input_ids": ids, "attention_mask": mask}
+
+    emb = vf.HipEmbeddings(Tok(), vf.HipEncoder.from_hf(_hf_bert(128, 2, 2, 512)), max_length=64)
+    docs = [f"doc number {i} about topic {i % 7} and item {i * 3}" for i in range(300)]
+    vecs = emb.embed_documents(docs)
+    assert len(vecs) == 300 and len(vecs[0]) == 128 and abs(np.linalg.norm(vecs[5]) - 1.0) < 1e-3
+    q = emb.embed_query(docs[17])
+    assert np.abs(np.asarray(q) - np.asarray(vecs[17])).max() < 2e-3      # batch-size independence
+    fr = vf.FaissRetriever(vecs, emb)                                      # the reference's constructor call shape
+    I, D = fr.invoke([docs[17], docs[250]], 10)
+    assert I[0, 0] == 17 and I[1, 0] == 250 and D[0, 0] > 0.999
+    mtx = vf.compute_similarity_mtx(emb, docs[:12])
+    assert tuple(mtx.shape) == (12, 12) and float(mtx[3, 3]) > 0.999
+    rr = vf.HipReranker(Tok(), vf.HipEncoder.from_hf(_hf_xlmr_cls(128, 2, 2, 512)), max_length=64)
+    pairs = [["what is topic 3", d] for d in docs[:20]]
+    s8 = rr.compute_score(pairs, batch_size=8)
+    s20 = rr.compute_score(pairs, batch_size=20)
+    assert len(s8) == 20 and all(isinstance(v, float) for v in s8)
+    assert np.abs(np.asarray(s8) - np.asarray(s20)).max() < 5e-3           # micro-batching does not change scores
+    scores, order = vf.fuse_and_rank(s8, [0.1] * 20)
+    assert sorted(order) == list(range(20)) and scores[order[0]] == max(scores)
+
+
+def test_encoder_errors(vf):
+    model = _hf_bert(128, 1, 2, 512)
+    cfg, w16, w32 = vf.pack_hf_weights(model)
+    with pytest.raises(ValueError):
+        vf.HipEncoder(cfg, w16[:-1], w32)
+    bad = dict(cfg, hidden=96)
+    with pytest.raises((RuntimeError, ValueError)):
+        vf.HipEncoder(bad, w16, w32)
+    e = vf.HipEncoder(cfg, w16, w32)
+    with pytest.raises(ValueError):
+        e.forward(np.zeros((1, 600), np.int64), np.ones((1, 600), np.int64))
+    e.close()

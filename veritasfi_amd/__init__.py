@@ -11,6 +11,8 @@ Drop-in names (same signatures as the reference):
                                          -- ``experiments/retriever/step3_mul.py`` / ``continuous_retrieval.py``
 * ``compute_similarity_mtx``, ``fuse_and_rank``, ``time_scores``
                                          -- ``src/utils/ensembleRetriever.py:265-281``, ``src/utils/vllmManager.py:443-457``
+* ``HipEmbeddings`` / ``HipReranker``   -- ``HuggingFaceEmbeddings`` (``src/utils/ragManager.py:50``) /
+                                            ``reranker.compute_score`` (``src/utils/vllmManager.py:451``)
 * ``ShardedRetriever``                   -- row-sharded multi-GPU search
 """
 from .index import DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device  # noqa: F401
@@ -18,5 +20,6 @@ from .faiss_retriever import FaissRetriever  # noqa: F401
 from .retrieval import get_embeddings, last_token_pool, select_top_chunks, select_top_chunks_batch  # noqa: F401
 from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_rank, time_scores  # noqa: F401
 from .sharded import ShardedRetriever, shard_bounds  # noqa: F401
+from .encoder import HipEmbeddings, HipEncoder, HipModel, HipReranker, pack_hf_weights  # noqa: F401
 
 __version__ = "0.1.0"

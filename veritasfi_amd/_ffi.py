@@ -20,6 +20,14 @@ p_i32, p_i64, p_f32 = ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.POINT
 vp = ctypes.c_void_p
 
 
+class EncoderConfig(ctypes.Structure):
+    _fields_ = [
+        ("vocab", c_i32), ("hidden", c_i32), ("layers", c_i32), ("heads", c_i32), ("ffn", c_i32), ("max_pos", c_i32),
+        ("type_vocab", c_i32), ("roberta_pad_idx", c_i32), ("pooling", c_i32), ("normalize", c_i32), ("head", c_i32),
+        ("ln_eps", c_f32),
+    ]
+
+
 class SearchStats(ctypes.Structure):
     _fields_ = [
         ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
@@ -52,6 +60,15 @@ SIGNATURES = {
     "vf_cosine_scores": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32]),
     "vf_merge_topk_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
     "vf_fuse_rank": (ctypes.c_int, [vp, vp, c_i32, vp, vp, c_i32]),
+    "vf_encoder_weight_sizes": (ctypes.c_int, [ctypes.POINTER(EncoderConfig), p_i64, p_i64]),
+    "vf_encoder_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(EncoderConfig), vp, c_i64, vp, c_i64, c_i32]),
+    "vf_encoder_forward": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, c_i32, vp]),
+    "vf_encoder_forward_hidden": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, vp]),
+    "vf_encoder_info": (ctypes.c_int, [vp, ctypes.POINTER(EncoderConfig)]),
+    "vf_encoder_destroy": (ctypes.c_int, [vp]),
+    "vf_reranker_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(EncoderConfig), vp, c_i64, vp, c_i64, c_i32]),
+    "vf_reranker_score": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, vp]),
+    "vf_reranker_destroy": (ctypes.c_int, [vp]),
 }
 
 _lib = None

@@ -28,6 +28,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+int vf::set_error(int code, const std::string& msg) { return fail(code, msg); }
 
 #define VF_HIP(expr)                                                                                   \
     do {                                                                                               \

@@ -4,7 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace vf {
+
+// records the thread-local message vf_last_error() returns; returns `code` (defined in vf_api.hip)
+int set_error(int code, const std::string& msg);
 
 typedef unsigned long long u64;
 typedef unsigned int u32;

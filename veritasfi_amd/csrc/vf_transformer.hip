@@ -1,0 +1,680 @@
+// vf_transformer.hip -- encoder forward for the embedding model and the cross-encoder re-ranker,
+// hand-written for gfx950 (wave64, v_mfma_f32_32x32x16_f16).  Replaces what the reference delegates to
+//   * HuggingFaceEmbeddings.embed_query / embed_documents (src/utils/ragManager.py:50;
+//     src/utils/faissRetriever.py:33; src/load_data.py:99,124) -- BERT / XLM-R encoder + pooling
+//   * get_embeddings (experiments/retriever/step3_mul.py:191-209, continuous_retrieval.py:127-152)
+//   * the re-ranker's compute_score (src/utils/vllmManager.py:450-452), encoder-style cross-encoder
+//     (XLM-R + RobertaClassificationHead: BASELINE.json configs[3], [4])
+//
+// Post-LN BERT-family layer, inference only:
+//   x   = LN(word[ids] + pos[p] + type[tt])
+//   qkv = x Wqkv^T + b ;  ctx = softmax(q k^T / sqrt(dh) + mask) v
+//   x   = LN(ctx Wo^T + b + x) ;  x = LN(gelu(x W1^T + b) W2^T + b + x)
+// fp16 weights and activations, fp32 accumulation (MFMA), fp32 LayerNorm / softmax / GELU / pooling.
+//
+// Kernels
+//   k_embed_ln     gather three embeddings, add, LayerNorm                     (HBM-bound, tiny)
+//   k_gemm_tn<EPI> C = A[M,K] W[N,K]^T + bias (+GELU | +residual), 128x128x64 tiles, LDS double buffer
+//   k_attention    fused q k^T -> online softmax -> p v per (batch, head, 128 queries); K and V^T in LDS
+//   k_layernorm    row LayerNorm, one wave per row
+//   k_pool         CLS / mean / last-token pooling (+ L2 normalise)  or  RoBERTa classification head
+#include "../../include/veritasfi_hip.h"
+#include "vf_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace vft {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+static int fail(int code, const std::string& msg) { return vf::set_error(code, msg); }
+
+#define VFT_HIP(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(VF_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (vf_transformer.hip:" + \
+                                     std::to_string(__LINE__) + ")");                                     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// position ids: BERT 0..t-1; RoBERTa cumsum(mask) * mask + pad_idx  (pos_offset = pad_idx = 1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_position_ids(const int* mask, int B, int T, int roberta_pad, int* pos) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int run = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int m = t < T ? (mask[b * T + t] != 0) : 0;
+        int inc = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (t < T) pos[b * T + t] = roberta_pad >= 0 ? (m ? run + inc + roberta_pad : roberta_pad) : t;
+        run += __shfl(inc, 63);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings + LayerNorm: one wave per token.  H multiple of 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_ln(const int* ids, const int* pos, const int* tts, const half_t* word,
+                                                   const half_t* posw, const half_t* typew, const float* g,
+                                                   const float* bta, float eps, int M, int H, half_t* out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const half_t* w = word + (long long)ids[row] * H;
+    const half_t* p = posw + (long long)pos[row] * H;
+    const half_t* t = typew + (long long)(tts ? tts[row] : 0) * H;
+    float v[16];  // H <= 1024; loops are fully unrolled with a predicate so v[] stays in registers
+    const int per = H >> 6;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = i < per ? (float)w[j] + (float)p[j] + (float)t[j] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = i < per ? v[i] - mean : 0.f; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / H + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        if (i < per) out[(long long)row * H + j] = (half_t)((v[i] - mean) * rstd * g[j] + bta[j]);
+    }
+}
+
+// row LayerNorm of y -> x, one wave per row
+__global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float* g, const float* bta, float eps, int M,
+                                                    int H, half_t* x) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const half_t* src = y + (long long)row * H;
+    float v[16];
+    const int per = H >> 6;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = i < per ? (float)src[lane + 64 * i] : 0.f; s += v[i]; }
+    const float mean = wave_sum(s) / H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = i < per ? v[i] - mean : 0.f; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / H + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        if (i < per) x[(long long)row * H + j] = (half_t)((v[i] - mean) * rstd * g[j] + bta[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[M,N] = A[M,K] * W[N,K]^T + bias (+ epilogue).  Both operands K-contiguous ("TN"), which is
+// how nn.Linear stores W.  128x128 tile per 256-thread workgroup (4 waves as 2x2, 64x64 each = 2x2
+// MFMA 32x32 tiles), BK = 64, two LDS buffers, register-staged global->LDS with the next tile's loads
+// issued before the MFMAs of the current one and written to the other buffer after them (one barrier
+// per K-tile).  LDS rows padded to 144 B: ds_read_b128 fragment reads are conflict-free.
+// Requires M % 128 == 0 (buffers are padded), N % 128 == 0, K % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                  const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                  half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* As = (half_t*)smem;              // [2][GBM][GLD]
+    half_t* Ws = As + 2 * GBM * GLD;         // [2][GBN][GLD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5, wr = wid >> 1, wc = wid & 1;
+    const long long m0 = (long long)blockIdx.y * GBM, n0 = (long long)blockIdx.x * GBN;
+    uint4 ra[4], rw[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+            ra[i] = *(const uint4*)(A + (m0 + row) * K + (long long)kt * GBK + kc * 8);
+            rw[i] = *(const uint4*)(W + (n0 + row) * K + (long long)kt * GBK + kc * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+            *(uint4*)(As + (buf * GBM + row) * GLD + kc * 8) = ra[i];
+            *(uint4*)(Ws + (buf * GBN + row) * GLD + kc * 8) = rw[i];
+        }
+    };
+    f16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int nk = K / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const half_t* a_base = As + (buf * GBM + wr * 64 + r31) * GLD + h * 8;
+        const half_t* w_base = Ws + (buf * GBN + wc * 64 + r31) * GLD + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            h8 af[2], wf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *(const h8*)(a_base + t * 32 * GLD + ks * 16);
+                wf[t] = *(const h8*)(w_base + t * 32 * GLD + ks * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: acc[mt][nt][reg] -> row m0 + wr*64 + mt*32 + (reg&3) + 8*(reg>>2) + 4*h, col n0 + wc*64 + nt*32 + r31
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const long long n = n0 + wc * 64 + nt * 32 + r31;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long long m = m0 + wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float v = acc[mt][nt][reg] + bv;
+                if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if (EPI == EPI_BIAS_RESIDUAL) v += (float)R[m * N + n];
+                C[m * N + n] = (half_t)v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused attention.  grid (ceil(T/128), heads, B), 256 threads; wave w handles queries
+// [qb*128 + 32w, +32) of sequence b, head hd; K [T][64] and V^T [64][T] of that (b, head) live in LDS.
+// S^T = K Q^T is computed with the KEY on the MFMA row, so a lane holds 16 key scores of ONE query
+// (its partner lane + 32 the other 16): softmax reductions are in-lane plus one lane^32 exchange, and
+// the probabilities are already the B operand of O^T = V^T P^T (k-slot order (j&3) + 8*(j>>2) + 4*h,
+// matched by reading V^T as two 8-byte groups).  Online softmax over 32-key tiles.
+// dh = 64, T % 32 == 0, T <= 512.
+// ------------------------------------------------------------------------------------------------
+constexpr int ADH = 64, AKLD = ADH + 8;
+
+__global__ __launch_bounds__(256) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
+                                                    int H, int vt_ld, half_t* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* Ks = (half_t*)smem;                   // [T][AKLD]
+    half_t* Vt = Ks + (size_t)T * AKLD;           // [64][vt_ld]
+    float* mb = (float*)(Vt + (size_t)ADH * vt_ld);  // [T] additive mask
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y, qb = blockIdx.x;
+    const long long row0 = (long long)b * T;
+    const int ld = 3 * H;
+    const half_t* Kg = qkv + row0 * ld + H + hd * ADH;
+    const half_t* Vg = qkv + row0 * ld + 2 * H + hd * ADH;
+    for (int c = tid; c < T * 8; c += 256) {  // 16-byte chunks: key t, dh [8*kc, +8)
+        const int t = c >> 3, kc = c & 7;
+        *(uint4*)(Ks + t * AKLD + kc * 8) = *(const uint4*)(Kg + (long long)t * ld + kc * 8);
+        const h8 v = *(const h8*)(Vg + (long long)t * ld + kc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(kc * 8 + e) * vt_ld + t] = v[e];
+    }
+    for (int t = tid; t < T; t += 256) mb[t] = mask[row0 + t] ? 0.f : -30000.f;
+    __syncthreads();
+    const int q0 = qb * 128 + wid * 32;
+    if (q0 >= T) return;
+    // Q fragments (B operand): lane (query r31, half h) holds q[8h + j + 16 ks], scaled by 1/sqrt(64)
+    h8 qf[4];
+    {
+        const int q = q0 + r31 < T ? q0 + r31 : T - 1;
+        const half_t* Qg = qkv + (row0 + q) * ld + hd * ADH + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            h8 v = *(const h8*)(Qg + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
+            qf[ks] = v;
+        }
+    }
+    f16v o[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float LOG2E = 1.4426950408889634f;
+    for (int kt = 0; kt < T; kt += 32) {
+        f16v s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h8 kf = *(const h8*)(Ks + (kt + r31) * AKLD + ks * 16 + h * 8);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        }
+        float tmax = -1e30f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int key = kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            s[reg] += mb[key];
+            tmax = fmaxf(tmax, s[reg]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        float psum = 0.f;
+        h8 pf[2];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float p = exp2f((s[reg] - m_new) * LOG2E);
+            psum += p;
+            pf[reg >> 3][reg & 7] = (half_t)p;
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+        // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half_t* vrow = Vt + (mt * 32 + r31) * vt_ld + kt + 16 * st + 4 * h;
+                const h4 lo4 = *(const h4*)(vrow);
+                const h4 hi4 = *(const h4*)(vrow + 8);
+                h8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
+                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
+            }
+    }
+    if (q0 + r31 < T) {
+        const float inv = 1.0f / l_run;
+        half_t* dst = ctx + (row0 + q0 + r31) * H + hd * ADH;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
+                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling / heads: one 256-thread block per sequence -> out[b, :]
+//   pooling 0 CLS (token 0), 1 unmasked mean over T (continuous_retrieval.py:148 quirk), 2 last
+//   token per last_token_pool (step3_mul.py:181-188: position T-1 if EVERY row's last mask bit is 1,
+//   else sum(mask)-1);  normalize: L2 (sentence-transformers Normalize module)
+//   head 1: RobertaClassificationHead  logit = out_proj(tanh(dense(x_cls)))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool(const half_t* x, const int* mask, int T, int Tv, int H, int pooling,
+                                               int normalize, int all_last_set, int head, const half_t* Wd,
+                                               const float* bd, const half_t* Wp, const float* bp, float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* v = (float*)smem;        // [H]
+    float* red = v + H;             // [256]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const half_t* xb = x + (long long)b * T * H;
+    int tok = 0;
+    if (pooling == 2) {
+        if (all_last_set) tok = Tv - 1;
+        else {
+            int c = 0;
+            for (int t = 0; t < Tv; ++t) c += mask[b * T + t] != 0;
+            tok = c > 0 ? c - 1 : 0;
+        }
+    }
+    for (int j = tid; j < H; j += 256) {
+        float s = 0.f;
+        if (pooling == 1) {
+            for (int t = 0; t < Tv; ++t) s += (float)xb[(long long)t * H + j];
+            s /= Tv;
+        } else {
+            s = (float)xb[(long long)tok * H + j];
+        }
+        v[j] = s;
+    }
+    __syncthreads();
+    if (head == 1) {
+        // dense + tanh -> red-free second stage: each thread computes some outputs of dense
+        float* y = red + 256;  // [H]
+        for (int o = tid; o < H; o += 256) {
+            float s = bd[o];
+            for (int j = 0; j < H; ++j) s += (float)Wd[(long long)o * H + j] * v[j];
+            y[o] = tanhf(s);
+        }
+        __syncthreads();
+        float part = 0.f;
+        for (int j = tid; j < H; j += 256) part += (float)Wp[j] * y[j];
+        red[tid] = part;
+        __syncthreads();
+        for (int s2 = 128; s2; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+        if (tid == 0) out[b] = red[0] + bp[0];
+        return;
+    }
+    float scale = 1.f;
+    if (normalize) {
+        float part = 0.f;
+        for (int j = tid; j < H; j += 256) part += v[j] * v[j];
+        red[tid] = part;
+        __syncthreads();
+        for (int s2 = 128; s2; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+        const float nrm = sqrtf(red[0]);
+        scale = 1.0f / fmaxf(nrm, 1e-12f);
+    }
+    for (int j = tid; j < H; j += 256) out[(long long)b * H + j] = v[j] * scale;
+}
+
+__global__ void k_to_f32(const half_t* x, long long n, float* out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = (float)x[i];
+}
+
+// returns 1 if mask[:, T-1] is all ones (last_token_pool's left-padding test)
+__global__ void k_all_last_set(const int* mask, int B, int T, int Tv, int* out) {
+    int ok = 1;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) ok &= mask[b * T + Tv - 1] != 0;
+    ok = __all(ok);
+    if (threadIdx.x == 0) *out = ok;
+}
+
+}  // namespace vft
+
+// ------------------------------------------------------------------------------------------------
+// handle + C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace vft;
+
+struct vf_encoder {
+    vf_encoder_config cfg{};
+    int device = 0;
+    half_t* w16 = nullptr;   // all fp16 matrices
+    float* w32 = nullptr;    // all fp32 vectors (biases, LayerNorm)
+    // fp16 offsets (elements)
+    size_t o_word = 0, o_pos = 0, o_type = 0, o_layers = 0, o_head_dense = 0, o_head_out = 0, layer16 = 0;
+    // fp32 offsets
+    size_t f_emb_g = 0, f_emb_b = 0, f_layers = 0, f_head_bd = 0, f_head_bp = 0, layer32 = 0;
+    // workspace (grown on demand)
+    int cap_tokens = 0, cap_b = 0;
+    half_t *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *hbuf = nullptr;
+    int *d_ids = nullptr, *d_mask = nullptr, *d_tt = nullptr, *d_pos = nullptr, *d_flag = nullptr;
+    float* d_out = nullptr;
+    float* d_hidden = nullptr;  // [cap_tokens, H] fp32, for vf_encoder_forward_hidden
+    std::mutex mu;
+};
+
+static size_t enc_n16(const vf_encoder_config& c) {
+    const size_t H = c.hidden, F = c.ffn;
+    size_t n = (size_t)c.vocab * H + (size_t)c.max_pos * H + (size_t)c.type_vocab * H;
+    n += (size_t)c.layers * (3 * H * H + H * H + F * H + H * F);
+    if (c.head == 1) n += H * H + H;
+    return n;
+}
+static size_t enc_n32(const vf_encoder_config& c) {
+    const size_t H = c.hidden, F = c.ffn;
+    size_t n = 2 * H + (size_t)c.layers * (3 * H + H + 2 * H + F + H + 2 * H);
+    if (c.head == 1) n += H + 1;
+    return n;
+}
+
+extern "C" int vf_encoder_weight_sizes(const vf_encoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32) {
+    if (!cfg || !n_fp16 || !n_fp32) return fail(VF_EINVAL, "vf_encoder_weight_sizes: null argument");
+    *n_fp16 = (int64_t)enc_n16(*cfg);
+    *n_fp32 = (int64_t)enc_n32(*cfg);
+    return VF_OK;
+}
+
+static void enc_free_ws(vf_encoder* e) {
+    void* p[] = {e->x, e->y, e->qkv, e->ctx, e->hbuf, e->d_ids, e->d_mask, e->d_tt, e->d_pos, e->d_out, e->d_hidden};
+    for (void* q : p) if (q) (void)hipFree(q);
+    e->x = e->y = e->qkv = e->ctx = e->hbuf = nullptr;
+    e->d_ids = e->d_mask = e->d_tt = e->d_pos = nullptr;
+    e->d_out = nullptr; e->d_hidden = nullptr;
+    e->cap_tokens = 0; e->cap_b = 0;
+}
+
+extern "C" int vf_encoder_destroy(vf_encoder* e) {
+    if (!e) return VF_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    enc_free_ws(e);
+    if (e->w16) (void)hipFree(e->w16);
+    if (e->w32) (void)hipFree(e->w32);
+    if (e->d_flag) (void)hipFree(e->d_flag);
+    delete e;
+    return VF_OK;
+}
+
+extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg, const void* w16, int64_t n16,
+                                 const float* w32, int64_t n32, int32_t device_id) {
+    if (!out) return fail(VF_EINVAL, "vf_encoder_create: null out");
+    *out = nullptr;
+    if (!cfg || !w16 || !w32) return fail(VF_EINVAL, "vf_encoder_create: null argument");
+    const vf_encoder_config& c = *cfg;
+    if (c.hidden <= 0 || c.hidden % 128 != 0 || c.hidden > 1024) return fail(VF_EUNSUPPORTED, "hidden must be a multiple of 128, <= 1024");
+    if (c.heads <= 0 || c.hidden / c.heads != 64 || c.hidden % c.heads) return fail(VF_EUNSUPPORTED, "head dim must be 64");
+    if (c.ffn <= 0 || c.ffn % 128 != 0) return fail(VF_EUNSUPPORTED, "ffn must be a multiple of 128");
+    if (c.layers <= 0 || c.vocab <= 0 || c.max_pos <= 0 || c.type_vocab <= 0) return fail(VF_EINVAL, "bad encoder config");
+    if (c.pooling < 0 || c.pooling > 2 || c.head < 0 || c.head > 1) return fail(VF_EINVAL, "bad pooling / head");
+    if ((size_t)n16 != enc_n16(c) || (size_t)n32 != enc_n32(c))
+        return fail(VF_EINVAL, "vf_encoder_create: weight blob sizes do not match the config (see vf_encoder_weight_sizes)");
+    int ndev = 0;
+    VFT_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(VF_EINVAL, "vf_encoder_create: bad device_id");
+    VFT_HIP(hipSetDevice(device_id));
+    vf_encoder* e = new (std::nothrow) vf_encoder();
+    if (!e) return fail(VF_ENOMEM, "host allocation failed");
+    e->cfg = c; e->device = device_id;
+    const size_t H = c.hidden, F = c.ffn;
+    e->o_word = 0; e->o_pos = e->o_word + (size_t)c.vocab * H; e->o_type = e->o_pos + (size_t)c.max_pos * H;
+    e->o_layers = e->o_type + (size_t)c.type_vocab * H;
+    e->layer16 = 3 * H * H + H * H + F * H + H * F;
+    e->o_head_dense = e->o_layers + (size_t)c.layers * e->layer16;
+    e->o_head_out = e->o_head_dense + H * H;
+    e->f_emb_g = 0; e->f_emb_b = H; e->f_layers = 2 * H;
+    e->layer32 = 3 * H + H + 2 * H + F + H + 2 * H;
+    e->f_head_bd = e->f_layers + (size_t)c.layers * e->layer32;
+    e->f_head_bp = e->f_head_bd + H;
+    hipError_t er = hipMalloc((void**)&e->w16, (size_t)n16 * 2);
+    if (er == hipSuccess) er = hipMalloc((void**)&e->w32, (size_t)n32 * 4);
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_flag, 4);
+    if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er != hipSuccess) {
+        const std::string msg = std::string("vf_encoder_create: ") + hipGetErrorString(er);
+        vf_encoder_destroy(e);
+        return fail(VF_EHIP, msg);
+    }
+    *out = e;
+    return VF_OK;
+}
+
+static int enc_ensure_ws(vf_encoder* e, int B, int T) {
+    const int tokens = (B * T + 127) / 128 * 128;
+    if (tokens <= e->cap_tokens && B <= e->cap_b) return VF_OK;
+    enc_free_ws(e);
+    const size_t H = e->cfg.hidden, F = e->cfg.ffn, Mp = tokens;
+    const int out_dim = e->cfg.head == 1 ? 1 : (int)H;
+    VFT_HIP(hipMalloc((void**)&e->x, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&e->y, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&e->qkv, Mp * 3 * H * 2));
+    VFT_HIP(hipMalloc((void**)&e->ctx, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&e->hbuf, Mp * F * 2));
+    VFT_HIP(hipMalloc((void**)&e->d_ids, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&e->d_mask, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&e->d_tt, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&e->d_pos, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&e->d_out, (size_t)B * out_dim * 4));
+    VFT_HIP(hipMalloc((void**)&e->d_hidden, Mp * H * 4));
+    // padded rows are read by the GEMMs: keep them finite
+    VFT_HIP(hipMemset(e->x, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(e->y, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(e->qkv, 0, Mp * 3 * H * 2));
+    VFT_HIP(hipMemset(e->ctx, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(e->hbuf, 0, Mp * F * 2));
+    e->cap_tokens = tokens; e->cap_b = B;
+    return VF_OK;
+}
+
+template <int EPI>
+static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
+                       int K, hipStream_t st) {
+    const dim3 grid(N / GBN, M / GBM);
+    const size_t lds = (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t);
+    hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
+    return hipGetLastError();
+}
+
+// ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
+static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, hipStream_t st) {
+    const vf_encoder_config& c = e->cfg;
+    const int H = c.hidden, F = c.ffn, M = B * T, Mp = (M + 127) / 128 * 128;
+    hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
+    hipLaunchKernelGGL(k_embed_ln, dim3((M + 3) / 4), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
+                       e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
+                       c.ln_eps, M, H, e->x);
+    // V^T row stride: (T + pad) halves with (T + pad) / 2 == 2 (mod 64) -> conflict-free 8-byte reads
+    int pad = 4;
+    while ((((T + pad) / 2) & 63) != 2) pad += 4;
+    const int vt_ld = T + pad;
+    const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4;
+    for (int l = 0; l < c.layers; ++l) {
+        const half_t* w = e->w16 + e->o_layers + (size_t)l * e->layer16;
+        const float* f = e->w32 + e->f_layers + (size_t)l * e->layer32;
+        const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
+        const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F, *g2 = b2 + H,
+                    *b2n = g2 + H;
+        VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
+        hipLaunchKernelGGL(k_attention, dim3((T + 127) / 128, c.heads, B), dim3(256), att_lds, st, e->qkv, e->d_mask, T, H,
+                           vt_ld, e->ctx);
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
+        VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st));
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
+    }
+    int all_last = 0;
+    if (c.pooling == 2) {
+        hipLaunchKernelGGL(k_all_last_set, dim3(1), dim3(64), 0, st, e->d_mask, B, T, Tv, e->d_flag);
+        VFT_HIP(hipMemcpyAsync(&all_last, e->d_flag, 4, hipMemcpyDeviceToHost, st));
+        VFT_HIP(hipStreamSynchronize(st));
+    }
+    const size_t pool_lds = ((size_t)H * 2 + 256) * sizeof(float);
+    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), pool_lds, st, e->x, e->d_mask, T, Tv, H, c.pooling, c.normalize, all_last,
+                       c.head, e->w16 + e->o_head_dense, e->w32 + e->f_head_bd, e->w16 + e->o_head_out,
+                       e->w32 + e->f_head_bp, e->d_out);
+    VFT_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                                  int32_t b, int32_t t, int32_t t_valid, float* out) {
+    if (!e) return fail(VF_EINVAL, "vf_encoder_forward: null handle");
+    if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_encoder_forward: negative sizes");
+    if (b == 0) return VF_OK;
+    if (!ids || !mask || !out) return fail(VF_EINVAL, "vf_encoder_forward: null buffer");
+    if (t == 0 || t % 32 != 0 || t > 512) return fail(VF_EINVAL, "vf_encoder_forward: t must be a multiple of 32 in [32, 512] (pad with mask 0)");
+    if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_encoder_forward: t_valid must be in [1, t]");
+    if (t > e->cfg.max_pos - (e->cfg.roberta_pad_idx >= 0 ? e->cfg.roberta_pad_idx + 1 : 0))
+        return fail(VF_EINVAL, "vf_encoder_forward: t exceeds the position table");
+    std::lock_guard<std::mutex> g(e->mu);
+    VFT_HIP(hipSetDevice(e->device));
+    int rc = enc_ensure_ws(e, b, t);
+    if (rc != VF_OK) return rc;
+    const size_t n = (size_t)b * t;
+    VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, nullptr));
+    VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, nullptr));
+    if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, nullptr));
+    rc = enc_forward_device(e, b, t, t_valid, type_ids != nullptr, nullptr);
+    if (rc != VF_OK) return rc;
+    const int out_dim = e->cfg.head == 1 ? 1 : e->cfg.hidden;
+    VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
+    VFT_HIP(hipStreamSynchronize(nullptr));
+    return VF_OK;
+}
+
+// last_hidden_state [b, t, hidden] fp32 (what the reference's get_embeddings pools itself:
+// experiments/retriever/step3_mul.py:203-207, continuous_retrieval.py:146-149)
+extern "C" int vf_encoder_forward_hidden(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                                         int32_t b, int32_t t, float* out_hidden) {
+    if (!e) return fail(VF_EINVAL, "vf_encoder_forward_hidden: null handle");
+    if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_encoder_forward_hidden: negative sizes");
+    if (b == 0) return VF_OK;
+    if (!ids || !mask || !out_hidden) return fail(VF_EINVAL, "vf_encoder_forward_hidden: null buffer");
+    if (t == 0 || t % 32 != 0 || t > 512) return fail(VF_EINVAL, "vf_encoder_forward_hidden: t must be a multiple of 32 in [32, 512]");
+    std::lock_guard<std::mutex> g(e->mu);
+    VFT_HIP(hipSetDevice(e->device));
+    int rc = enc_ensure_ws(e, b, t);
+    if (rc != VF_OK) return rc;
+    const size_t n = (size_t)b * t;
+    VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, nullptr));
+    VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, nullptr));
+    if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, nullptr));
+    rc = enc_forward_device(e, b, t, t, type_ids != nullptr, nullptr);
+    if (rc != VF_OK) return rc;
+    const long long tot = (long long)n * e->cfg.hidden;
+    hipLaunchKernelGGL(k_to_f32, dim3(1024), dim3(256), 0, nullptr, e->x, tot, e->d_hidden);
+    VFT_HIP(hipMemcpyAsync(out_hidden, e->d_hidden, (size_t)tot * 4, hipMemcpyDeviceToHost, nullptr));
+    VFT_HIP(hipStreamSynchronize(nullptr));
+    return VF_OK;
+}
+
+extern "C" int vf_encoder_info(vf_encoder* e, vf_encoder_config* out) {
+    if (!e || !out) return fail(VF_EINVAL, "vf_encoder_info: null argument");
+    *out = e->cfg;
+    return VF_OK;
+}
+
+// the re-ranker is an encoder with head == 1: same object, named entry points for the reference's
+// compute_score (src/utils/vllmManager.py:451)
+extern "C" int vf_reranker_create(vf_encoder** out, const vf_encoder_config* cfg, const void* w16, int64_t n16,
+                                  const float* w32, int64_t n32, int32_t device_id) {
+    if (cfg && cfg->head != 1) return fail(VF_EINVAL, "vf_reranker_create: config.head must be 1");
+    return vf_encoder_create(out, cfg, w16, n16, w32, n32, device_id);
+}
+extern "C" int vf_reranker_score(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                                 int32_t b, int32_t t, float* out_scores) {
+    if (e && e->cfg.head != 1) return fail(VF_EINVAL, "vf_reranker_score: handle is not a re-ranker");
+    return vf_encoder_forward(e, ids, mask, type_ids, b, t, t, out_scores);
+}
+extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e); }

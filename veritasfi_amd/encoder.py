@@ -1,0 +1,227 @@
+"""Encoder forward on the GPU: the embedding model and the cross-encoder re-ranker.
+
+Drop-in objects for the reference's third-party model handles:
+
+* ``HipEmbeddings`` -- ``.embed_query(str)`` / ``.embed_documents(list[str])``, the surface of
+  ``HuggingFaceEmbeddings`` constructed at ``src/utils/ragManager.py:50`` and used at
+  ``src/utils/faissRetriever.py:33``, ``src/utils/ensembleRetriever.py:248,275`` and (through
+  ``Chroma.add_texts``) by the embed loop ``src/load_data.py:98-99,120-128``.
+* ``HipReranker`` -- ``.compute_score(pairs, batch_size=8) -> list[float]`` (raw logits), the call at
+  ``src/utils/vllmManager.py:450-452``; encoder-style cross-encoder (XLM-R + classification head), the
+  model family BASELINE.json configs[3]/[4] name.
+* ``HipModel`` -- callable with the HF signature returning ``.last_hidden_state`` so that
+  ``get_embeddings`` (``experiments/retriever/step3_mul.py:191-209``) runs its own pooling on it.
+
+Weights come from any HF BERT / RoBERTa / XLM-R module (``pack_hf_weights``); tokenisation stays in Python
+(any HF-style tokenizer callable).  All arithmetic is HIP (``csrc/vf_transformer.hip``) behind
+``vf_encoder_*`` / ``vf_reranker_*``; there is no torch or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import types
+
+import numpy as np
+
+from . import _ffi
+
+POOL_CLS, POOL_MEAN_UNMASKED, POOL_LAST_TOKEN = 0, 1, 2
+
+
+def _np16(t):
+    return t.detach().cpu().float().numpy().astype(np.float16).ravel()
+
+
+def _np32(t):
+    return t.detach().cpu().float().numpy().astype(np.float32).ravel()
+
+
+def pack_hf_weights(model, pooling=POOL_CLS, normalize=True):
+    """Flatten a HF ``BertModel`` / ``RobertaModel`` / ``XLMRobertaModel`` or ``...ForSequenceClassification``
+    into the two blobs ``vf_encoder_create`` takes (layout: include/veritasfi_hip.h).  Returns (cfg, w16, w32)."""
+    sd = model.state_dict()
+    cfgm = model.config
+    prefix = ""
+    for cand in ("roberta.", "bert.", ""):
+        if f"{cand}embeddings.word_embeddings.weight" in sd:
+            prefix = cand
+            break
+    has_head = "classifier.out_proj.weight" in sd
+    is_roberta = cfgm.model_type in ("roberta", "xlm-roberta")
+    H, F, L = cfgm.hidden_size, cfgm.intermediate_size, cfgm.num_hidden_layers
+    if has_head and sd["classifier.out_proj.weight"].shape[0] != 1:
+        raise ValueError("only single-logit classification heads are supported (num_labels=1)")
+    if getattr(cfgm, "hidden_act", "gelu") != "gelu":
+        raise ValueError("only exact GELU is implemented")
+    g = lambda k: sd[prefix + k]
+    w16 = [_np16(g("embeddings.word_embeddings.weight")), _np16(g("embeddings.position_embeddings.weight")),
+           _np16(g("embeddings.token_type_embeddings.weight"))]
+    w32 = [_np32(g("embeddings.LayerNorm.weight")), _np32(g("embeddings.LayerNorm.bias"))]
+    for l in range(L):
+        p = f"encoder.layer.{l}."
+        w16 += [_np16(g(p + "attention.self.query.weight")), _np16(g(p + "attention.self.key.weight")),
+                _np16(g(p + "attention.self.value.weight")), _np16(g(p + "attention.output.dense.weight")),
+                _np16(g(p + "intermediate.dense.weight")), _np16(g(p + "output.dense.weight"))]
+        w32 += [_np32(g(p + "attention.self.query.bias")), _np32(g(p + "attention.self.key.bias")),
+                _np32(g(p + "attention.self.value.bias")), _np32(g(p + "attention.output.dense.bias")),
+                _np32(g(p + "attention.output.LayerNorm.weight")), _np32(g(p + "attention.output.LayerNorm.bias")),
+                _np32(g(p + "intermediate.dense.bias")), _np32(g(p + "output.dense.bias")),
+                _np32(g(p + "output.LayerNorm.weight")), _np32(g(p + "output.LayerNorm.bias"))]
+    if has_head:
+        w16 += [_np16(sd["classifier.dense.weight"]), _np16(sd["classifier.out_proj.weight"])]
+        w32 += [_np32(sd["classifier.dense.bias"]), _np32(sd["classifier.out_proj.bias"])]
+    cfg = dict(vocab=cfgm.vocab_size, hidden=H, layers=L, heads=cfgm.num_attention_heads, ffn=F,
+               max_pos=cfgm.max_position_embeddings, type_vocab=cfgm.type_vocab_size,
+               roberta_pad_idx=(cfgm.pad_token_id if is_roberta else -1), pooling=pooling,
+               normalize=int(bool(normalize)) if not has_head else 0, head=int(has_head),
+               ln_eps=float(cfgm.layer_norm_eps))
+    return cfg, np.ascontiguousarray(np.concatenate(w16)), np.ascontiguousarray(np.concatenate(w32))
+
+
+class HipEncoder:
+    """Handle over ``vf_encoder_*``.  ``forward`` takes int token ids / mask [b, t] (any t <= 512)."""
+
+    def __init__(self, cfg: dict, w16: np.ndarray, w32: np.ndarray, device_id: int = 0):
+        L = _ffi.lib()
+        self.cfg = dict(cfg)
+        c = _ffi.EncoderConfig(**cfg)
+        n16, n32 = _ffi.c_i64(0), _ffi.c_i64(0)
+        _ffi.check(L.vf_encoder_weight_sizes(ctypes.byref(c), ctypes.byref(n16), ctypes.byref(n32)), "vf_encoder_weight_sizes")
+        w16 = np.ascontiguousarray(w16, dtype=np.float16)
+        w32 = np.ascontiguousarray(w32, dtype=np.float32)
+        if w16.size != n16.value or w32.size != n32.value:
+            raise ValueError(f"weight blobs have {w16.size}/{w32.size} elements, config needs {n16.value}/{n32.value}")
+        self._h = _ffi.vp()
+        create = L.vf_reranker_create if cfg.get("head", 0) == 1 else L.vf_encoder_create
+        _ffi.check(create(ctypes.byref(self._h), ctypes.byref(c), w16.ctypes.data, w16.size, w32.ctypes.data, w32.size,
+                          int(device_id)), "vf_encoder_create")
+        self.hidden = int(cfg["hidden"])
+        self.out_dim = 1 if cfg.get("head", 0) == 1 else self.hidden
+
+    @classmethod
+    def from_hf(cls, model, pooling=POOL_CLS, normalize=True, device_id: int = 0):
+        return cls(*pack_hf_weights(model, pooling, normalize), device_id=device_id)
+
+    @staticmethod
+    def _pad(ids, mask, type_ids):
+        ids = np.asarray(ids, dtype=np.int32)
+        mask = np.asarray(mask, dtype=np.int32)
+        b, t = ids.shape
+        tp = max(32, -(-t // 32) * 32)
+        if tp > 512:
+            raise ValueError("sequences longer than 512 tokens are not supported")
+        def pad(a):
+            if a is None:
+                return None
+            out = np.zeros((b, tp), dtype=np.int32)
+            out[:, :t] = np.asarray(a, dtype=np.int32)
+            return out
+        return pad(ids), pad(mask), pad(type_ids), b, t, tp
+
+    def forward(self, ids, mask, type_ids=None) -> np.ndarray:
+        """Pooled output: [b, hidden] embeddings, or [b] logits for a re-ranker."""
+        ids, mask, tt, b, t, tp = self._pad(ids, mask, type_ids)
+        out = np.empty((b, self.out_dim), dtype=np.float32)
+        ptt = tt.ctypes.data if tt is not None else None
+        if self.cfg.get("head", 0) == 1:
+            rc = _ffi.lib().vf_reranker_score(self._h, ids.ctypes.data, mask.ctypes.data, ptt, b, tp, out.ctypes.data)
+        else:
+            rc = _ffi.lib().vf_encoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, ptt, b, tp, t, out.ctypes.data)
+        _ffi.check(rc, "vf_encoder_forward")
+        return out[:, 0] if self.out_dim == 1 else out
+
+    def hidden_states(self, ids, mask, type_ids=None) -> np.ndarray:
+        """last_hidden_state [b, t, hidden] fp32 (padding columns beyond the given t removed)."""
+        ids, mask, tt, b, t, tp = self._pad(ids, mask, type_ids)
+        out = np.empty((b, tp, self.hidden), dtype=np.float32)
+        _ffi.check(_ffi.lib().vf_encoder_forward_hidden(self._h, ids.ctypes.data, mask.ctypes.data,
+                                                        tt.ctypes.data if tt is not None else None, b, tp,
+                                                        out.ctypes.data), "vf_encoder_forward_hidden")
+        return out[:, :t]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _ffi.lib().vf_encoder_destroy(self._h)
+            self._h = _ffi.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _tok_arrays(enc):
+    """ids / mask / token_type_ids as numpy from whatever an HF-style tokenizer returned."""
+    def arr(x):
+        if x is None:
+            return None
+        if hasattr(x, "detach"):
+            x = x.detach().cpu().numpy()
+        return np.asarray(x)
+    return arr(enc["input_ids"]), arr(enc["attention_mask"]), arr(enc.get("token_type_ids") if hasattr(enc, "get") else None)
+
+
+class HipModel:
+    """HF-signature callable: ``model(**inputs).last_hidden_state`` (torch tensor), for get_embeddings."""
+
+    def __init__(self, encoder: HipEncoder):
+        self.encoder = encoder
+
+    def __call__(self, input_ids=None, attention_mask=None, token_type_ids=None, **_):
+        import torch
+        ids, mask, tt = _tok_arrays({"input_ids": input_ids, "attention_mask": attention_mask,
+                                     "token_type_ids": token_type_ids})
+        return types.SimpleNamespace(last_hidden_state=torch.from_numpy(self.encoder.hidden_states(ids, mask, tt)))
+
+
+class HipEmbeddings:
+    """``HuggingFaceEmbeddings``-shaped embedder.  ``tokenizer(texts, padding=True, truncation=True,
+    max_length=..., return_tensors="np")`` must return input_ids / attention_mask."""
+
+    def __init__(self, tokenizer, encoder: HipEncoder, max_length: int = 512, batch_size: int = 32):
+        self.tokenizer, self.encoder = tokenizer, encoder
+        self.max_length, self.batch_size = max_length, batch_size
+
+    def _embed(self, texts):
+        out = []
+        for i in range(0, len(texts), self.batch_size):
+            enc = self.tokenizer(list(texts[i:i + self.batch_size]), padding=True, truncation=True,
+                                 max_length=self.max_length, return_tensors="np")
+            ids, mask, tt = _tok_arrays(enc)
+            out.append(self.encoder.forward(ids, mask, tt))
+        return np.vstack(out) if out else np.zeros((0, self.encoder.hidden), np.float32)
+
+    def embed_documents(self, texts):
+        return self._embed(list(texts)).tolist()
+
+    def embed_query(self, text):
+        return self._embed([text])[0].tolist()
+
+    def embed_queries(self, texts):
+        """Batched queries (one forward) -- used by FaissRetriever.invoke instead of len(texts) forwards."""
+        return self._embed(list(texts)).tolist()
+
+
+class HipReranker:
+    """``reranker.compute_score(pairs, batch_size=8)`` (vllmManager.py:451): raw logits, one per pair."""
+
+    def __init__(self, tokenizer, encoder: HipEncoder, max_length: int = 512):
+        if encoder.cfg.get("head", 0) != 1:
+            raise ValueError("HipReranker needs an encoder built from a sequence-classification model")
+        self.tokenizer, self.encoder, self.max_length = tokenizer, encoder, max_length
+
+    def compute_score(self, sentence_pairs, batch_size: int = 8, max_length: int = None, normalize: bool = False):
+        if len(sentence_pairs) and isinstance(sentence_pairs[0], str):
+            sentence_pairs = [sentence_pairs]
+        scores = []
+        for i in range(0, len(sentence_pairs), batch_size):
+            batch = sentence_pairs[i:i + batch_size]
+            enc = self.tokenizer([p[0] for p in batch], [p[1] for p in batch], padding=True, truncation=True,
+                                 max_length=max_length or self.max_length, return_tensors="np")
+            ids, mask, tt = _tok_arrays(enc)
+            s = self.encoder.forward(ids, mask, tt)
+            scores.extend(float(v) for v in np.atleast_1d(s))
+        if normalize:
+            scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]
+        return scores
