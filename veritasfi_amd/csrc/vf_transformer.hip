@@ -107,26 +107,40 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* ids, const int* pos
     }
 }
 
-// row LayerNorm of y -> x, one wave per row
+// row LayerNorm of y -> x, one wave per row; lane l owns the contiguous block [l*per, (l+1)*per), per = H/64
+// (even), moved as 4-byte pairs so the compiler can merge them into wide loads / stores
 __global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float* g, const float* bta, float eps, int M,
                                                     int H, half_t* x) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
-    const half_t* src = y + (long long)row * H;
+    const int per = H >> 6, pairs = per >> 1;
+    const h2* src = (const h2*)(y + (long long)row * H + lane * per);
     float v[16];
-    const int per = H >> 6;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { v[i] = i < per ? (float)src[lane + 64 * i] : 0.f; s += v[i]; }
+    for (int i = 0; i < 8; ++i) {
+        const h2 t = src[i < pairs ? i : 0];
+        v[2 * i] = i < pairs ? (float)t[0] : 0.f;
+        v[2 * i + 1] = i < pairs ? (float)t[1] : 0.f;
+        s += v[2 * i] + v[2 * i + 1];
+    }
     const float mean = wave_sum(s) / H;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const float d = i < per ? v[i] - mean : 0.f; q += d * d; }
     const float rstd = rsqrtf(wave_sum(q) / H + eps);
+    h2* dst = (h2*)(x + (long long)row * H + lane * per);
+    const float* gp = g + lane * per;
+    const float* bp = bta + lane * per;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        if (i < per) x[(long long)row * H + j] = (half_t)((v[i] - mean) * rstd * g[j] + bta[j]);
+    for (int i = 0; i < 8; ++i) {
+        if (i < pairs) {
+            h2 o;
+            o[0] = (half_t)((v[2 * i] - mean) * rstd * gp[2 * i] + bp[2 * i]);
+            o[1] = (half_t)((v[2 * i + 1] - mean) * rstd * gp[2 * i + 1] + bp[2 * i + 1]);
+            dst[i] = o;
+        }
     }
 }
 
@@ -150,24 +164,56 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
     half_t* Ws = As + 2 * GBM * GLD;         // [2][GBN][GLD]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5, wr = wid >> 1, wc = wid & 1;
-    const long long m0 = (long long)blockIdx.y * GBM, n0 = (long long)blockIdx.x * GBN;
-    uint4 ra[4], rw[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-            ra[i] = *(const uint4*)(A + (m0 + row) * K + (long long)kt * GBK + kc * 8);
-            rw[i] = *(const uint4*)(W + (n0 + row) * K + (long long)kt * GBK + kc * 8);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-            *(uint4*)(As + (buf * GBM + row) * GLD + kc * 8) = ra[i];
-            *(uint4*)(Ws + (buf * GBN + row) * GLD + kc * 8) = rw[i];
-        }
-    };
+    // Tile order (speed only): blocks are dealt round-robin over the 8 XCDs, each with a private 4 MB L2.
+    // Give every XCD a CONTIGUOUS run of the tile sequence (bijective remap), and order that sequence in
+    // groups of 8 m-tiles x all n-tiles, n-major inside a group: the 64 workgroups an XCD runs at once then
+    // share 8 A row-panels and 8 W row-panels (~3 MB at K=768), so operands are fetched into L2 once.
+    int mt_idx, nt_idx;
+    {
+        const int Mt = M / GBM, Nt = N / GBN, nwg = Mt * Nt;
+        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        constexpr int GM = 8;
+        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
+        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+        nt_idx = r / gm;
+        mt_idx = g * GM + (r - nt_idx * gm);
+    }
+    const long long m0 = (long long)mt_idx * GBM, n0 = (long long)nt_idx * GBN;
+    // register staging of the next K-tile: thread t moves chunks t, t+256, t+512, t+768 (16 B each;
+    // chunk c = row c>>3, k-chunk c&7) of both operands.  Plain named registers + macros: arrays captured
+    // by a lambda are not promoted to registers by hipcc and end up in scratch.
+    const int srow = tid >> 3, skc = tid & 7;
+    const half_t* Ag = A + (m0 + srow) * K + skc * 8;
+    const half_t* Wg = W + (n0 + srow) * K + skc * 8;
+    half_t* Asw = As + srow * GLD + skc * 8;
+    half_t* Wsw = Ws + srow * GLD + skc * 8;
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define VFT_GLOAD(KT)                                                          \
+    {                                                                          \
+        const long long ko = (long long)(KT) * GBK;                            \
+        ra0 = *(const uint4*)(Ag + ko);                                        \
+        ra1 = *(const uint4*)(Ag + ko + 32LL * K);                             \
+        ra2 = *(const uint4*)(Ag + ko + 64LL * K);                             \
+        ra3 = *(const uint4*)(Ag + ko + 96LL * K);                             \
+        rw0 = *(const uint4*)(Wg + ko);                                        \
+        rw1 = *(const uint4*)(Wg + ko + 32LL * K);                             \
+        rw2 = *(const uint4*)(Wg + ko + 64LL * K);                             \
+        rw3 = *(const uint4*)(Wg + ko + 96LL * K);                             \
+    }
+#define VFT_LSTORE(BUF)                                                        \
+    {                                                                          \
+        half_t* a_ = Asw + (BUF) * GBM * GLD;                                  \
+        half_t* w_ = Wsw + (BUF) * GBN * GLD;                                  \
+        *(uint4*)(a_) = ra0;                                                   \
+        *(uint4*)(a_ + 32 * GLD) = ra1;                                        \
+        *(uint4*)(a_ + 64 * GLD) = ra2;                                        \
+        *(uint4*)(a_ + 96 * GLD) = ra3;                                        \
+        *(uint4*)(w_) = rw0;                                                   \
+        *(uint4*)(w_ + 32 * GLD) = rw1;                                        \
+        *(uint4*)(w_ + 64 * GLD) = rw2;                                        \
+        *(uint4*)(w_ + 96 * GLD) = rw3;                                        \
+    }
     f16v acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -176,12 +222,14 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const int nk = K / GBK;
-    gload(0);
-    lstore(0);
+    VFT_GLOAD(0)
+    VFT_LSTORE(0)
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        const int ktn = kt + 1 < nk ? kt + 1 : kt;  // unconditional (clamped) prefetch
+        VFT_GLOAD(ktn)
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
         const half_t* a_base = As + (buf * GBM + wr * 64 + r31) * GLD + h * 8;
         const half_t* w_base = Ws + (buf * GBN + wc * 64 + r31) * GLD + h * 8;
 #pragma unroll
@@ -198,9 +246,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        VFT_LSTORE(buf ^ 1)
         __syncthreads();
     }
+#undef VFT_GLOAD
+#undef VFT_LSTORE
     // epilogue: acc[mt][nt][reg] -> row m0 + wr*64 + mt*32 + (reg&3) + 8*(reg>>2) + 4*h, col n0 + wc*64 + nt*32 + r31
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -228,101 +278,112 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
 // matched by reading V^T as two 8-byte groups).  Online softmax over 32-key tiles.
 // dh = 64, T % 32 == 0, T <= 512.
 // ------------------------------------------------------------------------------------------------
-constexpr int ADH = 64, AKLD = ADH + 8;
+constexpr int ADH = 64, AKLD = ADH + 8, ATHREADS = 512;
 
-__global__ __launch_bounds__(256) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
-                                                    int H, int vt_ld, half_t* __restrict__ ctx) {
+__global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask,
+                                                         int T, int H, int vt_ld, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Ks = (half_t*)smem;                   // [T][AKLD]
     half_t* Vt = Ks + (size_t)T * AKLD;           // [64][vt_ld]
     float* mb = (float*)(Vt + (size_t)ADH * vt_ld);  // [T] additive mask
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y, qb = blockIdx.x;
+    const int b = blockIdx.y, hd = blockIdx.x;
     const long long row0 = (long long)b * T;
     const int ld = 3 * H;
     const half_t* Kg = qkv + row0 * ld + H + hd * ADH;
     const half_t* Vg = qkv + row0 * ld + 2 * H + hd * ADH;
-    for (int c = tid; c < T * 8; c += 256) {  // 16-byte chunks: key t, dh [8*kc, +8)
+    // K: verbatim rows.  16-byte chunks: key t, dh [8*kc, +8)
+    for (int c = tid; c < T * 8; c += ATHREADS) {
         const int t = c >> 3, kc = c & 7;
         *(uint4*)(Ks + t * AKLD + kc * 8) = *(const uint4*)(Kg + (long long)t * ld + kc * 8);
-        const h8 v = *(const h8*)(Vg + (long long)t * ld + kc * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(kc * 8 + e) * vt_ld + t] = v[e];
     }
-    for (int t = tid; t < T; t += 256) mb[t] = mask[row0 + t] ? 0.f : -30000.f;
+    // V^T: a thread takes an 8-key x 8-dh block (8 loads of 16 B), transposes it in registers and writes
+    // 8 rows of 8 keys (16 B each): 8x fewer LDS stores than element-wise transposition
+    for (int c = tid; c < (T >> 3) * 8; c += ATHREADS) {
+        const int tb = c >> 3, kc = c & 7;  // keys [8*tb, +8), dh [8*kc, +8)
+        h8 blk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) blk[i] = *(const h8*)(Vg + (long long)(tb * 8 + i) * ld + kc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h8 rowv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rowv[i] = blk[i][e];
+            *(h8*)(Vt + (kc * 8 + e) * vt_ld + tb * 8) = rowv;
+        }
+    }
+    for (int t = tid; t < T; t += ATHREADS) mb[t] = mask[row0 + t] ? 0.f : -30000.f;
     __syncthreads();
-    const int q0 = qb * 128 + wid * 32;
-    if (q0 >= T) return;
-    // Q fragments (B operand): lane (query r31, half h) holds q[8h + j + 16 ks], scaled by 1/sqrt(64)
-    h8 qf[4];
-    {
-        const int q = q0 + r31 < T ? q0 + r31 : T - 1;
-        const half_t* Qg = qkv + (row0 + q) * ld + hd * ADH + h * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            h8 v = *(const h8*)(Qg + ks * 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
-            qf[ks] = v;
-        }
-    }
-    f16v o[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
     const float LOG2E = 1.4426950408889634f;
-    for (int kt = 0; kt < T; kt += 32) {
-        f16v s;
+    // each wave walks 32-query blocks wid, wid + 8, ...
+    for (int q0 = wid * 32; q0 < T; q0 += (ATHREADS / 64) * 32) {
+        // Q fragments (B operand): lane (query r31, half h) holds q[8h + j + 16 ks], scaled by 1/sqrt(64)
+        h8 qf[4];
+        {
+            const half_t* Qg = qkv + (row0 + q0 + r31) * ld + hd * ADH + h * 8;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            for (int ks = 0; ks < 4; ++ks) {
+                h8 v = *(const h8*)(Qg + ks * 16);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const h8 kf = *(const h8*)(Ks + (kt + r31) * AKLD + ks * 16 + h * 8);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
+                qf[ks] = v;
+            }
         }
-        float tmax = -1e30f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int key = kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            s[reg] += mb[key];
-            tmax = fmaxf(tmax, s[reg]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f((m_run - m_new) * LOG2E);
-        float psum = 0.f;
-        h8 pf[2];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float p = exp2f((s[reg] - m_new) * LOG2E);
-            psum += p;
-            pf[reg >> 3][reg & 7] = (half_t)p;
-        }
-        psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        f16v o[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
-        // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
+            for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+        float m_run = -1e30f, l_run = 0.f;
+        for (int kt = 0; kt < T; kt += 32) {
+            f16v s;
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const half_t* vrow = Vt + (mt * 32 + r31) * vt_ld + kt + 16 * st + 4 * h;
-                const h4 lo4 = *(const h4*)(vrow);
-                const h4 hi4 = *(const h4*)(vrow + 8);
-                h8 vf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
-                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const h8 kf = *(const h8*)(Ks + (kt + r31) * AKLD + ks * 16 + h * 8);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
             }
-    }
-    if (q0 + r31 < T) {
+            float tmax = -1e30f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                s[reg] += mb[key];
+                tmax = fmaxf(tmax, s[reg]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = exp2f((m_run - m_new) * LOG2E);
+            float psum = 0.f;
+            h8 pf[2];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float p = exp2f((s[reg] - m_new) * LOG2E);
+                psum += p;
+                pf[reg >> 3][reg & 7] = (half_t)p;
+            }
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+            // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const half_t* vrow = Vt + (mt * 32 + r31) * vt_ld + kt + 16 * st + 4 * h;
+                    const h4 lo4 = *(const h4*)(vrow);
+                    const h4 hi4 = *(const h4*)(vrow + 8);
+                    h8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
+                }
+        }
         const float inv = 1.0f / l_run;
         half_t* dst = ctx + (row0 + q0 + r31) * H + hd * ADH;
 #pragma unroll
@@ -559,7 +620,7 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st) {
-    const dim3 grid(N / GBN, M / GBM);
+    const dim3 grid((N / GBN) * (M / GBM));
     const size_t lds = (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t);
     hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
     return hipGetLastError();
@@ -574,8 +635,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
                        c.ln_eps, M, H, e->x);
     // V^T row stride: (T + pad) halves with (T + pad) / 2 == 2 (mod 64) -> conflict-free 8-byte reads
-    int pad = 4;
-    while ((((T + pad) / 2) & 63) != 2) pad += 4;
+    // (rows must also be 16-byte aligned for the transposed staging writes -> multiple of 8 halves; a
+    //  row stride of 4 (mod 64) dwords keeps the 8-byte reads of 32 lanes within a 2-way conflict)
+    int pad = 8;
+    while ((((T + pad) / 2) & 63) != 4) pad += 8;
     const int vt_ld = T + pad;
     const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4;
     for (int l = 0; l < c.layers; ++l) {
@@ -585,8 +648,8 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F, *g2 = b2 + H,
                     *b2n = g2 + H;
         VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
-        hipLaunchKernelGGL(k_attention, dim3((T + 127) / 128, c.heads, B), dim3(256), att_lds, st, e->qkv, e->d_mask, T, H,
-                           vt_ld, e->ctx);
+        hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
+                           e->ctx);
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
         hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
