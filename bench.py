@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--opt", action="append", default=[], help="index option name=value (tuning)")
+    ap.add_argument("--no-rerank", action="store_true")
+    ap.add_argument("--rerank-shape", default="xlmr-base", help="cross-encoder shape (tools/bench_rerank.py SHAPES)")
+    ap.add_argument("--rerank-pairs", type=int, default=100)
+    ap.add_argument("--rerank-tokens", type=int, default=512)
     return ap.parse_args()
 
 
@@ -87,6 +91,30 @@ def cpu_baseline(args):
         "sample": f"oracle/vf_oracle.c exact cosine top-{args.k}, {args.batch} queries x {n} of the {args.rows} "
                   f"rows (fp16, d={args.dim}), best of {reps} runs = {best:.3f}s, scaled x{args.rows / n:.1f} to the full corpus",
     }
+
+
+def rerank_p50(args):
+    """p50 latency of scoring top-100 candidates (100 pairs x 512 tokens) with a cross-encoder of the given
+    shape and seeded random weights (no checkpoints offline): BASELINE configs[3].  Each rank runs a replica."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_rerank import random_encoder, flops
+    enc, cfg = random_encoder(args.rerank_shape, head=1)
+    rng = np.random.default_rng(99)
+    ids = rng.integers(5, cfg["vocab"], size=(args.rerank_pairs, args.rerank_tokens)).astype(np.int32)
+    mask = np.ones_like(ids)
+    enc.forward(ids, mask)
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        enc.forward(ids, mask)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    enc.close()
+    p50 = float(np.median(ts))
+    tf = flops(cfg, args.rerank_pairs, args.rerank_tokens) / p50 / 1e9
+    return p50, {"model_shape": args.rerank_shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens,
+                 "tflops": round(tf, 1), "bound": "mfma", "peak_tflops": 2500.0, "frac": round(tf / 2500.0, 4),
+                 "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of logits"}
 
 
 def main():
@@ -160,6 +188,9 @@ def main():
     prof = index.profile()
     stats = index.stats()
     index.set_option("profile", 0)
+    rr_ms, rr_info = (None, None)
+    if rank == 0 and not args.no_rerank:
+        rr_ms, rr_info = rerank_p50(args)
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -183,7 +214,8 @@ def main():
             "roofline": roof,
             "search_stats": {"candidates_per_query": round(stats["candidates"] / max(1, stats["n_queries"]), 1),
                              "exact_reruns_last_batch": stats["exact_reruns"], "path": stats["path"]},
-            "rerank_p50_ms": None,
+            "rerank_p50_ms": None if rr_ms is None else round(rr_ms, 3),
+            "rerank": rr_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
