@@ -141,19 +141,21 @@ def main():
         name, val = o.split("=")
         index.set_option(name, int(val))
     nslots = index.slots
-    out_ids = [torch.empty((args.batch, args.k), dtype=torch.int64, device=device) for _ in range(nslots)]
-    out_sc = [torch.empty((args.batch, args.k), dtype=torch.float32, device=device) for _ in range(nslots)]
+    # per in-flight batch: one packed result blob [ids | scores] with typed views (single all-gather per batch)
+    bufs = [vf.packed_result_buffer(args.batch, args.k, device) for _ in range(nslots)]
+    out_ids = [b[1] for b in bufs]
+    out_sc = [b[2] for b in bufs]
     if world > 1:
-        g_ids = torch.empty((world * args.batch, args.k), dtype=torch.int64, device=device)
-        g_sc = torch.empty((world * args.batch, args.k), dtype=torch.float32, device=device)
+        g_blob = torch.empty(world * args.batch * args.k * 12, dtype=torch.uint8, device=device)
+        m_ids = torch.empty((args.batch, args.k), dtype=torch.int64, device=device)
+        m_sc = torch.empty((args.batch, args.k), dtype=torch.float32, device=device)
     merged = [None]
 
     def finish(slot):
         index.search_end(slot)
-        if world > 1:  # the exchange step: all-gather of per-shard top-k over xGMI, then the merge kernel
-            dist.all_gather_into_tensor(g_ids, out_ids[slot])
-            dist.all_gather_into_tensor(g_sc, out_sc[slot])
-            merged[0] = vf.merge_topk_device(g_ids.view(world, args.batch, args.k), g_sc.view(world, args.batch, args.k), args.k)
+        if world > 1:  # the exchange step: ONE all-gather of the packed per-shard top-k over xGMI, then the merge kernel
+            dist.all_gather_into_tensor(g_blob, bufs[slot][0])
+            merged[0] = vf.merge_topk_packed_device(g_blob, world, args.batch, args.k, m_ids, m_sc)
         else:
             merged[0] = (out_ids[slot], out_sc[slot])
 

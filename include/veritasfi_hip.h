@@ -126,6 +126,11 @@ int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts,
                          int32_t nq, int32_t k, int64_t* d_ids, float* d_scores, int32_t device_id,
                          void* stream);
 
+/* Same, from ONE all-gathered buffer: part g is the blob [ids nq*k int64][scores nq*k fp32] at byte offset
+ * g * nq*k*12 (a rank packs its result that way so that a batch needs a single collective). */
+int vf_merge_topk_packed_device(const void* d_parts, int32_t nparts, int32_t nq, int32_t k, int64_t* d_ids,
+                                float* d_scores, int32_t device_id, void* stream);
+
 /* src/utils/vllmManager.py:443-457 (rank_chunk score fusion): scores = rerank + time_score,
  * order = argsort descending (ties lower index first).  Host buffers, n <= 4096. */
 int vf_fuse_rank(const float* rerank_scores, const float* time_scores, int32_t n, float* out_scores,

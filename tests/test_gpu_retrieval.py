@@ -219,6 +219,17 @@ def test_sharding_invariance_and_merge(vf, oracle):
     assert np.array_equal(_bits(ms.cpu().numpy()), _bits(full_s))
     omi, oms = oracle.merge_topk(torch.stack(parts_i).cpu().numpy(), torch.stack(parts_s).cpu().numpy(), k)
     assert np.array_equal(omi, full_i) and np.array_equal(_bits(oms), _bits(full_s))
+    # packed form (what ShardedRetriever all-gathers): one blob per shard, merged in place
+    nq = q.shape[0]
+    blobs = []
+    for i, s in zip(parts_i, parts_s):
+        blob, vi, vs = vf.packed_result_buffer(nq, k, i.device)
+        vi.copy_(i)
+        vs.copy_(s)
+        blobs.append(blob)
+    pi, ps = vf.merge_topk_packed_device(torch.cat(blobs), len(blobs), nq, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(pi.cpu().numpy(), full_i) and np.array_equal(_bits(ps.cpu().numpy()), _bits(full_s))
 
 
 def test_device_and_pipelined_api(vf, oracle):

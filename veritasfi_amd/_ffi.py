@@ -59,6 +59,7 @@ SIGNATURES = {
     "vf_cosine_matrix": (ctypes.c_int, [vp, c_i32, c_i32, vp, c_i32]),
     "vf_cosine_scores": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32]),
     "vf_merge_topk_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
+    "vf_merge_topk_packed_device": (ctypes.c_int, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
     "vf_fuse_rank": (ctypes.c_int, [vp, vp, c_i32, vp, vp, c_i32]),
     "vf_encoder_weight_sizes": (ctypes.c_int, [ctypes.POINTER(EncoderConfig), p_i64, p_i64]),
     "vf_encoder_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(EncoderConfig), vp, c_i64, vp, c_i64, c_i32]),

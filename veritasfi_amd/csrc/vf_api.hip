@@ -84,7 +84,8 @@ struct Slot {
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
     DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
-    DevBuf dbg;
+    DevBuf dbg, wgbase;
+    int64_t wgbase_n = -1; int wgbase_grid = -1;
     DevBuf dense_s, cn_tmp, parts_ids, parts_sc, run_ids, run_sc, qsel; // exact-path scratch
     int* h_flags = nullptr;      // pinned, [max batches * 64]
     u32* h_counts = nullptr;     // pinned
@@ -188,7 +189,7 @@ static void destroy_index(vf_index* ix) {
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = ix->slots[i];
         DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.hist_coarse, &s.cand, &s.flags, &s.counts, &s.dense_s,
-                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg};
+                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg, &s.wgbase};
         for (DevBuf* b : bufs) b->release();
         if (s.h_flags) (void)hipHostFree(s.h_flags);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
@@ -459,6 +460,13 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     VF_TRY(s.cand.ensure((size_t)kMaxBatch * p.cap * sizeof(u64)));
     s.timed = ix->profile;
     if (s.timed) VF_HIP(hipEventRecord(s.ev_t[2], st));
+    if (s.wgbase_n != ix->n || s.wgbase_grid != p.grid) {  // first row of every scan workgroup (k_sel0 maps sample slots back to rows)
+        std::vector<long long> base(p.grid);
+        for (int w = 0; w < p.grid; ++w) base[w] = ix->n * (long long)w / p.grid;
+        VF_TRY(s.wgbase.ensure((size_t)p.grid * sizeof(long long)));
+        VF_HIP(hipMemcpy(s.wgbase.p, base.data(), (size_t)p.grid * sizeof(long long), hipMemcpyHostToDevice));
+        s.wgbase_n = ix->n; s.wgbase_grid = p.grid;
+    }
     for (int b0 = 0; b0 < nq; b0 += bl) {
         const int nb = std::min(bl, nq - b0);
         const int qt = qn_tile_for(nb);
@@ -467,7 +475,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         ScanArgs a{};
         a.rows = (const char*)ix->rows_scan; a.inv_scan = ix->inv_scan; a.qimg = s.qimg.as<_Float16>();
         a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * 2; a.total_waves = p.total_waves; a.samp = p.samp;
-        a.s0 = s.s0.as<float>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>(); a.hist = s.hist.as<u32>();
+        a.s0 = s.s0.as<float>(); a.wg_base = s.wgbase.as<long long>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>(); a.hist = s.hist.as<u32>();
         a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
         a.hist_coarse = s.hist_coarse.as<u32>(); a.stage_cap = scan_stage_cap(ix->dp, qt);
         a.dbg = nullptr;
@@ -677,6 +685,18 @@ extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_s
     VF_HIP(scan_configure());
     VF_HIP(launch_merge_topk((const long long*)d_ids_parts, d_score_parts, nparts, nq, k, (long long*)d_ids, d_scores,
                              (hipStream_t)stream));
+    return VF_OK;
+}
+
+extern "C" int vf_merge_topk_packed_device(const void* d_parts, int32_t nparts, int32_t nq, int32_t k, int64_t* d_ids,
+                                           float* d_scores, int32_t device_id, void* stream) {
+    if (nparts <= 0 || nq < 0 || k < 0) return fail(VF_EINVAL, "vf_merge_topk_packed_device: bad sizes");
+    if (nq == 0 || k == 0) return VF_OK;
+    if (!d_parts || !d_ids || !d_scores) return fail(VF_EINVAL, "vf_merge_topk_packed_device: null buffer");
+    if ((size_t)nparts * k > 16384) return fail(VF_EUNSUPPORTED, "vf_merge_topk_packed_device: nparts * k > 16384");
+    VF_HIP(hipSetDevice(device_id));
+    VF_HIP(scan_configure());
+    VF_HIP(launch_merge_topk_packed(d_parts, nparts, nq, k, (long long*)d_ids, d_scores, (hipStream_t)stream));
     return VF_OK;
 }
 

@@ -39,6 +39,7 @@ struct ScanArgs {
     int samp;                // sample rows at the head of each wave's range
     // sample mode output
     float* s0;               // [QN][TW * samp] approx scores of the sample rows (-inf = empty)
+    const long long* wg_base; // [grid] first row of each scan workgroup's range (n * wg / grid)
     // main mode state (all zeroed / seeded per batch)
     u32* cnt;                // [QN * kCntStride] candidates appended (one counter per 128-B line)
     int* tau_bin;            // [QN] current threshold bin (monotone non-decreasing)
@@ -88,6 +89,8 @@ hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
 hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s);
 hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,
                              int k, long long* ids, float* scores, hipStream_t s);
+hipError_t launch_merge_topk_packed(const void* parts, int nparts, int nq, int k, long long* ids, float* scores,
+                                    hipStream_t s);
 hipError_t launch_fuse_rank(const float* a, const float* b, int n, float* out, long long* order,
                             hipStream_t s);
 size_t scan_lds_bytes(int dp, int qn_tile);

@@ -16,6 +16,8 @@
 
 #include <float.h>
 
+#include <mutex>
+
 namespace vf {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -259,8 +261,11 @@ hipError_t launch_sort_rows(const float* scores, long long score_stride, int nq,
 }
 
 // Merge nparts ranked lists per query (parts in ascending id-range order, -1 = padding).
-__global__ __launch_bounds__(1024) void k_merge_topk(const long long* ids_parts, const float* score_parts, int nparts,
-                                                      int nq, int k, long long* ids, float* scores) {
+// Part g's ids start at ids_base + g * part_stride_bytes, its scores at score_base + g * part_stride_bytes
+// (two separate [G][nq][k] arrays, or one packed blob per part: [ids nq*k int64][scores nq*k fp32]).
+__global__ __launch_bounds__(1024) void k_merge_topk(const char* ids_base, const char* score_base,
+                                                      long long ids_stride, long long score_stride, int nparts, int nq,
+                                                      int k, long long* ids, float* scores) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     u64* keys = (u64*)smem_raw;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -270,9 +275,10 @@ __global__ __launch_bounds__(1024) void k_merge_topk(const long long* ids_parts,
         u64 kv = 0ull;
         if (i < m) {
             const int g = i / k, j = i - g * k;
-            const long long o = ((long long)g * nq + q) * k + j;
+            const long long o = (long long)q * k + j;
+            const long long id = ((const long long*)(ids_base + g * ids_stride))[o];
             // equal scores: earlier part / earlier rank first == lower id first
-            if (ids_parts[o] >= 0) kv = ((u64)orderkey(score_parts[o]) << 32) | (u64)(0xFFFFFFFFu - (u32)i);
+            if (id >= 0) kv = ((u64)orderkey(((const float*)(score_base + g * score_stride))[o]) << 32) | (u64)(0xFFFFFFFFu - (u32)i);
         }
         keys[i] = kv;
     }
@@ -285,24 +291,36 @@ __global__ __launch_bounds__(1024) void k_merge_topk(const long long* ids_parts,
         if (kv != 0ull) {
             const int src = (int)(0xFFFFFFFFu - (u32)kv);
             const int g = src / k, j = src - g * k;
-            const long long o = ((long long)g * nq + q) * k + j;
-            id = ids_parts[o];
-            sc = score_parts[o];
+            const long long o = (long long)q * k + j;
+            id = ((const long long*)(ids_base + g * ids_stride))[o];
+            sc = ((const float*)(score_base + g * score_stride))[o];
         }
         ids[(long long)q * k + i] = id;
         scores[(long long)q * k + i] = sc;
     }
 }
 
-hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq, int k,
-                             long long* ids, float* scores, hipStream_t s) {
+static hipError_t launch_merge_impl(const char* ib, const char* sb, long long is, long long ss, int nparts, int nq, int k,
+                                    long long* ids, float* scores, hipStream_t s) {
     if (nq <= 0 || k <= 0) return hipSuccess;
     int P = 1;
     while (P < nparts * k) P <<= 1;
     if ((size_t)P * 8 > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(1024), (size_t)P * 8, s, ids_parts, score_parts, nparts, nq, k, ids,
-                       scores);
+    hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(1024), (size_t)P * 8, s, ib, sb, is, ss, nparts, nq, k, ids, scores);
     return hipGetLastError();
+}
+
+hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq, int k,
+                             long long* ids, float* scores, hipStream_t s) {
+    return launch_merge_impl((const char*)ids_parts, (const char*)score_parts, (long long)nq * k * 8, (long long)nq * k * 4,
+                             nparts, nq, k, ids, scores, s);
+}
+
+hipError_t launch_merge_topk_packed(const void* parts, int nparts, int nq, int k, long long* ids, float* scores,
+                                    hipStream_t s) {
+    const long long stride = (long long)nq * k * 12;
+    return launch_merge_impl((const char*)parts, (const char*)parts + (long long)nq * k * 8, stride, stride, nparts, nq, k,
+                             ids, scores, s);
 }
 
 // rank_chunk fusion (src/utils/vllmManager.py:454-457): out = a + b, order = argsort desc (stable).
@@ -348,14 +366,9 @@ hipError_t launch_fuse_rank(const float* a, const float* b, int n, float* out, l
 // Accumulator layout (v_mfma_f32_32x32x16_f16 C/D): lane holds query (lane & 31) of N-tile nt and
 // corpus rows (reg & 3) + 8 * (reg >> 2) + 4 * h, reg = 0..15.
 // ------------------------------------------------------------------------------------------------
-struct TileCursor {
-    long long t0;  // first row of the tile
-    int ss;        // superstep within the tile
-};
-
 template <int G>
 __device__ __forceinline__ void issue_loads(h8 (&buf)[4 * G], const char* rows, long long row_bytes, long long myrow,
-                                            int ss, int h) {
+                                            int ss /* superstep within the tile */, int h) {
     const char* p = rows + myrow * row_bytes + (long long)(ss * G) * 128 + h * 64;
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -798,21 +811,47 @@ __global__ __launch_bounds__(1024) void k_sel0(ScanArgs a) {
     __syncthreads();
     const long long len = (long long)a.total_waves * a.samp;
     const float* s = a.s0 + (long long)q * len;
-    const long long swg = (long long)a.samp * (kScanThreads / 64), grid = a.total_waves / (kScanThreads / 64);
+    const long long swg = (long long)a.samp * (kScanThreads / 64);
     constexpr int kKeep = 32;  // sample scores per thread kept in registers between the two phases
     float v[kKeep];
     const bool in_regs = len <= (long long)kKeep * 1024;
+    // Pre-threshold from bucket maxima: each wave takes the r-th largest (r = ceil(k'/16)) of its 64 per-lane
+    // maxima with r wave-max rounds; the minimum of the 16 wave values has >= 16 r >= k' sample scores at or
+    // above it, so only scores >= it can matter.  This keeps a few hundred values out of 32K for the LDS
+    // histogram (whose atomics pile onto ~100 hot bins otherwise: 14 of this kernel's 21 us).
+    __shared__ float wave_thr[16];
+    float pre = -INFINITY;
     if (q < a.nq) {
         if (in_regs) {
+            float mx = -INFINITY;
 #pragma unroll
             for (int u = 0; u < kKeep; ++u) {
                 const long long i = tid + (long long)u * 1024;
                 const float x = s[i < len ? i : len - 1];
                 v[u] = i < len ? x : -INFINITY;
+                mx = fmaxf(mx, v[u]);
+            }
+            if (a.kprime <= 1024) {
+                const int rounds = (a.kprime + 15) / 16;
+                const int lane = tid & 63;
+                float cur = mx, thr = -INFINITY;
+                for (int i = 0; i < rounds; ++i) {
+                    float wm = cur;
+#pragma unroll
+                    for (int o = 32; o; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+                    thr = wm;
+                    const unsigned long long bal = __ballot(cur == wm);
+                    if (bal && lane == __ffsll((long long)bal) - 1) cur = -INFINITY;  // drop ONE holder of the max
+                }
+                if (lane == 0) wave_thr[tid >> 6] = thr;
+                __syncthreads();
+                pre = wave_thr[0];
+#pragma unroll
+                for (int w = 1; w < 16; ++w) pre = fminf(pre, wave_thr[w]);
             }
 #pragma unroll
             for (int u = 0; u < kKeep; ++u)
-                if (v[u] > -INFINITY) atomicAdd(&lh[bin_of_x(bin_x(v[u]))], 1u);
+                if (v[u] > -INFINITY && v[u] >= pre) atomicAdd(&lh[bin_of_x(bin_x(v[u]))], 1u);
         } else {
             for (long long i = tid; i < len; i += 1024) {
                 const float x = s[i];
@@ -830,8 +869,8 @@ __global__ __launch_bounds__(1024) void k_sel0(ScanArgs a) {
     auto emit = [&](float x, long long i) {
         if (x > -INFINITY && bin_of_x(bin_x(x)) >= tb) {
             const u32 slot = atomicAdd(&lcnt, 1u);
-            const long long wg = i / swg;
-            const long long row = a.n * wg / grid + (i - wg * swg);
+            const u32 wg = (u32)i / (u32)swg;  // 32-bit: the sample has < 2^31 slots
+            const long long row = a.wg_base[wg] + (long long)((u32)i - wg * (u32)swg);
             if (slot < (u32)a.cap) a.cand[(long long)q * a.cap + slot] = ((u64)orderkey(x) << 32) | (u64)(u32)row;
         }
     };
@@ -1057,8 +1096,16 @@ hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Opt the kernels into > 64 KB of dynamic LDS.  Once per device per process (hipFuncSetAttribute is not free
+// and the merge entry points sit on the per-batch path of the multi-GPU loop).
 hipError_t scan_configure() {
-    hipError_t e;
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
 #define VF_CFG(NTV, GV) \
     if ((e = configure_one<NTV, GV, kModeSample>()) != hipSuccess) return e; \
     if ((e = configure_one<NTV, GV, kModeMain>()) != hipSuccess) return e;
@@ -1068,6 +1115,7 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) done[dev] = true;
     return hipSuccess;
 }
 

@@ -180,6 +180,31 @@ def merge_topk_device(ids_parts, score_parts, k: int):
     return ids, sc
 
 
+def packed_result_buffer(nq: int, k: int, device):
+    """One contiguous device blob [ids nq*k int64][scores nq*k fp32] plus the two typed views into it: a shard
+    writes its search result through the views and ships the blob with a single all-gather."""
+    import torch
+    blob = torch.empty(nq * k * 12, dtype=torch.uint8, device=device)
+    ids = blob[: nq * k * 8].view(torch.int64).view(nq, k)
+    scores = blob[nq * k * 8:].view(torch.float32).view(nq, k)
+    return blob, ids, scores
+
+
+def merge_topk_packed_device(parts_blob, nparts: int, nq: int, k: int, out_ids=None, out_scores=None):
+    """parts_blob: uint8 tensor of nparts packed results (rank order == ascending id ranges)."""
+    import torch
+    dev = parts_blob.device
+    if out_ids is None:
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if out_scores is None:
+        out_scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib().vf_merge_topk_packed_device(parts_blob.data_ptr(), nparts, nq, k, out_ids.data_ptr(),
+                                                      out_scores.data_ptr(), dev.index or 0,
+                                                      torch.cuda.current_stream(dev).cuda_stream),
+               "vf_merge_topk_packed_device")
+    return out_ids, out_scores
+
+
 def fuse_rank(rerank_scores, time_scores, device_id: int = 0):
     a = np.ascontiguousarray(np.asarray(rerank_scores, dtype=np.float32))
     b = np.ascontiguousarray(np.asarray(time_scores, dtype=np.float32))
