@@ -89,3 +89,25 @@ def fuse_and_rank(rerank_scores, time_sc) -> np.ndarray:
     here and in the product)."""
     s = np.asarray(rerank_scores, dtype=np.float32) + np.asarray(time_sc, dtype=np.float32)
     return np.lexsort((np.arange(s.shape[0]), -s)).astype(np.int64)
+
+
+def rank_chunk(bundle_ids, rerank_scores, time_sc, embeddings, chunk_topk, similar_threshhold=0.9):
+    """vllmManager.rank_chunk :430-483 after the model calls: bundle_ids per chunk, the re-ranker's scores,
+    time scores and the chunk embeddings -> selected bundle ids (reverse selection order), including the
+    reference's quirk of indexing the chunk similarity matrix with bundle ids (:476)."""
+    n = len(bundle_ids)
+    bundle_map = {}
+    for idx, b in enumerate(bundle_ids):
+        bundle_map.setdefault(b, []).append(idx)
+    ranked = fuse_and_rank(rerank_scores, time_sc).tolist()
+    sim = similarity_matrix(np.asarray(embeddings, dtype=np.float32)) if n else np.zeros((0, 0), np.float32)
+    selected, size = [], 0
+    for idx in ranked:
+        b = bundle_ids[idx]
+        if b in selected or size + len(bundle_map[b]) > chunk_topk:
+            continue
+        if selected and np.any(sim[idx, selected] > similar_threshhold):
+            continue
+        selected.append(b)
+        size += len(bundle_map[b])
+    return selected[::-1]

@@ -186,3 +186,53 @@ def test_encoder_errors(vf):
     with pytest.raises(ValueError):
         e.forward(np.zeros((1, 600), np.int64), np.ones((1, 600), np.int64))
     e.close()
+
+
+def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):
+    """BASELINE configs[3] in miniature, every stage on the GPU: embed the corpus (embed loop,
+    src/load_data.py:120-128) -> FaissRetriever top-100 -> cross-encoder scores -> rank_chunk
+    (src/utils/vllmManager.py:430-483) -> top bundles; rank_chunk is checked against the oracle's restatement fed
+    with the same model outputs."""
+    from datetime import datetime
+    from oracle import ref_numpy as R
+
+    class Tok:
+        def __call__(self, a, b=None, padding=True, truncation=True, max_length=64, return_tensors="np"):
+            a = [a] if isinstance(a, str) else list(a)
+            b = [None] * len(a) if b is None else list(b)
+            rows = []
+            for x, y in zip(a, b):
+                toks = [2] + [5 + (sum(map(ord, w)) * 31 % 900) for w in x.split()] + [3]
+                if y is not None:
+                    toks += [5 + (sum(map(ord, w)) * 31 % 900) for w in y.split()] + [3]
+                rows.append(toks[:max_length])
+            t = max(len(r) for r in rows)
+            ids = np.ones((len(rows), t), np.int64)
+            mask = np.zeros((len(rows), t), np.int64)
+            for i, r in enumerate(rows):
+                ids[i, :len(r)] = r
+                mask[i, :len(r)] = 1
+            return {"input_ids": ids, "attention_mask": mask}
+
+    emb = vf.HipEmbeddings(Tok(), vf.HipEncoder.from_hf(_hf_bert(128, 2, 2, 512)), max_length=64, batch_size=100)
+    rr = vf.HipReranker(Tok(), vf.HipEncoder.from_hf(_hf_xlmr_cls(128, 2, 2, 512)), max_length=64)
+    docs = [f"filing {i} reports revenue item {i % 13} for segment {i % 5} in year {2015 + i % 9}" for i in range(1200)]
+    docs[700] = docs[3]  # a verbatim duplicate: the 0.9 similarity rule must drop one of them
+    vecs = emb.embed_documents(docs)                       # batches of 100, as load_data.py:151
+    fr = vf.FaissRetriever(vecs, emb)
+    question = "revenue item 3 for segment 3 in year 2018"
+    I, D = fr.invoke([question], 100)
+    assert I.shape == (1, 100) and np.all(np.diff(D[0]) <= 0)
+    hits = [int(i) for i in I[0][:40]]
+    if 3 in hits and 700 not in hits:
+        hits[-1] = 700
+    chunks = [{"page_content": docs[i], "bundle_id": j // 2, "metadata": {"date_published": f"20{15 + i % 9:02d}-0{1 + i % 9}-15"}}
+              for j, i in enumerate(hits)]
+    qt = datetime(2020, 6, 1)
+    got = vf.rank_chunk(chunks, question, qt, rr, emb, chunk_topk=20, similar_threshhold=0.9)
+    # restatement fed with the SAME model outputs (scores, embeddings): isolates the fusion / selection logic
+    scores = rr.compute_score([[question, c["page_content"]] for c in chunks], batch_size=8)
+    ts = vf.time_scores(qt, [c["metadata"]["date_published"] for c in chunks])
+    embs = np.asarray(emb.embed_documents([c["page_content"] for c in chunks]), np.float32)
+    want = R.rank_chunk([c["bundle_id"] for c in chunks], scores, ts, embs, 20, 0.9)
+    assert got == want and 0 < len(got) <= 10 and len(set(got)) == len(got)

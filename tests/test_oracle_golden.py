@@ -155,3 +155,19 @@ def test_rank_fusion_restatement():
     assert np.allclose(t, [1.0, 1 - 10 / 365, 0.0, 0.0, 1 - 30 / 365])
     order = R.fuse_and_rank([0.5, 2.0, 2.0, -1.0, 0.1], t)
     assert order.tolist() == [1, 2, 0, 4, 3]
+
+
+def test_rank_chunk_restatement_logic():
+    """vllmManager.rank_chunk :430-483 on hand-made inputs: bundle size cap, bundle-id-as-column quirk, reverse order."""
+    rng = np.random.default_rng(9)
+    emb = rng.standard_normal((6, 16)).astype(np.float32)
+    emb[4] = emb[0]                                  # chunk 4 duplicates chunk 0
+    bundles = [0, 0, 1, 2, 3, 3]
+    scores = [5.0, 1.0, 4.0, 3.0, 2.0, 0.5]
+    t = [0.0] * 6
+    # ranked: 0,2,3,4,1,5 -> bundle 0 (size 2), bundle 1, bundle 2, then bundle 3 (chunk 4): sim[4, [0,1,2]]:
+    # column 0 is chunk 0 == chunk 4 -> similarity 1 > 0.9 -> skipped; chunk 5 (bundle 3): sim[5,[0,1,2]] small -> kept
+    out = R.rank_chunk(bundles, scores, t, emb, chunk_topk=10, similar_threshhold=0.9)
+    assert out == [3, 2, 1, 0]
+    assert R.rank_chunk(bundles, scores, t, emb, chunk_topk=3, similar_threshhold=0.9) == [1, 0]
+    assert R.rank_chunk([], [], [], np.zeros((0, 16), np.float32), 5) == []

@@ -22,5 +22,6 @@ from .retrieval import get_embeddings, last_token_pool, select_top_chunks, selec
 from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_rank, time_scores  # noqa: F401
 from .sharded import ShardedRetriever, shard_bounds  # noqa: F401
 from .encoder import HipEmbeddings, HipEncoder, HipModel, HipReranker, pack_hf_weights  # noqa: F401
+from .rank import rank_chunk  # noqa: F401
 
 __version__ = "0.1.0"
