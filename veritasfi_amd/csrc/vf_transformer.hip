@@ -284,6 +284,129 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large-tile GEMM: 256 x 256 output tile per 512-thread workgroup (8 waves as 2 (M) x 4 (N), each 128 x 64 =
+// 4 x 2 MFMA 32x32 tiles, 128 accumulator VGPRs), BK = 64, two LDS buffers of 64 KB (A 256x64 + W 256x64 fp16).
+// Operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write): a wave
+// instruction fills 1 KB = 8 rows x 128 B linearly; the 16-byte chunk a lane FETCHES is XOR-swizzled
+// (chunk ^ ((row >> 1) & 7)) and the fragment reads apply the same involution, which makes the ds_read_b128
+// of 16 consecutive rows hit 16 distinct 16-byte slots (conflict-free) without padding.  Per K-tile: stage the
+// next tile, 32 MFMAs per wave on the current one, vmcnt(0) + barrier (the guide's minimum two-phase form).
+// Twice the FLOP per operand byte of the 128 x 128 kernel.  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int LBM = 256, LBN = 256, LTHREADS = 512;
+
+template <int EPI>
+__global__ __launch_bounds__(LTHREADS) void k_gemm256_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                          half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ONE array: [2][A 256x64 | W 256x64] fp16 = 128 KB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5, wr = wid >> 2, wc = wid & 3;
+    int mt_idx, nt_idx;
+    {   // XCD-contiguous, n-major groups of 4 m-tiles (same idea as k_gemm_tn; 32 workgroups per XCD at a time)
+        const int Mt = M / LBM, Nt = N / LBN, nwg = Mt * Nt;
+        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        constexpr int GM = 4;
+        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
+        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+        nt_idx = r / gm;
+        mt_idx = g * GM + (r - nt_idx * gm);
+    }
+    const long long m0 = (long long)mt_idx * LBM, n0 = (long long)nt_idx * LBN;
+    // staging: the A tile is 32 wave-instructions (8 rows each), the W tile 32 more; wave w issues A rows
+    // [32w, 32w+32) and W rows [32w, 32w+32): 4 + 4 instructions per K-tile.
+    // lane l of an instruction lands at LDS slot l: row (l >> 3) of the 8, physical chunk l & 7, and fetches the
+    // LOGICAL chunk (l & 7) ^ ((row >> 1) & 7) of that row.
+    const int srow8 = lane >> 3, spc = lane & 7;
+    const half_t* a_src[4];
+    const half_t* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wid * 32 + j * 8 + srow8;
+        const int lc = spc ^ ((row >> 1) & 7);
+        a_src[j] = A + (m0 + row) * K + lc * 8;
+        w_src[j] = W + (n0 + row) * K + lc * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* abase = smem + buf * 65536 + (wid * 32) * 128;          // A rows of this wave
+        char* wbase = smem + buf * 65536 + 32768 + (wid * 32) * 128;  // W rows of this wave
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * GBK),
+                                             (__attribute__((address_space(3))) void*)(abase + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * GBK),
+                                             (__attribute__((address_space(3))) void*)(wbase + j * 1024), 16, 0, 0);
+        }
+    };
+    f16v acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // fragment addresses: row = wr*128 + mt*32 + r31 (A) / wc*64 + nt*32 + r31 (W); chunk (2 ks + h) ^ ((row >> 1) & 7)
+    const int swz = (r31 >> 1) & 7;  // wr*128, mt*32, wc*64, nt*32 are multiples of 16: they do not change (row >> 1) & 7
+    const char* a_row = smem + (wr * 128 + r31) * 128;
+    const char* w_row = smem + 32768 + (wc * 64 + r31) * 128;
+    const int nk = K / GBK;
+    stage(0, 0);
+    __syncthreads();  // (emits the vmcnt(0) the LDS-DMA needs)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        stage(buf ^ 1, kt + 1 < nk ? kt + 1 : kt);
+        const char* ab = a_row + buf * 65536;
+        const char* wb = w_row + buf * 65536;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int pc = ((2 * ks + h) ^ swz) * 16;
+            h8 af[4], wf[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = *(const h8*)(ab + t * 32 * 128 + pc);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wf[t] = *(const h8*)(wb + t * 32 * 128 + pc);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [256][256] fp16 image (128 KB = the operand buffers),
+    // then 16-byte row chunks out (residual added in fp32 on the vector side)
+    half_t* Es = (half_t*)smem;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = wc * 64 + nt * 32 + r31;
+        const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = wr * 128 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float v = acc[mt][nt][reg] + bv;
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                Es[row * LBN + col] = (half_t)v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + LTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
+        h8 o = *(const h8*)(Es + row * LBN + cc * 8);
+        const long long off = (m0 + row) * N + n0 + cc * 8;
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const h8 r = *(const h8*)(R + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+        }
+        *(h8*)(C + off) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused attention.  grid (ceil(T/128), heads, B), 256 threads; wave w handles queries
 // [qb*128 + 32w, +32) of sequence b, head hd; K [T][64] and V^T [64][T] of that (b, head) live in LDS.
 // S^T = K Q^T is computed with the KEY on the MFMA row, so a lane holds 16 key scores of ONE query
@@ -594,6 +717,9 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er != hipSuccess) {
         const std::string msg = std::string("vf_encoder_create: ") + hipGetErrorString(er);
@@ -605,7 +731,7 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
 }
 
 static int enc_ensure_ws(vf_encoder* e, int B, int T) {
-    const int tokens = (B * T + 127) / 128 * 128;
+    const int tokens = (B * T + 255) / 256 * 256;
     if (tokens <= e->cap_tokens && B <= e->cap_b) return VF_OK;
     enc_free_ws(e);
     const size_t H = e->cfg.hidden, F = e->cfg.ffn, Mp = tokens;
@@ -634,6 +760,11 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st) {
+    if (M % LBM == 0 && N % LBN == 0) {
+        hipLaunchKernelGGL(k_gemm256_tn<EPI>, dim3((N / LBN) * (M / LBM)), dim3(LTHREADS), 131072, st, A, W, bias, R, C, M,
+                           N, K);
+        return hipGetLastError();
+    }
     const dim3 grid((N / GBN) * (M / GBM));
     const size_t lds = (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t);
     hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
@@ -643,7 +774,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
 // ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
 static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, hipStream_t st) {
     const vf_encoder_config& c = e->cfg;
-    const int H = c.hidden, F = c.ffn, M = B * T, Mp = (M + 127) / 128 * 128;
+    const int H = c.hidden, F = c.ffn, M = B * T, Mp = (M + 255) / 256 * 256;
     hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 3) / 4), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
