@@ -128,7 +128,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # VF_BENCH_FORCE_EXCHANGE=1 runs the all-gather + merge even with one rank (rehearsal of the N>1 path)
+    exchange = world > 1 or os.environ.get("VF_BENCH_FORCE_EXCHANGE") == "1"
+    if world > 1 or (exchange and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=device)
 
     lo, hi = vf.shard_bounds(args.rows, world, rank)
@@ -145,7 +147,7 @@ def main():
     bufs = [vf.packed_result_buffer(args.batch, args.k, device) for _ in range(nslots)]
     out_ids = [b[1] for b in bufs]
     out_sc = [b[2] for b in bufs]
-    if world > 1:
+    if exchange:
         g_blob = torch.empty(world * args.batch * args.k * 12, dtype=torch.uint8, device=device)
         m_ids = torch.empty((args.batch, args.k), dtype=torch.int64, device=device)
         m_sc = torch.empty((args.batch, args.k), dtype=torch.float32, device=device)
@@ -153,7 +155,7 @@ def main():
 
     def finish(slot):
         index.search_end(slot)
-        if world > 1:  # the exchange step: ONE all-gather of the packed per-shard top-k over xGMI, then the merge kernel
+        if exchange:  # the exchange step: ONE all-gather of the packed per-shard top-k over xGMI, then the merge kernel
             dist.all_gather_into_tensor(g_blob, bufs[slot][0])
             merged[0] = vf.merge_topk_packed_device(g_blob, world, args.batch, args.k, m_ids, m_sc)
         else:
@@ -172,7 +174,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -183,7 +185,7 @@ def main():
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -233,7 +235,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
     index.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -283,6 +283,37 @@ __global__ __launch_bounds__(1024) void k_merge_topk(const char* ids_base, const
         keys[i] = kv;
     }
     __syncthreads();
+    if (m <= 2048) {
+        // rank by counting (keys are unique; padding keys are 0): no barriers, ~m/16 LDS batches per thread.
+        // A thread owns keys tid and tid + 1024; the key of rank r < k is written straight to output slot r.
+        u64 mine[2];
+        int rank[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mine[u] = tid + u * 1024 < P ? keys[tid + u * 1024] : 0ull;
+        for (int j = 0; j < P; j += 16) {
+            u64 kj[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) kj[t] = j + t < P ? keys[j + t] : 0ull;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) rank[u] += kj[t] > mine[u] ? 1 : 0;
+        }
+        // outputs default to padding; ranks of real keys are distinct and < number of real keys
+        for (int i = tid; i < k; i += 1024) { ids[(long long)q * k + i] = -1; scores[(long long)q * k + i] = -FLT_MAX; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (mine[u] != 0ull && rank[u] < k) {
+                const int src = (int)(0xFFFFFFFFu - (u32)mine[u]);
+                const int g = src / k, j = src - g * k;
+                const long long o = (long long)q * k + j;
+                ids[(long long)q * k + rank[u]] = ((const long long*)(ids_base + g * ids_stride))[o];
+                scores[(long long)q * k + rank[u]] = ((const float*)(score_base + g * score_stride))[o];
+            }
+        }
+        return;
+    }
     bitonic_sort_desc(keys, P, tid, 1024);
     for (int i = tid; i < k; i += 1024) {
         long long id = -1;
