@@ -343,3 +343,50 @@ def test_c2_full_size_bit_exact(vf, oracle):
     print("C2 stats", st)
     assert st["path"] == 1 and st["overflowed"] == 0
     _assert_exact(oracle, c, q, k, ids, sc)
+
+
+# ---- edge cases: branches the main cases do not reach -------------------------------------------------
+def test_wide_rows_and_path_limits(vf, oracle):
+    # d = 1536: the 64-query LDS image does not fit -> 32-query passes (NT = 1), here 40 queries = two passes
+    c, q = _data(31, 20_000, 1536, 40, np.float16)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, 50)
+        assert ix.stats()["path"] == 1
+    _assert_exact(oracle, c, q, 50, ids, sc)
+    # d = 2560 (Qwen3-Embedding-4B, step3_mul.py:384): no LDS-resident query tile -> chunked exact path
+    c, q = _data(32, 17_000, 2560, 3, np.float16)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, 10)
+        assert ix.stats()["path"] == 2
+    _assert_exact(oracle, c, q, 10, ids, sc)
+    # n just past the small-path limit, k = 1
+    c, q = _data(33, 16_385, 256, 2, np.float16)
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, 1)
+        assert ix.stats()["path"] == 1
+    _assert_exact(oracle, c, q, 1, ids, sc)
+
+
+def test_fp32_rows_extreme_ranges_and_ties(vf, oracle):
+    rng = np.random.default_rng(34)
+    n, d = 24_000, 384
+    c = rng.standard_normal((n, d)).astype(np.float32)
+    c[::3] *= 1e-20           # tiny rows: the fp16 scan copy needs the per-row power-of-two scale
+    c[1::3] *= 3e18           # huge rows
+    c[5] = 0                  # zero row
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    q[2] *= 1e-25
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, 64)
+        st = ix.stats()
+    print("extreme-range stats", st)
+    _assert_exact(oracle, c, q, 64, ids, sc)
+    # every row identical: one giant tie group -> certificate fails for every query, exact path, ids 0..k-1
+    c2 = np.tile(rng.standard_normal((1, 128)).astype(np.float16), (18_000, 1))
+    q2 = rng.standard_normal((3, 128)).astype(np.float32)
+    with vf.DenseIndex(c2) as ix:
+        ids, sc = ix.search(q2, 20)
+        st = ix.stats()
+    assert st["exact_reruns"] == 3
+    assert np.array_equal(ids, np.tile(np.arange(20), (3, 1)))
+    _assert_exact(oracle, c2, q2, 20, ids, sc)
