@@ -142,7 +142,7 @@ def main():
     for o in args.opt:
         name, val = o.split("=")
         index.set_option(name, int(val))
-    nslots = index.slots
+    nslots = min(index.slots, int(os.environ.get("VF_BENCH_DEPTH", index.slots)))  # batches in flight
     # per in-flight batch: one packed result blob [ids | scores] with typed views (single all-gather per batch)
     bufs = [vf.packed_result_buffer(args.batch, args.k, device) for _ in range(nslots)]
     out_ids = [b[1] for b in bufs]

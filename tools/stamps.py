@@ -15,7 +15,7 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(4321)
     q = torch.randn((64, 768), generator=g, device=dev)
     ix = vf.DenseIndex(corpus)
-    for dbg in (128, 128 + 4, 128 + 2):
+    for dbg in [128 + int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('0', '4', '2'))]:
         ix.set_option("debug", dbg)
         for _ in range(3):
             ix.search_device(q, 100)

@@ -61,7 +61,7 @@ extern "C" int vf_device_count(int32_t* out) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int kSlots = 2;
+constexpr int kSlots = 4;
 
 struct DevBuf {
     void* p = nullptr;
@@ -120,7 +120,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 32, debug = 0;
+            refresh_every = 128, debug = 0;
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
@@ -480,7 +480,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         a.hist_coarse = s.hist_coarse.as<u32>(); a.stage_cap = scan_stage_cap(ix->dp, qt);
         a.dbg = nullptr;
         if (ix->debug & 128) { VF_TRY(s.dbg.ensure((size_t)p.total_waves * 4 * sizeof(u64))); a.dbg = s.dbg.as<u64>(); }
-        a.refresh_every = (int)std::min<int64_t>(64, std::max<int64_t>(1, ix->refresh_every)); a.nq = nb; a.debug = (int)ix->debug;
+        a.refresh_every = (int)std::min<int64_t>(256, std::max<int64_t>(1, ix->refresh_every)); a.nq = nb; a.debug = (int)ix->debug;
         // sample slots no wave writes (a wave range shorter than samp) must read as empty: 0xFF bytes
         // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
         if (ix->n / p.total_waves < p.samp)

@@ -548,7 +548,7 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
     u32* stage_cnt = (u32*)ctl;
     uint4* stage_ent = (uint4*)(ctl + kCtlBytes);
     const u32 c = (u32)__popc(mask);
-    const u32 R = (u32)a.refresh_every;  // 1..64
+    const u32 R = (u32)a.refresh_every;  // 1..256
     u32 slot = 0;
     bool need = false;
     if (c > 0) {
@@ -596,8 +596,9 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
         //     Entries other waves claimed but have not written yet read w == 0 (the stage is zeroed at
         //     kernel start) and are skipped: the histogram then under-counts, which only makes tau
         //     less tight.
-        const u32 idx = blk * R + (u32)lane;
-        if ((u32)lane < R && idx < (u32)a.stage_cap) {
+        for (u32 j = (u32)lane; j < R; j += 64u) {
+            const u32 idx = blk * R + j;
+            if (idx >= (u32)a.stage_cap) break;
             const uint4 en = stage_ent[idx];
             if (en.w == 1u) {
                 const u32 q = en.z & 0xFFu, bin = en.z >> 8;

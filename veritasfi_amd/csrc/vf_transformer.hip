@@ -619,6 +619,20 @@ __global__ void k_all_last_set(const int* mask, int B, int T, int Tv, int* out) 
 // ------------------------------------------------------------------------------------------------
 using namespace vft;
 
+// Opt every kernel into its dynamic LDS size (idempotent; cheap).
+static hipError_t configure_once() {
+    hipError_t er = hipSuccess;
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return er;
+}
+
+
 struct vf_encoder {
     vf_encoder_config cfg{};
     int device = 0;
@@ -714,13 +728,7 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_flag, 4);
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = configure_once();
     if (er != hipSuccess) {
         const std::string msg = std::string("vf_encoder_create: ") + hipGetErrorString(er);
         vf_encoder_destroy(e);
@@ -886,3 +894,19 @@ extern "C" int vf_reranker_score(vf_encoder* e, const int32_t* ids, const int32_
     return vf_encoder_forward(e, ids, mask, type_ids, b, t, t, out_scores);
 }
 extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e); }
+
+
+// Test hook (not part of the public header; tools/bench_gemm.py and the GEMM parity test bind it):
+// C[M][N] = epi(A[M][K] . W[N][K]^T + bias [, + R]) on device pointers, fp16 in/out, fp32 accumulation.
+extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, const void* R, void* C, int M, int N, int K,
+                             int epi, void* stream) {
+    hipError_t er = configure_once();
+    if (er != hipSuccess) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
+    half_t* c = (half_t*)C;
+    if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st);
+    else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st);
+    else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st);
+    return er == hipSuccess ? 0 : -1;
+}
