@@ -111,3 +111,26 @@ def rank_chunk(bundle_ids, rerank_scores, time_sc, embeddings, chunk_topk, simil
         selected.append(b)
         size += len(bundle_map[b])
     return selected[::-1]
+
+
+def e4m3_table() -> np.ndarray:
+    """All 256 OCP FP8 E4M3 codes -> float32 (1-4-3, bias 7, no infinities, S.1111.111 = NaN).  The storage format
+    BASELINE.json config [4] names; restated from the OCP 8-bit floating point specification (e4m3, "fn" flavour) and
+    pinned against torch.float8_e4m3fn in tests/test_oracle_golden.py."""
+    t = np.empty(256, dtype=np.float32)
+    for b in range(256):
+        sign = -1.0 if b & 0x80 else 1.0
+        e, m = (b >> 3) & 0xF, b & 7
+        if e == 0:
+            v = m * 2.0 ** -9
+        elif e == 15 and m == 7:
+            v = float("nan")
+        else:
+            v = (1.0 + m / 8.0) * 2.0 ** (e - 7)
+        t[b] = sign * v
+    return t
+
+
+def decode_e4m3(codes: np.ndarray) -> np.ndarray:
+    """uint8 e4m3 codes -> float32 values (exactly representable in fp16 as well)."""
+    return e4m3_table()[np.asarray(codes, dtype=np.uint8)]

@@ -317,11 +317,11 @@ def test_drop_in_classes(vf, oracle):
 
 def test_errors_are_reported_not_fatal(vf):
     from veritasfi_amd import _ffi
-    with pytest.raises(RuntimeError, match="fp8"):
+    with pytest.raises(RuntimeError, match="unknown dtype"):
         h = _ffi.vp()
         x = np.zeros((4, 16), np.uint8)
         import ctypes
-        _ffi.check(_ffi.lib().vf_index_create(ctypes.byref(h), x.ctypes.data, 4, 16, _ffi.VF_DTYPE_FP8_E4M3, 0, 0), "create")
+        _ffi.check(_ffi.lib().vf_index_create(ctypes.byref(h), x.ctypes.data, 4, 16, 7, 0, 0), "create")
     with pytest.raises(RuntimeError):
         vf.DenseIndex(np.zeros((4, 16), np.float32), device_id=99)
     with vf.DenseIndex(np.ones((4, 16), np.float32)) as ix:
@@ -390,3 +390,53 @@ def test_fp32_rows_extreme_ranges_and_ties(vf, oracle):
     assert st["exact_reruns"] == 3
     assert np.array_equal(ids, np.tile(np.arange(20), (3, 1)))
     _assert_exact(oracle, c2, q2, 20, ids, sc)
+
+
+# ---- fp8 (OCP e4m3) corpus: BASELINE.json config [4] storage format, decoded exactly to fp16 at build ----------
+def _e4m3_codes(n, d, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, d), generator=g) * 0.5
+    x[::97] *= 40.0          # exercise the top of the range (|x| up to ~100) ...
+    x[5::89] *= 2.0 ** -8    # ... and the subnormals
+    return x.to(torch.float8_e4m3fn).view(torch.uint8).numpy().copy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,k", [(3000, 5, 50), (40000, 96, 1000)])
+def test_fp8_corpus_matches_oracle_on_decoded_rows(vf, oracle, n, nq, k):
+    from oracle import ref_numpy as R
+    d = 1024
+    codes = _e4m3_codes(n, d, 21)
+    rows16 = R.decode_e4m3(codes).astype(np.float16)          # exact
+    assert np.array_equal(rows16.astype(np.float32), R.decode_e4m3(codes))
+    q = np.random.default_rng(22).standard_normal((nq, d)).astype(np.float32)
+    want_i, want_s = oracle.search(rows16, q, k)
+    ix = vf.DenseIndex.from_e4m3(codes)
+    try:
+        got_i, got_s = ix.search(q, k)
+        assert np.array_equal(got_i, want_i)
+        assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+        # the same index built from the decoded fp16 rows is indistinguishable
+        ix16 = vf.DenseIndex(rows16)
+        i16, s16 = ix16.search(q, k)
+        ix16.close()
+        assert np.array_equal(i16, got_i) and np.array_equal(s16.view(np.uint32), got_s.view(np.uint32))
+    finally:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_fp8_corpus_from_cuda_float8_tensor(vf, oracle):
+    import torch
+    from oracle import ref_numpy as R
+    codes = _e4m3_codes(20000, 256, 23)
+    t = torch.from_numpy(codes).cuda().view(torch.float8_e4m3fn)
+    q = np.random.default_rng(24).standard_normal((7, 256)).astype(np.float32)
+    ix = vf.DenseIndex(t)
+    try:
+        got_i, got_s = ix.search(q, 100)
+    finally:
+        ix.close()
+    want_i, want_s = oracle.search(R.decode_e4m3(codes).astype(np.float16), q, 100)
+    assert np.array_equal(got_i, want_i) and np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))

@@ -171,3 +171,19 @@ def test_rank_chunk_restatement_logic():
     assert out == [3, 2, 1, 0]
     assert R.rank_chunk(bundles, scores, t, emb, chunk_topk=3, similar_threshhold=0.9) == [1, 0]
     assert R.rank_chunk([], [], [], np.zeros((0, 16), np.float32), 5) == []
+
+
+def test_e4m3_decode_matches_torch():
+    """The oracle's fp8 decoder against an independent implementation (torch.float8_e4m3fn), all 256 codes;
+    every finite value survives a round trip through fp16 (the product decodes fp8 rows to fp16)."""
+    torch = pytest.importorskip("torch")
+    if not hasattr(torch, "float8_e4m3fn"):
+        pytest.skip("torch without float8_e4m3fn")
+    codes = np.arange(256, dtype=np.uint8)
+    ref = torch.from_numpy(codes.copy()).view(torch.float8_e4m3fn).float().numpy()
+    got = R.decode_e4m3(codes)
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    fin = ~np.isnan(ref)
+    assert np.array_equal(ref[fin].view(np.uint32), got[fin].view(np.uint32))
+    assert np.array_equal(got[fin].astype(np.float16).astype(np.float32), got[fin])
+    assert np.nanmax(np.abs(got)) == 448.0 and got[1] == 2.0 ** -9

@@ -106,7 +106,8 @@ struct Slot {
 struct vf_index {
     int device = 0;
     int64_t n = 0;
-    int d = 0, dp = 0, dtype = 0;
+    int d = 0, dp = 0, dtype = 0;  // dtype: how rows are HELD (F32 / F16); fp8 input is decoded to fp16 at build
+    int user_dtype = 0;              // what the caller handed over (vf_index_info)
     int64_t id_offset = 0;
     int n_cu = 256;
     bool owns_rows = false;
@@ -212,8 +213,8 @@ static int create_impl(vf_index** out, const void* rows, bool rows_on_device, in
     if (!out) return fail(VF_EINVAL, "vf_index_create: null out");
     *out = nullptr;
     if (n < 0 || d <= 0 || (n > 0 && !rows)) return fail(VF_EINVAL, "vf_index_create: bad rows/n/d");
-    if (dtype == VF_DTYPE_FP8_E4M3) return fail(VF_EUNSUPPORTED, "vf_index_create: fp8 corpus not implemented in this build");
-    if (dtype != VF_DTYPE_F32 && dtype != VF_DTYPE_F16) return fail(VF_EINVAL, "vf_index_create: unknown dtype");
+    if (dtype != VF_DTYPE_F32 && dtype != VF_DTYPE_F16 && dtype != VF_DTYPE_FP8_E4M3)
+        return fail(VF_EINVAL, "vf_index_create: unknown dtype");
     if (n >= (int64_t)0xFFFFFFFFll) return fail(VF_EUNSUPPORTED, "vf_index_create: more than 2^32-1 rows per shard");
     int ndev = 0;
     VF_HIP(hipGetDeviceCount(&ndev));
@@ -221,10 +222,38 @@ static int create_impl(vf_index** out, const void* rows, bool rows_on_device, in
     VF_HIP(hipSetDevice(device_id));
     vf_index* ix = new (std::nothrow) vf_index();
     if (!ix) return fail(VF_ENOMEM, "vf_index_create: host allocation failed");
-    ix->device = device_id; ix->n = n; ix->d = d; ix->dtype = dtype; ix->id_offset = id_offset;
-    const size_t esz = dtype == VF_DTYPE_F16 ? 2 : 4;
+    ix->device = device_id; ix->n = n; ix->d = d; ix->user_dtype = dtype; ix->id_offset = id_offset;
+    ix->dtype = dtype == VF_DTYPE_F32 ? VF_DTYPE_F32 : VF_DTYPE_F16;
+    const size_t esz = dtype == VF_DTYPE_F32 ? 4 : (dtype == VF_DTYPE_F16 ? 2 : 1);
     int rc = VF_OK;
-    if (rows_on_device) {
+    if (dtype == VF_DTYPE_FP8_E4M3) {
+        // fp8 rows (OCP e4m3) are decoded to fp16 once, exactly; from here on the corpus IS those fp16 values.
+        // (Per-row scales of a scaled-fp8 store cancel in the cosine, so none is taken.)  The scan therefore
+        // still reads 2 bytes per element: an fp8-resident scan is the follow-up.
+        void* raw = const_cast<void*>(rows);
+        bool own_raw = false;
+        hipError_t e = hipSuccess;
+        if (n > 0) {
+            e = hipMalloc(&ix->rows_orig, (size_t)n * d * 2);
+            if (e != hipSuccess) rc = fail(VF_ENOMEM, std::string("hipMalloc(corpus): ") + hipGetErrorString(e));
+            else ix->owns_rows = true;
+            if (rc == VF_OK && !rows_on_device) {
+                e = hipMalloc(&raw, (size_t)n * d);
+                if (e != hipSuccess) rc = fail(VF_ENOMEM, std::string("hipMalloc(fp8 staging): ") + hipGetErrorString(e));
+                else {
+                    own_raw = true;
+                    e = hipMemcpy(raw, rows, (size_t)n * d, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) rc = fail(VF_EHIP, std::string("hipMemcpy(corpus): ") + hipGetErrorString(e));
+                }
+            }
+            if (rc == VF_OK) {
+                e = launch_decode_e4m3(raw, ix->rows_orig, (long long)n * d, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) rc = fail(VF_EHIP, std::string("decode_e4m3: ") + hipGetErrorString(e));
+            }
+            if (own_raw) (void)hipFree(raw);
+        }
+    } else if (rows_on_device) {
         ix->rows_orig = const_cast<void*>(rows);
         ix->owns_rows = false;
     } else if (n > 0) {
@@ -262,7 +291,7 @@ extern "C" int vf_index_info(vf_index* ix, int64_t* n, int32_t* d, int32_t* dtyp
     if (!ix) return fail(VF_EINVAL, "vf_index_info: null handle");
     if (n) *n = ix->n;
     if (d) *d = ix->d;
-    if (dtype) *dtype = ix->dtype;
+    if (dtype) *dtype = ix->user_dtype;
     if (device_id) *device_id = ix->device;
     return VF_OK;
 }

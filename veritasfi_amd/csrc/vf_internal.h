@@ -74,6 +74,8 @@ struct FinalArgs {
 hipError_t launch_prep_rows(const void* rows, int is_half, long long n, int d, int dp,
                             _Float16* scan /*may be null when rows are used in place*/,
                             float* norm, float* inv_scan, hipStream_t s);
+// OCP e4m3 bytes -> fp16 (exact); in / out are device pointers, count elements
+hipError_t launch_decode_e4m3(const void* in, void* out_f16, long long count, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, int nq, int d, int dp, int qn_tile /*32 or 64*/,
                                float* qn, _Float16* qimg, hipStream_t s);
 hipError_t launch_normalize_rows(const void* rows, int is_half, long long row0, long long nrows, int d,

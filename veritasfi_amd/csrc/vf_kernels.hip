@@ -748,6 +748,63 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_decode_e4m3: OCP FP8 E4M3 (1-4-3, bias 7, no infinities, S.1111.111 = NaN) -> fp16, EXACT: every
+// finite e4m3 value (|x| <= 448, subnormals m * 2^-9) is representable in fp16.  16 bytes per thread.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short e4m3_to_f16_bits(u32 b) {
+    const u32 sign = (b & 0x80u) << 8, e = (b >> 3) & 0xFu, m = b & 7u;
+    if (e == 0u) {  // zero / subnormal: m * 2^-9 = m * 2^-24 * 2^15 -> normalise by hand
+        if (m == 0u) return (unsigned short)sign;
+        const int sh = m >= 4u ? 0 : (m >= 2u ? 1 : 2);            // leading one at bit 2 - sh
+        const u32 frac = ((m << (sh + 1)) & 7u) << 7;              // bits below the leading one -> fp16 mantissa
+        return (unsigned short)(sign | ((u32)(15 - 7 - sh) << 10) | frac);  // value 1.f * 2^(-7 - sh)
+    }
+    if (e == 15u && m == 7u) return (unsigned short)(sign | 0x7E00u);  // NaN
+    return (unsigned short)(sign | ((e + 8u) << 10) | (m << 7));       // exponent e - 7 + 15
+}
+
+__global__ void k_decode_e4m3(const uint4* __restrict__ in, uint4* __restrict__ out, long long nvec,
+                              const unsigned char* __restrict__ in_tail, unsigned short* __restrict__ out_tail, int ntail) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvec) {
+        const uint4 v = in[i];
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        u32 o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[2 * j] = (u32)e4m3_to_f16_bits(w[j] & 0xFFu) | ((u32)e4m3_to_f16_bits((w[j] >> 8) & 0xFFu) << 16);
+            o[2 * j + 1] = (u32)e4m3_to_f16_bits((w[j] >> 16) & 0xFFu) | ((u32)e4m3_to_f16_bits(w[j] >> 24) << 16);
+        }
+        out[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+        out[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    if (i < ntail) out_tail[i] = e4m3_to_f16_bits(in_tail[i]);
+}
+
+hipError_t launch_decode_e4m3(const void* in, void* out_f16, long long count, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    const long long nvec = ((uintptr_t)in % 16 == 0) ? count / 16 : 0;
+    const int ntail = (int)(count - nvec * 16);  // < 16 when aligned; unaligned input takes the scalar path below
+    if (nvec == 0 && count > 0) {
+        // unaligned device pointer: scalar decode, 256 threads x as many blocks as needed
+        const long long blocks = (count + 255) / 256;
+        for (long long b0 = 0; b0 < blocks; b0 += 1 << 20) {
+            const long long nb = blocks - b0 < (1 << 20) ? blocks - b0 : (1 << 20);
+            const long long off = b0 * 256;
+            const long long left = count - off;
+            const int chunk_tail = (int)(left < nb * 256 ? left : nb * 256);
+            hipLaunchKernelGGL(k_decode_e4m3, dim3((unsigned)nb), dim3(256), 0, s, (const uint4*)nullptr, (uint4*)nullptr, 0ll,
+                               (const unsigned char*)in + off, (unsigned short*)out_f16 + off, chunk_tail);
+        }
+        return hipGetLastError();
+    }
+    const long long threads = nvec > ntail ? nvec : ntail;
+    hipLaunchKernelGGL(k_decode_e4m3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint4*)in,
+                       (uint4*)out_f16, nvec, (const unsigned char*)in + nvec * 16, (unsigned short*)out_f16 + nvec * 16, ntail);
+    return hipGetLastError();
+}
+
 // dynamic LDS of k_scan: query image + (main mode) candidate stage
 size_t scan_lds_bytes(int dp, int qn_tile) { return (size_t)dp * qn_tile * 2 + kCtlBytes; }
 int scan_stage_cap(int dp, int qn_tile) {

@@ -20,19 +20,26 @@ def _is_torch_tensor(x) -> bool:
 
 class DenseIndex:
     def __init__(self, rows, device_id: int = 0, id_offset: int = 0):
-        """rows: [n, d] float32 / float16 ndarray (copied to HBM) or a CUDA torch tensor (borrowed)."""
+        """rows: [n, d] float32 / float16 ndarray (copied to HBM) or a CUDA torch tensor (borrowed).
+        FP8: a torch.float8_e4m3fn tensor (CPU or CUDA), or a uint8 ndarray / tensor of OCP e4m3 codes passed with
+        ``DenseIndex.from_e4m3``; decoded exactly to fp16 at build."""
         L = _ffi.lib()
         self._h = _ffi.vp()
         self._keepalive = None
         self.device_id = int(device_id)
+        e4m3 = getattr(self, "_e4m3", False)
         if _is_torch_tensor(rows):
             import torch
+            if rows.dtype == getattr(torch, "float8_e4m3fn", None):
+                rows, e4m3 = rows.view(torch.uint8), True
             if not rows.is_cuda:
                 rows = rows.cpu().numpy()
             else:
                 if rows.dim() != 2 or not rows.is_contiguous():
                     raise ValueError("rows must be a contiguous [n, d] tensor")
-                if rows.dtype == torch.float16:
+                if e4m3 and rows.dtype == torch.uint8:
+                    dt = _ffi.VF_DTYPE_FP8_E4M3
+                elif rows.dtype == torch.float16:
                     dt = _ffi.VF_DTYPE_F16
                 elif rows.dtype == torch.float32:
                     dt = _ffi.VF_DTYPE_F32
@@ -48,7 +55,11 @@ class DenseIndex:
         rows = np.asarray(rows)
         if rows.ndim != 2:
             raise ValueError("rows must be [n, d]")
-        if rows.dtype == np.float16:
+        if e4m3:
+            if rows.dtype != np.uint8:
+                raise TypeError("e4m3 rows must be uint8 codes")
+            dt = _ffi.VF_DTYPE_FP8_E4M3
+        elif rows.dtype == np.float16:
             dt = _ffi.VF_DTYPE_F16
         else:
             rows = rows.astype(np.float32, copy=False)  # faissRetriever.py:21  x = embeddings.astype('float32')
@@ -58,6 +69,14 @@ class DenseIndex:
         self.id_offset = int(id_offset)
         _ffi.check(L.vf_index_create(ctypes.byref(self._h), rows.ctypes.data, self.n, self.d, dt, self.device_id,
                                      self.id_offset), "vf_index_create")
+
+    @classmethod
+    def from_e4m3(cls, codes, device_id: int = 0, id_offset: int = 0):
+        """codes: [n, d] uint8 OCP-e4m3 bytes (ndarray, CPU or CUDA tensor)."""
+        self = cls.__new__(cls)
+        self._e4m3 = True
+        self.__init__(codes, device_id=device_id, id_offset=id_offset)
+        return self
 
     # -- host buffers ------------------------------------------------------------------------------
     def search(self, queries, k: int):
