@@ -171,6 +171,11 @@ int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg, const void
  * out [b, hidden] (head 0) or [b] (head 1) fp32 host. */
 int vf_encoder_forward(vf_encoder* enc, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
                        int32_t b, int32_t t, int32_t t_valid, float* out);
+/* Same, with pooling / normalize chosen for this call (-1 = the handle's setting); embedding handles only.
+ * get_embeddings picks the pooling per call site on one loaded model (step3_mul.py:203-207 last token,
+ * continuous_retrieval.py:146-149 unmasked mean). */
+int vf_encoder_forward_pooled(vf_encoder* enc, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                              int32_t b, int32_t t, int32_t t_valid, int32_t pooling, int32_t normalize, float* out);
 /* last_hidden_state [b, t, hidden] fp32 host (callers that pool themselves: step3_mul.py:203-207) */
 int vf_encoder_forward_hidden(vf_encoder* enc, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
                               int32_t b, int32_t t, float* out_hidden);

@@ -110,6 +110,19 @@ def test_pooling_variants(vf):
             return {"input_ids": torch.from_numpy(np.stack(rows)), "attention_mask": torch.from_numpy(np.stack(m))}
     emb = get_embeddings(["0", "1", "2", "3"], vf.HipModel(e), Tok(), "cpu", batch_size=2, pooling="last_token")
     assert emb.shape == (4, 128) and np.abs(emb - want).max() < 3e-2
+    # get_embeddings took HipModel.pooled (forward + pooling in one GPU call); the generic route -- an HF-style
+    # callable whose hidden states the reference's own pooling code reduces on the host -- must agree with it,
+    # for both poolings, whatever the handle was built with (per-call override, vf_encoder_forward_pooled)
+    class HiddenOnly:
+        def __init__(self, m): self.m = m
+        def __call__(self, **kw): return self.m(**kw)
+    for pooling, ref in (("last_token", want), ("mean", h.mean(dim=1).numpy())):
+        fast = get_embeddings(["0", "1", "2", "3"], vf.HipModel(e), Tok(), "cpu", batch_size=4, pooling=pooling)
+        slow = get_embeddings(["0", "1", "2", "3"], HiddenOnly(vf.HipModel(e)), Tok(), "cpu", batch_size=4, pooling=pooling)
+        assert np.abs(fast - slow).max() < 2e-3 and np.abs(fast - ref).max() < 3e-2
+    assert np.abs(e.forward(ids, mask) - want).max() < 3e-2                 # the handle's own setting is untouched
+    with pytest.raises(RuntimeError):
+        e.forward(ids, mask, pooling=5)
     e.close()
 
 

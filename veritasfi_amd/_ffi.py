@@ -64,6 +64,7 @@ SIGNATURES = {
     "vf_encoder_weight_sizes": (ctypes.c_int, [ctypes.POINTER(EncoderConfig), p_i64, p_i64]),
     "vf_encoder_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(EncoderConfig), vp, c_i64, vp, c_i64, c_i32]),
     "vf_encoder_forward": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, c_i32, vp]),
+    "vf_encoder_forward_pooled": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
     "vf_encoder_forward_hidden": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, vp]),
     "vf_encoder_info": (ctypes.c_int, [vp, ctypes.POINTER(EncoderConfig)]),
     "vf_encoder_destroy": (ctypes.c_int, [vp]),

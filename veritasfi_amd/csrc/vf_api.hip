@@ -172,14 +172,19 @@ static int build_common(vf_index* ix) {
         VF_HIP(hipMalloc((void**)&ix->cn_cache, (size_t)ix->n * ix->d * sizeof(float)));
         VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, 0, ix->n, ix->d, ix->norm, ix->cn_cache, nullptr));
     }
-    for (int i = 0; i < kSlots; ++i) {
-        VF_HIP(hipStreamCreateWithFlags(&ix->slots[i].stream, hipStreamNonBlocking));
-        VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_in, hipEventDisableTiming));
-        VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_done, hipEventDisableTiming));
-        VF_HIP(hipEventCreateWithFlags(&ix->slots[i].ev_scan, hipEventDisableTiming));
-        for (int e = 0; e < 4; ++e) VF_HIP(hipEventCreate(&ix->slots[i].ev_t[e]));
-    }
     VF_HIP(hipDeviceSynchronize());
+    return VF_OK;
+}
+
+// A slot's stream and events are created on its first use: a one-shot index (the reference builds one per
+// select_top_chunks call, step3_mul.py:233-253) only ever touches slot 0.
+static int ensure_slot(Slot& s) {
+    if (s.stream) return VF_OK;
+    VF_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    VF_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+    VF_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    VF_HIP(hipEventCreateWithFlags(&s.ev_scan, hipEventDisableTiming));
+    for (int e = 0; e < 4; ++e) VF_HIP(hipEventCreate(&s.ev_t[e]));
     return VF_OK;
 }
 
@@ -457,6 +462,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     if (s.pending) return fail(VF_EINVAL, "vf_index_search_begin: slot already has a pending search");
     const int path = select_path(ix, k);
     if (path < 0) return fail(VF_EUNSUPPORTED, "forced fused path is not possible for this n / k / d");
+    VF_TRY(ensure_slot(s));
     VF_HIP(hipEventRecord(s.ev_in, user));
     VF_HIP(hipStreamWaitEvent(s.stream, s.ev_in, 0));
     hipStream_t st = s.stream;
@@ -520,7 +526,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // back to back anyway; ordering them explicitly keeps queueing time out of the timed bracket
         // while this slot's prep / sample / seed kernels still overlap the other slot's scan.
         for (int o = 0; o < kSlots; ++o)
-            if (o != slot_id) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
+            if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
         if (s.timed && b0 == 0) VF_HIP(hipEventRecord(s.ev_t[0], st));
         VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, st));
         VF_HIP(hipEventRecord(s.ev_scan, st));

@@ -768,7 +768,9 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st) {
-    if (M % LBM == 0 && N % LBN == 0) {
+    // 256 x 256 tiles only when they still give every CU a workgroup; smaller problems (micro-batches of 8 pairs,
+    // single queries) take the 128 x 128 kernel, which launches 4x the workgroups (2 resident per CU).
+    if (M % LBM == 0 && N % LBN == 0 && (long long)(M / LBM) * (N / LBN) >= 192) {
         hipLaunchKernelGGL(k_gemm256_tn<EPI>, dim3((N / LBN) * (M / LBM)), dim3(LTHREADS), 131072, st, A, W, bias, R, C, M,
                            N, K);
         return hipGetLastError();
@@ -823,8 +825,8 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     return VF_OK;
 }
 
-extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
-                                  int32_t b, int32_t t, int32_t t_valid, float* out) {
+static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids, int32_t b,
+                        int32_t t, int32_t t_valid, int32_t pooling, int32_t normalize, float* out) {
     if (!e) return fail(VF_EINVAL, "vf_encoder_forward: null handle");
     if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_encoder_forward: negative sizes");
     if (b == 0) return VF_OK;
@@ -834,6 +836,13 @@ extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32
     if (t > e->cfg.max_pos - (e->cfg.roberta_pad_idx >= 0 ? e->cfg.roberta_pad_idx + 1 : 0))
         return fail(VF_EINVAL, "vf_encoder_forward: t exceeds the position table");
     std::lock_guard<std::mutex> g(e->mu);
+    // per-call pooling / normalisation: swapped in under the handle's lock, restored on every exit path
+    struct Restore {
+        vf_encoder_config& c; int p, n;
+        ~Restore() { c.pooling = p; c.normalize = n; }
+    } restore{e->cfg, e->cfg.pooling, e->cfg.normalize};
+    if (pooling >= 0) e->cfg.pooling = pooling;
+    if (normalize >= 0) e->cfg.normalize = normalize;
     VFT_HIP(hipSetDevice(e->device));
     int rc = enc_ensure_ws(e, b, t);
     if (rc != VF_OK) return rc;
@@ -847,6 +856,24 @@ extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32
     VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
     VFT_HIP(hipStreamSynchronize(nullptr));
     return VF_OK;
+}
+
+extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                                  int32_t b, int32_t t, int32_t t_valid, float* out) {
+    return forward_impl(e, ids, mask, type_ids, b, t, t_valid, -1, -1, out);
+}
+
+// Same forward with the pooling / normalisation chosen per call (-1 keeps the handle's setting): get_embeddings'
+// callers pick "last token" or "unmasked mean" per call site (step3_mul.py:203-207, continuous_retrieval.py:146-149)
+// on one loaded model.  Only for embedding handles (head == 0).
+extern "C" int vf_encoder_forward_pooled(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
+                                         int32_t b, int32_t t, int32_t t_valid, int32_t pooling, int32_t normalize,
+                                         float* out) {
+    if (!e) return fail(VF_EINVAL, "vf_encoder_forward_pooled: null handle");
+    if (e->cfg.head != 0) return fail(VF_EINVAL, "vf_encoder_forward_pooled: handle is a re-ranker");
+    if (pooling < -1 || pooling > 2 || normalize < -1 || normalize > 1)
+        return fail(VF_EINVAL, "vf_encoder_forward_pooled: pooling must be -1..2, normalize -1..1");
+    return forward_impl(e, ids, mask, type_ids, b, t, t_valid, pooling, normalize, out);
 }
 
 // last_hidden_state [b, t, hidden] fp32 (what the reference's get_embeddings pools itself:

@@ -38,6 +38,9 @@ def get_embeddings(texts, model, tokenizer, device, batch_size=32, pooling="last
     for i in range(0, len(texts), batch_size):
         batch_texts = texts[i:i + batch_size]
         inputs = tokenizer(batch_texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length)
+        if hasattr(model, "pooled"):  # this package's HipModel: forward + pooling in one GPU call
+            all_embeddings.append(np.asarray(model.pooled(pooling, **inputs), dtype=np.float32))
+            continue
         inputs = {k: v.to(device) for k, v in inputs.items()}
         with torch.no_grad():
             outputs = model(**inputs)
