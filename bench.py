@@ -86,11 +86,26 @@ def cpu_baseline(args):
         best = min(best, time.time() - t0)
         reps += 1
     t_full = best * (args.rows / n)
-    return {
+    out = {
         "value": round(args.batch / t_full, 3), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
         "sample": f"oracle/vf_oracle.c exact cosine top-{args.k}, {args.batch} queries x {n} of the {args.rows} "
                   f"rows (fp16, d={args.dim}), best of {reps} runs = {best:.3f}s, scaled x{args.rows / n:.1f} to the full corpus",
     }
+    # (A) of BASELINE.md 3: the reference's literal experiment path (step3_mul.py:275-283: sklearn-style
+    # normalise-both-every-call + fp32 matmul + full argsort per row), NumPy restatement, on a smaller slice
+    from oracle import ref_numpy
+    na = min(n, 100_000)
+    ca = corpus[:na].astype(np.float32)
+    t0 = time.time()
+    ref_numpy.select_top_chunks_batch(q, ca, args.k)
+    ta = time.time() - t0
+    out["reference_faithful"] = {
+        "value": round(args.batch / (ta * args.rows / na), 3), "unit": "queries/s", "kind": "port",
+        "cores": os.cpu_count(),
+        "sample": f"oracle/ref_numpy.py select_top_chunks_batch (normalise every call + full argsort), {args.batch} queries "
+                  f"x {na} rows, one run = {ta:.3f}s, scaled x{args.rows / na:.1f}; BLAS threads = NumPy default",
+    }
+    return out
 
 
 def rerank_p50(args):
