@@ -38,7 +38,17 @@ def main():
         for _ in range(a.iters): run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.iters
-        print(json.dumps({"shape": sh, "us": round(us, 1), "tflops": round(2 * M * N * K / us / 1e6, 1), "max_err": err,
+        lib_us = None
+        if a.check:
+            lin = torch.nn.functional.linear
+            bh = bias.half()
+            for _ in range(3): lin(A, W, bh)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(a.iters): lin(A, W, bh)
+            e1.record(); torch.cuda.synchronize()
+            lib_us = round(e0.elapsed_time(e1) * 1e3 / a.iters, 1)
+        print(json.dumps({"shape": sh, "us": round(us, 1), "vendor_lib_us": lib_us, "tflops": round(2 * M * N * K / us / 1e6, 1), "max_err": err,
                           "ring": os.environ.get("VF_GEMM_RING"), "ablate": os.environ.get("VF_GEMM_ABLATE")}), flush=True)
 
 if __name__ == "__main__":

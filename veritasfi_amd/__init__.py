@@ -13,6 +13,7 @@ Drop-in names (same signatures as the reference):
                                          -- ``src/utils/ensembleRetriever.py:265-281``, ``src/utils/vllmManager.py:443-457``
 * ``HipEmbeddings`` / ``HipReranker``   -- ``HuggingFaceEmbeddings`` (``src/utils/ragManager.py:50``) /
                                             ``reranker.compute_score`` (``src/utils/vllmManager.py:451``)
+* ``EnsembleRetriever``                  -- ``src/utils/ensembleRetriever.py:19-232`` (candidate gathering around the search)
 * ``ShardedRetriever``                   -- row-sharded multi-GPU search
 """
 from .index import (DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device,  # noqa: F401
@@ -23,5 +24,6 @@ from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_ran
 from .sharded import ShardedRetriever, shard_bounds  # noqa: F401
 from .encoder import HipEmbeddings, HipEncoder, HipModel, HipReranker, pack_hf_weights  # noqa: F401
 from .rank import rank_chunk  # noqa: F401
+from .ensemble import EnsembleRetriever  # noqa: F401
 
 __version__ = "0.1.0"

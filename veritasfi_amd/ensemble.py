@@ -1,0 +1,155 @@
+"""Candidate gathering around the dense search: ``EnsembleRetriever`` with the reference's constructor and
+``invoke(input, hyde_chunks) -> list[dict]`` (``src/utils/ensembleRetriever.py:19-48`` ctor, ``:50-232`` invoke).
+
+What the reference does per hit with an O(N) scan over every chunk's metadata -- "all rows of this bundle"
+(``:77-82,155-160,203-208``) and "all rows whose title summary is this string" (``:144``) -- is answered here from
+three maps built once at construction: ``bundle_id -> rows`` (ascending row order, as the scan yields them),
+``title_summary -> rows`` and ``doc_id -> row`` (the reference's ``docid2idx``, ``:45``).  The dense searches go
+through this package's ``FaissRetriever`` (GPU).  Output schema, ordering, the ``seen_ids`` bookkeeping, the
+neighbour expansion (score > 0.72, neighbours > 0.66 in the 2048-deep score map, at most 4 rows, ``:85-107``) and
+the running ``bundle_id`` counter are the reference's.
+
+BM25 is outside this path: pass any object with ``invoke(query, k) -> (ids, scores)`` (the reference's
+``BM25Retriever.invoke`` surface, ``src/utils/bm25Retriever.py:50-87``) or leave ``bm25_retriever=None`` with
+``bm25_k=0``.  The stores are anything with Chroma's ``get(include=[...])`` / ``get(ids=[...], include=[...])``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+from .faiss_retriever import FaissRetriever
+from .similarity import compute_similarity, compute_similarity_mtx
+
+EXPAND_SCORE, NEIGHBOUR_SCORE, MAX_EXPANDED, SEARCH_DEPTH = 0.72, 0.66, 4, 2048
+
+
+class EnsembleRetriever:
+    def __init__(self, bm25_dir, chroma, ts_chroma, k: int, embeddings, faiss_k: int = None, bm25_k: int = None,
+                 faiss_ts_k: int = None, enable_expand: bool = False, bm25_retriever=None, retriever_cls=FaissRetriever,
+                 prefetch_documents: bool = False):
+        """Positional arguments as upstream (``ragManager.py:112`` passes bm25_dir, chroma, ts_chroma, k, embeddings).
+        ``bm25_dir`` is kept for signature compatibility; hand the BM25 object itself in ``bm25_retriever``.
+        ``prefetch_documents=True`` loads every chunk's text once and serves bundles from memory in the requested
+        row order instead of one ``chroma.get(ids=...)`` per bundle (Chroma returns rows in ITS order, so leave this
+        off when byte-identical ordering inside a bundle matters)."""
+        self.embeddings = embeddings
+        self.faiss_k = faiss_k if faiss_k is not None else k
+        self.bm25_k = bm25_k if bm25_k is not None else k
+        self.faiss_ts_k = faiss_ts_k if faiss_ts_k is not None else k
+        self.enable_expand = enable_expand
+        self.chroma = chroma
+        self.bm25_dir = bm25_dir
+        self.bm25_retriever = bm25_retriever
+        if self.bm25_retriever is None:
+            self.bm25_k = 0
+
+        include = ["metadatas", "embeddings"] + (["documents"] if prefetch_documents else [])
+        docs = chroma.get(include=include)
+        self.faiss_retriever = retriever_cls(docs["embeddings"], embeddings)
+        ts_docs = ts_chroma.get(include=["documents", "embeddings"])
+        self.title_summary_faiss_retriever = retriever_cls(ts_docs["embeddings"], embeddings)
+
+        self.chunk_metadata = docs["metadatas"]
+        self.num_chunk = len(self.chunk_metadata)
+        self.title_summaries = ts_docs["documents"]
+        self._documents = docs["documents"] if prefetch_documents else None
+        # the three maps that replace the per-hit scans
+        self.docid2idx: Dict[str, int] = {}
+        self._bundle_rows: Dict[object, List[int]] = {}
+        self._title_rows: Dict[str, List[int]] = {}
+        for row, md in enumerate(self.chunk_metadata):
+            self.docid2idx[md["doc_id"]] = row
+            b = md.get("bundle_id", None)
+            if b is not None:
+                self._bundle_rows.setdefault(b, []).append(row)
+            self._title_rows.setdefault(md.get("title_summary", ""), []).append(row)
+
+    # -- pieces -------------------------------------------------------------------------------------
+    def _bundle_of(self, row: int, seen: set) -> List[int]:
+        """Rows emitted for a hit: the whole bundle when the chunk has one (all marked seen), else the row."""
+        b = self.chunk_metadata[row].get("bundle_id", None)
+        if b is None:
+            return [row]
+        rows = list(self._bundle_rows[b])
+        seen.update(rows)
+        return rows
+
+    def _fetch(self, rows: List[int]):
+        if self._documents is not None:
+            return [self._documents[r] for r in rows], [self.chunk_metadata[r] for r in rows]
+        got = self.chroma.get(ids=[self.chunk_metadata[r]["doc_id"] for r in rows], include=["documents", "metadatas"])
+        return got["documents"], got["metadatas"]
+
+    def _emit(self, out: list, name: str, score, rows: List[int], bundle_cnt: int) -> None:
+        documents, metadatas = self._fetch(rows)
+        for text, md in zip(documents, metadatas):
+            out.append({"retriever": name, "score": float(score), "page_content": text, "metadata": md,
+                        "bundle_id": bundle_cnt})
+
+    def _expand(self, rows: List[int], hit_md: dict, score_map: dict, seen: set) -> None:
+        prev_doc, next_doc = hit_md["prev_chunk_id"], hit_md["next_chunk_id"]
+        while len(rows) < MAX_EXPANDED:
+            grew = False
+            p = self.docid2idx.get(prev_doc, -1) if prev_doc != "" else -1
+            if p != -1 and score_map.get(p, 0) > NEIGHBOUR_SCORE and p not in seen:
+                grew = True
+                seen.add(p)
+                rows.insert(0, p)
+                prev_doc = self.chunk_metadata[p]["prev_chunk_id"]
+            n = self.docid2idx.get(next_doc, -1) if next_doc != "" else -1
+            if n != -1 and score_map.get(n, 0) > NEIGHBOUR_SCORE and n not in seen:
+                grew = True
+                seen.add(n)
+                rows.append(n)
+                next_doc = self.chunk_metadata[n]["next_chunk_id"]
+            if not grew:
+                break
+
+    # -- the reference's entry point ------------------------------------------------------------------
+    def invoke(self, input: str, hyde_chunks: List[str]) -> List[Dict]:
+        seen: set = set()
+        out: list = []
+        bundle_cnt = 0
+        if self.faiss_k > 0:
+            inputs = [input] + list(hyde_chunks)
+            ids_list, scores_list = self.faiss_retriever.invoke(inputs, SEARCH_DEPTH)
+            for ids, scores in zip(ids_list, scores_list):
+                ids = [int(i) for i in ids]
+                score_map = dict(zip(ids, scores))
+                for row, score in zip(ids[:self.faiss_k], scores[:self.faiss_k]):
+                    if row < 0 or row in seen:   # -1 pads a corpus smaller than the search depth
+                        continue
+                    seen.add(row)
+                    md = self.chunk_metadata[row]
+                    rows = self._bundle_of(row, seen)
+                    if score > EXPAND_SCORE and self.enable_expand:
+                        self._expand(rows, md, score_map, seen)
+                    self._emit(out, "FAISS", score, rows, bundle_cnt)
+                    bundle_cnt += 1
+        if self.faiss_ts_k > 0:
+            t_ids, t_scores = self.title_summary_faiss_retriever.invoke([input], self.faiss_ts_k)
+            for t, score in zip(t_ids[0], t_scores[0]):
+                if t < 0:
+                    continue
+                for row in self._title_rows.get(self.title_summaries[int(t)], ()):
+                    if row in seen:
+                        continue
+                    seen.add(row)
+                    self._emit(out, "Title Summary", score, self._bundle_of(row, seen), bundle_cnt)
+                    bundle_cnt += 1
+        if self.bm25_k > 0:
+            b_ids, b_scores = self.bm25_retriever.invoke(input, self.num_chunk)
+            for row, score in zip(b_ids[:self.bm25_k], b_scores[:self.bm25_k]):
+                if row in seen:
+                    continue
+                seen.add(row)
+                self._emit(out, "BM25", score, self._bundle_of(row, seen), bundle_cnt)
+                bundle_cnt += 1
+        return out
+
+    # ensembleRetriever.py:235-281
+    def compute_similarity(self, chunks, selected_indices, candidate_index):
+        return compute_similarity(self.embeddings, chunks, selected_indices, candidate_index)
+
+    def compute_similarity_mtx(self, chunks):
+        return compute_similarity_mtx(self.embeddings, chunks)
