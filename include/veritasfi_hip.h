@@ -75,6 +75,15 @@ int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int3
 int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
                            int32_t device_id, int64_t id_offset);
 
+/* Corpus file (.vfc): 64-byte header {char magic[8]="VFCORPUS"; u32 version=1; u32 dtype; u64 n; u32 d; u32 flags;
+ * u8 reserved[32]} + n*d row-major elements (+ int64[n] external ids when flags bit 0 is set).  Stands where the
+ * reference pulls every embedding out of Chroma into Python lists at start-up (src/utils/ensembleRetriever.py:39-43,
+ * src/utils/faissRetriever.py:14): rows [row_lo, row_hi) are streamed from disk through pinned staging straight
+ * into HBM (a rank loads only its shard).  veritasfi_amd/corpus_file.py writes the format. */
+int vf_corpus_file_info(const char* path, int64_t* n, int32_t* d, int32_t* dtype, int32_t* has_ids);
+int vf_index_create_from_file(vf_index** out, const char* path, int64_t row_lo, int64_t row_hi, int32_t device_id,
+                              int64_t id_offset);
+
 /* src/utils/faissRetriever.py:34-38 (FaissRetriever.invoke after embed_query): queries [nq,d] fp32,
  * NOT normalised (the library normalises, like faiss.normalize_L2 at :35); out_ids [nq,k] int64,
  * out_scores [nq,k] fp32, best first.  Synchronous; host buffers. */

@@ -138,3 +138,30 @@ def test_sharded_retriever_gloo(world, tmp_path):
                                       stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_corpus_file_roundtrip_on_cpu(tmp_path):
+    """Writer / pure-Python reader of the .vfc format (header last, ids table, fp8 codes); no GPU library calls."""
+    from veritasfi_amd import corpus_file as cf
+    rng = np.random.default_rng(0)
+    rows = rng.standard_normal((1000, 48)).astype(np.float16)
+    ids = rng.permutation(10_000)[:1000].astype(np.int64)
+    p = str(tmp_path / "c.vfc")
+    with cf.CorpusWriter(p, 48, np.float16) as w:
+        for i in range(0, 1000, 300):                       # the embed loop's batches (load_data.py:120-128)
+            w.append(rows[i:i + 300], ids[i:i + 300])
+    h = cf.read_header(p)
+    assert h == {"n": 1000, "d": 48, "dtype": 1, "has_ids": True}
+    assert np.array_equal(np.asarray(cf.rows_memmap(p)), rows) and np.array_equal(np.asarray(cf.external_ids(p)), ids)
+    p8 = str(tmp_path / "c8.vfc")
+    codes = rng.integers(0, 255, size=(10, 16), dtype=np.uint8)
+    cf.write(p8, codes, e4m3=True)
+    assert cf.read_header(p8)["dtype"] == 2 and cf.external_ids(p8) is None
+    assert np.array_equal(np.asarray(cf.rows_memmap(p8)), codes)
+    bad = tmp_path / "bad.vfc"
+    bad.write_bytes(b"NOTACORPUS" + b"\0" * 100)
+    with pytest.raises(ValueError):
+        cf.read_header(str(bad))
+    with pytest.raises(ValueError):
+        with cf.CorpusWriter(str(tmp_path / "x.vfc"), 8) as w:
+            w.append(np.zeros((2, 9), np.float16))

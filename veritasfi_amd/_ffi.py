@@ -45,6 +45,8 @@ SIGNATURES = {
     "vf_device_count": (ctypes.c_int, [p_i32]),
     "vf_index_create": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, c_i32, c_i64]),
     "vf_index_create_device": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, c_i32, c_i64]),
+    "vf_corpus_file_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "vf_index_create_from_file": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_char_p, c_i64, c_i64, c_i32, c_i64]),
     "vf_index_search": (ctypes.c_int, [vp, vp, c_i32, c_i32, vp, vp]),
     "vf_index_search_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, vp, vp, vp]),
     "vf_index_slots": (ctypes.c_int, [vp, p_i32]),

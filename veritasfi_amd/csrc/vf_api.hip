@@ -8,7 +8,10 @@
 #include "../../include/veritasfi_hip.h"
 #include "vf_internal.h"
 
+#include <fcntl.h>
 #include <float.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <math.h>
 #include <string.h>
 
@@ -284,6 +287,110 @@ extern "C" int vf_index_create(vf_index** out, const void* rows, int64_t n, int3
 extern "C" int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
                                       int32_t device_id, int64_t id_offset) {
     return create_impl(out, d_rows, true, n, d, dtype, device_id, id_offset);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Corpus file (.vfc): a 64-byte header followed by n * d elements, row-major.  Replaces "pull every
+// embedding out of Chroma into Python lists at start-up" (src/utils/ensembleRetriever.py:39-43,
+// src/utils/faissRetriever.py:14) for corpora that size cannot go through.
+//   +0  char[8] "VFCORPUS"   +8 u32 version (1)   +12 u32 dtype (VF_DTYPE_*)   +16 u64 n   +24 u32 d
+//   +28 u32 flags (bit 0: an int64[n] external-id table follows the rows)   +32 .. +63 reserved (0)
+// ------------------------------------------------------------------------------------------------
+struct VfcHeader {
+    char magic[8];
+    uint32_t version, dtype;
+    uint64_t n;
+    uint32_t d, flags;
+    uint8_t reserved[32];
+};
+static_assert(sizeof(VfcHeader) == 64, "corpus file header is 64 bytes");
+
+static int read_vfc_header(int fd, const char* path, VfcHeader* h, size_t* esz) {
+    if (pread(fd, h, sizeof(*h), 0) != (ssize_t)sizeof(*h)) return fail(VF_EINVAL, std::string("corpus file too short: ") + path);
+    if (memcmp(h->magic, "VFCORPUS", 8) != 0) return fail(VF_EINVAL, std::string("not a corpus file (bad magic): ") + path);
+    if (h->version != 1) return fail(VF_EUNSUPPORTED, std::string("corpus file version not supported: ") + path);
+    if (h->dtype > VF_DTYPE_FP8_E4M3 || h->d == 0) return fail(VF_EINVAL, std::string("corpus file header is corrupt: ") + path);
+    *esz = h->dtype == VF_DTYPE_F32 ? 4 : (h->dtype == VF_DTYPE_F16 ? 2 : 1);
+    struct stat st;
+    if (fstat(fd, &st) != 0) return fail(VF_EINVAL, std::string("cannot stat corpus file: ") + path);
+    const unsigned long long need = 64ull + (unsigned long long)h->n * h->d * *esz + ((h->flags & 1u) ? h->n * 8ull : 0ull);
+    if ((unsigned long long)st.st_size < need) return fail(VF_EINVAL, std::string("corpus file is truncated: ") + path);
+    return VF_OK;
+}
+
+extern "C" int vf_corpus_file_info(const char* path, int64_t* n, int32_t* d, int32_t* dtype, int32_t* has_ids) {
+    if (!path) return fail(VF_EINVAL, "vf_corpus_file_info: null path");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(VF_EINVAL, std::string("cannot open corpus file: ") + path);
+    VfcHeader h; size_t esz = 0;
+    const int rc = read_vfc_header(fd, path, &h, &esz);
+    close(fd);
+    if (rc != VF_OK) return rc;
+    if (n) *n = (int64_t)h.n;
+    if (d) *d = (int32_t)h.d;
+    if (dtype) *dtype = (int32_t)h.dtype;
+    if (has_ids) *has_ids = (int32_t)(h.flags & 1u);
+    return VF_OK;
+}
+
+// Rows [row_lo, row_hi) of the file become an index on `device_id` (a rank's shard: SURVEY.md 8e).  The rows are
+// streamed through two pinned staging buffers (read() of one overlaps the H2D copy of the other).
+extern "C" int vf_index_create_from_file(vf_index** out, const char* path, int64_t row_lo, int64_t row_hi,
+                                         int32_t device_id, int64_t id_offset) {
+    if (!out || !path) return fail(VF_EINVAL, "vf_index_create_from_file: null argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(VF_EINVAL, std::string("cannot open corpus file: ") + path);
+    VfcHeader h; size_t esz = 0;
+    int rc = read_vfc_header(fd, path, &h, &esz);
+    if (rc == VF_OK && (row_lo < 0 || row_hi < row_lo || (uint64_t)row_hi > h.n))
+        rc = fail(VF_EINVAL, "vf_index_create_from_file: row range outside the file");
+    int ndev = 0;
+    if (rc == VF_OK && (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev))
+        rc = fail(VF_EINVAL, "vf_index_create_from_file: bad device_id");
+    if (rc != VF_OK) { close(fd); return rc; }
+    const int64_t n = row_hi - row_lo;
+    const size_t row_bytes = (size_t)h.d * esz, total = (size_t)n * row_bytes;
+    void* d_rows = nullptr;
+    char* stage[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const size_t chunk = 64u << 20;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess && total) e = hipMalloc(&d_rows, total);
+    for (int i = 0; i < 2 && e == hipSuccess && total; ++i) {
+        e = hipHostMalloc((void**)&stage[i], chunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) rc = fail(VF_ENOMEM, std::string("vf_index_create_from_file: ") + hipGetErrorString(e));
+    size_t done = 0;
+    for (int i = 0; rc == VF_OK && done < total; i ^= 1) {
+        const size_t len = std::min(chunk, total - done);
+        if (hipEventSynchronize(ev[i]) != hipSuccess) { rc = fail(VF_EHIP, "vf_index_create_from_file: event wait failed"); break; }
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t r = pread(fd, stage[i] + got, len - got, (off_t)(64 + (size_t)row_lo * row_bytes + done + got));
+            if (r <= 0) { rc = fail(VF_EINVAL, std::string("read error in corpus file: ") + path); break; }
+            got += (size_t)r;
+        }
+        if (rc != VF_OK) break;
+        e = hipMemcpyAsync((char*)d_rows + done, stage[i], len, hipMemcpyHostToDevice, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(ev[i], nullptr);
+        if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("vf_index_create_from_file: ") + hipGetErrorString(e)); break; }
+        done += len;
+    }
+    close(fd);
+    if (rc == VF_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(VF_EHIP, "vf_index_create_from_file: copy failed");
+    for (int i = 0; i < 2; ++i) {
+        if (stage[i]) (void)hipHostFree(stage[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    if (rc == VF_OK) {
+        rc = create_impl(out, d_rows, true, n, (int32_t)h.d, (int32_t)h.dtype, device_id, id_offset);
+        // fp8 rows were decoded into an owned fp16 copy; f32 / f16 rows are borrowed by create_impl: hand them over
+        if (rc == VF_OK && h.dtype != VF_DTYPE_FP8_E4M3) { (*out)->owns_rows = true; d_rows = nullptr; }
+    }
+    if (d_rows) (void)hipFree(d_rows);
+    return rc;
 }
 
 extern "C" int vf_index_destroy(vf_index* ix) {

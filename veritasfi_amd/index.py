@@ -71,6 +71,25 @@ class DenseIndex:
                                      self.id_offset), "vf_index_create")
 
     @classmethod
+    def from_file(cls, path: str, rank: int = 0, world: int = 1, device_id: int = 0):
+        """Rows of this rank's shard of a corpus file (veritasfi_amd/corpus_file.py), streamed disk -> HBM by the
+        library; returned ids are file row numbers (id_offset = the shard's first row)."""
+        from .sharded import shard_bounds
+        n, d, dt, has = _ffi.c_i64(0), _ffi.c_i32(0), _ffi.c_i32(0), _ffi.c_i32(0)
+        L = _ffi.lib()
+        _ffi.check(L.vf_corpus_file_info(path.encode(), ctypes.byref(n), ctypes.byref(d), ctypes.byref(dt),
+                                         ctypes.byref(has)), "vf_corpus_file_info")
+        lo, hi = shard_bounds(n.value, world, rank)
+        self = cls.__new__(cls)
+        self._h = _ffi.vp()
+        self._keepalive = None
+        self.device_id, self.id_offset = int(device_id), int(lo)
+        self.n, self.d = int(hi - lo), int(d.value)
+        _ffi.check(L.vf_index_create_from_file(ctypes.byref(self._h), path.encode(), lo, hi, self.device_id, lo),
+                   "vf_index_create_from_file")
+        return self
+
+    @classmethod
     def from_e4m3(cls, codes, device_id: int = 0, id_offset: int = 0):
         """codes: [n, d] uint8 OCP-e4m3 bytes (ndarray, CPU or CUDA tensor)."""
         self = cls.__new__(cls)
