@@ -157,7 +157,7 @@ def main():
     for o in args.opt:
         name, val = o.split("=")
         index.set_option(name, int(val))
-    nslots = min(index.slots, int(os.environ.get("VF_BENCH_DEPTH", index.slots)))  # batches in flight
+    nslots = min(index.slots, int(os.environ.get("VF_BENCH_DEPTH", "2")))  # batches in flight (deeper measured no faster)
     # per in-flight batch: one packed result blob [ids | scores] with typed views (single all-gather per batch)
     bufs = [vf.packed_result_buffer(args.batch, args.k, device) for _ in range(nslots)]
     out_ids = [b[1] for b in bufs]
