@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <string>
@@ -407,6 +408,135 @@ __global__ __launch_bounds__(LTHREADS) void k_gemm256_tn(const half_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemm_dma_tn: 128 (M) x 256 (N) tile, 4 waves (2 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles), BK = 32,
+// THREE 24 KB LDS slots filled by LDS-DMA (72 KB per workgroup), so that TWO workgroups share a CU.
+// The two are independent: one's barrier bubbles, DMA tail and whole epilogue (the output's HBM write) run
+// under the other's MFMAs -- the overlap a single lock-stepped 128 KB workgroup per CU cannot have.
+// Iteration t: issue the DMA of stage t+1 into slot (t+1) % 3 (last read in iteration t-2, which every wave
+// finished before the barrier of iteration t-1), wait with a COUNTED vmcnt(6) (this wave's 6 DMA instructions
+// of stage t+1 stay in flight), one raw s_barrier, 16 MFMAs per wave on slot t % 3.
+// LDS rows are 64 B (4 chunks of 16 B); chunk c of row r sits at physical chunk c ^ ((r >> 2) & 3): the DMA
+// lanes fetch the matching logical chunk, and a ds_read_b128 lane group (16 rows) touches 16 distinct slots.
+// ------------------------------------------------------------------------------------------------
+constexpr int DBM = 128, DBN = 256, DBK = 32, DTHREADS = 256, DSLOT = 24576, DLDS = 3 * DSLOT;
+
+template <int EPI>
+__global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                          half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 slots x [A 128x32 | W 256x32] fp16
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5, wr = wid >> 1, wc = wid & 1;
+    int mt_idx, nt_idx;
+    {   // XCD-contiguous, n-major groups of 8 m-tiles (64 workgroups resident per XCD)
+        const int Mt = M / DBM, Nt = N / DBN, nwg = Mt * Nt;
+        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        constexpr int GM = 8;
+        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
+        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+        nt_idx = r / gm;
+        mt_idx = g * GM + (r - nt_idx * gm);
+    }
+    const long long m0 = (long long)mt_idx * DBM, n0 = (long long)nt_idx * DBN;
+    // one DMA instruction fills 16 rows x 64 B; the A tile is 8 of them (wave w: rows [32w, 32w+32)), the W tile 16
+    // (wave w: rows [64w, 64w+64)).  lane l -> row l >> 2 of the 16, physical chunk l & 3.
+    const half_t* a_src[2];
+    const half_t* w_src[4];
+    const int drow = lane >> 2, dpc = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wid * 32 + j * 16 + drow;
+        a_src[j] = A + (m0 + row) * K + (dpc ^ ((row >> 2) & 3)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wid * 64 + j * 16 + drow;
+        w_src[j] = W + (n0 + row) * K + (dpc ^ ((row >> 2) & 3)) * 8;
+    }
+    auto stage = [&](int slot, int kt) {
+        char* abase = smem + slot * DSLOT + (wid * 32) * 64;
+        char* wbase = smem + slot * DSLOT + 8192 + (wid * 64) * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * DBK),
+                                             (__attribute__((address_space(3))) void*)(abase + j * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * DBK),
+                                             (__attribute__((address_space(3))) void*)(wbase + j * 1024), 16, 0, 0);
+    };
+    f16v acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int swz = (r31 >> 2) & 3;  // tile offsets are multiples of 32 rows: they do not change (row >> 2) & 3
+    const char* a_row = smem + (wr * 64 + r31) * 64;
+    const char* w_row = smem + 8192 + (wc * 128 + r31) * 64;
+    const int nk = K / DBK;
+    stage(0, 0);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        stage(nslot, kt + 1 < nk ? kt + 1 : nk - 1);            // past the end: re-reads the last tile (unused)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // stage kt landed (this wave's DMA)
+        __builtin_amdgcn_s_barrier();                           // ... and every wave's
+        const char* ab = a_row + slot * DSLOT;
+        const char* wb = w_row + slot * DSLOT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pc = ((2 * ks + h) ^ swz) * 16;
+            h8 af[2], wf[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) af[t] = *(const h8*)(ab + t * 32 * 64 + pc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *(const h8*)(wb + t * 32 * 64 + pc);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        slot = nslot;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the trailing dummy stage before LDS is reused
+    __syncthreads();
+    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [128][256] fp16 image (64 KB of the 72), then 16-byte
+    // row chunks out (residual added in fp32 on the vector side)
+    half_t* Es = (half_t*)smem;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = wc * 128 + nt * 32 + r31;
+        const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float v = acc[mt][nt][reg] + bv;
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                Es[row * DBN + col] = (half_t)v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + DTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
+        h8 o = *(const h8*)(Es + row * DBN + cc * 8);
+        const long long off = (m0 + row) * N + n0 + cc * 8;
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const h8 r = *(const h8*)(R + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+        }
+        *(h8*)(C + off) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused attention.  grid (ceil(T/128), heads, B), 256 threads; wave w handles queries
 // [qb*128 + 32w, +32) of sequence b, head hd; K [T][64] and V^T [64][T] of that (b, head) live in LDS.
 // S^T = K Q^T is computed with the KEY on the MFMA row, so a lane holds 16 key scores of ONE query
@@ -628,6 +758,9 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return er;
 }
@@ -768,9 +901,20 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st) {
-    // 256 x 256 tiles only when they still give every CU a workgroup; smaller problems (micro-batches of 8 pairs,
-    // single queries) take the 128 x 128 kernel, which launches 4x the workgroups (2 resident per CU).
-    if (M % LBM == 0 && N % LBN == 0 && (long long)(M / LBM) * (N / LBN) >= 192) {
+    // Tile choice (VF_GEMM_KIND overrides for A/B runs: 1 = DMA 128x256, 2 = 256x256, 3 = 128x128):
+    //  * 128 x 256 DMA tiles, two workgroups per CU, when they give at least VF_GEMM_DMA_MIN_WGS workgroups;
+    //  * 128 x 128 register-staged tiles for everything smaller (micro-batches of 8 pairs, single queries).
+    // The 256 x 256 single-workgroup-per-CU kernel measured equal in isolation and 6 % slower inside the forward
+    // (its GELU epilogue has nothing to hide under); it stays selectable for experiments.
+    static const int kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
+    static const long long dma_min = getenv("VF_GEMM_DMA_MIN_WGS") ? atoll(getenv("VF_GEMM_DMA_MIN_WGS")) : 384;
+    const bool dma_ok = M % DBM == 0 && N % DBN == 0 && K % DBK == 0;
+    const bool big_ok = M % LBM == 0 && N % LBN == 0;
+    if (dma_ok && (kind == 1 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
+        hipLaunchKernelGGL(k_gemm_dma_tn<EPI>, dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
+        return hipGetLastError();
+    }
+    if (big_ok && kind == 2) {
         hipLaunchKernelGGL(k_gemm256_tn<EPI>, dim3((N / LBN) * (M / LBM)), dim3(LTHREADS), 131072, st, A, W, bias, R, C, M,
                            N, K);
         return hipGetLastError();
