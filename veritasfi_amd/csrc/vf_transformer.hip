@@ -547,6 +547,114 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma_tn(const half_t* __res
 // ------------------------------------------------------------------------------------------------
 constexpr int ADH = 64, AKLD = ADH + 8, ATHREADS = 512;
 
+// Both 32-lane halves of v in every lane, without an LDS round trip: gfx950's v_permlane32_swap exchanges lanes
+// [32, 64) of its first operand with lanes [0, 32) of its second, so two copies of v become (lower half everywhere,
+// upper half everywhere).  Written as inline asm on two distinct registers: the compiler builtin, fed the same value
+// twice, returned the first result for both (measured), and the instruction needs one wait state after a VALU write.
+__device__ __forceinline__ void halves(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+
+// Single-instruction helpers: plain -O3 SLP-packs adjacent f32 adds into v_pk_add_f32 (slower than two v_add_f32 beside
+// MFMAs) and puts a canonicalising v_max in front of every fmaxf on an MFMA output (guide, attention pitfalls).
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vadd(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// S^T tile = K[kt .. kt+32) . Q^T (key on the MFMA row): 4 k-steps of 16 over dh = 64
+__device__ __forceinline__ void attn_qk(f16v& s, const half_t* Ks, const h8 (&qf)[4], int kt, int r31, int h) {
+    f16v z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    const half_t* krow = Ks + (kt + r31) * AKLD + h * 8;
+    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow), qf[0], z, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), qf[ks], s, 0, 0, 0);
+}
+
+// online-softmax update with the scores of key tile kt (state 0: all keys valid, 1: mixed) and O^T += V^T P^T
+__device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], float& m_run, float& l_run, const half_t* Vt,
+                                                int vt_ld, const float* mb, int kt, int state, int r31, int h) {
+    const float LOG2E = 1.4426950408889634f;
+    // this tile's V^T fragments first (their LDS latency hides under the softmax):
+    // k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
+    h8 vf[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const half_t* vrow = Vt + (mt * 32 + r31) * vt_ld + kt + 16 * st + 4 * h;
+            const h4 lo4 = *(const h4*)(vrow);
+            const h4 hi4 = *(const h4*)(vrow + 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vf[st][mt][e] = lo4[e]; vf[st][mt][4 + e] = hi4[e]; }
+        }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches (next tile's MFMAs, these reads) above the softmax
+    f16v s = sc;
+    if (state == 1) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) s[reg] += mb[kt + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+    }
+    float tmax = vmax3(s[0], s[1], s[2]);
+    float tmax2 = vmax3(s[3], s[4], s[5]);   // two chains: shorter dependency path
+#pragma unroll
+    for (int reg = 6; reg < 14; reg += 4) {
+        tmax = vmax3(tmax, s[reg], s[reg + 1]);
+        tmax2 = vmax3(tmax2, s[reg + 2], s[reg + 3]);
+    }
+    tmax = vmax3(tmax, s[14], s[15]);
+    tmax = vmax3(tmax, tmax2, tmax2);
+    {
+        float lo, hi;
+        halves(tmax, lo, hi);
+        tmax = fmaxf(lo, hi);
+    }
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // raw v_exp_f32: arguments <= 0, underflow -> 0
+    const float mneg = -m_new * LOG2E;
+    float psum = 0.f;
+    h8 pf[2];
+    float psum2 = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[reg], LOG2E, mneg));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[reg + 1], LOG2E, mneg));
+        psum = vadd(psum, p0);
+        psum2 = vadd(psum2, p1);
+        pf[reg >> 3][reg & 7] = (half_t)p0;
+        pf[reg >> 3][(reg & 7) + 1] = (half_t)p1;
+    }
+    psum = vadd(psum, psum2);
+    {
+        float lo, hi;
+        halves(psum, lo, hi);
+        psum = lo + hi;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__ballot(alpha != 1.0f) != 0ull) {  // the running max moved for some query of this wave (rare after the first tiles)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pf[st], o[mt], 0, 0, 0);
+}
+
 __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask,
                                                          int T, int H, int vt_ld, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -582,7 +690,29 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
     }
     for (int t = tid; t < T; t += ATHREADS) mb[t] = mask[row0 + t] ? 0.f : -30000.f;
     __syncthreads();
-    const float LOG2E = 1.4426950408889634f;
+    // per 32-key tile: 0 = every key valid (no mask arithmetic), 1 = mixed, 2 = every key masked (tile skipped: its
+    // probabilities underflow to exactly 0 either way).  A sequence with no valid key at all keeps every tile (HF
+    // then attends uniformly; so does the masked path).
+    int* tstate = (int*)(mb + T);
+    if (tid < (T >> 5)) {
+        int nvalid = 0;
+        for (int j = 0; j < 32; ++j) nvalid += mb[tid * 32 + j] == 0.f;
+        tstate[tid] = nvalid == 32 ? 0 : (nvalid == 0 ? 2 : 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bool any = false;
+        for (int j = 0; j < (T >> 5); ++j) any |= tstate[j] != 2;
+        if (!any) for (int j = 0; j < (T >> 5); ++j) tstate[j] = 1;
+    }
+    __syncthreads();
+    // tile masks in SGPRs (bit i = key tile i): `act` = not fully masked, `mixed` = needs the additive mask
+    unsigned act = 0, mixed = 0;
+    for (int j = 0; j < (T >> 5); ++j) {
+        const int st = __builtin_amdgcn_readfirstlane(tstate[j]);
+        act |= (st != 2 ? 1u : 0u) << j;
+        mixed |= (st == 1 ? 1u : 0u) << j;
+    }
     // each wave walks 32-query blocks wid, wid + 8, ...
     for (int q0 = wid * 32; q0 < T; q0 += (ATHREADS / 64) * 32) {
         // Q fragments (B operand): lane (query r31, half h) holds q[8h + j + 16 ks], scaled by 1/sqrt(64)
@@ -603,53 +733,26 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
         float m_run = -1e30f, l_run = 0.f;
-        for (int kt = 0; kt < T; kt += 32) {
-            f16v s;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h8 kf = *(const h8*)(Ks + (kt + r31) * AKLD + ks * 16 + h * 8);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-            }
-            float tmax = -1e30f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int key = kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                s[reg] += mb[key];
-                tmax = fmaxf(tmax, s[reg]);
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = exp2f((m_run - m_new) * LOG2E);
-            float psum = 0.f;
-            h8 pf[2];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float p = exp2f((s[reg] - m_new) * LOG2E);
-                psum += p;
-                pf[reg >> 3][reg & 7] = (half_t)p;
-            }
-            psum += __shfl_xor(psum, 32);
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
-            // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const half_t* vrow = Vt + (mt * 32 + r31) * vt_ld + kt + 16 * st + 4 * h;
-                    const h4 lo4 = *(const h4*)(vrow);
-                    const h4 hi4 = *(const h4*)(vrow + 8);
-                    h8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
-                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
-                }
+        // Software pipeline inside the wave: the S^T MFMAs of the NEXT active key tile and the V^T fragments of the
+        // current one are issued before the current tile's softmax, so the matrix pipe and the LDS work under the
+        // VALU chain (max -> exchange -> 16 exp -> exchange) instead of after it.  Two score registers ping-pong
+        // (loop unrolled by two): no register copies, and the prefetch is unconditional (past the last tile it
+        // recomputes the current one; unused).  The tile walk is scalar bit arithmetic: no LDS on the critical path.
+        int kt = __builtin_ctz(act);                      // first active tile (act != 0: see above)
+        f16v sA, sB;
+        attn_qk(sA, Ks, qf, kt * 32, r31, h);
+        while (true) {
+            const unsigned rest = act & (~1u << kt);      // active tiles after kt
+            const int kn = rest ? __builtin_ctz(rest) : kt;
+            attn_qk(sB, Ks, qf, kn * 32, r31, h);
+            attn_softmax_pv(sA, o, m_run, l_run, Vt, vt_ld, mb, kt * 32, (mixed >> kt) & 1, r31, h);
+            if (!rest) break;
+            const unsigned rest2 = act & (~1u << kn);
+            const int kn2 = rest2 ? __builtin_ctz(rest2) : kn;
+            attn_qk(sA, Ks, qf, kn2 * 32, r31, h);
+            attn_softmax_pv(sB, o, m_run, l_run, Vt, vt_ld, mb, kn * 32, (mixed >> kn) & 1, r31, h);
+            if (!rest2) break;
+            kt = kn2;
         }
         const float inv = 1.0f / l_run;
         half_t* dst = ctx + (row0 + q0 + r31) * H + hd * ADH;
@@ -939,7 +1042,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     int pad = 8;
     while ((((T + pad) / 2) & 63) != 4) pad += 8;
     const int vt_ld = T + pad;
-    const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4;
+    const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4 + 64;  // K, V^T, mask, tile states
     for (int l = 0; l < c.layers; ++l) {
         const half_t* w = e->w16 + e->o_layers + (size_t)l * e->layer16;
         const float* f = e->w32 + e->f_layers + (size_t)l * e->layer32;
