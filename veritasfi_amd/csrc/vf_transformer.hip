@@ -558,19 +558,6 @@ __device__ __forceinline__ void halves(float v, float& lo, float& hi) {
     hi = b;
 }
 
-// Single-instruction helpers: plain -O3 SLP-packs adjacent f32 adds into v_pk_add_f32 (slower than two v_add_f32 beside
-// MFMAs) and puts a canonicalising v_max in front of every fmaxf on an MFMA output (guide, attention pitfalls).
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float vadd(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // S^T tile = K[kt .. kt+32) . Q^T (key on the MFMA row): 4 k-steps of 16 over dh = 64
 __device__ __forceinline__ void attn_qk(f16v& s, const half_t* Ks, const h8 (&qf)[4], int kt, int r31, int h) {
     f16v z;
@@ -605,15 +592,9 @@ __device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], fl
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) s[reg] += mb[kt + (reg & 3) + 8 * (reg >> 2) + 4 * h];
     }
-    float tmax = vmax3(s[0], s[1], s[2]);
-    float tmax2 = vmax3(s[3], s[4], s[5]);   // two chains: shorter dependency path
+    float tmax = fmaxf(s[0], s[1]);
 #pragma unroll
-    for (int reg = 6; reg < 14; reg += 4) {
-        tmax = vmax3(tmax, s[reg], s[reg + 1]);
-        tmax2 = vmax3(tmax2, s[reg + 2], s[reg + 3]);
-    }
-    tmax = vmax3(tmax, s[14], s[15]);
-    tmax = vmax3(tmax, tmax2, tmax2);
+    for (int reg = 2; reg < 16; reg += 2) tmax = fmaxf(tmax, fmaxf(s[reg], s[reg + 1]));  // v_max3
     {
         float lo, hi;
         halves(tmax, lo, hi);
@@ -624,17 +605,14 @@ __device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], fl
     const float mneg = -m_new * LOG2E;
     float psum = 0.f;
     h8 pf[2];
-    float psum2 = 0.f;
+    // (plain C on purpose: an inline-asm v_add consuming a v_exp_f32 result hides the TRANS -> VALU forwarding hazard
+    // from the compiler's wait-state insertion; measured as placement-dependent accuracy loss)
 #pragma unroll
-    for (int reg = 0; reg < 16; reg += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[reg], LOG2E, mneg));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[reg + 1], LOG2E, mneg));
-        psum = vadd(psum, p0);
-        psum2 = vadd(psum2, p1);
-        pf[reg >> 3][reg & 7] = (half_t)p0;
-        pf[reg >> 3][(reg & 7) + 1] = (half_t)p1;
+    for (int reg = 0; reg < 16; ++reg) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[reg], LOG2E, mneg));
+        psum += p;
+        pf[reg >> 3][reg & 7] = (half_t)p;
     }
-    psum = vadd(psum, psum2);
     {
         float lo, hi;
         halves(psum, lo, hi);
