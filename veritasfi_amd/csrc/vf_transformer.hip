@@ -77,72 +77,92 @@ __global__ __launch_bounds__(64) void k_position_ids(const int* mask, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// embeddings + LayerNorm: one wave per token.  H multiple of 64.
+// Row kernels (embeddings + LayerNorm, LayerNorm): HALF a wave per row, 8 rows per 256-thread workgroup.  A row is
+// moved as 16-byte chunks of 8 halves; lane l of the half takes chunks l, l + 32, ... (H <= 1024: at most 4), so a
+// load instruction of the half-wave covers 512 contiguous bytes.  fp32 statistics, two passes over registers;
+// reductions stay inside the 32-lane half (xor offsets < 32).  H % 8 == 0.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embed_ln(const int* ids, const int* pos, const int* tts, const half_t* word,
-                                                   const half_t* posw, const half_t* typew, const float* g,
-                                                   const float* bta, float eps, int M, int H, half_t* out) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const half_t* w = word + (long long)ids[row] * H;
-    const half_t* p = posw + (long long)pos[row] * H;
-    const half_t* t = typew + (long long)(tts ? tts[row] : 0) * H;
-    float v[16];  // H <= 1024; loops are fully unrolled with a predicate so v[] stays in registers
-    const int per = H >> 6;
-    float s = 0.f;
+__device__ __forceinline__ float half_wave_sum(float v) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        v[i] = i < per ? (float)w[j] + (float)p[j] + (float)t[j] : 0.f;
-        s += v[i];
-    }
-    const float mean = wave_sum(s) / H;
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void ln_finish(float (&v)[4][8], float s, int l32, int nch, int H, const float* g, const float* bta,
+                                          float eps, half_t* dst_row) {
+    const float mean = half_wave_sum(s) / H;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const float d = i < per ? v[i] - mean : 0.f; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / H + eps);
+    for (int i = 0; i < 4; ++i)
+        if (l32 + 32 * i < nch) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        if (i < per) out[(long long)row * H + j] = (half_t)((v[i] - mean) * rstd * g[j] + bta[j]);
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    const float rstd = rsqrtf(half_wave_sum(q) / H + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l32 + 32 * i;
+        if (c < nch) {
+            const float4 g0 = *(const float4*)(g + c * 8), g1 = *(const float4*)(g + c * 8 + 4);
+            const float4 b0 = *(const float4*)(bta + c * 8), b1 = *(const float4*)(bta + c * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[i][e] - mean) * rstd * gg[e] + bb[e]);
+            *(h8*)(dst_row + c * 8) = o;
+        }
     }
 }
 
-// row LayerNorm of y -> x, one wave per row; lane l owns the contiguous block [l*per, (l+1)*per), per = H/64
-// (even), moved as 4-byte pairs so the compiler can merge them into wide loads / stores
-__global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float* g, const float* bta, float eps, int M,
-                                                    int H, half_t* x) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void k_embed_ln(const int* ids, const int* pos, const int* tts, const half_t* word,
+                                                   const half_t* posw, const half_t* typew, const float* g,
+                                                   const float* bta, float eps, int M, int H, half_t* out) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
-    const int per = H >> 6, pairs = per >> 1;
-    const h2* src = (const h2*)(y + (long long)row * H + lane * per);
-    float v[16];
+    const h8* w = (const h8*)(word + (long long)ids[row] * H);
+    const h8* p = (const h8*)(posw + (long long)pos[row] * H);
+    const h8* t = (const h8*)(typew + (long long)(tts ? tts[row] : 0) * H);
+    const int nch = H >> 3;
+    float v[4][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const h2 t = src[i < pairs ? i : 0];
-        v[2 * i] = i < pairs ? (float)t[0] : 0.f;
-        v[2 * i + 1] = i < pairs ? (float)t[1] : 0.f;
-        s += v[2 * i] + v[2 * i + 1];
-    }
-    const float mean = wave_sum(s) / H;
-    float q = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const int c = l32 + 32 * i;
+        if (c < nch) {
+            const h8 a = w[c], b = p[c], d = t[c];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const float d = i < per ? v[i] - mean : 0.f; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / H + eps);
-    h2* dst = (h2*)(x + (long long)row * H + lane * per);
-    const float* gp = g + lane * per;
-    const float* bp = bta + lane * per;
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e] + (float)b[e] + (float)d[e]; s += v[i][e]; }
+        } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < pairs) {
-            h2 o;
-            o[0] = (half_t)((v[2 * i] - mean) * rstd * gp[2 * i] + bp[2 * i]);
-            o[1] = (half_t)((v[2 * i + 1] - mean) * rstd * gp[2 * i + 1] + bp[2 * i + 1]);
-            dst[i] = o;
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
         }
     }
+    ln_finish(v, s, l32, nch, H, g, bta, eps, out + (long long)row * H);
+}
+
+// row LayerNorm of y -> x
+__global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float* g, const float* bta, float eps, int M,
+                                                    int H, half_t* x) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    if (row >= M) return;
+    const h8* src = (const h8*)(y + (long long)row * H);
+    const int nch = H >> 3;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l32 + 32 * i;
+        if (c < nch) {
+            const h8 a = src[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e]; s += v[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    ln_finish(v, s, l32, nch, H, g, bta, eps, x + (long long)row * H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1011,7 +1031,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     const vf_encoder_config& c = e->cfg;
     const int H = c.hidden, F = c.ffn, M = B * T, Mp = (M + 255) / 256 * 256;
     hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
-    hipLaunchKernelGGL(k_embed_ln, dim3((M + 3) / 4), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
+    hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
                        c.ln_eps, M, H, e->x);
     // V^T row stride: (T + pad) halves with (T + pad) / 2 == 2 (mod 64) -> conflict-free 8-byte reads
@@ -1031,10 +1051,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
                            e->ctx);
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st));
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
     }
     int all_last = 0;
     if (c.pooling == 2) {
