@@ -43,23 +43,26 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--opt", action="append", default=[], help="index option name=value (tuning)")
     ap.add_argument("--no-rerank", action="store_true")
+    ap.add_argument("--corpus-dtype", choices=["f16", "fp8"], default="f16",
+                    help="storage of the corpus rows: fp16 (the BASELINE metric) or OCP fp8-e4m3 (configs[4] storage)")
     ap.add_argument("--rerank-shape", default="xlmr-base", help="cross-encoder shape (tools/bench_rerank.py SHAPES)")
     ap.add_argument("--rerank-pairs", type=int, default=100)
     ap.add_argument("--rerank-tokens", type=int, default=512)
     return ap.parse_args()
 
 
-def make_shard(torch, lo, hi, d, device):
-    """Rows [lo, hi) of the synthetic corpus: N(0,1) -> fp16, seeded per global GEN_CHUNK so the corpus
-    does not depend on the number of ranks."""
-    out = torch.empty((hi - lo, d), dtype=torch.float16, device=device)
+def make_shard(torch, lo, hi, d, device, dtype="f16"):
+    """Rows [lo, hi) of the synthetic corpus: N(0,1) -> fp16 (or OCP fp8-e4m3 with --corpus-dtype fp8), seeded per
+    global GEN_CHUNK so the corpus does not depend on the number of ranks."""
+    tdt = torch.float16 if dtype == "f16" else torch.float8_e4m3fn
+    out = torch.empty((hi - lo, d), dtype=tdt, device=device)
     c0 = lo // GEN_CHUNK
     c1 = (hi + GEN_CHUNK - 1) // GEN_CHUNK
     g = torch.Generator(device=device)
     for c in range(c0, c1):
         g.manual_seed(1234 + c)
         a, b = c * GEN_CHUNK, (c + 1) * GEN_CHUNK
-        blk = torch.randn((GEN_CHUNK, d), generator=g, device=device, dtype=torch.float32).to(torch.float16)
+        blk = torch.randn((GEN_CHUNK, d), generator=g, device=device, dtype=torch.float32).to(tdt)
         s, e = max(a, lo), min(b, hi)
         out[s - lo:e - lo] = blk[s - a:e - a]
         del blk
@@ -149,7 +152,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     lo, hi = vf.shard_bounds(args.rows, world, rank)
-    corpus = make_shard(torch, lo, hi, args.dim, device)
+    corpus = make_shard(torch, lo, hi, args.dim, device, args.corpus_dtype)
     gq = torch.Generator(device=device)
     gq.manual_seed(4321)
     qpool = [torch.randn((args.batch, args.dim), generator=gq, device=device, dtype=torch.float32) for _ in range(4)]
@@ -220,7 +223,7 @@ def main():
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_scan_10Mx768.json")))
             w = rec["workload"]
-            if (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (args.rows, args.dim, args.batch, args.k, world):
+            if args.corpus_dtype == "f16" and (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (args.rows, args.dim, args.batch, args.k, world):
                 traffic = round(rec["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
@@ -235,8 +238,8 @@ def main():
             "metric": "queries/sec top-100 over 10Mx768 corpus", "value": round(qps, 1), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.rows}x{args.dim} fp16 corpus, batch-{args.batch} queries, exact cosine "
+            "vs_baseline": None, "dtype": "f16" if args.corpus_dtype == "f16" else "fp8-e4m3 rows, f16 MFMA", "data": "synthetic",
+            "config": {"workload": f"{args.rows}x{args.dim} {'fp16' if args.corpus_dtype == 'f16' else 'fp8-e4m3'} corpus, batch-{args.batch} queries, exact cosine "
                                    f"top-{args.k}, row-sharded over {world} GPU(s) + RCCL all-gather of per-shard top-k",
                        "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
                        "rows_per_gpu": hi - lo, "in_flight_batches": nslots},

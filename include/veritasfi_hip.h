@@ -63,9 +63,10 @@ int vf_device_count(int32_t* out);
  * src/utils/faissRetriever.py:11-26 (FaissRetriever.__init__): rows [n,d] row-major of `dtype`,
  * copied to device `device_id`.  Rows are stored as given (fp16 rows are the corpus; fp32 rows keep
  * an fp32 copy for exact scoring plus an fp16 scan copy); per-row norms are computed on the GPU.
- * VF_DTYPE_FP8_E4M3 rows (one byte per element, OCP e4m3: bias 7, no infinities, 0x7F / 0xFF = NaN) are
- * decoded EXACTLY to fp16 at build and held as fp16; a per-row scale of a scaled-fp8 store cancels in the
- * cosine, so none is taken.
+ * VF_DTYPE_FP8_E4M3 rows (one byte per element, OCP e4m3: bias 7, no infinities, 0x7F / 0xFF = NaN) STAY fp8 in
+ * HBM: the fused scan reads the bytes (half the traffic of fp16) and converts them to fp16 in registers -- exactly,
+ * every e4m3 value is an fp16 value -- and the exact re-score decodes the same bytes.  A per-row scale of a
+ * scaled-fp8 store cancels in the cosine, so none is taken.
  * `id_offset` is added to every returned id (row-sharding across ranks). */
 int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
                     int32_t device_id, int64_t id_offset);

@@ -392,7 +392,7 @@ def test_fp32_rows_extreme_ranges_and_ties(vf, oracle):
     _assert_exact(oracle, c2, q2, 20, ids, sc)
 
 
-# ---- fp8 (OCP e4m3) corpus: BASELINE.json config [4] storage format, decoded exactly to fp16 at build ----------
+# ---- fp8 (OCP e4m3) corpus: BASELINE.json config [4] storage format; rows stay fp8 in HBM, converted in registers ----
 def _e4m3_codes(n, d, seed):
     import torch
     g = torch.Generator().manual_seed(seed)
@@ -402,11 +402,29 @@ def _e4m3_codes(n, d, seed):
     return x.to(torch.float8_e4m3fn).view(torch.uint8).numpy().copy()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("n,nq,k", [(3000, 5, 50), (40000, 96, 1000)])
-def test_fp8_corpus_matches_oracle_on_decoded_rows(vf, oracle, n, nq, k):
+def test_hardware_e4m3_conversion_matches_oracle_table(vf):
+    """The fused scan converts fp8 codes with v_cvt_scalef32_pk_f16_fp8; pin that instruction (all 256 codes, in
+    both halves of a word) against the oracle's table, which is itself pinned against torch.float8_e4m3fn."""
+    import ctypes
     from oracle import ref_numpy as R
-    d = 1024
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_cvt_e4m3.restype = ctypes.c_int
+    L.vf_debug_cvt_e4m3.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    codes = np.concatenate([np.arange(256, dtype=np.uint8), np.arange(255, -1, -1, dtype=np.uint8),
+                            np.random.default_rng(0).integers(0, 256, 1003, dtype=np.uint8)])
+    out = np.empty(codes.size, np.float32)
+    _ffi.check(L.vf_debug_cvt_e4m3(codes.ctypes.data, out.ctypes.data, codes.size), "vf_debug_cvt_e4m3")
+    want = R.decode_e4m3(codes)
+    assert np.array_equal(np.isnan(out), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(out[ok].view(np.uint32), want[ok].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,k,d", [(3000, 5, 50, 1024), (40000, 96, 1000, 1024), (30000, 64, 100, 768), (25000, 8, 10, 200)])
+def test_fp8_corpus_matches_oracle_on_decoded_rows(vf, oracle, n, nq, k, d):
+    from oracle import ref_numpy as R
     codes = _e4m3_codes(n, d, 21)
     rows16 = R.decode_e4m3(codes).astype(np.float16)          # exact
     assert np.array_equal(rows16.astype(np.float32), R.decode_e4m3(codes))
@@ -415,6 +433,7 @@ def test_fp8_corpus_matches_oracle_on_decoded_rows(vf, oracle, n, nq, k):
     ix = vf.DenseIndex.from_e4m3(codes)
     try:
         got_i, got_s = ix.search(q, k)
+        assert ix.stats()["path"] == (0 if n <= 16384 else 1)      # the large cases run the fp8 scan kernel
         assert np.array_equal(got_i, want_i)
         assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
         # the same index built from the decoded fp16 rows is indistinguishable

@@ -109,13 +109,12 @@ struct Slot {
 struct vf_index {
     int device = 0;
     int64_t n = 0;
-    int d = 0, dp = 0, dtype = 0;  // dtype: how rows are HELD (F32 / F16); fp8 input is decoded to fp16 at build
-    int user_dtype = 0;              // what the caller handed over (vf_index_info)
+    int d = 0, dp = 0, dtype = 0;  // dtype: how rows are HELD in HBM (VF_DTYPE_F32 / _F16 / _FP8_E4M3)
     int64_t id_offset = 0;
     int n_cu = 256;
     bool owns_rows = false;
     void* rows_orig = nullptr;        // as given (fp32 or fp16), [n][d]
-    _Float16* rows_scan = nullptr;    // fp16 [n][dp]; may alias rows_orig
+    void* rows_scan = nullptr;    // fp16 [n][dp]; may alias rows_orig
     bool owns_scan = false;
     float* norm = nullptr;            // canonical norms [n]
     float* inv_scan = nullptr;        // [n]
@@ -151,29 +150,30 @@ static int build_common(vf_index* ix) {
     VF_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     VF_HIP(scan_configure());
-    const int is_half = ix->dtype == VF_DTYPE_F16;
-    ix->dp = (ix->d + 127) / 128 * 128;  // whole 128-element (256 B) segments pairs: see pick_G
+    const int dt = ix->dtype;
+    const size_t scan_esz = dt == VF_DTYPE_FP8_E4M3 ? 1 : 2;  // fp8 rows are scanned as bytes, everything else as fp16
+    ix->dp = (ix->d + 127) / 128 * 128;  // whole 128-element segment pairs: see pick_G
     const size_t npad = (size_t)ix->n + 64;
     VF_HIP(hipMalloc((void**)&ix->norm, npad * sizeof(float)));
     VF_HIP(hipMalloc((void**)&ix->inv_scan, npad * sizeof(float)));
     VF_HIP(hipMemset(ix->norm, 0, npad * sizeof(float)));
     VF_HIP(hipMemset(ix->inv_scan, 0, npad * sizeof(float)));
     const bool need_scan = ix->n > kSmallN;  // small corpora never run the fused scan
-    _Float16* scan_out = nullptr;
+    void* scan_out = nullptr;
     if (need_scan) {
-        if (is_half && ix->dp == ix->d && ((uintptr_t)ix->rows_orig % 16) == 0) {
-            ix->rows_scan = (_Float16*)ix->rows_orig;
+        if (dt != VF_DTYPE_F32 && ix->dp == ix->d && ((uintptr_t)ix->rows_orig % 16) == 0) {
+            ix->rows_scan = ix->rows_orig;  // fp16 / fp8 rows of a whole number of segments are scanned in place
             ix->owns_scan = false;
         } else {
-            VF_HIP(hipMalloc((void**)&ix->rows_scan, (size_t)ix->n * ix->dp * sizeof(_Float16)));
+            VF_HIP(hipMalloc((void**)&ix->rows_scan, (size_t)ix->n * ix->dp * scan_esz));
             ix->owns_scan = true;
             scan_out = ix->rows_scan;
         }
     }
-    VF_HIP(launch_prep_rows(ix->rows_orig, is_half, ix->n, ix->d, ix->dp, scan_out, ix->norm, ix->inv_scan, nullptr));
+    VF_HIP(launch_prep_rows(ix->rows_orig, dt, ix->n, ix->d, ix->dp, scan_out, ix->norm, ix->inv_scan, nullptr));
     if (ix->n > 0 && ix->n <= kSmallN) {
         VF_HIP(hipMalloc((void**)&ix->cn_cache, (size_t)ix->n * ix->d * sizeof(float)));
-        VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, 0, ix->n, ix->d, ix->norm, ix->cn_cache, nullptr));
+        VF_HIP(launch_normalize_rows(ix->rows_orig, dt, 0, ix->n, ix->d, ix->norm, ix->cn_cache, nullptr));
     }
     VF_HIP(hipDeviceSynchronize());
     return VF_OK;
@@ -230,38 +230,11 @@ static int create_impl(vf_index** out, const void* rows, bool rows_on_device, in
     VF_HIP(hipSetDevice(device_id));
     vf_index* ix = new (std::nothrow) vf_index();
     if (!ix) return fail(VF_ENOMEM, "vf_index_create: host allocation failed");
-    ix->device = device_id; ix->n = n; ix->d = d; ix->user_dtype = dtype; ix->id_offset = id_offset;
-    ix->dtype = dtype == VF_DTYPE_F32 ? VF_DTYPE_F32 : VF_DTYPE_F16;
+    ix->device = device_id; ix->n = n; ix->d = d; ix->id_offset = id_offset;
+    ix->dtype = dtype;  // fp8 (OCP e4m3) rows stay fp8 in HBM: scanned as bytes, converted in registers
     const size_t esz = dtype == VF_DTYPE_F32 ? 4 : (dtype == VF_DTYPE_F16 ? 2 : 1);
     int rc = VF_OK;
-    if (dtype == VF_DTYPE_FP8_E4M3) {
-        // fp8 rows (OCP e4m3) are decoded to fp16 once, exactly; from here on the corpus IS those fp16 values.
-        // (Per-row scales of a scaled-fp8 store cancel in the cosine, so none is taken.)  The scan therefore
-        // still reads 2 bytes per element: an fp8-resident scan is the follow-up.
-        void* raw = const_cast<void*>(rows);
-        bool own_raw = false;
-        hipError_t e = hipSuccess;
-        if (n > 0) {
-            e = hipMalloc(&ix->rows_orig, (size_t)n * d * 2);
-            if (e != hipSuccess) rc = fail(VF_ENOMEM, std::string("hipMalloc(corpus): ") + hipGetErrorString(e));
-            else ix->owns_rows = true;
-            if (rc == VF_OK && !rows_on_device) {
-                e = hipMalloc(&raw, (size_t)n * d);
-                if (e != hipSuccess) rc = fail(VF_ENOMEM, std::string("hipMalloc(fp8 staging): ") + hipGetErrorString(e));
-                else {
-                    own_raw = true;
-                    e = hipMemcpy(raw, rows, (size_t)n * d, hipMemcpyHostToDevice);
-                    if (e != hipSuccess) rc = fail(VF_EHIP, std::string("hipMemcpy(corpus): ") + hipGetErrorString(e));
-                }
-            }
-            if (rc == VF_OK) {
-                e = launch_decode_e4m3(raw, ix->rows_orig, (long long)n * d, nullptr);
-                if (e == hipSuccess) e = hipDeviceSynchronize();
-                if (e != hipSuccess) rc = fail(VF_EHIP, std::string("decode_e4m3: ") + hipGetErrorString(e));
-            }
-            if (own_raw) (void)hipFree(raw);
-        }
-    } else if (rows_on_device) {
+    if (rows_on_device) {
         ix->rows_orig = const_cast<void*>(rows);
         ix->owns_rows = false;
     } else if (n > 0) {
@@ -386,8 +359,8 @@ extern "C" int vf_index_create_from_file(vf_index** out, const char* path, int64
     }
     if (rc == VF_OK) {
         rc = create_impl(out, d_rows, true, n, (int32_t)h.d, (int32_t)h.dtype, device_id, id_offset);
-        // fp8 rows were decoded into an owned fp16 copy; f32 / f16 rows are borrowed by create_impl: hand them over
-        if (rc == VF_OK && h.dtype != VF_DTYPE_FP8_E4M3) { (*out)->owns_rows = true; d_rows = nullptr; }
+        // create_impl borrowed the device rows: hand them over to the index
+        if (rc == VF_OK) { (*out)->owns_rows = true; d_rows = nullptr; }
     }
     if (d_rows) (void)hipFree(d_rows);
     return rc;
@@ -403,7 +376,7 @@ extern "C" int vf_index_info(vf_index* ix, int64_t* n, int32_t* d, int32_t* dtyp
     if (!ix) return fail(VF_EINVAL, "vf_index_info: null handle");
     if (n) *n = ix->n;
     if (d) *d = ix->d;
-    if (dtype) *dtype = ix->user_dtype;
+    if (dtype) *dtype = ix->dtype;
     if (device_id) *device_id = ix->device;
     return VF_OK;
 }
@@ -467,7 +440,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
 // ------------------------------------------------------------------------------------------------
 static int exact_search(vf_index* ix, Slot& s, const float* qn_dev, int nq, int k, int64_t* out_ids,
                         float* out_scores, hipStream_t st) {
-    const int is_half = ix->dtype == VF_DTYPE_F16;
+    const int dt = ix->dtype;
     const int64_t chunk = kSmallN;
     const int64_t nchunks = ix->n == 0 ? 1 : (ix->n + chunk - 1) / chunk;
     if (nchunks > 1 && (int64_t)k * 2 * 8 > 160 * 1024)
@@ -477,7 +450,7 @@ static int exact_search(vf_index* ix, Slot& s, const float* qn_dev, int nq, int 
         const float* cn = ix->cn_cache;
         if (!cn && ix->n > 0) {
             VF_TRY(s.cn_tmp.ensure((size_t)chunk * ix->d * sizeof(float)));
-            VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, 0, ix->n, ix->d, ix->norm, s.cn_tmp.as<float>(), st));
+            VF_HIP(launch_normalize_rows(ix->rows_orig, dt, 0, ix->n, ix->d, ix->norm, s.cn_tmp.as<float>(), st));
             cn = s.cn_tmp.as<float>();
         }
         VF_HIP(launch_dense_dot16(qn_dev, nq, cn, ix->n, ix->d, s.dense_s.as<float>(), chunk, st));
@@ -497,7 +470,7 @@ static int exact_search(vf_index* ix, Slot& s, const float* qn_dev, int nq, int 
     VF_HIP(hipMemsetAsync(psc, 0, part * sizeof(float), st));
     for (int64_t c = 0; c < nchunks; ++c) {
         const int64_t r0 = c * chunk, nr = std::min(chunk, ix->n - r0);
-        VF_HIP(launch_normalize_rows(ix->rows_orig, is_half, r0, nr, ix->d, ix->norm, s.cn_tmp.as<float>(), st));
+        VF_HIP(launch_normalize_rows(ix->rows_orig, dt, r0, nr, ix->d, ix->norm, s.cn_tmp.as<float>(), st));
         VF_HIP(launch_dense_dot16(qn_dev, nq, s.cn_tmp.as<float>(), nr, ix->d, s.dense_s.as<float>(), chunk, st));
         VF_HIP(launch_sort_rows(s.dense_s.as<float>(), chunk, nq, (int)nr, k, ix->id_offset + r0, pid + part, psc + part,
                                 k, st));
@@ -616,7 +589,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         VF_HIP(launch_prep_queries(d_queries + (size_t)b0 * ix->d, nb, ix->d, ix->dp, qt, qn_b, s.qimg.as<_Float16>(), st));
         ScanArgs a{};
         a.rows = (const char*)ix->rows_scan; a.inv_scan = ix->inv_scan; a.qimg = s.qimg.as<_Float16>();
-        a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * 2; a.total_waves = p.total_waves; a.samp = p.samp;
+        a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * (ix->dtype == VF_DTYPE_FP8_E4M3 ? 1 : 2); a.total_waves = p.total_waves; a.samp = p.samp;
         a.s0 = s.s0.as<float>(); a.wg_base = s.wgbase.as<long long>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>(); a.hist = s.hist.as<u32>();
         a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
         a.hist_coarse = s.hist_coarse.as<u32>(); a.stage_cap = scan_stage_cap(ix->dp, qt);
@@ -627,7 +600,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
         if (ix->n / p.total_waves < p.samp)
             VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qt * p.total_waves * p.samp * sizeof(float), st));
-        VF_HIP(launch_scan(a, kModeSample, qt, p.grid, (int)ix->scan_g, st));
+        VF_HIP(launch_scan(a, kModeSample, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, st));
         VF_HIP(launch_sel0(a, qt, st));
         // Main scans of different slots cannot share a CU (one 96 KB+ LDS workgroup each), so they run
         // back to back anyway; ordering them explicitly keeps queueing time out of the timed bracket
@@ -635,17 +608,17 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         for (int o = 0; o < kSlots; ++o)
             if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
         if (s.timed && b0 == 0) VF_HIP(hipEventRecord(s.ev_t[0], st));
-        VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, st));
+        VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, st));
         VF_HIP(hipEventRecord(s.ev_scan, st));
         if (s.timed && b0 == 0) {
             VF_HIP(hipEventRecord(s.ev_t[1], st));
             const int64_t per_wave = ix->n / p.total_waves;
             const int64_t sampled = std::min<int64_t>(ix->n, (int64_t)p.total_waves * std::min<int64_t>(p.samp, per_wave));
-            ix->prof_bytes = (ix->n - sampled) * ((int64_t)ix->d * 2 + 4);
+            ix->prof_bytes = (ix->n - sampled) * ((int64_t)ix->d * (ix->dtype == VF_DTYPE_FP8_E4M3 ? 1 : 2) + 4);
         }
         FinalArgs f{};
         f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.tau_bin = a.tau_bin; f.rows_orig = ix->rows_orig;
-        f.orig_is_half = ix->dtype == VF_DTYPE_F16; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
+        f.orig_dtype = ix->dtype; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
         f.d = ix->d; f.k = k; f.kprime = p.kprime; f.eps = p.eps; f.n_rows = ix->n; f.id_offset = ix->id_offset;
         f.out_ids = (long long*)(d_ids + (size_t)b0 * k); f.out_scores = d_scores + (size_t)b0 * k;
         f.flags = s.d_flags + b0; f.cand_count_out = s.d_counts + b0;
@@ -859,4 +832,19 @@ extern "C" int vf_fuse_rank(const float* rerank_scores, const float* time_scores
     if (e == hipSuccess) e = hipMemcpy(out_order, ord.p, n * 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return done(fail(VF_EHIP, std::string("vf_fuse_rank: ") + hipGetErrorString(e)));
     return done(VF_OK);
+}
+
+// Test hook (not in the public header): the fused scan's HARDWARE e4m3 -> fp16 conversion applied to `count` codes,
+// so that tests can pin it against the oracle's table instead of trusting the instruction's documentation.
+extern "C" int vf_debug_cvt_e4m3(const unsigned char* codes, float* out, int32_t count) {
+    if (!codes || !out || count < 0) return fail(VF_EINVAL, "vf_debug_cvt_e4m3: bad argument");
+    unsigned char* d_in = nullptr; float* d_out = nullptr;
+    VF_HIP(hipMalloc((void**)&d_in, (size_t)count + 8));
+    hipError_t e = hipMalloc((void**)&d_out, ((size_t)count + 8) * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_in, codes, count, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_debug_cvt_e4m3(d_in, d_out, count, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)count * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(VF_EHIP, std::string("vf_debug_cvt_e4m3: ") + hipGetErrorString(e));
+    return VF_OK;
 }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/veritasfi_hip.h"  // VF_DTYPE_*
+
 #include <string>
 
 namespace vf {
@@ -58,7 +60,7 @@ struct ScanArgs {
 struct FinalArgs {
     const u32* cnt; const u64* cand; int cap;
     const int* tau_bin;      // final thresholds of the scan (validity check)
-    const void* rows_orig; int orig_is_half; long long orig_row_elems;  // exact rows for rescoring
+    const void* rows_orig; int orig_dtype; long long orig_row_elems;  // exact rows for rescoring (VF_DTYPE_*)
     const float* norm;       // canonical norms [n]
     const float* qn;         // canonical normalised queries [nq][d] fp32
     int d; int k; int kprime; float eps;
@@ -71,14 +73,12 @@ struct FinalArgs {
 };
 
 // ---- launchers (defined in vf_kernels.hip) -----------------------------------------------------
-hipError_t launch_prep_rows(const void* rows, int is_half, long long n, int d, int dp,
-                            _Float16* scan /*may be null when rows are used in place*/,
+hipError_t launch_prep_rows(const void* rows, int dt /* VF_DTYPE_* */, long long n, int d, int dp,
+                            void* scan /*fp16 [n][dp] (fp8 rows: bytes [n][dp]); null when rows are used in place*/,
                             float* norm, float* inv_scan, hipStream_t s);
-// OCP e4m3 bytes -> fp16 (exact); in / out are device pointers, count elements
-hipError_t launch_decode_e4m3(const void* in, void* out_f16, long long count, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, int nq, int d, int dp, int qn_tile /*32 or 64*/,
                                float* qn, _Float16* qimg, hipStream_t s);
-hipError_t launch_normalize_rows(const void* rows, int is_half, long long row0, long long nrows, int d,
+hipError_t launch_normalize_rows(const void* rows, int dt /* VF_DTYPE_* */, long long row0, long long nrows, int d,
                                  const float* norm, float* out, hipStream_t s);
 hipError_t launch_dense_dot16(const float* qn, int nq, const float* cn, long long nrows, int d,
                               float* out, long long out_stride, hipStream_t s);
@@ -86,7 +86,9 @@ hipError_t launch_sort_rows(const float* scores, long long score_stride, int nq,
                             long long id_base, long long* out_ids, float* out_scores, int out_stride,
                             hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int want_g /*0 = auto*/,
-                       hipStream_t s);
+                       int rows_are_fp8, hipStream_t s);
+// test hook: the scan's hardware e4m3 -> fp16 conversion over `count` codes (device pointers)
+hipError_t launch_debug_cvt_e4m3(const unsigned char* in, float* out, int count, hipStream_t s);
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
 hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s);
 hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,

@@ -15,6 +15,7 @@
 #include "vf_internal.h"
 
 #include <float.h>
+#include <type_traits>
 
 #include <mutex>
 
@@ -52,8 +53,27 @@ __device__ __forceinline__ float canon_norm_from_sumsq(float s) {
     return n == 0.0f ? 1.0f : n;
 }
 
-__device__ __forceinline__ float load_elem(const void* rows, int is_half, long long idx) {
-    return is_half ? (float)((const _Float16*)rows)[idx] : ((const float*)rows)[idx];
+__device__ __forceinline__ unsigned short e4m3_to_f16_bits(u32 b) {
+    const u32 sign = (b & 0x80u) << 8, e = (b >> 3) & 0xFu, m = b & 7u;
+    if (e == 0u) {  // zero / subnormal: m * 2^-9 = m * 2^-24 * 2^15 -> normalise by hand
+        if (m == 0u) return (unsigned short)sign;
+        const int sh = m >= 4u ? 0 : (m >= 2u ? 1 : 2);            // leading one at bit 2 - sh
+        const u32 frac = ((m << (sh + 1)) & 7u) << 7;              // bits below the leading one -> fp16 mantissa
+        return (unsigned short)(sign | ((u32)(15 - 7 - sh) << 10) | frac);  // value 1.f * 2^(-7 - sh)
+    }
+    if (e == 15u && m == 7u) return (unsigned short)(sign | 0x7E00u);  // NaN
+    return (unsigned short)(sign | ((e + 8u) << 10) | (m << 7));       // exponent e - 7 + 15
+}
+
+__device__ __forceinline__ float e4m3_to_float(u32 b) {
+    return (float)__builtin_bit_cast(_Float16, e4m3_to_f16_bits(b));
+}
+
+// element `idx` of a row-major corpus of storage dtype dt (VF_DTYPE_F32 / _F16 / _FP8_E4M3), as fp32 (exact)
+__device__ __forceinline__ float load_elem(const void* rows, int dt, long long idx) {
+    if (dt == VF_DTYPE_F16) return (float)((const _Float16*)rows)[idx];
+    if (dt == VF_DTYPE_FP8_E4M3) return e4m3_to_float(((const unsigned char*)rows)[idx]);
+    return ((const float*)rows)[idx];
 }
 
 // histogram bin of a cosine score: 2048 uniform bins over [-1, 1]; monotone in s.
@@ -90,16 +110,17 @@ __device__ __forceinline__ int next_pow2(int n) {
 //   fp32 rows: scan = fp16(x * 2^e), e chosen so the row max lands in [2^13, 2^14)  (no overflow,
 //   underflow below 2^-38 of the row max); inv_scan = 1 / (norm * 2^e).
 //   fp16 rows: scan copy only when dp != d (zero padding); scale 1.
+//   fp8 (e4m3) rows: the scan copy stays fp8 BYTES (dp bytes per row, zero padded); scale 1.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep_rows(const void* rows, int is_half, long long n, int d, int dp,
-                                                    _Float16* scan, float* norm, float* inv_scan) {
+__global__ __launch_bounds__(256) void k_prep_rows(const void* rows, int dt, long long n, int d, int dp,
+                                                    void* scan, float* norm, float* inv_scan) {
     const int l = threadIdx.x & 15;
     const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (r >= n) return;  // whole 16-lane group leaves together
     const long long base = r * (long long)d;
     float acc = 0.0f, mx = 0.0f;
     for (int j = l; j < d; j += 16) {
-        const float x = load_elem(rows, is_half, base + j);
+        const float x = load_elem(rows, dt, base + j);
         acc = __builtin_fmaf(x, x, acc);
         mx = fmaxf(mx, fabsf(x));
     }
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(const void* rows, int is_half
     for (int o = 8; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
     const float nm = canon_norm_from_sumsq(acc);
     float scale = 1.0f;
-    if (!is_half && mx > 0.0f && mx <= FLT_MAX) {
+    if (dt == VF_DTYPE_F32 && mx > 0.0f && mx <= FLT_MAX) {
         int e;
         frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
         scale = ldexpf(1.0f, 14 - e);
@@ -117,20 +138,24 @@ __global__ __launch_bounds__(256) void k_prep_rows(const void* rows, int is_half
         norm[r] = nm;
         inv_scan[r] = 1.0f / (nm * scale);
     }
-    if (scan) {
-        _Float16* out = scan + r * (long long)dp;
+    if (scan && dt == VF_DTYPE_FP8_E4M3) {
+        unsigned char* out = (unsigned char*)scan + r * (long long)dp;
+        const unsigned char* in = (const unsigned char*)rows + base;
+        for (int j = l; j < dp; j += 16) out[j] = j < d ? in[j] : (unsigned char)0;
+    } else if (scan) {
+        _Float16* out = (_Float16*)scan + r * (long long)dp;
         for (int j = l; j < dp; j += 16) {
-            const float x = j < d ? load_elem(rows, is_half, base + j) * scale : 0.0f;
+            const float x = j < d ? load_elem(rows, dt, base + j) * scale : 0.0f;
             out[j] = (_Float16)x;
         }
     }
 }
 
-hipError_t launch_prep_rows(const void* rows, int is_half, long long n, int d, int dp, _Float16* scan,
+hipError_t launch_prep_rows(const void* rows, int dt, long long n, int d, int dp, void* scan,
                             float* norm, float* inv_scan, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const long long blocks = (n + 15) / 16;
-    hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)blocks), dim3(256), 0, s, rows, is_half, n, d, dp, scan, norm,
+    hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)blocks), dim3(256), 0, s, rows, dt, n, d, dp, scan, norm,
                        inv_scan);
     return hipGetLastError();
 }
@@ -181,21 +206,21 @@ hipError_t launch_prep_queries(const float* q, int nq, int d, int dp, int qn_til
 // ------------------------------------------------------------------------------------------------
 // exact dense path
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_normalize_rows(const void* rows, int is_half, long long row0,
+__global__ __launch_bounds__(256) void k_normalize_rows(const void* rows, int dt, long long row0,
                                                          long long nrows, int d, const float* norm, float* out) {
     const long long total = nrows * (long long)d;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / d;
-        out[i] = load_elem(rows, is_half, (row0 + r) * (long long)d + (i - r * d)) * canon_inv(norm[row0 + r]);
+        out[i] = load_elem(rows, dt, (row0 + r) * (long long)d + (i - r * d)) * canon_inv(norm[row0 + r]);
     }
 }
 
-hipError_t launch_normalize_rows(const void* rows, int is_half, long long row0, long long nrows, int d,
+hipError_t launch_normalize_rows(const void* rows, int dt, long long row0, long long nrows, int d,
                                  const float* norm, float* out, hipStream_t s) {
     if (nrows <= 0) return hipSuccess;
     long long blocks = (nrows * (long long)d + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_normalize_rows, dim3((unsigned)blocks), dim3(256), 0, s, rows, is_half, row0, nrows, d, norm,
+    hipLaunchKernelGGL(k_normalize_rows, dim3((unsigned)blocks), dim3(256), 0, s, rows, dt, row0, nrows, d, norm,
                        out);
     return hipGetLastError();
 }
@@ -423,6 +448,71 @@ __device__ __forceinline__ void compute_superstep(f16v (&acc)[NT], const h8 (&bu
             }
 }
 
+// ---- fp8 (e4m3) corpus rows: the same supersteps on HALF the bytes -------------------------------------------
+// A 64-element segment is 64 B; lane (r, h) reads elements [32h, 32h + 32) = 32 B (2 x global_load_dwordx4) and
+// converts them to the four h8 A-operands in registers (v_cvt_scalef32_pk_f16_fp8, scale 1: two codes -> two halves
+// per VALU op; every e4m3 value is an fp16 value, so the MFMA sees exactly the corpus).  Query image, MFMAs,
+// accumulators and epilogue are the fp16 kernel's.
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h8 cvt8_e4m3(u32 w0, u32 w1) {
+    const h2v a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false);
+    const h2v b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true);
+    const h2v c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false);
+    const h2v d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true);
+    h8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
+    return r;
+}
+
+template <int G>
+__device__ __forceinline__ void issue_loads_f8(uint4 (&buf)[2 * G], const char* rows, long long row_bytes, long long myrow,
+                                               int ss, int h) {
+    const char* p = rows + myrow * row_bytes + (long long)(ss * G) * 64 + h * 32;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) buf[g * 2 + i] = *(const uint4*)(p + g * 64 + i * 16);
+}
+
+template <int NT, int G>
+__device__ __forceinline__ void compute_superstep_f8(f16v (&acc)[NT], const uint4 (&buf)[2 * G], const char* lds_lane,
+                                                     int ss) {
+    constexpr int QN = NT * kQueryTile;
+    const char* base = lds_lane + (long long)(ss * G) * (8 * QN * 16);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 w = buf[g * 2 + (i >> 1)];
+            const h8 afrag = (i & 1) ? cvt8_e4m3(w.z, w.w) : cvt8_e4m3(w.x, w.y);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const h8 b = *(const h8*)(base + (g * 8 + i) * (QN * 16) + nt * (kQueryTile * 16));
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, b, acc[nt], 0, 0, 0);
+            }
+        }
+}
+
+__global__ void k_debug_cvt_e4m3(const unsigned char* in, float* out, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per group of 8 codes
+    if (i * 8 >= count) return;
+    u32 w0 = 0, w1 = 0;
+    for (int j = 0; j < 4; ++j) {
+        w0 |= (u32)(i * 8 + j < count ? in[i * 8 + j] : 0) << (8 * j);
+        w1 |= (u32)(i * 8 + 4 + j < count ? in[i * 8 + 4 + j] : 0) << (8 * j);
+    }
+    const h8 r = cvt8_e4m3(w0, w1);
+    for (int j = 0; j < 8; ++j) if (i * 8 + j < count) out[i * 8 + j] = (float)r[j];
+}
+
+hipError_t launch_debug_cvt_e4m3(const unsigned char* in, float* out, int count, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    const int groups = (count + 7) / 8;
+    hipLaunchKernelGGL(k_debug_cvt_e4m3, dim3((groups + 63) / 64), dim3(64), 0, s, in, out, count);
+    return hipGetLastError();
+}
+
 // Recompute tau for query q: the largest fine bin b with sum(fine[b..]) >= kprime, found in two
 // round trips through a two-level histogram (64 coarse bins of 32 fine bins): lane l reads coarse[l],
 // a suffix scan finds the coarse bin L where the count crosses kprime, then lanes 0..31 read the 32
@@ -611,11 +701,23 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
     }
 }
 
+// stage helpers of k_scan, picked by its F8 template flag (if constexpr keeps one kernel body for both element types)
+#define VF_ISSUE(BUF, ...)                                                        \
+    do {                                                                          \
+        if constexpr (F8 != 0) issue_loads_f8<G>(BUF, __VA_ARGS__);               \
+        else issue_loads<G>(BUF, __VA_ARGS__);                                    \
+    } while (0)
+#define VF_COMPUTE(ACC, BUF, ...)                                                 \
+    do {                                                                          \
+        if constexpr (F8 != 0) compute_superstep_f8<NT, G>(ACC, BUF, __VA_ARGS__); \
+        else compute_superstep<NT, G>(ACC, BUF, __VA_ARGS__);                      \
+    } while (0)
+
 // k_scan: see the block comment above.  One workgroup (8 waves) per CU; the workgroup owns the row
 // range [n*wg/grid, n*(wg+1)/grid); its first 8*samp rows are the sample part, the rest the main part.
 // Waves claim 32-row tiles of the part dynamically from an LDS counter: a wave that stalls (tau
 // refresh, unlucky memory channel) simply takes fewer tiles, so the workgroup finishes together.
-template <int NT, int G, int MODE>
+template <int NT, int G, int MODE, int F8>
 __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QN = NT * kQueryTile;
@@ -638,7 +740,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     // the next step is issued UNCONDITIONALLY before the current one is consumed (past the end it
     // re-reads the last step: harmless), so the compiler's counted vmcnt waits never cover the stage
     // in flight.
-    h8 A0[4 * G], A1[4 * G];
+    // register stages: fp16 rows 4 x h8 per segment, fp8 rows 2 x uint4 (raw codes, converted at the MFMA)
+    typedef typename std::conditional<F8 != 0, uint4, h8>::type stage_t;
+    stage_t A0[F8 ? 2 * G : 4 * G], A1[F8 ? 2 * G : 4 * G];
     EpiRegs<NT> epi;
     int cur_tile = wid, claimed = 0x7fffffff, tiles_done = 0;
     const bool active = cur_tile < ntiles;
@@ -649,7 +753,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
         return (long long)(r < hi32m1 ? r : hi32m1);
     };
     // first corpus stage goes out before the query image is staged, so HBM latency overlaps the fill
-    if (active) issue_loads<G>(A0, a.rows, a.row_bytes, rowof(cur_tile), 0, h);
+    if (active) VF_ISSUE(A0, a.rows, a.row_bytes, rowof(cur_tile), 0, h);
     {   // query image -> LDS, verbatim; control block + candidate stage zeroed; tau copied
         const uint4* src = (const uint4*)a.qimg;
         uint4* dst = (uint4*)smem;
@@ -685,22 +789,22 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
             }
             const long long myrow = rowof(cur_tile);
             for (int p = 0; p + 1 < pairs; ++p) {
-                issue_loads<G>(A1, a.rows, a.row_bytes, myrow, 2 * p + 1, h);
+                VF_ISSUE(A1, a.rows, a.row_bytes, myrow, 2 * p + 1, h);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs
-                compute_superstep<NT, G>(acc, A0, lds_lane, 2 * p);
-                issue_loads<G>(A0, a.rows, a.row_bytes, myrow, 2 * p + 2, h);
+                VF_COMPUTE(acc, A0, lds_lane, 2 * p);
+                VF_ISSUE(A0, a.rows, a.row_bytes, myrow, 2 * p + 2, h);
                 __builtin_amdgcn_sched_barrier(0);
-                compute_superstep<NT, G>(acc, A1, lds_lane, 2 * p + 1);
+                VF_COMPUTE(acc, A1, lds_lane, 2 * p + 1);
             }
-            issue_loads<G>(A1, a.rows, a.row_bytes, myrow, SS - 1, h);
+            VF_ISSUE(A1, a.rows, a.row_bytes, myrow, SS - 1, h);
             __builtin_amdgcn_sched_barrier(0);
-            compute_superstep<NT, G>(acc, A0, lds_lane, SS - 2);
+            VF_COMPUTE(acc, A0, lds_lane, SS - 2);
             // last superstep of the tile: epilogue operands first, then the next tile's first stage
             const bool more = claimed < ntiles;
             epi_prefetch<NT, MODE>(epi, a, t0, lane, ((tiles_done & (WAVES - 1)) == wid));
-            issue_loads<G>(A0, a.rows, a.row_bytes, rowof(more ? claimed : cur_tile), 0, h);
+            VF_ISSUE(A0, a.rows, a.row_bytes, rowof(more ? claimed : cur_tile), 0, h);
             __builtin_amdgcn_sched_barrier(0);
-            compute_superstep<NT, G>(acc, A1, lds_lane, SS - 1);
+            VF_COMPUTE(acc, A1, lds_lane, SS - 1);
             tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, (long long)blockIdx.x * swg + (t0 - lo), lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -748,63 +852,6 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_decode_e4m3: OCP FP8 E4M3 (1-4-3, bias 7, no infinities, S.1111.111 = NaN) -> fp16, EXACT: every
-// finite e4m3 value (|x| <= 448, subnormals m * 2^-9) is representable in fp16.  16 bytes per thread.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned short e4m3_to_f16_bits(u32 b) {
-    const u32 sign = (b & 0x80u) << 8, e = (b >> 3) & 0xFu, m = b & 7u;
-    if (e == 0u) {  // zero / subnormal: m * 2^-9 = m * 2^-24 * 2^15 -> normalise by hand
-        if (m == 0u) return (unsigned short)sign;
-        const int sh = m >= 4u ? 0 : (m >= 2u ? 1 : 2);            // leading one at bit 2 - sh
-        const u32 frac = ((m << (sh + 1)) & 7u) << 7;              // bits below the leading one -> fp16 mantissa
-        return (unsigned short)(sign | ((u32)(15 - 7 - sh) << 10) | frac);  // value 1.f * 2^(-7 - sh)
-    }
-    if (e == 15u && m == 7u) return (unsigned short)(sign | 0x7E00u);  // NaN
-    return (unsigned short)(sign | ((e + 8u) << 10) | (m << 7));       // exponent e - 7 + 15
-}
-
-__global__ void k_decode_e4m3(const uint4* __restrict__ in, uint4* __restrict__ out, long long nvec,
-                              const unsigned char* __restrict__ in_tail, unsigned short* __restrict__ out_tail, int ntail) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nvec) {
-        const uint4 v = in[i];
-        const u32 w[4] = {v.x, v.y, v.z, v.w};
-        u32 o[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            o[2 * j] = (u32)e4m3_to_f16_bits(w[j] & 0xFFu) | ((u32)e4m3_to_f16_bits((w[j] >> 8) & 0xFFu) << 16);
-            o[2 * j + 1] = (u32)e4m3_to_f16_bits((w[j] >> 16) & 0xFFu) | ((u32)e4m3_to_f16_bits(w[j] >> 24) << 16);
-        }
-        out[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
-        out[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-    }
-    if (i < ntail) out_tail[i] = e4m3_to_f16_bits(in_tail[i]);
-}
-
-hipError_t launch_decode_e4m3(const void* in, void* out_f16, long long count, hipStream_t s) {
-    if (count <= 0) return hipSuccess;
-    const long long nvec = ((uintptr_t)in % 16 == 0) ? count / 16 : 0;
-    const int ntail = (int)(count - nvec * 16);  // < 16 when aligned; unaligned input takes the scalar path below
-    if (nvec == 0 && count > 0) {
-        // unaligned device pointer: scalar decode, 256 threads x as many blocks as needed
-        const long long blocks = (count + 255) / 256;
-        for (long long b0 = 0; b0 < blocks; b0 += 1 << 20) {
-            const long long nb = blocks - b0 < (1 << 20) ? blocks - b0 : (1 << 20);
-            const long long off = b0 * 256;
-            const long long left = count - off;
-            const int chunk_tail = (int)(left < nb * 256 ? left : nb * 256);
-            hipLaunchKernelGGL(k_decode_e4m3, dim3((unsigned)nb), dim3(256), 0, s, (const uint4*)nullptr, (uint4*)nullptr, 0ll,
-                               (const unsigned char*)in + off, (unsigned short*)out_f16 + off, chunk_tail);
-        }
-        return hipGetLastError();
-    }
-    const long long threads = nvec > ntail ? nvec : ntail;
-    hipLaunchKernelGGL(k_decode_e4m3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint4*)in,
-                       (uint4*)out_f16, nvec, (const unsigned char*)in + nvec * 16, (unsigned short*)out_f16 + nvec * 16, ntail);
-    return hipGetLastError();
-}
-
 // dynamic LDS of k_scan: query image + (main mode) candidate stage
 size_t scan_lds_bytes(int dp, int qn_tile) { return (size_t)dp * qn_tile * 2 + kCtlBytes; }
 int scan_stage_cap(int dp, int qn_tile) {
@@ -814,11 +861,11 @@ int scan_stage_cap(int dp, int qn_tile) {
     return (int)(area / 16);
 }
 
-template <int NT, int G, int MODE>
+template <int NT, int G, int MODE, int F8>
 static hipError_t launch_scan_inst(const ScanArgs& a, int grid, hipStream_t s) {
     size_t lds = scan_lds_bytes(a.dp, NT * kQueryTile);
     if (MODE == kModeMain) lds += (size_t)a.stage_cap * 16;
-    hipLaunchKernelGGL((k_scan<NT, G, MODE>), dim3(grid), dim3(kScanThreads), lds, s, a);
+    hipLaunchKernelGGL((k_scan<NT, G, MODE, F8>), dim3(grid), dim3(kScanThreads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -826,9 +873,14 @@ static hipError_t launch_scan_inst(const ScanArgs& a, int grid, hipStream_t s) {
 // tile loop alternates two register stages).  Main mode: G=2 keeps the kernel spill-free with its
 // filter epilogue (234 VGPRs at NT=2).  Sample mode is latency-bound (a workgroup has only 128 rows):
 // the deepest spill-free G (4) puts a third of a 32-row tile in flight per stage.
-static int pick_G(int dp, int want, int mode) {
+static int pick_G(int dp, int want, int mode, int f8) {
     const int segs = dp >> 6;  // dp is a multiple of 128, so segs is even
     auto ok = [&](int g) { return g >= 1 && segs % g == 0 && ((segs / g) & 1) == 0; };
+    if (f8 && !(want >= 1 && want <= 4 && ok(want))) {
+        // fp8 rows: a stage of G segments holds half the bytes of the fp16 kernel's, so go as deep as divides
+        for (int g : {4, 3, 2}) if (ok(g)) return g;
+        return 1;
+    }
     if (mode == kModeSample) {
         for (int g : {4, 3, 2}) if (ok(g)) return g;
         return 1;
@@ -839,11 +891,12 @@ static int pick_G(int dp, int want, int mode) {
     return 1;  // segs even => always ok
 }
 
-hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int want_g, hipStream_t s) {
-    const int G = pick_G(a.dp, want_g, mode);
+hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int want_g, int rows_are_fp8, hipStream_t s) {
+    const int G = pick_G(a.dp, want_g, mode, rows_are_fp8);
     const int NT = qn_tile / kQueryTile;
-#define VF_CASE(NTV, GV, MODEV) \
-    if (NT == NTV && G == GV && mode == MODEV) return launch_scan_inst<NTV, GV, MODEV>(a, grid, s);
+#define VF_CASE(NTV, GV, MODEV)                                                                         \
+    if (NT == NTV && G == GV && mode == MODEV)                                                          \
+        return rows_are_fp8 ? launch_scan_inst<NTV, GV, MODEV, 1>(a, grid, s) : launch_scan_inst<NTV, GV, MODEV, 0>(a, grid, s);
     VF_CASE(1, 1, kModeMain) VF_CASE(1, 2, kModeMain) VF_CASE(1, 3, kModeMain) VF_CASE(1, 4, kModeMain)
     VF_CASE(2, 1, kModeMain) VF_CASE(2, 2, kModeMain) VF_CASE(2, 3, kModeMain) VF_CASE(2, 4, kModeMain)
     VF_CASE(1, 1, kModeSample) VF_CASE(1, 2, kModeSample) VF_CASE(1, 3, kModeSample) VF_CASE(1, 4, kModeSample)
@@ -854,8 +907,10 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
 
 template <int NT, int G, int MODE>
 static hipError_t configure_one() {
-    return hipFuncSetAttribute((const void*)k_scan<NT, G, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_scan<NT, G, MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_scan<NT, G, MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1046,7 +1101,7 @@ __device__ __forceinline__ void rank_select_desc(const u64* keys, int n, u64* ou
 // issued UNCONDITIONALLY (index clamped, value masked afterwards) with the dtype a template
 // parameter: a per-element runtime condition around a load makes hipcc branch around each one and
 // wait vmcnt(0) per element -- 48 serialized round trips per row, 18 us measured.
-template <bool IS_HALF>
+template <int DT>
 __device__ __forceinline__ float rescore_row(const void* rows, long long base, int d, const float* qv, float nm,
                                              int l) {
     float acc = 0.0f;
@@ -1057,13 +1112,16 @@ __device__ __forceinline__ float rescore_row(const void* rows, long long base, i
         for (int u = 0; u < 48; ++u) {
             const int j = j0 + 16 * u;
             const long long idx = base + (j < d ? j : d - 1);
-            cv[u] = IS_HALF ? (float)((const _Float16*)rows)[idx] : ((const float*)rows)[idx];
+            cv[u] = DT == VF_DTYPE_F16 ? (float)((const _Float16*)rows)[idx]
+                    : DT == VF_DTYPE_FP8_E4M3 ? (float)((const unsigned char*)rows)[idx]   // raw code; decoded below
+                                              : ((const float*)rows)[idx];
         }
 #pragma unroll
         for (int u = 0; u < 48; ++u) {
             const int j = j0 + 16 * u;
             const float qq = qv[j < d ? j : d - 1];
-            const float t = __builtin_fmaf(qq, cv[u] * inv, acc);
+            const float cx = DT == VF_DTYPE_FP8_E4M3 ? e4m3_to_float((u32)cv[u]) : cv[u];
+            const float t = __builtin_fmaf(qq, cx * inv, acc);
             acc = j < d ? t : acc;
         }
     }
@@ -1134,9 +1192,10 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     const float* qv = q_in_lds ? qs : a.qn + (long long)q * a.d;
     for (int i = g; i < m; i += kFinalThreads / 16) {
         const u32 row = (u32)top[i];
-        const float acc = a.orig_is_half
-                              ? rescore_row<true>(a.rows_orig, (long long)row * a.orig_row_elems, a.d, qv, a.norm[row], l)
-                              : rescore_row<false>(a.rows_orig, (long long)row * a.orig_row_elems, a.d, qv, a.norm[row], l);
+        const long long rbase = (long long)row * a.orig_row_elems;
+        const float acc = a.orig_dtype == VF_DTYPE_F16       ? rescore_row<VF_DTYPE_F16>(a.rows_orig, rbase, a.d, qv, a.norm[row], l)
+                          : a.orig_dtype == VF_DTYPE_FP8_E4M3 ? rescore_row<VF_DTYPE_FP8_E4M3>(a.rows_orig, rbase, a.d, qv, a.norm[row], l)
+                                                              : rescore_row<VF_DTYPE_F32>(a.rows_orig, rbase, a.d, qv, a.norm[row], l);
         if (l == 0) rk[i] = ((u64)orderkey(acc) << 32) | (u64)(0xFFFFFFFFu - row);
     }
     __syncthreads();

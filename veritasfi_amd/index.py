@@ -22,7 +22,7 @@ class DenseIndex:
     def __init__(self, rows, device_id: int = 0, id_offset: int = 0):
         """rows: [n, d] float32 / float16 ndarray (copied to HBM) or a CUDA torch tensor (borrowed).
         FP8: a torch.float8_e4m3fn tensor (CPU or CUDA), or a uint8 ndarray / tensor of OCP e4m3 codes passed with
-        ``DenseIndex.from_e4m3``; decoded exactly to fp16 at build."""
+        ``DenseIndex.from_e4m3``; the bytes stay fp8 in HBM (scanned as fp8, converted exactly in registers)."""
         L = _ffi.lib()
         self._h = _ffi.vp()
         self._keepalive = None
