@@ -249,3 +249,36 @@ def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):
     embs = np.asarray(emb.embed_documents([c["page_content"] for c in chunks]), np.float32)
     want = R.rank_chunk([c["bundle_id"] for c in chunks], scores, ts, embs, 20, 0.9)
     assert got == want and 0 < len(got) <= 10 and len(set(got)) == len(got)
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_kernels_match_torch(vf, kind, epi):
+    """Every GEMM kernel (1 = LDS-DMA 128x256 with two workgroups per CU, 2 = 256x256, 3 = register-staged 128x128) x every
+    epilogue (bias, bias + erf-GELU, bias + residual) against torch fp32 on the same fp16 operands, at a shape with a
+    ragged tile grid for the XCD-aware tile order (M = 1792 -> 14 / 7 m-tiles, N = 768, K = 320 -> 5 / 10 K-steps)."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_gemm.restype = ctypes.c_int
+    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(100 * kind + epi)
+    for (M, N, K) in ((1792, 768, 320), (512, 1024, 3072)):
+        A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
+        W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()
+        bias = torch.randn(N, device=dev, generator=g)
+        R = torch.randn(M, N, device=dev, generator=g).half()
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), R.data_ptr(), C.data_ptr(), M, N, K, epi,
+                             torch.cuda.current_stream().cuda_stream, kind)
+        assert rc == 0
+        torch.cuda.synchronize()
+        ref = A.float() @ W.float().T + bias
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if epi == 2:
+            ref = ref.half().float() + R.float()   # the kernels round the biased product to fp16 before adding the residual
+        err = (C.float() - ref).abs().max().item()
+        assert not torch.isnan(C).any() and err < 2e-2, (M, N, K, err)

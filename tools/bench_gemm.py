@@ -12,10 +12,11 @@ def main():
     ap.add_argument("--shapes", default="51200x2304x768,51200x768x768,51200x3072x768,51200x768x3072")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--kind", type=int, default=0, help="0 auto, 1 DMA 128x256, 2 256x256, 3 128x128")
     a = ap.parse_args()
     L = _ffi.lib()
     L.vf_debug_gemm.restype = ctypes.c_int
-    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")
     for sh in a.shapes.split(","):
         M, N, K = map(int, sh.split("x"))
@@ -26,7 +27,7 @@ def main():
         C = torch.empty(M, N, device=dev, dtype=torch.float16)
         st = torch.cuda.current_stream().cuda_stream
         def run():
-            rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, C.data_ptr(), M, N, K, 0, st)
+            rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, C.data_ptr(), M, N, K, 0, st, a.kind)
             assert rc == 0
         run(); torch.cuda.synchronize()
         err = None

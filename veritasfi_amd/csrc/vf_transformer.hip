@@ -1009,13 +1009,14 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
 
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
-                       int K, hipStream_t st) {
+                       int K, hipStream_t st, int force_kind = 0) {
     // Tile choice (VF_GEMM_KIND overrides for A/B runs: 1 = DMA 128x256, 2 = 256x256, 3 = 128x128):
     //  * 128 x 256 DMA tiles, two workgroups per CU, when they give at least VF_GEMM_DMA_MIN_WGS workgroups;
     //  * 128 x 128 register-staged tiles for everything smaller (micro-batches of 8 pairs, single queries).
     // The 256 x 256 single-workgroup-per-CU kernel measured equal in isolation and 6 % slower inside the forward
     // (its GELU epilogue has nothing to hide under); it stays selectable for experiments.
-    static const int kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
+    static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
+    const int kind = force_kind ? force_kind : env_kind;
     static const long long dma_min = getenv("VF_GEMM_DMA_MIN_WGS") ? atoll(getenv("VF_GEMM_DMA_MIN_WGS")) : 384;
     const bool dma_ok = M % DBM == 0 && N % DBN == 0 && K % DBK == 0;
     const bool big_ok = M % LBM == 0 && N % LBN == 0;
@@ -1179,14 +1180,17 @@ extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e)
 // Test hook (not part of the public header; tools/bench_gemm.py and the GEMM parity test bind it):
 // C[M][N] = epi(A[M][K] . W[N][K]^T + bias [, + R]) on device pointers, fp16 in/out, fp32 accumulation.
 extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, const void* R, void* C, int M, int N, int K,
-                             int epi, void* stream) {
+                             int epi, void* stream, int kind /* 0 auto, 1 DMA 128x256, 2 256x256, 3 128x128 */) {
     hipError_t er = configure_once();
     if (er != hipSuccess) return -1;
+    if (M % 128 || N % 128 || K % 64) return -2;
+    if (kind == 1 && (M % DBM || N % DBN)) return -2;
+    if (kind == 2 && (M % LBM || N % LBN)) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;
-    if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st);
-    else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st);
-    else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st);
+    if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st, kind);
+    else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st, kind);
+    else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st, kind);
     return er == hipSuccess ? 0 : -1;
 }
