@@ -56,6 +56,7 @@ def _batch(rng, b, t, vocab, pad_id=0, ragged=True):
     ("tiny", 128, 2, 2, 512, 3, 48),
     ("small-odd-t", 256, 3, 4, 1024, 5, 100),
     ("bge-base-shape", 768, 12, 12, 3072, 4, 128),
+    ("single-query", 768, 3, 12, 3072, 1, 40),     # <= 64 tokens with ffn >= 2048: the split-K FFN-down kernel
 ])
 def test_embedding_encoder_matches_torch_fp32(vf, name, hidden, layers, heads, ffn, b, t):
     import torch

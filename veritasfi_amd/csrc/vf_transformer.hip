@@ -305,6 +305,127 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemm_splitk: the same product for FEW rows and LONG K (a single short query's FFN-down: M <= 64, K = ffn).  At that size
+// the tiled kernels launch a dozen workgroups that each walk the whole K serially (26 us for K = 3072) while 240
+// CUs idle; here a 64 x 64 output tile is computed by S workgroups, each over K / S, so the weight matrix
+// streams through the whole chip.  Deterministic: every split writes its fp32 partial tile to its own slab
+// part[s][M][N]; the workgroup that arrives LAST at the tile's counter sums the slabs in split order, applies
+// the epilogue and resets the counter (slabs cross XCDs, whose L2s are not coherent: see the hand-off below).
+// 256 threads = 4 waves, one 32 x 32 MFMA tile each; BK = 64, two register-staged LDS buffers.
+// Requires M % 64 == 0, N % 64 == 0, (K / S) % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int SBM = 64, SBN = 64, SBK = 64, SLD = SBK + 8;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_splitk(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                      const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                      half_t* __restrict__ C, int M, int N, int K, int S,
+                                                      float* __restrict__ part, unsigned* __restrict__ counters) {
+    __shared__ __attribute__((aligned(16))) half_t As[2][SBM][SLD];
+    __shared__ __attribute__((aligned(16))) half_t Ws[2][SBN][SLD];
+    __shared__ unsigned s_old;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5, wr = wid >> 1, wc = wid & 1;
+    const int Nt = N / SBN;
+    const int sp = blockIdx.x % S, t = blockIdx.x / S, nt = t % Nt, mt = t / Nt;
+    const long long m0 = (long long)mt * SBM, n0 = (long long)nt * SBN;
+    const int klen = K / S, k0 = sp * klen, nk = klen / SBK;
+    // a K-tile of A / W is 64 rows x 128 B = 512 chunks of 16 B: two per thread (rows c >> 3, chunk c & 7)
+    const int row0 = tid >> 3, kc = tid & 7;
+    const half_t* ap = A + (m0 + row0) * K + k0 + kc * 8;
+    const half_t* wp = W + (n0 + row0) * K + k0 + kc * 8;
+    h8 ra[2], rw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ra[j] = *(const h8*)(ap + (long long)(32 * j) * K);
+        rw[j] = *(const h8*)(wp + (long long)(32 * j) * K);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        *(h8*)(&As[0][row0 + 32 * j][kc * 8]) = ra[j];
+        *(h8*)(&Ws[0][row0 + 32 * j][kc * 8]) = rw[j];
+    }
+    __syncthreads();
+    f16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ra[j] = *(const h8*)(ap + (long long)(32 * j) * K + (kt + 1) * SBK);
+                rw[j] = *(const h8*)(wp + (long long)(32 * j) * K + (kt + 1) * SBK);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h8 af = *(const h8*)(&As[cur][wr * 32 + r31][ks * 16 + h * 8]);
+            const h8 wf = *(const h8*)(&Ws[cur][wc * 32 + r31][ks * 16 + h * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *(h8*)(&As[cur ^ 1][row0 + 32 * j][kc * 8]) = ra[j];
+                *(h8*)(&Ws[cur ^ 1][row0 + 32 * j][kc * 8]) = rw[j];
+            }
+        }
+        __syncthreads();
+    }
+    // this split's partial tile -> its slab
+    float* slab = part + ((long long)sp * M + m0) * N + n0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        // agent-scope store: written through the (per-XCD, mutually non-coherent) L2 to memory
+        __hip_atomic_store(slab + (long long)row * N + wc * 32 + r31, acc[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The slab must have reached memory before the arrival is counted.  A full release fence would write back AND
+    // (on the acquire side) invalidate the whole L2 per workgroup -- measured 2-3x slower than no split at all, it
+    // evicts the weights; the partials alone bypass L2 instead (agent-scope stores above, agent-scope loads below),
+    // and all this needs is that the stores have completed: vmcnt(0), then the barrier, then the counter.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_old = __hip_atomic_fetch_add(counters + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_old != (unsigned)(S - 1)) return;  // not the last split of this tile
+    // the last arrival reduces in split order (deterministic) and applies the epilogue: thread -> row tid >> 2,
+    // 16 consecutive columns
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) {
+        const float* src = part + ((long long)s2 * M + m0 + row) * N + n0 + c0;
+        float x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += x[e];
+    }
+    const long long off = (m0 + row) * N + n0 + c0;
+    h8 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float x = v[e] + (bias ? bias[n0 + c0 + e] : 0.f);
+        if (EPI == EPI_BIAS_GELU) x = gelu_erf(x);
+        o[e >> 3][e & 7] = (half_t)x;
+    }
+    if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const h8 r = *(const h8*)(R + off + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[q][e] = (half_t)((float)o[q][e] + (float)r[e]);
+        }
+    }
+    *(h8*)(C + off) = o[0];
+    *(h8*)(C + off + 8) = o[1];
+    if (tid == 0) __hip_atomic_store(counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+}
+
+// ------------------------------------------------------------------------------------------------
 // Large-tile GEMM: 256 x 256 output tile per 512-thread workgroup (8 waves as 2 (M) x 4 (N), each 128 x 64 =
 // 4 x 2 MFMA 32x32 tiles, 128 accumulator VGPRs), BK = 64, two LDS buffers of 64 KB (A 256x64 + W 256x64 fp16).
 // Operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write): a wave
@@ -875,6 +996,8 @@ static hipError_t configure_once() {
 }
 
 
+constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
+
 struct vf_encoder {
     vf_encoder_config cfg{};
     int device = 0;
@@ -890,6 +1013,9 @@ struct vf_encoder {
     int *d_ids = nullptr, *d_mask = nullptr, *d_tt = nullptr, *d_pos = nullptr, *d_flag = nullptr;
     float* d_out = nullptr;
     float* d_hidden = nullptr;  // [cap_tokens, H] fp32, for vf_encoder_forward_hidden
+    // split-K GEMM (forwards of <= kSplitMaxRows tokens): fp32 slabs [kSplitMax][kSplitMaxRows][max(3H, F)] + tile counters
+    float* sk_part = nullptr;
+    unsigned* sk_cnt = nullptr;
     std::mutex mu;
 };
 
@@ -931,6 +1057,8 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     if (e->w16) (void)hipFree(e->w16);
     if (e->w32) (void)hipFree(e->w32);
     if (e->d_flag) (void)hipFree(e->d_flag);
+    if (e->sk_part) (void)hipFree(e->sk_part);
+    if (e->sk_cnt) (void)hipFree(e->sk_cnt);
     delete e;
     return VF_OK;
 }
@@ -968,6 +1096,12 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
     hipError_t er = hipMalloc((void**)&e->w16, (size_t)n16 * 2);
     if (er == hipSuccess) er = hipMalloc((void**)&e->w32, (size_t)n32 * 4);
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_flag, 4);
+    {
+        const size_t nmax = std::max<size_t>(3 * (size_t)cfg->hidden, (size_t)cfg->ffn);
+        if (er == hipSuccess) er = hipMalloc((void**)&e->sk_part, (size_t)kSplitMax * kSplitMaxRows * nmax * sizeof(float));
+        if (er == hipSuccess) er = hipMalloc((void**)&e->sk_cnt, 4096 * sizeof(unsigned));
+        if (er == hipSuccess) er = hipMemset(e->sk_cnt, 0, 4096 * sizeof(unsigned));
+    }
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = configure_once();
@@ -1007,6 +1141,24 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
     return VF_OK;
 }
 
+// split count for the small-M kernel: enough workgroups to cover the chip, at least two K-steps per split
+static int pick_splits(int tiles, int K) {
+    const int steps = K / SBK;
+    int best = 1;
+    for (int sp = 1; sp <= kSplitMax; ++sp)
+        if (steps % sp == 0 && steps / sp >= 2 && tiles * sp <= 512) best = sp;
+    return best;
+}
+
+template <int EPI>
+static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int Mrows,
+                              int N, int K, float* part, unsigned* cnt, hipStream_t st) {
+    const int tiles = (Mrows / SBM) * (N / SBN);
+    const int sp = pick_splits(tiles, K);
+    hipLaunchKernelGGL(k_gemm_splitk<EPI>, dim3(tiles * sp), dim3(256), 0, st, A, W, bias, R, C, Mrows, N, K, sp, part, cnt);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st, int force_kind = 0) {
@@ -1039,6 +1191,9 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
 static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, hipStream_t st) {
     const vf_encoder_config& c = e->cfg;
     const int H = c.hidden, F = c.ffn, M = B * T, Mp = (M + 255) / 256 * 256;
+    const int Ms = (M + 63) / 64 * 64;
+    static const bool no_splitk = getenv("VF_NO_SPLITK") != nullptr;  // A/B switch
+    const bool small = !no_splitk && Ms <= kSplitMaxRows && H % 64 == 0 && F % 64 == 0;
     hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
@@ -1062,7 +1217,14 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
-        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st));
+        if (small && F >= 2048) {
+            // a single short sequence: the long-K product (K = ffn) is split over K across the chip (1.17 -> 1.00 ms per
+            // forward); the K = hidden products are not (the split's extra dependent memory round trips cost more than
+            // 12 short K-steps), nor anything from 256 tokens up (measured slower)
+            VFT_HIP(gemm_splitk<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Ms, H, F, e->sk_part, e->sk_cnt, st));
+        } else {
+            VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st));
+        }
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
     }
     int all_last = 0;
