@@ -4,10 +4,11 @@
 // np.argsort (experiments/retriever/step3_mul.py:275-283).
 //
 // Kernels
-//   k_prep_rows        index build: canonical row norms, fp16 scan copy (+ per-row pow2 scale)
+//   k_prep_rows        index build: canonical row norms, fp16 scan copy (+ per-row pow2 scale); fp8 rows stay bytes
 //   k_prep_queries     per batch: canonical query normalisation, fp16 LDS image for the MFMA scan
-//   k_scan<NT,G,MODE>  THE hot kernel: streams the fp16 corpus once, 32x32x16 f16 MFMA against the
-//                      LDS-resident query tile, threshold-filter epilogue (no score matrix written)
+//   k_scan<NT,G,MODE,F8>  THE hot kernel: streams the corpus once (fp16 rows, or fp8-e4m3 bytes converted in
+//                      registers), 32x32x16 f16 MFMA against the LDS-resident query tile, threshold-filter
+//                      epilogue (no score matrix written)
 //   k_sel0             threshold seed from the sample scores
 //   k_final            per query: top-k' of candidates, canonical fp32 re-score, sort, certificate
 //   k_normalize_rows / k_dense_dot16 / k_sort_rows   exact dense path (small N, repairs)

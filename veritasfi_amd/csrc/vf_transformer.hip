@@ -13,11 +13,15 @@
 // fp16 weights and activations, fp32 accumulation (MFMA), fp32 LayerNorm / softmax / GELU / pooling.
 //
 // Kernels
-//   k_embed_ln     gather three embeddings, add, LayerNorm                     (HBM-bound, tiny)
-//   k_gemm_tn<EPI> C = A[M,K] W[N,K]^T + bias (+GELU | +residual), 128x128x64 tiles, LDS double buffer
-//   k_attention    fused q k^T -> online softmax -> p v per (batch, head, 128 queries); K and V^T in LDS
-//   k_layernorm    row LayerNorm, one wave per row
-//   k_pool         CLS / mean / last-token pooling (+ L2 normalise)  or  RoBERTa classification head
+//   k_embed_ln        gather three embeddings, add, LayerNorm (half a wave per row, 16-byte chunks)
+//   k_gemm_dma_tn<E>  C = A[M,K] W[N,K]^T + bias (+GELU | +residual): 128x256x32 tiles, LDS-DMA ring, TWO workgroups
+//                     per CU -- the large-problem kernel (100 pairs x 512 tokens)
+//   k_gemm_tn<E>      128x128x64 tiles, register-staged LDS double buffer -- everything smaller
+//   k_gemm_splitk<E>  64x64 tiles split over K with a deterministic slab reduction -- a single short query's FFN-down
+//   k_gemm256_tn<E>   256x256x64 tiles, one workgroup per CU -- kept selectable for experiments (VF_GEMM_KIND=2)
+//   k_attention       fused q k^T -> online softmax -> p v per (sequence, head); K and V^T in LDS
+//   k_layernorm       row LayerNorm (half a wave per row)
+//   k_pool            CLS / mean / last-token pooling (+ L2 normalise)  or  RoBERTa classification head
 #include "../../include/veritasfi_hip.h"
 #include "vf_internal.h"
 
