@@ -283,3 +283,28 @@ def test_gemm_kernels_match_torch(vf, kind, epi):
             ref = ref.half().float() + R.float()   # the kernels round the biased product to fp16 before adding the residual
         err = (C.float() - ref).abs().max().item()
         assert not torch.isnan(C).any() and err < 2e-2, (M, N, K, err)
+
+
+def test_encoder_handle_is_thread_safe(vf):
+    """The reference shares one embedder between request threads without a lock (ragManager.py:17-30 singleton): concurrent
+    forwards on one handle, with different batch shapes and per-call poolings, must each equal the serial result."""
+    import threading
+    enc = vf.HipEncoder.from_hf(_hf_bert(128, 2, 2, 512), pooling=0, normalize=True)
+    rng = np.random.default_rng(8)
+    jobs = []
+    for i in range(12):
+        b, t = int(rng.integers(1, 9)), int(rng.choice([16, 40, 64, 100]))
+        ids, mask = _batch(rng, b, t, 1000)
+        jobs.append((ids, mask, [None, 1, 2][i % 3]))
+    want = [enc.forward(i, m, pooling=p, normalize=None if p is None else False) for i, m, p in jobs]
+    got = [None] * len(jobs)
+    def work(lo):
+        for j in range(lo, len(jobs), 4):
+            i, m, p = jobs[j]
+            got[j] = enc.forward(i, m, pooling=p, normalize=None if p is None else False)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    enc.close()
+    for w, g in zip(want, got):
+        assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
