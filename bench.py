@@ -43,6 +43,11 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--opt", action="append", default=[], help="index option name=value (tuning)")
     ap.add_argument("--no-rerank", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed run push one bucket through the exchange path and compare the merged result "
+                         "with per-batch searches (exact on one rank; sortedness + id ranges on several)")
+    ap.add_argument("--exchange-every", type=int, default=0,
+                    help="multi-GPU: batches per all-gather + merge (results are bucketed, nothing is skipped); 0 = auto (4)")
     ap.add_argument("--corpus-dtype", choices=["f16", "fp8"], default="f16",
                     help="storage of the corpus rows: fp16 (the BASELINE metric) or OCP fp8-e4m3 (configs[4] storage)")
     ap.add_argument("--rerank-shape", default="xlmr-base", help="cross-encoder shape (tools/bench_rerank.py SHAPES)")
@@ -161,34 +166,44 @@ def main():
         name, val = o.split("=")
         index.set_option(name, int(val))
     nslots = min(index.slots, int(os.environ.get("VF_BENCH_DEPTH", "2")))  # batches in flight (deeper measured no faster)
-    # per in-flight batch: one packed result blob [ids | scores] with typed views (single all-gather per batch)
-    bufs = [vf.packed_result_buffer(args.batch, args.k, device) for _ in range(nslots)]
-    out_ids = [b[1] for b in bufs]
-    out_sc = [b[2] for b in bufs]
+    # Results are written straight into a BUCKET: one packed blob [ids (E, nq, k) int64 | scores (E, nq, k) fp32] that
+    # collects E consecutive batches and is shipped with ONE all-gather + ONE merge launch over E * nq queries
+    # (--exchange-every E; E = 1 is one exchange per batch).  Every result is exchanged and merged either way; bucketing
+    # only divides the fixed cost of the collective.  Two buckets alternate (the previous one is in flight on the wire).
+    E = args.exchange_every if args.exchange_every > 0 else (4 if exchange else 1)
+    nbuckets = 2 if E >= max(1, nslots - 1) else nslots + 1
+    buckets = [vf.packed_result_buffer(E * args.batch, args.k, device) for _ in range(nbuckets)]
+    def views(i):
+        blob, ids, sc = buckets[(i // E) % nbuckets]
+        e = i % E
+        return ids[e * args.batch:(e + 1) * args.batch], sc[e * args.batch:(e + 1) * args.batch]
     if exchange:
-        g_blob = torch.empty(world * args.batch * args.k * 12, dtype=torch.uint8, device=device)
-        m_ids = torch.empty((args.batch, args.k), dtype=torch.int64, device=device)
-        m_sc = torch.empty((args.batch, args.k), dtype=torch.float32, device=device)
+        g_blob = torch.empty(world * E * args.batch * args.k * 12, dtype=torch.uint8, device=device)
+        m_ids = torch.empty((E * args.batch, args.k), dtype=torch.int64, device=device)
+        m_sc = torch.empty((E * args.batch, args.k), dtype=torch.float32, device=device)
     merged = [None]
 
-    def finish(slot):
+    def finish(slot, i, last):
         index.search_end(slot)
-        if exchange:  # the exchange step: ONE all-gather of the packed per-shard top-k over xGMI, then the merge kernel
-            dist.all_gather_into_tensor(g_blob, bufs[slot][0])
-            merged[0] = vf.merge_topk_packed_device(g_blob, world, args.batch, args.k, m_ids, m_sc)
-        else:
-            merged[0] = (out_ids[slot], out_sc[slot])
+        if not exchange:
+            merged[0] = views(i)
+        elif i % E == E - 1 or last:  # bucket complete: ONE all-gather of the packed per-shard top-k over xGMI + the merge kernel
+            dist.all_gather_into_tensor(g_blob, buckets[(i // E) % nbuckets][0])
+            merged[0] = vf.merge_topk_packed_device(g_blob, world, E * args.batch, args.k, m_ids, m_sc)
 
     def run(steps):
         pending = []
         for i in range(steps):
             slot = i % nslots
             if len(pending) == nslots:
-                finish(pending.pop(0))
-            index.search_begin(slot, qpool[i % len(qpool)], args.k, out_ids[slot], out_sc[slot])
-            pending.append(slot)
+                ps, pi = pending.pop(0)
+                finish(ps, pi, False)
+            oi, osc = views(i)
+            index.search_begin(slot, qpool[i % len(qpool)], args.k, oi, osc)
+            pending.append((slot, i))
         while pending:
-            finish(pending.pop(0))
+            ps, pi = pending.pop(0)
+            finish(ps, pi, not pending)
 
     def fence():
         torch.cuda.synchronize()
@@ -209,6 +224,20 @@ def main():
         elapsed = float(t.item())
     prof = index.profile()
     stats = index.stats()
+    if args.verify and exchange:
+        run(E)                      # exactly one full bucket: batches 0 .. E-1 of the query pool
+        fence()
+        mi, ms = merged[0]
+        assert mi.shape == (E * args.batch, args.k)
+        assert bool((ms[:, :-1] >= ms[:, 1:]).all()), "merged scores are not sorted"
+        assert bool(((mi >= 0) & (mi < args.rows)).all()), "merged ids outside the corpus"
+        if world == 1:
+            for e in range(E):
+                di, ds = index.search_device(qpool[e % len(qpool)], args.k)
+                assert torch.equal(di, mi[e * args.batch:(e + 1) * args.batch]), "bucketed exchange changed the ids"
+                assert torch.equal(ds, ms[e * args.batch:(e + 1) * args.batch]), "bucketed exchange changed the scores"
+        if rank == 0:
+            print(f"verify ok: bucket of {E} batches through all-gather + merge", file=sys.stderr)
     index.set_option("profile", 0)
     rr_ms, rr_info = (None, None)
     if rank == 0 and not args.no_rerank:
@@ -242,7 +271,7 @@ def main():
             "config": {"workload": f"{args.rows}x{args.dim} {'fp16' if args.corpus_dtype == 'f16' else 'fp8-e4m3'} corpus, batch-{args.batch} queries, exact cosine "
                                    f"top-{args.k}, row-sharded over {world} GPU(s) + RCCL all-gather of per-shard top-k",
                        "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
-                       "rows_per_gpu": hi - lo, "in_flight_batches": nslots},
+                       "rows_per_gpu": hi - lo, "in_flight_batches": nslots, "batches_per_exchange": E if exchange else None},
             "roofline": roof,
             "search_stats": {"candidates_per_query": round(stats["candidates"] / max(1, stats["n_queries"]), 1),
                              "exact_reruns_last_batch": stats["exact_reruns"], "path": stats["path"]},
