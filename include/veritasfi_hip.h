@@ -191,6 +191,34 @@ int vf_encoder_forward_hidden(vf_encoder* enc, const int32_t* ids, const int32_t
                               int32_t b, int32_t t, float* out_hidden);
 int vf_encoder_info(vf_encoder* enc, vf_encoder_config* out);
 int vf_encoder_destroy(vf_encoder* enc);
+/* ---- decoder-only models: the embedder / re-ranker family the reference configures by default ----------------
+ * Qwen3-Embedding with last_token_pool -- get_embeddings in experiments/retriever/step3_mul.py:181-209 (model :384),
+ * continuous_retrieval.py:127-152 -- and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225:
+ * score = logits[:, -1, yes_loc]).  Pre-norm layer: x += Wo attn(rope(qnorm(q)), rope(knorm(k)), v) ; x += Wdown
+ * (silu(Wgate n) * Wup n), n = RMSNorm(x); causal grouped-query attention; final RMSNorm.  fp16 weights and
+ * activations, fp32 accumulation / norms / softmax.  head_dim 64 or 128, t <= 512. */
+typedef struct vf_decoder vf_decoder;
+typedef struct vf_decoder_config {
+    int32_t vocab, hidden, layers, heads, kv_heads, head_dim, ffn;
+    float rope_theta, rms_eps;
+    int32_t qk_norm;    /* 1: RMSNorm over head_dim on q and k before RoPE (Qwen3) */
+    int32_t pooling;    /* 0 first token, 1 unmasked mean, 2 last token (step3_mul.py:181-188) */
+    int32_t normalize;  /* 1: L2-normalise the pooled vector */
+    int32_t head;       /* 0: embeddings [b, hidden]; 2: one vocabulary token's logit at the last position -> [b] */
+} vf_decoder_config;
+/* Weight blobs (host).  fp16: embed[vocab,H], then per layer Wqkv[(heads+2*kv_heads)*head_dim, H] (q rows, k rows,
+ * v rows) Wo[H, heads*head_dim] Wgate_up[2*ffn, H] (gate rows, up rows) Wdown[H, ffn], then (head == 2) the lm_head
+ * row of the scored token [H].  fp32: per layer input_norm[H] post_attention_norm[H] q_norm[head_dim] k_norm[head_dim],
+ * then final_norm[H].  nn.Linear layout [out, in]. */
+int vf_decoder_weight_sizes(const vf_decoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
+int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg, const void* w_fp16, int64_t n_fp16,
+                      const float* w_fp32, int64_t n_fp32, int32_t device_id);
+/* ids / mask [b, t] int32 host, t % 32 == 0, t <= 512 (left- or right-padded, mask 0); positions are column indices
+ * (what HF does when no position_ids are passed); out [b, hidden] (head 0) or [b] (head 2) fp32 host. */
+int vf_decoder_forward(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
+                       float* out);
+int vf_decoder_destroy(vf_decoder* dec);
+
 /* re-ranker = encoder with head == 1 */
 int vf_reranker_create(vf_encoder** out, const vf_encoder_config* cfg, const void* w_fp16, int64_t n_fp16,
                        const float* w_fp32, int64_t n_fp32, int32_t device_id);

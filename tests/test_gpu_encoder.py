@@ -308,3 +308,71 @@ def test_encoder_handle_is_thread_safe(vf):
     enc.close()
     for w, g in zip(want, got):
         assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
+
+
+# ---- decoder-only family: Qwen3-style embedder with last_token_pool, token-logit scorer -----------
+def _hf_qwen3(hidden, layers, heads, kv_heads, head_dim, ffn, vocab=800, seed=3, causal_lm=False):
+    import torch
+    from transformers import Qwen3Config, Qwen3ForCausalLM, Qwen3Model
+    torch.manual_seed(seed)
+    cfg = Qwen3Config(vocab_size=vocab, hidden_size=hidden, intermediate_size=ffn, num_hidden_layers=layers,
+                      num_attention_heads=heads, num_key_value_heads=kv_heads, head_dim=head_dim, max_position_embeddings=512,
+                      rope_theta=1000000.0, tie_word_embeddings=False)
+    m = (Qwen3ForCausalLM if causal_lm else Qwen3Model)(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():                     # weights exactly representable in fp16 on both sides
+            p_.copy_(p_.half().float())
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.1).copy_(p_.half().float())   # norm gains away from 1
+    return m
+
+
+@pytest.mark.parametrize("name,hidden,layers,heads,kv_heads,head_dim,ffn,b,t,left_pad", [
+    ("gqa-dh64", 256, 2, 4, 2, 64, 512, 3, 48, False),
+    ("gqa-dh128-leftpad", 512, 3, 4, 1, 128, 1024, 4, 100, True),
+    ("mha-dh128-long", 256, 2, 2, 2, 128, 768, 2, 300, False),
+])
+def test_decoder_embedder_matches_hf_fp32(vf, name, hidden, layers, heads, kv_heads, head_dim, ffn, b, t, left_pad):
+    """last_token_pool embeddings of a random Qwen3-architecture model against HF fp32 on the CPU (same weights,
+    fp16-rounded): RMSNorm, q/k-norm, RoPE, causal grouped-query attention (streaming kernel), SwiGLU, final norm,
+    both padding sides (the reference's tokenizer is padding_side='left', continuous_retrieval.py:58)."""
+    import torch
+    from veritasfi_amd.retrieval import last_token_pool
+    model = _hf_qwen3(hidden, layers, heads, kv_heads, head_dim, ffn)
+    rng = np.random.default_rng(12)
+    ids = rng.integers(5, 800, size=(b, t)).astype(np.int64)
+    mask = np.ones((b, t), np.int64)
+    for i in range(1, b):                                  # row 0 stays full
+        n_pad = int(rng.integers(1, t // 2))
+        if left_pad:
+            mask[i, :n_pad] = 0
+        else:
+            mask[i, t - n_pad:] = 0
+    with torch.no_grad():
+        hs = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state
+        want = last_token_pool(hs, torch.from_numpy(mask)).numpy()
+    dec = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    got = dec.forward(ids, mask)
+    dec.close()
+    assert got.shape == (b, hidden)
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    assert cos.min() > 0.9995 and rel < 2e-2, (name, cos, rel)
+
+
+def test_decoder_token_logit_scorer_matches_hf_fp32(vf):
+    """The LLM re-ranker's score = the logit of one token ("Yes") at the last position (stress_test.py:197,212-225)."""
+    import torch
+    model = _hf_qwen3(256, 2, 4, 2, 64, 512, causal_lm=True)
+    rng = np.random.default_rng(13)
+    ids = rng.integers(5, 800, size=(5, 64)).astype(np.int64)
+    mask = np.ones((5, 64), np.int64)
+    mask[2, :20] = 0                                       # left padding, as the reference pads re-ranker inputs
+    yes = 123
+    with torch.no_grad():
+        logits = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits
+        want = logits[:, -1, yes].numpy()
+    dec = vf.HipDecoder.from_hf(model, score_token=yes)
+    got = dec.forward(ids, mask)
+    dec.close()
+    assert got.shape == (5,) and np.abs(got - want).max() < 2e-2 * max(1.0, np.abs(want).max()), (got, want)

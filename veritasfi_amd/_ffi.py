@@ -28,6 +28,14 @@ class EncoderConfig(ctypes.Structure):
     ]
 
 
+class DecoderConfig(ctypes.Structure):
+    _fields_ = [
+        ("vocab", c_i32), ("hidden", c_i32), ("layers", c_i32), ("heads", c_i32), ("kv_heads", c_i32), ("head_dim", c_i32),
+        ("ffn", c_i32), ("rope_theta", c_f32), ("rms_eps", c_f32), ("qk_norm", c_i32), ("pooling", c_i32),
+        ("normalize", c_i32), ("head", c_i32),
+    ]
+
+
 class SearchStats(ctypes.Structure):
     _fields_ = [
         ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
@@ -73,6 +81,10 @@ SIGNATURES = {
     "vf_reranker_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(EncoderConfig), vp, c_i64, vp, c_i64, c_i32]),
     "vf_reranker_score": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i32, vp]),
     "vf_reranker_destroy": (ctypes.c_int, [vp]),
+    "vf_decoder_weight_sizes": (ctypes.c_int, [vp, p_i64, p_i64]),
+    "vf_decoder_create": (ctypes.c_int, [ctypes.POINTER(vp), vp, vp, c_i64, vp, c_i64, c_i32]),
+    "vf_decoder_forward": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, c_i32, vp]),
+    "vf_decoder_destroy": (ctypes.c_int, [vp]),
 }
 
 _lib = None

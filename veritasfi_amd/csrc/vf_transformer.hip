@@ -30,8 +30,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace vft {
@@ -892,6 +894,207 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_attention_stream<DH, CAUSAL>: the same fused attention with K / V STREAMED through LDS in 64-key tiles instead of
+// held whole (head dim 128 with T = 512 would need 270 KB; and a 37 KB workgroup lets four share a CU).
+// grid (ceil(T / 128), heads, B), 256 threads = 4 waves, wave w owns queries [qb*128 + 32w, +32).  Grouped-query
+// attention: head hd reads K / V of kv head hd / (heads / kv_heads).  Per tile: the next tile's K rows and V block
+// (transposed in registers) are fetched into registers before the current tile is consumed and written to the other
+// LDS buffer afterwards -- one barrier per tile.  S^T = K Q^T as in k_attention (a lane owns one query's scores),
+// two 32-key score tiles per iteration share one max / exchange / rescale.  CAUSAL: tiles past the workgroup's
+// last query are never visited, tiles past a wave's last query are skipped by that wave (it still stages), the
+// diagonal tile is masked per element.  Key padding mask as in k_attention (additive -30000).
+// qkv rows: [q (heads*DH) | k (kv_heads*DH) | v (kv_heads*DH)], row stride ld.  T % 32 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int SKT = 64;  // keys per tile
+
+template <int DH>
+struct AttnStreamLds {
+    half_t k[2][SKT][DH + 8];
+    half_t vt[2][DH][SKT + 8];
+    float mb[2][SKT];
+};
+
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attention_stream(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
+                                                           int ld, int heads, int kv_heads, float scale,
+                                                           half_t* __restrict__ ctx, int ctx_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AttnStreamLds<DH>& L = *reinterpret_cast<AttnStreamLds<DH>*>(smem);
+    constexpr int KS = DH / 16;   // k-steps of a QK^T tile
+    constexpr int MT = DH / 32;   // 32-row output tiles of O^T
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int hk = hd / (heads / kv_heads);
+    const long long row0 = (long long)b * T;
+    const int q_dim = heads * DH, kv_dim = kv_heads * DH;
+    const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
+    const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
+    const int q0 = qb * 128 + wid * 32;
+    const bool wave_active = q0 < T;
+    // tiles this workgroup visits: all of them, or (causal) up to its last query
+    const int last_q = (qb * 128 + 127 < T - 1) ? qb * 128 + 127 : T - 1;
+    const int ntiles = CAUSAL ? (last_q / SKT + 1) : (T + SKT - 1) / SKT;
+    // ---- staging assignment: K tile = SKT rows x DH halves = SKT*DH/8 chunks of 16 B over 256 threads;
+    //      V tile = (SKT/8) x (DH/8) blocks of 8 keys x 8 dh, one per thread of the first SKT*DH/64 threads
+    constexpr int KCH = SKT * DH / 8 / 256;  // chunks per thread (2 at DH = 64, 4 at DH = 128)
+    constexpr int VBLK = SKT * DH / 64;      // 64 or 128
+    h8 rk[KCH];
+    h8 rv[8];
+    float rmb = 0.f;
+    auto fetch = [&](int tile) {
+        const int kt = tile * SKT;
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            const int c = tid + 256 * j, t = c / (DH / 8), kc = c % (DH / 8);
+            const int key = kt + t < T ? kt + t : T - 1;
+            rk[j] = *(const h8*)(Kg + (long long)key * ld + kc * 8);
+        }
+        if (tid < VBLK) {
+            const int tb = tid / (DH / 8), kc = tid % (DH / 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int key = kt + tb * 8 + i < T ? kt + tb * 8 + i : T - 1;
+                rv[i] = *(const h8*)(Vg + (long long)key * ld + kc * 8);
+            }
+        }
+        if (tid < SKT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            const int c = tid + 256 * j, t = c / (DH / 8), kc = c % (DH / 8);
+            *(h8*)(&L.k[buf][t][kc * 8]) = rk[j];
+        }
+        if (tid < VBLK) {
+            const int tb = tid / (DH / 8), kc = tid % (DH / 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h8 rowv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rowv[i] = rv[i][e];
+                *(h8*)(&L.vt[buf][kc * 8 + e][tb * 8]) = rowv;
+            }
+        }
+        if (tid < SKT) L.mb[buf][tid] = rmb;
+    };
+    // Q fragments (B operand), pre-scaled
+    h8 qf[KS];
+    {
+        const int qrow = q0 + r31 < T ? q0 + r31 : T - 1;
+        const half_t* Qg = qkv + (row0 + qrow) * ld + hd * DH + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            h8 v = *(const h8*)(Qg + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
+            qf[ks] = v;
+        }
+    }
+    f16v o[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float LOG2E = 1.4426950408889634f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1, kt = tile * SKT;
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        const bool visit = wave_active && (!CAUSAL || kt <= q0 + 31);
+        if (visit) {
+            f16v s[2];
+#pragma unroll
+            for (int half_t_ = 0; half_t_ < 2; ++half_t_) {
+                f16v z;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                const half_t* krow = &L.k[buf][half_t_ * 32 + r31][h * 8];
+                s[half_t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow), qf[0], z, 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks)
+                    s[half_t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), qf[ks], s[half_t_], 0, 0, 0);
+            }
+            // masks: key padding (and tile tail) always; causal only on tiles that reach past the wave's first query
+            const bool diag = CAUSAL && (kt + SKT - 1 > q0);
+            float tmax = -1e30f;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int kl = sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    float v = s[sx][reg] + L.mb[buf][kl];
+                    if (diag && kt + kl > q0 + r31) v = -30000.f;
+                    s[sx][reg] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            {
+                float lo, hi;
+                halves(tmax, lo, hi);
+                tmax = fmaxf(lo, hi);
+            }
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const float mneg = -m_new * LOG2E;
+            float psum = 0.f;
+            h8 pf[4];
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[sx][reg], LOG2E, mneg));
+                    psum += p;
+                    pf[sx * 2 + (reg >> 3)][reg & 7] = (half_t)p;
+                }
+            {
+                float lo, hi;
+                halves(psum, lo, hi);
+                psum = lo + hi;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            if (__ballot(alpha != 1.0f) != 0ull) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+            }
+            // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h of 16-key group st <-> key 16 st + (j&3) + 8 (j>>2) + 4 h
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half_t* vrow = &L.vt[buf][mt * 32 + r31][16 * st + 4 * h];
+                    const h4 lo4 = *(const h4*)(vrow);
+                    const h4 hi4 = *(const h4*)(vrow + 8);
+                    h8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
+                }
+        }
+        if (tile + 1 < ntiles) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (wave_active && q0 + r31 < T) {
+        const float inv = 1.0f / l_run;
+        half_t* dst = ctx + (row0 + q0 + r31) * ctx_ld + hd * DH;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
+                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooling / heads: one 256-thread block per sequence -> out[b, :]
 //   pooling 0 CLS (token 0), 1 unmasked mean over T (continuous_retrieval.py:148 quirk), 2 last
 //   token per last_token_pool (step3_mul.py:181-188: position T-1 if EVERY row's last mask bit is 1,
@@ -971,6 +1174,129 @@ __global__ void k_all_last_set(const int* mask, int B, int T, int Tv, int* out) 
     if (threadIdx.x == 0) *out = ok;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoder-only (pre-norm, RMSNorm, RoPE, grouped-query attention, SwiGLU) layer pieces: the family of the models the
+// reference configures by default -- Qwen3-Embedding with last_token_pool (experiments/retriever/step3_mul.py:181-209,
+// :384) and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225).  GEMMs and the streaming
+// attention are the kernels above; these are the small row kernels around them (half a wave per row, 16-byte chunks).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rows(const int* ids, const half_t* table, int M, int H, half_t* out) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    if (row >= M) return;
+    const h8* src = (const h8*)(table + (long long)ids[row] * H);
+    h8* dst = (h8*)(out + (long long)row * H);
+    for (int c = l32; c < (H >> 3); c += 32) dst[c] = src[c];
+}
+
+// y = x * rsqrt(mean(x^2) + eps) * w   (fp32 statistics; H <= 8192: chunks are re-read in the second pass)
+__global__ __launch_bounds__(256) void k_rmsnorm(const half_t* x, const float* w, float eps, int M, int H, half_t* y) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    if (row >= M) return;
+    const h8* src = (const h8*)(x + (long long)row * H);
+    const int nch = H >> 3;
+    float q = 0.f;
+    for (int c = l32; c < nch; c += 32) {
+        const h8 a = src[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += (float)a[e] * (float)a[e];
+    }
+    const float r = rsqrtf(half_wave_sum(q) / H + eps);
+    h8* dst = (h8*)(y + (long long)row * H);
+    for (int c = l32; c < nch; c += 32) {
+        const h8 a = src[c];
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] * r * w[c * 8 + e]);
+        dst[c] = o;
+    }
+}
+
+// cos / sin of pos * theta^(-2i/dh), i < dh/2, pos < T  ->  tab[pos][i] = (cos, sin)
+__global__ void k_rope_table(float theta, int T, int dh, float2* tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, half_dh = dh >> 1;
+    if (i >= T * half_dh) return;
+    const int pos = i / half_dh, j = i - pos * half_dh;
+    const float inv_freq = powf(theta, -2.0f * (float)j / (float)dh);
+    float sn, cs;
+    sincosf((float)pos * inv_freq, &sn, &cs);
+    tab[i] = make_float2(cs, sn);
+}
+
+// In place on the q and k parts of a qkv row: optional per-head RMSNorm over head_dim (weights qw / kw), then rotary
+// embedding in the "rotate half" convention (element i pairs with i + dh/2).  One 32-lane half per (token, head);
+// lane l owns elements l, l + 32, ... of the first half and their partners.  dh in {64, 128}.
+__global__ __launch_bounds__(256) void k_qknorm_rope(half_t* qkv, int M, int T, int ld, int heads, int kv_heads, int dh,
+                                                      const float* qw, const float* kw, float eps, int qk_norm,
+                                                      const float2* tab) {
+    const int unit = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    const int per_tok = heads + kv_heads;
+    if (unit >= M * per_tok) return;
+    const int tok = unit / per_tok, hh = unit - tok * per_tok;
+    const bool is_q = hh < heads;
+    half_t* v = qkv + (long long)tok * ld + (is_q ? hh * dh : heads * dh + (hh - heads) * dh);
+    const float* w = is_q ? qw : kw;
+    const int half_dh = dh >> 1, pos = tok % T;
+    float a[2], b[2];  // up to 2 pairs per lane (dh = 128)
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = l32 + 32 * j;
+        a[j] = i < half_dh ? (float)v[i] : 0.f;
+        b[j] = i < half_dh ? (float)v[i + half_dh] : 0.f;
+        q += a[j] * a[j] + b[j] * b[j];
+    }
+    float r = 1.f;
+    if (qk_norm) r = rsqrtf(half_wave_sum(q) / dh + eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = l32 + 32 * j;
+        if (i < half_dh) {
+            // HF casts the normalised value to the activation dtype before the weight multiply and again before RoPE
+            float x1 = a[j] * r, x2 = b[j] * r;
+            if (qk_norm) { x1 = (float)(half_t)x1 * w[i]; x2 = (float)(half_t)x2 * w[i + half_dh]; }
+            x1 = (float)(half_t)x1; x2 = (float)(half_t)x2;
+            const float2 cs = tab[pos * half_dh + i];
+            v[i] = (half_t)(x1 * cs.x - x2 * cs.y);
+            v[i + half_dh] = (half_t)(x2 * cs.x + x1 * cs.y);
+        }
+    }
+}
+
+// act[m][f] = silu(gu[m][f]) * gu[m][F + f]
+__global__ __launch_bounds__(256) void k_swiglu(const half_t* gu, long long M, int F, half_t* act) {
+    const long long nch = M * (F >> 3);
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long long)gridDim.x * 256) {
+        const long long m = c / (F >> 3);
+        const int fc = (int)(c - m * (F >> 3));
+        const h8 g = *(const h8*)(gu + m * 2 * F + fc * 8);
+        const h8 u = *(const h8*)(gu + m * 2 * F + F + fc * 8);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)g[e];
+            o[e] = (half_t)(x / (1.0f + __expf(-x)) * (float)u[e]);
+        }
+        *(h8*)(act + m * F + fc * 8) = o;
+    }
+}
+
+// one vocabulary token's logit at the pooled (last) position: out[b] = x[last_b] . row     (the "Yes" score)
+__global__ __launch_bounds__(64) void k_token_logit(const half_t* x, const int* mask, int T, int Tv, int H, int all_last_set,
+                                                    const half_t* row, float* out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int tok = Tv - 1;
+    if (!all_last_set) {
+        int c = 0;
+        for (int t = 0; t < Tv; ++t) c += mask[b * T + t] != 0;
+        tok = c > 0 ? c - 1 : 0;
+    }
+    const half_t* xr = x + ((long long)b * T + tok) * H;
+    float s = 0.f;
+    for (int j = lane; j < H; j += 64) s += (float)xr[j] * (float)row[j];
+    s = wave_sum(s);
+    if (lane == 0) out[b] = s;
+}
+
 }  // namespace vft
 
 // ------------------------------------------------------------------------------------------------
@@ -991,6 +1317,10 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
     return er;
 }
 
@@ -1211,8 +1541,14 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F, *g2 = b2 + H,
                     *b2n = g2 + H;
         VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
-        hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
-                           e->ctx);
+        static const bool att_stream = getenv("VF_ATT_STREAM") != nullptr;  // A/B switch: streaming kernel on the BERT path
+        if (att_stream) {
+            hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
+                               sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads, 0.125f, e->ctx, H);
+        } else {
+            hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
+                               e->ctx);
+        }
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
@@ -1337,6 +1673,217 @@ extern "C" int vf_reranker_score(vf_encoder* e, const int32_t* ids, const int32_
 }
 extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e); }
 
+
+// ------------------------------------------------------------------------------------------------
+// Decoder-only model handle (vf_decoder_*): see the kernel block above and include/veritasfi_hip.h.
+// ------------------------------------------------------------------------------------------------
+struct vf_decoder {
+    vf_decoder_config cfg{};
+    int device = 0;
+    half_t* w16 = nullptr;
+    float* w32 = nullptr;
+    size_t o_embed = 0, o_layers = 0, layer16 = 0, o_head_row = 0;  // fp16 offsets (elements)
+    size_t f_layers = 0, layer32 = 0, f_final = 0;                   // fp32 offsets
+    int cap_tokens = 0, cap_b = 0, rope_T = 0;
+    half_t *x = nullptr, *y = nullptr, *n = nullptr, *qkv = nullptr, *ctx = nullptr, *gu = nullptr, *act = nullptr;
+    int *d_ids = nullptr, *d_mask = nullptr, *d_flag = nullptr;
+    float* d_out = nullptr;
+    float2* rope = nullptr;
+    std::mutex mu;
+};
+
+static size_t dec_qd(const vf_decoder_config& c) { return (size_t)c.heads * c.head_dim; }
+static size_t dec_kd(const vf_decoder_config& c) { return (size_t)c.kv_heads * c.head_dim; }
+static size_t dec_layer16(const vf_decoder_config& c) {
+    const size_t H = c.hidden, F = c.ffn, QD = dec_qd(c), KD = dec_kd(c);
+    return (QD + 2 * KD) * H + H * QD + 2 * F * H + H * F;
+}
+static size_t dec_layer32(const vf_decoder_config& c) { return 2 * (size_t)c.hidden + 2 * (size_t)c.head_dim; }
+static size_t dec_n16(const vf_decoder_config& c) {
+    return (size_t)c.vocab * c.hidden + (size_t)c.layers * dec_layer16(c) + (c.head == 2 ? (size_t)c.hidden : 0);
+}
+static size_t dec_n32(const vf_decoder_config& c) { return (size_t)c.layers * dec_layer32(c) + (size_t)c.hidden; }
+
+static int dec_check_cfg(const vf_decoder_config* c) {
+    if (!c) return fail(VF_EINVAL, "vf_decoder: null config");
+    if (c->vocab <= 0 || c->layers <= 0 || c->heads <= 0 || c->kv_heads <= 0 || c->heads % c->kv_heads != 0)
+        return fail(VF_EINVAL, "vf_decoder: bad vocab / layers / heads / kv_heads");
+    if (c->head_dim != 64 && c->head_dim != 128) return fail(VF_EUNSUPPORTED, "vf_decoder: head_dim must be 64 or 128");
+    if (c->hidden <= 0 || c->hidden % 128 != 0 || c->ffn <= 0 || c->ffn % 64 != 0)
+        return fail(VF_EUNSUPPORTED, "vf_decoder: hidden must be a multiple of 128, ffn of 64");
+    if ((dec_qd(*c) + 2 * dec_kd(*c)) % 128 != 0 || dec_qd(*c) % 64 != 0)
+        return fail(VF_EUNSUPPORTED, "vf_decoder: (heads + 2 kv_heads) * head_dim must be a multiple of 128");
+    if (c->pooling < 0 || c->pooling > 2 || (c->head != 0 && c->head != 2)) return fail(VF_EINVAL, "vf_decoder: bad pooling / head");
+    if (!(c->rope_theta > 0.f) || !(c->rms_eps > 0.f)) return fail(VF_EINVAL, "vf_decoder: rope_theta and rms_eps must be positive");
+    return VF_OK;
+}
+
+extern "C" int vf_decoder_weight_sizes(const vf_decoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32) {
+    if (!n_fp16 || !n_fp32) return fail(VF_EINVAL, "vf_decoder_weight_sizes: null argument");
+    const int rc = dec_check_cfg(cfg);
+    if (rc != VF_OK) return rc;
+    *n_fp16 = (int64_t)dec_n16(*cfg);
+    *n_fp32 = (int64_t)dec_n32(*cfg);
+    return VF_OK;
+}
+
+static void dec_free_ws(vf_decoder* d) {
+    void* p[] = {d->x, d->y, d->n, d->qkv, d->ctx, d->gu, d->act, d->d_ids, d->d_mask, d->d_out, d->rope};
+    for (void* q : p) if (q) (void)hipFree(q);
+    d->x = d->y = d->n = d->qkv = d->ctx = d->gu = d->act = nullptr;
+    d->d_ids = d->d_mask = nullptr; d->d_out = nullptr; d->rope = nullptr;
+    d->cap_tokens = d->cap_b = d->rope_T = 0;
+}
+
+extern "C" int vf_decoder_destroy(vf_decoder* d) {
+    if (!d) return VF_OK;
+    (void)hipSetDevice(d->device);
+    (void)hipDeviceSynchronize();
+    dec_free_ws(d);
+    if (d->w16) (void)hipFree(d->w16);
+    if (d->w32) (void)hipFree(d->w32);
+    if (d->d_flag) (void)hipFree(d->d_flag);
+    delete d;
+    return VF_OK;
+}
+
+extern "C" int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg, const void* w16, int64_t n16,
+                                 const float* w32, int64_t n32, int32_t device_id) {
+    if (!out) return fail(VF_EINVAL, "vf_decoder_create: null out");
+    *out = nullptr;
+    int rc = dec_check_cfg(cfg);
+    if (rc != VF_OK) return rc;
+    if (!w16 || !w32 || n16 != (int64_t)dec_n16(*cfg) || n32 != (int64_t)dec_n32(*cfg))
+        return fail(VF_EINVAL, "vf_decoder_create: weight blobs do not match vf_decoder_weight_sizes");
+    int ndev = 0;
+    VFT_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(VF_EINVAL, "vf_decoder_create: bad device_id");
+    VFT_HIP(hipSetDevice(device_id));
+    vf_decoder* d = new (std::nothrow) vf_decoder();
+    if (!d) return fail(VF_ENOMEM, "vf_decoder_create: host allocation failed");
+    d->cfg = *cfg; d->device = device_id;
+    d->o_embed = 0;
+    d->o_layers = (size_t)cfg->vocab * cfg->hidden;
+    d->layer16 = dec_layer16(*cfg);
+    d->o_head_row = d->o_layers + (size_t)cfg->layers * d->layer16;
+    d->f_layers = 0; d->layer32 = dec_layer32(*cfg); d->f_final = (size_t)cfg->layers * d->layer32;
+    hipError_t er = hipMalloc((void**)&d->w16, (size_t)n16 * 2);
+    if (er == hipSuccess) er = hipMalloc((void**)&d->w32, (size_t)n32 * 4);
+    if (er == hipSuccess) er = hipMalloc((void**)&d->d_flag, 4);
+    if (er == hipSuccess) er = hipMemcpy(d->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(d->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = configure_once();
+    if (er != hipSuccess) {
+        const std::string msg = std::string("vf_decoder_create: ") + hipGetErrorString(er);
+        vf_decoder_destroy(d);
+        return fail(VF_EHIP, msg);
+    }
+    *out = d;
+    return VF_OK;
+}
+
+static int dec_ensure_ws(vf_decoder* d, int B, int T) {
+    const int tokens = (B * T + 255) / 256 * 256;
+    if (tokens <= d->cap_tokens && B <= d->cap_b && T <= d->rope_T) return VF_OK;
+    dec_free_ws(d);
+    const vf_decoder_config& c = d->cfg;
+    const size_t H = c.hidden, F = c.ffn, QKV = dec_qd(c) + 2 * dec_kd(c), QD = dec_qd(c), Mp = tokens;
+    VFT_HIP(hipMalloc((void**)&d->x, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&d->y, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&d->n, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&d->qkv, Mp * QKV * 2));
+    VFT_HIP(hipMalloc((void**)&d->ctx, Mp * QD * 2));
+    VFT_HIP(hipMalloc((void**)&d->gu, Mp * 2 * F * 2));
+    VFT_HIP(hipMalloc((void**)&d->act, Mp * F * 2));
+    VFT_HIP(hipMalloc((void**)&d->d_ids, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&d->d_mask, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&d->d_out, (size_t)B * (c.head == 2 ? 1 : H) * 4));
+    VFT_HIP(hipMalloc((void**)&d->rope, (size_t)512 * (c.head_dim / 2) * sizeof(float2)));
+    // padded rows are read by the GEMMs: keep them finite
+    VFT_HIP(hipMemset(d->x, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(d->y, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(d->n, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(d->qkv, 0, Mp * QKV * 2));
+    VFT_HIP(hipMemset(d->ctx, 0, Mp * QD * 2));
+    VFT_HIP(hipMemset(d->gu, 0, Mp * 2 * F * 2));
+    VFT_HIP(hipMemset(d->act, 0, Mp * F * 2));
+    const int cells = 512 * (c.head_dim / 2);
+    hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, nullptr, c.rope_theta, 512, c.head_dim, d->rope);
+    VFT_HIP(hipGetLastError());
+    d->cap_tokens = tokens; d->cap_b = B; d->rope_T = 512;
+    return VF_OK;
+}
+
+// ids / mask [b, t] int32 host (t % 32 == 0, t <= 512; right- or left-padded with mask 0); t_valid = columns the
+// tokenizer produced.  out: [b, hidden] fp32 (head 0) or [b] fp32 (head 2).
+extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
+                                  int32_t t_valid, float* out) {
+    if (!d) return fail(VF_EINVAL, "vf_decoder_forward: null handle");
+    if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_decoder_forward: negative sizes");
+    if (b == 0) return VF_OK;
+    if (!ids || !mask || !out) return fail(VF_EINVAL, "vf_decoder_forward: null buffer");
+    if (t == 0 || t % 32 != 0 || t > 512) return fail(VF_EINVAL, "vf_decoder_forward: t must be a multiple of 32 in [32, 512] (pad with mask 0)");
+    if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_decoder_forward: t_valid must be in [1, t]");
+    std::lock_guard<std::mutex> g(d->mu);
+    VFT_HIP(hipSetDevice(d->device));
+    int rc = dec_ensure_ws(d, b, t);
+    if (rc != VF_OK) return rc;
+    const vf_decoder_config& c = d->cfg;
+    const int H = c.hidden, F = c.ffn, DH = c.head_dim, QD = (int)dec_qd(c), KD = (int)dec_kd(c), QKV = QD + 2 * KD;
+    const int M = b * t, Mp = (M + 255) / 256 * 256;
+    hipStream_t st = nullptr;
+    const size_t ntok = (size_t)b * t;
+    VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
+    VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_rows, dim3((M + 7) / 8), dim3(256), 0, st, d->d_ids, d->w16 + d->o_embed, M, H, d->x);
+    half_t *px = d->x, *py = d->y;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const dim3 agrid((t + 127) / 128, c.heads, b);
+    for (int l = 0; l < c.layers; ++l) {
+        const half_t* W = d->w16 + d->o_layers + (size_t)l * d->layer16;
+        const half_t *Wqkv = W, *Wo = Wqkv + (size_t)QKV * H, *Wgu = Wo + (size_t)H * QD, *Wdn = Wgu + (size_t)2 * F * H;
+        const float* P = d->w32 + d->f_layers + (size_t)l * d->layer32;
+        const float *ln1 = P, *ln2 = P + H, *qn = P + 2 * H, *kn = qn + DH;
+        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, c.rms_eps, M, H, d->n);
+        VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st));
+        const int units = M * (c.heads + c.kv_heads);
+        hipLaunchKernelGGL(k_qknorm_rope, dim3((units + 7) / 8), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
+                           qn, kn, c.rms_eps, c.qk_norm, d->rope);
+        if (DH == 64) {
+            hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
+                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
+        } else {
+            hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
+                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
+        }
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->ctx, Wo, nullptr, px, py, Mp, H, QD, st));
+        std::swap(px, py);
+        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, c.rms_eps, M, H, d->n);
+        VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
+        hipLaunchKernelGGL(k_swiglu, dim3(1024), dim3(256), 0, st, d->gu, (long long)M, F, d->act);
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->act, Wdn, nullptr, px, py, Mp, H, F, st));
+        std::swap(px, py);
+    }
+    hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, d->w32 + d->f_final, c.rms_eps, M, H, d->n);
+    int all_last = 0;
+    if (c.pooling == 2 || c.head == 2) {
+        hipLaunchKernelGGL(k_all_last_set, dim3(1), dim3(64), 0, st, d->d_mask, b, t, t_valid, d->d_flag);
+        VFT_HIP(hipMemcpyAsync(&all_last, d->d_flag, 4, hipMemcpyDeviceToHost, st));
+        VFT_HIP(hipStreamSynchronize(st));
+    }
+    if (c.head == 2) {
+        hipLaunchKernelGGL(k_token_logit, dim3(b), dim3(64), 0, st, d->n, d->d_mask, t, t_valid, H, all_last, d->w16 + d->o_head_row,
+                           d->d_out);
+    } else {
+        const size_t pool_lds = ((size_t)H * 2 + 256) * sizeof(float);
+        hipLaunchKernelGGL(k_pool, dim3(b), dim3(256), pool_lds, st, d->n, d->d_mask, t, t_valid, H, c.pooling, c.normalize, all_last,
+                           0, nullptr, nullptr, nullptr, nullptr, d->d_out);
+    }
+    VFT_HIP(hipGetLastError());
+    VFT_HIP(hipMemcpyAsync(out, d->d_out, (size_t)b * (c.head == 2 ? 1 : H) * 4, hipMemcpyDeviceToHost, st));
+    VFT_HIP(hipStreamSynchronize(st));
+    return VF_OK;
+}
 
 // Test hook (not part of the public header; tools/bench_gemm.py and the GEMM parity test bind it):
 // C[M][N] = epi(A[M][K] . W[N][K]^T + bias [, + R]) on device pointers, fp16 in/out, fp32 accumulation.

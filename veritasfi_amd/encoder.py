@@ -249,3 +249,93 @@ class HipReranker:
         if normalize:
             scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]
         return scores
+
+
+# ---- decoder-only models (Qwen3-Embedding, "Yes"-logit LLM re-rankers) -----------------------------------------------
+def pack_hf_decoder_weights(model, pooling=POOL_LAST_TOKEN, normalize=False, score_token=None, lm_head=None):
+    """HF ``Qwen3Model`` (or ``Qwen3ForCausalLM`` with ``score_token``: head 2, the logit of that vocabulary token at
+    the last position -- stress_test.py:197,212-225) -> (cfg dict, fp16 blob, fp32 blob) in include/veritasfi_hip.h order."""
+    core = getattr(model, "model", model)
+    c = core.config
+    head_dim = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+    rope_theta = getattr(c, "rope_theta", None)
+    if rope_theta is None:
+        rope_theta = (getattr(c, "rope_parameters", None) or getattr(c, "rope_scaling", None) or {}).get("rope_theta", 10000.0)
+    if getattr(c, "hidden_act", "silu") != "silu":
+        raise ValueError("only SiLU-gated MLPs are supported")
+    cfg = dict(vocab=c.vocab_size, hidden=c.hidden_size, layers=c.num_hidden_layers, heads=c.num_attention_heads,
+               kv_heads=c.num_key_value_heads, head_dim=head_dim, ffn=c.intermediate_size, rope_theta=float(rope_theta),
+               rms_eps=float(c.rms_norm_eps), qk_norm=int(hasattr(core.layers[0].self_attn, "q_norm")), pooling=int(pooling),
+               normalize=int(bool(normalize)), head=2 if score_token is not None else 0)
+    p16, p32 = [_np16(core.embed_tokens.weight)], []
+    for lyr in core.layers:
+        a, m = lyr.self_attn, lyr.mlp
+        for lin in (a.q_proj, a.k_proj, a.v_proj, a.o_proj):
+            if getattr(lin, "bias", None) is not None:
+                raise ValueError("attention projections with bias are not supported")
+        p16 += [_np16(a.q_proj.weight), _np16(a.k_proj.weight), _np16(a.v_proj.weight), _np16(a.o_proj.weight),
+                _np16(m.gate_proj.weight), _np16(m.up_proj.weight), _np16(m.down_proj.weight)]
+        ones = np.ones(head_dim, np.float32)
+        p32 += [_np32(lyr.input_layernorm.weight), _np32(lyr.post_attention_layernorm.weight),
+                _np32(a.q_norm.weight) if cfg["qk_norm"] else ones, _np32(a.k_norm.weight) if cfg["qk_norm"] else ones]
+    p32.append(_np32(core.norm.weight))
+    if score_token is not None:
+        head = lm_head if lm_head is not None else getattr(model, "lm_head", None)
+        w = core.embed_tokens.weight if head is None else head.weight     # tied embeddings when there is no lm_head
+        p16.append(_np16(w[int(score_token)]))
+    return cfg, np.concatenate([a.ravel() for a in p16]), np.concatenate([a.ravel() for a in p32])
+
+
+class HipDecoder:
+    """Decoder-only encoder / scorer on the GPU (``vf_decoder_*``).  ``forward(ids, mask)`` -> [b, hidden] pooled
+    embeddings (head 0) or [b] logits of the scored token (head 2)."""
+
+    def __init__(self, cfg: dict, w16: np.ndarray, w32: np.ndarray, device_id: int = 0):
+        self.cfg = dict(cfg)
+        self._cfg = _ffi.DecoderConfig(**cfg)
+        self._h = _ffi.vp()
+        w16 = np.ascontiguousarray(w16, dtype=np.float16)
+        w32 = np.ascontiguousarray(w32, dtype=np.float32)
+        _ffi.check(_ffi.lib().vf_decoder_create(ctypes.byref(self._h), ctypes.byref(self._cfg), w16.ctypes.data, w16.size,
+                                                w32.ctypes.data, w32.size, int(device_id)), "vf_decoder_create")
+        self.hidden = int(cfg["hidden"])
+        self.out_dim = 1 if cfg.get("head", 0) == 2 else self.hidden
+
+    @classmethod
+    def from_hf(cls, model, pooling=POOL_LAST_TOKEN, normalize=False, score_token=None, device_id: int = 0):
+        return cls(*pack_hf_decoder_weights(model, pooling, normalize, score_token), device_id=device_id)
+
+    def forward(self, ids, mask) -> np.ndarray:
+        ids, mask, _, b, t, tp = HipEncoder._pad(ids, mask, None)
+        out = np.empty((b, self.out_dim), dtype=np.float32)
+        _ffi.check(_ffi.lib().vf_decoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, b, tp, t, out.ctypes.data),
+                   "vf_decoder_forward")
+        return out[:, 0] if self.out_dim == 1 else out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _ffi.lib().vf_decoder_destroy(self._h)
+            self._h = _ffi.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipDecoderModel:
+    """HF-signature callable for get_embeddings (``pooled`` fast path only: the pooling the reference applies to a
+    decoder embedder is last_token_pool, computed on the GPU)."""
+
+    def __init__(self, decoder: HipDecoder):
+        self.decoder = decoder
+
+    def pooled(self, pooling: str, input_ids=None, attention_mask=None, **_):
+        if pooling != "last_token":
+            raise ValueError("HipDecoderModel pools with last_token_pool (step3_mul.py:181-188)")
+        ids, mask, _ = _tok_arrays({"input_ids": input_ids, "attention_mask": attention_mask, "token_type_ids": None})
+        return self.decoder.forward(ids, mask)
+
+    def __call__(self, **kw):
+        raise NotImplementedError("use get_embeddings(..., pooling='last_token'): hidden states are not exported")
