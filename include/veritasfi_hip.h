@@ -196,7 +196,7 @@ int vf_encoder_destroy(vf_encoder* enc);
  * continuous_retrieval.py:127-152 -- and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225:
  * score = logits[:, -1, yes_loc]).  Pre-norm layer: x += Wo attn(rope(qnorm(q)), rope(knorm(k)), v) ; x += Wdown
  * (silu(Wgate n) * Wup n), n = RMSNorm(x); causal grouped-query attention; final RMSNorm.  fp16 weights and
- * activations, fp32 accumulation / norms / softmax.  head_dim 64 or 128, t <= 512. */
+ * activations, fp32 accumulation / norms / softmax.  head_dim 64 or 128, t <= 2048. */
 typedef struct vf_decoder vf_decoder;
 typedef struct vf_decoder_config {
     int32_t vocab, hidden, layers, heads, kv_heads, head_dim, ffn;
@@ -213,7 +213,7 @@ typedef struct vf_decoder_config {
 int vf_decoder_weight_sizes(const vf_decoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
 int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg, const void* w_fp16, int64_t n_fp16,
                       const float* w_fp32, int64_t n_fp32, int32_t device_id);
-/* ids / mask [b, t] int32 host, t % 32 == 0, t <= 512 (left- or right-padded, mask 0); positions are column indices
+/* ids / mask [b, t] int32 host, t % 32 == 0, t <= 2048 (left- or right-padded, mask 0); positions are column indices
  * (what HF does when no position_ids are passed); out [b, hidden] (head 0) or [b] (head 2) fp32 host. */
 int vf_decoder_forward(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
                        float* out);

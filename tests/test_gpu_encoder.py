@@ -376,3 +376,68 @@ def test_decoder_token_logit_scorer_matches_hf_fp32(vf):
     got = dec.forward(ids, mask)
     dec.close()
     assert got.shape == (5,) and np.abs(got - want).max() < 2e-2 * max(1.0, np.abs(want).max()), (got, want)
+
+
+class _StubLLMTokenizer:
+    """Word-hash tokenizer with the HF methods the reference's get_inputs calls (left padding, as decoder re-rankers use)."""
+    bos_token_id, pad_token_id, padding_side = 2, 0, "left"
+
+    def __call__(self, text, return_tensors=None, add_special_tokens=False, max_length=None, truncation=False, **_):
+        ids = [5 + (sum(map(ord, w)) * 31 + len(w)) % 780 for w in text.replace("\n", " \n ").split(" ") if w != ""]
+        if text == "\n":
+            ids = [4]
+        if truncation and max_length is not None:
+            ids = ids[:max_length]
+        return {"input_ids": ids}
+
+    def prepare_for_model(self, ids, pair_ids, truncation=None, max_length=None, **_):
+        assert truncation == "only_second"
+        over = len(ids) + len(pair_ids) - max_length
+        if over > 0:
+            pair_ids = pair_ids[:max(len(pair_ids) - over, 0)]
+        return {"input_ids": list(ids) + list(pair_ids)}
+
+    def pad(self, inputs, padding=True, max_length=None, pad_to_multiple_of=None, return_tensors=None):
+        width = max(len(x["input_ids"]) for x in inputs)
+        if pad_to_multiple_of:
+            width = -(-width // pad_to_multiple_of) * pad_to_multiple_of
+        ids = np.full((len(inputs), width), self.pad_token_id, np.int64)
+        mask = np.zeros((len(inputs), width), np.int64)
+        for i, x in enumerate(inputs):
+            n = len(x["input_ids"])
+            ids[i, width - n:], mask[i, width - n:] = x["input_ids"], 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+def test_llm_reranker_compute_score(vf):
+    """HipLLMReranker.compute_score == HF logits[:, -1, yes] on inputs built by the literal restatement of the reference's
+    get_inputs (oracle/ref_rerank_inputs.py); the product's own input builder yields the same token rows, including the
+    query (3/4) and only-second truncations."""
+    import torch
+    from oracle import ref_rerank_inputs as RI
+    tok = _StubLLMTokenizer()
+    rng = np.random.default_rng(14)
+    words = ["revenue", "lotus", "margin", "battery", "delivery", "2023", "guidance", "segment", "cash", "vehicle"]
+    sent = lambda n: " ".join(words[int(i)] for i in rng.integers(0, len(words), n))
+    pairs = [[sent(int(rng.integers(3, 12))), sent(int(rng.integers(5, 60)))] for _ in range(11)]
+    pairs.append([sent(80), sent(90)])                                 # forces both truncations at max_length = 96
+    max_length = 96
+    ref = RI.get_inputs(pairs, tok, max_length=max_length)
+    mine = vf.build_llm_reranker_inputs(pairs, tok, max_length=max_length)
+    for i, row in enumerate(mine):
+        n = int(ref["attention_mask"][i].sum())
+        assert row == ref["input_ids"][i][-n:].tolist()
+    assert max(len(r) for r in mine) > max_length                      # pair clipped to max_length, then sep + prompt appended
+    model = _hf_qwen3(256, 2, 4, 2, 64, 512, causal_lm=True)
+    yes = tok("Yes")["input_ids"][0]
+    with torch.no_grad():
+        want = model(input_ids=torch.from_numpy(ref["input_ids"]), attention_mask=torch.from_numpy(ref["attention_mask"])).logits[:, -1, yes].numpy()
+    rr = vf.HipLLMReranker(tok, vf.HipDecoder.from_hf(model, score_token=yes), max_length=max_length)
+    s8 = rr.compute_score(pairs, batch_size=8)
+    rr.fuse_batches = False
+    s4 = rr.compute_score(pairs, batch_size=4)                         # literal micro-batching: same scores
+    assert len(s8) == len(pairs) and all(isinstance(v, float) for v in s8)
+    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(np.asarray(s8) - want).max() < tol and np.abs(np.asarray(s4) - want).max() < tol
+    assert np.abs(np.asarray(s8) - np.asarray(s4)).max() < 5e-3
+    rr.decoder.close()

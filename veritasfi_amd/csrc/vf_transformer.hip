@@ -1677,6 +1677,8 @@ extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e)
 // ------------------------------------------------------------------------------------------------
 // Decoder-only model handle (vf_decoder_*): see the kernel block above and include/veritasfi_hip.h.
 // ------------------------------------------------------------------------------------------------
+constexpr int kDecMaxT = 2048;  // streaming attention has no residency limit; the RoPE table is sized for this
+
 struct vf_decoder {
     vf_decoder_config cfg{};
     int device = 0;
@@ -1798,7 +1800,7 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     VFT_HIP(hipMalloc((void**)&d->d_ids, Mp * 4));
     VFT_HIP(hipMalloc((void**)&d->d_mask, Mp * 4));
     VFT_HIP(hipMalloc((void**)&d->d_out, (size_t)B * (c.head == 2 ? 1 : H) * 4));
-    VFT_HIP(hipMalloc((void**)&d->rope, (size_t)512 * (c.head_dim / 2) * sizeof(float2)));
+    VFT_HIP(hipMalloc((void**)&d->rope, (size_t)kDecMaxT * (c.head_dim / 2) * sizeof(float2)));
     // padded rows are read by the GEMMs: keep them finite
     VFT_HIP(hipMemset(d->x, 0, Mp * H * 2));
     VFT_HIP(hipMemset(d->y, 0, Mp * H * 2));
@@ -1807,14 +1809,14 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     VFT_HIP(hipMemset(d->ctx, 0, Mp * QD * 2));
     VFT_HIP(hipMemset(d->gu, 0, Mp * 2 * F * 2));
     VFT_HIP(hipMemset(d->act, 0, Mp * F * 2));
-    const int cells = 512 * (c.head_dim / 2);
-    hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, nullptr, c.rope_theta, 512, c.head_dim, d->rope);
+    const int cells = kDecMaxT * (c.head_dim / 2);
+    hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, nullptr, c.rope_theta, kDecMaxT, c.head_dim, d->rope);
     VFT_HIP(hipGetLastError());
-    d->cap_tokens = tokens; d->cap_b = B; d->rope_T = 512;
+    d->cap_tokens = tokens; d->cap_b = B; d->rope_T = kDecMaxT;
     return VF_OK;
 }
 
-// ids / mask [b, t] int32 host (t % 32 == 0, t <= 512; right- or left-padded with mask 0); t_valid = columns the
+// ids / mask [b, t] int32 host (t % 32 == 0, t <= 2048; right- or left-padded with mask 0); t_valid = columns the
 // tokenizer produced.  out: [b, hidden] fp32 (head 0) or [b] fp32 (head 2).
 extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
                                   int32_t t_valid, float* out) {
@@ -1822,7 +1824,7 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
     if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_decoder_forward: negative sizes");
     if (b == 0) return VF_OK;
     if (!ids || !mask || !out) return fail(VF_EINVAL, "vf_decoder_forward: null buffer");
-    if (t == 0 || t % 32 != 0 || t > 512) return fail(VF_EINVAL, "vf_decoder_forward: t must be a multiple of 32 in [32, 512] (pad with mask 0)");
+    if (t == 0 || t % 32 != 0 || t > kDecMaxT) return fail(VF_EINVAL, "vf_decoder_forward: t must be a multiple of 32 in [32, 2048] (pad with mask 0)");
     if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_decoder_forward: t_valid must be in [1, t]");
     std::lock_guard<std::mutex> g(d->mu);
     VFT_HIP(hipSetDevice(d->device));

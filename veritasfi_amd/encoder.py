@@ -306,7 +306,17 @@ class HipDecoder:
         return cls(*pack_hf_decoder_weights(model, pooling, normalize, score_token), device_id=device_id)
 
     def forward(self, ids, mask) -> np.ndarray:
-        ids, mask, _, b, t, tp = HipEncoder._pad(ids, mask, None)
+        ids = np.asarray(ids, dtype=np.int32)
+        mask = np.asarray(mask, dtype=np.int32)
+        b, t = ids.shape
+        tp = max(32, -(-t // 32) * 32)
+        if tp > 2048:
+            raise ValueError("sequences longer than 2048 tokens are not supported")
+        if tp != t:     # alignment columns on the right with mask 0 (t_valid tells the pooling where the tokenizer stopped)
+            pi, pm = np.zeros((b, tp), np.int32), np.zeros((b, tp), np.int32)
+            pi[:, :t], pm[:, :t] = ids, mask
+            ids, mask = pi, pm
+        ids, mask = np.ascontiguousarray(ids), np.ascontiguousarray(mask)
         out = np.empty((b, self.out_dim), dtype=np.float32)
         _ffi.check(_ffi.lib().vf_decoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, b, tp, t, out.ctypes.data),
                    "vf_decoder_forward")
@@ -339,3 +349,64 @@ class HipDecoderModel:
 
     def __call__(self, **kw):
         raise NotImplementedError("use get_embeddings(..., pooling='last_token'): hidden states are not exported")
+
+
+DEFAULT_RERANK_PROMPT = ("Given a query A and a passage B, determine whether the passage contains an answer to the query by "
+                         "providing a prediction of either 'Yes' or 'No'.")
+
+
+def build_llm_reranker_inputs(pairs, tokenizer, prompt=None, max_length=1024):
+    """Token ids of the LLM re-ranker's inputs, as ``get_inputs`` builds them (experiments/profile/stress_test.py:97-134;
+    FlagLLMReranker): ``[bos] + tok("A: " + query)`` (query truncated to 3/4 of max_length) followed by
+    ``tok("\n") + tok("B: " + passage)`` with ONLY THE SECOND part truncated so that the pair fits max_length, then
+    ``tok("\n") + tok(prompt)``.  Returns a list of id lists (unpadded)."""
+    prompt = DEFAULT_RERANK_PROMPT if prompt is None else prompt
+    tok = lambda text, **kw: list(tokenizer(text, return_tensors=None, add_special_tokens=False, **kw)["input_ids"])
+    prompt_ids, sep_ids = tok(prompt), tok("\n")
+    out = []
+    for query, passage in pairs:
+        q_ids = tok(f"A: {query}", max_length=max_length * 3 // 4, truncation=True)
+        p_ids = tok(f"B: {passage}", max_length=max_length, truncation=True)
+        first = [tokenizer.bos_token_id] + q_ids
+        second = sep_ids + p_ids
+        room = max_length - len(first)
+        if len(second) > room:                       # truncation='only_second'
+            second = second[:max(room, 0)]
+        out.append(first + second + sep_ids + prompt_ids)
+    return out
+
+
+class HipLLMReranker:
+    """``compute_score(pairs, batch_size=8)`` of a decoder-only re-ranker (vllmManager.py:450-452 with the configured
+    ``bge-reranker-v2-gemma``-style scorer): the raw logit of the "Yes" token at the last position of each prompt-wrapped
+    pair.  ``decoder`` is a ``HipDecoder`` built with ``score_token=<id of "Yes">``."""
+
+    def __init__(self, tokenizer, decoder: HipDecoder, max_length: int = 1024, prompt: str = None, fuse_batches: bool = True,
+                 max_batch_tokens: int = 32768):
+        if decoder.cfg.get("head", 0) != 2:
+            raise ValueError("HipLLMReranker needs a decoder built with score_token=...")
+        self.tokenizer, self.decoder, self.max_length, self.prompt = tokenizer, decoder, max_length, prompt
+        self.fuse_batches, self.max_batch_tokens = fuse_batches, max_batch_tokens
+        self.pad_id = getattr(tokenizer, "pad_token_id", None) or 0
+
+    def compute_score(self, sentence_pairs, batch_size: int = 8, max_length: int = None, normalize: bool = False):
+        if len(sentence_pairs) and isinstance(sentence_pairs[0], str):
+            sentence_pairs = [sentence_pairs]
+        rows = build_llm_reranker_inputs(sentence_pairs, self.tokenizer, self.prompt, max_length or self.max_length)
+        step = int(batch_size)
+        if self.fuse_batches and rows:
+            longest = max(len(r) for r in rows)
+            step = max(step, (self.max_batch_tokens // max(longest, 1)) // step * step)
+        scores = []
+        for i in range(0, len(rows), step):
+            batch = rows[i:i + step]
+            width = -(-max(len(r) for r in batch) // 8) * 8          # pad_to_multiple_of=8, LEFT padding: the score is read
+            ids = np.full((len(batch), width), self.pad_id, np.int32)  # at the last column (logits[:, -1, yes_loc])
+            mask = np.zeros((len(batch), width), np.int32)
+            for j, r in enumerate(batch):
+                ids[j, width - len(r):] = r
+                mask[j, width - len(r):] = 1
+            scores.extend(float(v) for v in np.atleast_1d(self.decoder.forward(ids, mask)))
+        if normalize:
+            scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]
+        return scores
