@@ -915,7 +915,7 @@ struct AttnStreamLds {
 };
 
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attention_stream(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
+__global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
                                                            int ld, int heads, int kv_heads, float scale,
                                                            half_t* __restrict__ ctx, int ctx_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1223,42 +1223,46 @@ __global__ void k_rope_table(float theta, int T, int dh, float2* tab) {
 }
 
 // In place on the q and k parts of a qkv row: optional per-head RMSNorm over head_dim (weights qw / kw), then rotary
-// embedding in the "rotate half" convention (element i pairs with i + dh/2).  One 32-lane half per (token, head);
-// lane l owns elements l, l + 32, ... of the first half and their partners.  dh in {64, 128}.
+// embedding in the "rotate half" convention (element i pairs with i + dh/2).  dh/8 lanes per (token, head); a lane
+// owns elements [4j, 4j+4) of the first half AND their partners in the second half (two 8-byte accesses, 128 B
+// contiguous per unit and half): no cross-lane traffic for the rotation.  dh in {64, 128}.
 __global__ __launch_bounds__(256) void k_qknorm_rope(half_t* qkv, int M, int T, int ld, int heads, int kv_heads, int dh,
                                                       const float* qw, const float* kw, float eps, int qk_norm,
                                                       const float2* tab) {
-    const int unit = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    const int lpu = dh >> 3;                       // lanes per unit: 16 (dh 128) or 8 (dh 64)
+    const int upw = 256 / lpu;                     // units per workgroup
+    const int unit = blockIdx.x * upw + threadIdx.x / lpu, j = threadIdx.x % lpu;
     const int per_tok = heads + kv_heads;
-    if (unit >= M * per_tok) return;
-    const int tok = unit / per_tok, hh = unit - tok * per_tok;
+    const bool live = unit < M * per_tok;
+    const int u = live ? unit : 0;
+    const int tok = u / per_tok, hh = u - tok * per_tok;
     const bool is_q = hh < heads;
     half_t* v = qkv + (long long)tok * ld + (is_q ? hh * dh : heads * dh + (hh - heads) * dh);
     const float* w = is_q ? qw : kw;
     const int half_dh = dh >> 1, pos = tok % T;
-    float a[2], b[2];  // up to 2 pairs per lane (dh = 128)
-    float q = 0.f;
+    const h4 lo = *(const h4*)(v + 4 * j), hi = *(const h4*)(v + half_dh + 4 * j);
+    float a[4], b[4], q = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = l32 + 32 * j;
-        a[j] = i < half_dh ? (float)v[i] : 0.f;
-        b[j] = i < half_dh ? (float)v[i + half_dh] : 0.f;
-        q += a[j] * a[j] + b[j] * b[j];
-    }
+    for (int e = 0; e < 4; ++e) { a[e] = (float)lo[e]; b[e] = (float)hi[e]; q += a[e] * a[e] + b[e] * b[e]; }
     float r = 1.f;
-    if (qk_norm) r = rsqrtf(half_wave_sum(q) / dh + eps);
+    if (qk_norm) {
+        for (int o = lpu >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        r = rsqrtf(q / dh + eps);
+    }
+    h4 olo, ohi;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = l32 + 32 * j;
-        if (i < half_dh) {
-            // HF casts the normalised value to the activation dtype before the weight multiply and again before RoPE
-            float x1 = a[j] * r, x2 = b[j] * r;
-            if (qk_norm) { x1 = (float)(half_t)x1 * w[i]; x2 = (float)(half_t)x2 * w[i + half_dh]; }
-            x1 = (float)(half_t)x1; x2 = (float)(half_t)x2;
-            const float2 cs = tab[pos * half_dh + i];
-            v[i] = (half_t)(x1 * cs.x - x2 * cs.y);
-            v[i + half_dh] = (half_t)(x2 * cs.x + x1 * cs.y);
-        }
+    for (int e = 0; e < 4; ++e) {
+        // HF casts the normalised value to the activation dtype before the weight multiply and again before RoPE
+        float x1 = a[e] * r, x2 = b[e] * r;
+        if (qk_norm) { x1 = (float)(half_t)x1 * w[4 * j + e]; x2 = (float)(half_t)x2 * w[half_dh + 4 * j + e]; }
+        x1 = (float)(half_t)x1; x2 = (float)(half_t)x2;
+        const float2 cs = tab[pos * half_dh + 4 * j + e];
+        olo[e] = (half_t)(x1 * cs.x - x2 * cs.y);
+        ohi[e] = (half_t)(x2 * cs.x + x1 * cs.y);
+    }
+    if (live) {
+        *(h4*)(v + 4 * j) = olo;
+        *(h4*)(v + half_dh + 4 * j) = ohi;
     }
 }
 
@@ -1849,7 +1853,7 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
         hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, c.rms_eps, M, H, d->n);
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st));
         const int units = M * (c.heads + c.kv_heads);
-        hipLaunchKernelGGL(k_qknorm_rope, dim3((units + 7) / 8), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
+        hipLaunchKernelGGL(k_qknorm_rope, dim3((units + 256 / (DH / 8) - 1) / (256 / (DH / 8))), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
                            qn, kn, c.rms_eps, c.qk_norm, d->rope);
         if (DH == 64) {
             hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
