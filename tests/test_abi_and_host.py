@@ -165,3 +165,25 @@ def test_corpus_file_roundtrip_on_cpu(tmp_path):
     with pytest.raises(ValueError):
         with cf.CorpusWriter(str(tmp_path / "x.vfc"), 8) as w:
             w.append(np.zeros((2, 9), np.float16))
+
+
+def test_embed_loop_to_corpus_file(tmp_path):
+    """The embed loop (load_data.py:120-128: batches of 100 through embed_documents) written to a corpus file."""
+    from veritasfi_amd import corpus_file as cf
+
+    class Emb:
+        calls = []
+        def embed_documents(self, texts):
+            self.calls.append(len(texts))
+            return [[float(len(t)), float(ord(t[0])), 1.0, -2.0] for t in texts]
+
+    texts = [chr(65 + i % 26) * (1 + i % 7) for i in range(250)]
+    p = str(tmp_path / "emb.vfc")
+    seen = []
+    n = cf.embed_to_file(p, texts, Emb(), batch_size=100, ids=list(range(1000, 1250)), on_batch=lambda a, b: seen.append((a, b)))
+    assert n == 250 and Emb.calls == [100, 100, 50] and seen[-1] == (250, 250)
+    rows = np.asarray(cf.rows_memmap(p))
+    assert rows.shape == (250, 4) and rows.dtype == np.float16 and rows[3, 0] == len(texts[3]) and rows[3, 1] == ord(texts[3][0])
+    assert np.array_equal(np.asarray(cf.external_ids(p)), np.arange(1000, 1250))
+    with pytest.raises(ValueError):
+        cf.embed_to_file(str(tmp_path / "e.vfc"), [], Emb())

@@ -101,3 +101,29 @@ def external_ids(path: str):
         return None
     off = _HDR.size + h["n"] * h["d"] * _NP[h["dtype"]].itemsize
     return np.memmap(path, mode="r", dtype=np.int64, offset=off, shape=(h["n"],))
+
+
+def embed_to_file(path: str, texts, embedder, batch_size: int = 100, dtype=np.float16, ids=None, on_batch=None) -> int:
+    """The embed loop of ``import_collection_from_dir`` (``src/load_data.py:120-128,151``: batches of 100 texts through
+    ``embed_documents``) writing a corpus file instead of one Chroma insert per batch.  ``embedder`` is anything with
+    ``embed_documents(list[str]) -> list[list[float]]`` (``HipEmbeddings``, or the reference's ``HuggingFaceEmbeddings``).
+    Returns the number of rows written."""
+    texts = list(texts)
+    if ids is not None and len(ids) != len(texts):
+        raise ValueError("one id per text")
+    w = None
+    try:
+        for i in range(0, len(texts), batch_size):
+            vecs = np.asarray(embedder.embed_documents(texts[i:i + batch_size]), dtype=np.float32)
+            if w is None:
+                w = CorpusWriter(path, vecs.shape[1], dtype)
+            w.append(vecs.astype(dtype), None if ids is None else np.asarray(ids[i:i + batch_size], dtype=np.int64))
+            if on_batch is not None:
+                on_batch(i + vecs.shape[0], len(texts))
+        if w is None:
+            raise ValueError("no texts to embed")
+        n = w.n
+    finally:
+        if w is not None:
+            w.close()
+    return n
