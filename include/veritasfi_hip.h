@@ -196,7 +196,7 @@ int vf_encoder_destroy(vf_encoder* enc);
  * continuous_retrieval.py:127-152 -- and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225:
  * score = logits[:, -1, yes_loc]).  Pre-norm layer: x += Wo attn(rope(qnorm(q)), rope(knorm(k)), v) ; x += Wdown
  * (silu(Wgate n) * Wup n), n = RMSNorm(x); causal grouped-query attention; final RMSNorm.  fp16 weights and
- * activations, fp32 accumulation / norms / softmax.  head_dim 64 or 128, t <= 2048. */
+ * activations, fp32 accumulation / norms / softmax.  head_dim 64, 128 or 256 (gemma), t <= 2048. */
 typedef struct vf_decoder vf_decoder;
 typedef struct vf_decoder_config {
     int32_t vocab, hidden, layers, heads, kv_heads, head_dim, ffn;
@@ -205,6 +205,9 @@ typedef struct vf_decoder_config {
     int32_t pooling;    /* 0 first token, 1 unmasked mean, 2 last token (step3_mul.py:181-188) */
     int32_t normalize;  /* 1: L2-normalise the pooled vector */
     int32_t head;       /* 0: embeddings [b, hidden]; 2: one vocabulary token's logit at the last position -> [b] */
+    int32_t act;            /* gated MLP activation: 0 SiLU (Qwen3), 1 tanh-GELU (gemma's gelu_pytorch_tanh) */
+    int32_t norm_plus_one;  /* 1: RMSNorm gains are stored zero-centred, y = x_hat * (1 + w) (gemma) */
+    float embed_scale;      /* token embeddings are multiplied by this (gemma: sqrt(hidden)); 0 or 1 = none */
 } vf_decoder_config;
 /* Weight blobs (host).  fp16: embed[vocab,H], then per layer Wqkv[(heads+2*kv_heads)*head_dim, H] (q rows, k rows,
  * v rows) Wo[H, heads*head_dim] Wgate_up[2*ffn, H] (gate rows, up rows) Wdown[H, ffn], then (head == 2) the lm_head

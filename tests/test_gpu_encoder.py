@@ -441,3 +441,54 @@ def test_llm_reranker_compute_score(vf):
     assert np.abs(np.asarray(s8) - want).max() < tol and np.abs(np.asarray(s4) - want).max() < tol
     assert np.abs(np.asarray(s8) - np.asarray(s4)).max() < 5e-3
     rr.decoder.close()
+
+
+def _hf_gemma(hidden, layers, heads, kv_heads, head_dim, ffn, vocab=800, seed=5, causal_lm=False):
+    import torch
+    from transformers import GemmaConfig, GemmaForCausalLM, GemmaModel
+    torch.manual_seed(seed)
+    cfg = GemmaConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=ffn, num_hidden_layers=layers,
+                      num_attention_heads=heads, num_key_value_heads=kv_heads, head_dim=head_dim, max_position_embeddings=2048,
+                      rope_theta=10000.0)
+    m = (GemmaForCausalLM if causal_lm else GemmaModel)(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)          # zero-centred gains away from 0
+            p_.copy_(p_.half().float())
+    return m
+
+
+@pytest.mark.parametrize("b,t,left_pad", [(3, 100, True), (2, 300, False)])
+def test_gemma_style_decoder_matches_hf_fp32(vf, b, t, left_pad):
+    """The configured re-ranker's architecture (config/example.yaml:9, bge-reranker-v2-gemma = gemma): head dim 256
+    (Q tile in LDS, 32-key tiles), multi-query attention, (1 + w) RMSNorm, embeddings x sqrt(hidden), tanh-GELU gate;
+    last-token hidden state and the logit of one token at the last position against HF fp32."""
+    import torch
+    from veritasfi_amd.retrieval import last_token_pool
+    model = _hf_gemma(256, 2, 2, 1, 256, 512, causal_lm=True)
+    rng = np.random.default_rng(15)
+    ids = rng.integers(5, 800, size=(b, t)).astype(np.int64)
+    mask = np.ones((b, t), np.int64)
+    for i in range(1, b):
+        n_pad = int(rng.integers(1, t // 2))
+        if left_pad:
+            mask[i, :n_pad] = 0
+        else:
+            mask[i, t - n_pad:] = 0
+    tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    with torch.no_grad():
+        out = model(input_ids=tid, attention_mask=tm, output_hidden_states=True)
+        want_h = last_token_pool(out.hidden_states[-1], tm).numpy()
+        want_logit = last_token_pool(out.logits, tm)[:, 77].numpy()
+    emb = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    assert emb.cfg["head_dim"] == 256 and emb.cfg["act"] == 1 and emb.cfg["norm_plus_one"] == 1 and emb.cfg["qk_norm"] == 0
+    got_h = emb.forward(ids, mask)
+    emb.close()
+    cos = (got_h * want_h).sum(1) / (np.linalg.norm(got_h, axis=1) * np.linalg.norm(want_h, axis=1))
+    rel = np.abs(got_h - want_h).max() / np.abs(want_h).max()
+    assert cos.min() > 0.9995 and rel < 2e-2, (cos, rel)
+    sc = vf.HipDecoder.from_hf(model, score_token=77)
+    got_logit = sc.forward(ids, mask)
+    sc.close()
+    assert np.abs(got_logit - want_logit).max() < 2e-2 * max(1.0, float(np.abs(want_logit).max())), (got_logit, want_logit)

@@ -12,6 +12,7 @@ from veritasfi_amd import _ffi
 SHAPES = {  # hidden, layers, heads, kv_heads, head_dim, ffn, vocab
     "qwen3-0.6b": (1024, 28, 16, 8, 128, 3072, 151669),
     "qwen3-4b": (2560, 36, 32, 8, 128, 9728, 151669),
+    "gemma-2b": (2048, 18, 8, 1, 256, 16384, 256000),
     "tiny": (256, 2, 4, 2, 64, 512, 1000),
 }
 
@@ -24,7 +25,9 @@ def main():
     a = ap.parse_args()
     H, L, NH, KV, DH, F, V = SHAPES[a.shape]
     cfg = dict(vocab=V, hidden=H, layers=L, heads=NH, kv_heads=KV, head_dim=DH, ffn=F, rope_theta=1e6, rms_eps=1e-6,
-               qk_norm=1, pooling=2, normalize=1, head=0)
+               qk_norm=0 if a.shape.startswith("gemma") else 1, pooling=2, normalize=1, head=0,
+               act=1 if a.shape.startswith("gemma") else 0, norm_plus_one=1 if a.shape.startswith("gemma") else 0,
+               embed_scale=float(H ** 0.5) if a.shape.startswith("gemma") else 1.0)
     c = _ffi.DecoderConfig(**cfg); n16 = _ffi.c_i64(0); n32 = _ffi.c_i64(0)
     _ffi.check(_ffi.lib().vf_decoder_weight_sizes(ctypes.byref(c), ctypes.byref(n16), ctypes.byref(n32)), "sizes")
     rng = np.random.default_rng(0)
@@ -32,7 +35,7 @@ def main():
     for i in range(0, n16.value, 1 << 26):          # chunked: the 4B shape is 8 GB of fp16
         m = min(1 << 26, n16.value - i)
         w16[i:i + m] = (rng.standard_normal(m, dtype=np.float32) * 0.02).astype(np.float16)
-    w32 = np.ones(n32.value, np.float32)
+    w32 = np.zeros(n32.value, np.float32) if a.shape.startswith("gemma") else np.ones(n32.value, np.float32)
     dec = vf.HipDecoder(cfg, w16, w32)
     del w16
     ids = rng.integers(5, V, size=(a.batch, a.tokens)).astype(np.int32)

@@ -32,7 +32,7 @@ class DecoderConfig(ctypes.Structure):
     _fields_ = [
         ("vocab", c_i32), ("hidden", c_i32), ("layers", c_i32), ("heads", c_i32), ("kv_heads", c_i32), ("head_dim", c_i32),
         ("ffn", c_i32), ("rope_theta", c_f32), ("rms_eps", c_f32), ("qk_norm", c_i32), ("pooling", c_i32),
-        ("normalize", c_i32), ("head", c_i32),
+        ("normalize", c_i32), ("head", c_i32), ("act", c_i32), ("norm_plus_one", c_i32), ("embed_scale", c_f32),
     ]
 
 

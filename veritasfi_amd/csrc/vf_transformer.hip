@@ -1175,21 +1175,203 @@ __global__ void k_all_last_set(const int* mask, int B, int T, int Tv, int* out) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_attention_stream256<CAUSAL>: head dim 256 (gemma).  A wave's 32 queries x 256 dims no longer fit in registers
+// next to a 128-register output accumulator, so the workgroup's 128-query Q tile lives in LDS (66 KB, pre-scaled)
+// and K / V stream in 32-key tiles (two register-staged buffers): 139 KB, one workgroup per CU.  Same algebra as
+// k_attention_stream: S^T = K Q^T, online softmax per 32-key tile, O^T += V^T P^T.
+// ------------------------------------------------------------------------------------------------
+struct AttnStream256Lds {
+    half_t q[128][256 + 8];
+    half_t k[2][32][256 + 8];
+    half_t vt[2][256][32 + 4];
+    float mb[2][32];
+};
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attention_stream256(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
+                                                              int ld, int heads, int kv_heads, float scale,
+                                                              half_t* __restrict__ ctx, int ctx_ld) {
+    constexpr int DH = 256, KT = 32, KS = DH / 16, MT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AttnStream256Lds& L = *reinterpret_cast<AttnStream256Lds*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int hk = hd / (heads / kv_heads);
+    const long long row0 = (long long)b * T;
+    const int q_dim = heads * DH, kv_dim = kv_heads * DH;
+    const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
+    const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
+    const int q0 = qb * 128 + wid * 32;
+    const bool wave_active = q0 < T;
+    const int last_q = (qb * 128 + 127 < T - 1) ? qb * 128 + 127 : T - 1;
+    const int ntiles = CAUSAL ? (last_q / KT + 1) : (T + KT - 1) / KT;
+    // Q tile -> LDS, scaled: 128 rows x 32 chunks of 16 B, 16 per thread
+    for (int c = tid; c < 128 * (DH / 8); c += 256) {
+        const int r = c / (DH / 8), kc = c % (DH / 8);
+        const int qrow = qb * 128 + r < T ? qb * 128 + r : T - 1;
+        h8 v = *(const h8*)(qkv + (row0 + qrow) * ld + hd * DH + kc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
+        *(h8*)(&L.q[r][kc * 8]) = v;
+    }
+    h8 rk[4];   // K tile: 32 rows x 32 chunks = 1024 chunks, 4 per thread
+    h8 rv[8];   // V tile: (32/8) x (256/8) = 128 blocks of 8 keys x 8 dh, threads 0..127
+    float rmb = 0.f;
+    auto fetch = [&](int tile) {
+        const int kt = tile * KT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = tid + 256 * j, t = c >> 5, kc = c & 31;
+            const int key = kt + t < T ? kt + t : T - 1;
+            rk[j] = *(const h8*)(Kg + (long long)key * ld + kc * 8);
+        }
+        if (tid < 128) {
+            const int tb = tid >> 5, kc = tid & 31;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int key = kt + tb * 8 + i < T ? kt + tb * 8 + i : T - 1;
+                rv[i] = *(const h8*)(Vg + (long long)key * ld + kc * 8);
+            }
+        }
+        if (tid < KT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = tid + 256 * j, t = c >> 5, kc = c & 31;
+            *(h8*)(&L.k[buf][t][kc * 8]) = rk[j];
+        }
+        if (tid < 128) {
+            const int tb = tid >> 5, kc = tid & 31;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {   // rows are 72 B apart: 8-byte stores (a 16-byte store would be misaligned on odd rows)
+                h4 lo4, hi4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { lo4[i] = rv[i][e]; hi4[i] = rv[4 + i][e]; }
+                *(h4*)(&L.vt[buf][kc * 8 + e][tb * 8]) = lo4;
+                *(h4*)(&L.vt[buf][kc * 8 + e][tb * 8 + 4]) = hi4;
+            }
+        }
+        if (tid < KT) L.mb[buf][tid] = rmb;
+    };
+    f16v o[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float LOG2E = 1.4426950408889634f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const half_t* qrow_lds = &L.q[wid * 32 + r31][h * 8];
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1, kt = tile * KT;
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        const bool visit = wave_active && (!CAUSAL || kt <= q0 + 31);
+        if (visit) {
+            f16v s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            const half_t* krow = &L.k[buf][r31][h * 8];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), *(const h8*)(qrow_lds + ks * 16), s, 0, 0, 0);
+            const bool diag = CAUSAL && (kt + KT - 1 > q0);
+            float tmax = -1e30f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kl = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float v = s[reg] + L.mb[buf][kl];
+                if (diag && kt + kl > q0 + r31) v = -30000.f;
+                s[reg] = v;
+                tmax = fmaxf(tmax, v);
+            }
+            {
+                float lo, hi;
+                halves(tmax, lo, hi);
+                tmax = fmaxf(lo, hi);
+            }
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const float mneg = -m_new * LOG2E;
+            float psum = 0.f;
+            h8 pf[2];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[reg], LOG2E, mneg));
+                psum += p;
+                pf[reg >> 3][reg & 7] = (half_t)p;
+            }
+            {
+                float lo, hi;
+                halves(psum, lo, hi);
+                psum = lo + hi;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            if (__ballot(alpha != 1.0f) != 0ull) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half_t* vrow = &L.vt[buf][mt * 32 + r31][16 * st + 4 * h];
+                    const h4 lo4 = *(const h4*)(vrow);
+                    const h4 hi4 = *(const h4*)(vrow + 8);
+                    h8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
+                }
+        }
+        if (tile + 1 < ntiles) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (wave_active && q0 + r31 < T) {
+        const float inv = 1.0f / l_run;
+        half_t* dst = ctx + (row0 + q0 + r31) * ctx_ld + hd * DH;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
+                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Decoder-only (pre-norm, RMSNorm, RoPE, grouped-query attention, SwiGLU) layer pieces: the family of the models the
 // reference configures by default -- Qwen3-Embedding with last_token_pool (experiments/retriever/step3_mul.py:181-209,
 // :384) and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225).  GEMMs and the streaming
 // attention are the kernels above; these are the small row kernels around them (half a wave per row, 16-byte chunks).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_rows(const int* ids, const half_t* table, int M, int H, half_t* out) {
+__global__ __launch_bounds__(256) void k_gather_rows(const int* ids, const half_t* table, int M, int H, float scale, half_t* out) {
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
     const h8* src = (const h8*)(table + (long long)ids[row] * H);
     h8* dst = (h8*)(out + (long long)row * H);
-    for (int c = l32; c < (H >> 3); c += 32) dst[c] = src[c];
+    for (int c = l32; c < (H >> 3); c += 32) {
+        h8 v = src[c];
+        if (scale != 1.0f) {   // gemma: embeddings times sqrt(hidden)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
+        }
+        dst[c] = v;
+    }
 }
 
-// y = x * rsqrt(mean(x^2) + eps) * w   (fp32 statistics; H <= 8192: chunks are re-read in the second pass)
-__global__ __launch_bounds__(256) void k_rmsnorm(const half_t* x, const float* w, float eps, int M, int H, half_t* y) {
+// y = x * rsqrt(mean(x^2) + eps) * (w + woff)   (woff = 1 for gemma's zero-centred gains; fp32 statistics; chunks are
+// re-read in the second pass)
+__global__ __launch_bounds__(256) void k_rmsnorm(const half_t* x, const float* w, float woff, float eps, int M, int H, half_t* y) {
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
     const h8* src = (const h8*)(x + (long long)row * H);
@@ -1206,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const half_t* x, const float* w
         const h8 a = src[c];
         h8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] * r * w[c * 8 + e]);
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] * r * (w[c * 8 + e] + woff));
         dst[c] = o;
     }
 }
@@ -1266,8 +1448,8 @@ __global__ __launch_bounds__(256) void k_qknorm_rope(half_t* qkv, int M, int T, 
     }
 }
 
-// act[m][f] = silu(gu[m][f]) * gu[m][F + f]
-__global__ __launch_bounds__(256) void k_swiglu(const half_t* gu, long long M, int F, half_t* act) {
+// act[m][f] = act_fn(gu[m][f]) * gu[m][F + f];  act_fn = SiLU (0) or tanh-GELU (1: gemma's gelu_pytorch_tanh)
+__global__ __launch_bounds__(256) void k_swiglu(const half_t* gu, long long M, int F, int act_kind, half_t* act) {
     const long long nch = M * (F >> 3);
     for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long long)gridDim.x * 256) {
         const long long m = c / (F >> 3);
@@ -1278,7 +1460,9 @@ __global__ __launch_bounds__(256) void k_swiglu(const half_t* gu, long long M, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = (float)g[e];
-            o[e] = (half_t)(x / (1.0f + __expf(-x)) * (float)u[e]);
+            // tanh-GELU = x * sigmoid(2 * 0.7978845608 * (x + 0.044715 x^3));  SiLU = x * sigmoid(x)
+            const float z = act_kind == 1 ? 1.5957691216f * (x + 0.044715f * x * x * x) : x;
+            o[e] = (half_t)(x / (1.0f + __expf(-z)) * (float)u[e]);
         }
         *(h8*)(act + m * F + fc * 8) = o;
     }
@@ -1325,6 +1509,8 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
     return er;
 }
 
@@ -1714,7 +1900,9 @@ static int dec_check_cfg(const vf_decoder_config* c) {
     if (!c) return fail(VF_EINVAL, "vf_decoder: null config");
     if (c->vocab <= 0 || c->layers <= 0 || c->heads <= 0 || c->kv_heads <= 0 || c->heads % c->kv_heads != 0)
         return fail(VF_EINVAL, "vf_decoder: bad vocab / layers / heads / kv_heads");
-    if (c->head_dim != 64 && c->head_dim != 128) return fail(VF_EUNSUPPORTED, "vf_decoder: head_dim must be 64 or 128");
+    if (c->head_dim != 64 && c->head_dim != 128 && c->head_dim != 256)
+        return fail(VF_EUNSUPPORTED, "vf_decoder: head_dim must be 64, 128 or 256");
+    if (c->act != 0 && c->act != 1) return fail(VF_EINVAL, "vf_decoder: act must be 0 (SiLU) or 1 (tanh-GELU)");
     if (c->hidden <= 0 || c->hidden % 128 != 0 || c->ffn <= 0 || c->ffn % 64 != 0)
         return fail(VF_EUNSUPPORTED, "vf_decoder: hidden must be a multiple of 128, ffn of 64");
     if ((dec_qd(*c) + 2 * dec_kd(*c)) % 128 != 0 || dec_qd(*c) % 64 != 0)
@@ -1841,16 +2029,18 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
     const size_t ntok = (size_t)b * t;
     VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
     VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_rows, dim3((M + 7) / 8), dim3(256), 0, st, d->d_ids, d->w16 + d->o_embed, M, H, d->x);
+    hipLaunchKernelGGL(k_gather_rows, dim3((M + 7) / 8), dim3(256), 0, st, d->d_ids, d->w16 + d->o_embed, M, H,
+                       c.embed_scale > 0.f ? c.embed_scale : 1.0f, d->x);
     half_t *px = d->x, *py = d->y;
     const float scale = 1.0f / sqrtf((float)DH);
+    const float woff = c.norm_plus_one ? 1.0f : 0.0f;
     const dim3 agrid((t + 127) / 128, c.heads, b);
     for (int l = 0; l < c.layers; ++l) {
         const half_t* W = d->w16 + d->o_layers + (size_t)l * d->layer16;
         const half_t *Wqkv = W, *Wo = Wqkv + (size_t)QKV * H, *Wgu = Wo + (size_t)H * QD, *Wdn = Wgu + (size_t)2 * F * H;
         const float* P = d->w32 + d->f_layers + (size_t)l * d->layer32;
         const float *ln1 = P, *ln2 = P + H, *qn = P + 2 * H, *kn = qn + DH;
-        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, c.rms_eps, M, H, d->n);
+        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, woff, c.rms_eps, M, H, d->n);
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st));
         const int units = M * (c.heads + c.kv_heads);
         hipLaunchKernelGGL(k_qknorm_rope, dim3((units + 256 / (DH / 8) - 1) / (256 / (DH / 8))), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
@@ -1858,19 +2048,22 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
         if (DH == 64) {
             hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
                                t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
-        } else {
+        } else if (DH == 128) {
             hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
+                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
+        } else {
+            hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
                                t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
         }
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->ctx, Wo, nullptr, px, py, Mp, H, QD, st));
         std::swap(px, py);
-        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, c.rms_eps, M, H, d->n);
+        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, woff, c.rms_eps, M, H, d->n);
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
-        hipLaunchKernelGGL(k_swiglu, dim3(1024), dim3(256), 0, st, d->gu, (long long)M, F, d->act);
+        hipLaunchKernelGGL(k_swiglu, dim3(1024), dim3(256), 0, st, d->gu, (long long)M, F, c.act, d->act);
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->act, Wdn, nullptr, px, py, Mp, H, F, st));
         std::swap(px, py);
     }
-    hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, d->w32 + d->f_final, c.rms_eps, M, H, d->n);
+    hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, d->w32 + d->f_final, woff, c.rms_eps, M, H, d->n);
     int all_last = 0;
     if (c.pooling == 2 || c.head == 2) {
         hipLaunchKernelGGL(k_all_last_set, dim3(1), dim3(64), 0, st, d->d_mask, b, t, t_valid, d->d_flag);

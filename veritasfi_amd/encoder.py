@@ -253,20 +253,25 @@ class HipReranker:
 
 # ---- decoder-only models (Qwen3-Embedding, "Yes"-logit LLM re-rankers) -----------------------------------------------
 def pack_hf_decoder_weights(model, pooling=POOL_LAST_TOKEN, normalize=False, score_token=None, lm_head=None):
-    """HF ``Qwen3Model`` (or ``Qwen3ForCausalLM`` with ``score_token``: head 2, the logit of that vocabulary token at
-    the last position -- stress_test.py:197,212-225) -> (cfg dict, fp16 blob, fp32 blob) in include/veritasfi_hip.h order."""
+    """HF ``Qwen3Model`` / ``GemmaModel`` (or the ``...ForCausalLM`` with ``score_token``: head 2, the logit of that
+    vocabulary token at the last position -- stress_test.py:197,212-225; ``bge-reranker-v2-gemma`` of config/example.yaml:9
+    is a gemma) -> (cfg dict, fp16 blob, fp32 blob) in include/veritasfi_hip.h order."""
     core = getattr(model, "model", model)
     c = core.config
     head_dim = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
     rope_theta = getattr(c, "rope_theta", None)
     if rope_theta is None:
         rope_theta = (getattr(c, "rope_parameters", None) or getattr(c, "rope_scaling", None) or {}).get("rope_theta", 10000.0)
-    if getattr(c, "hidden_act", "silu") != "silu":
-        raise ValueError("only SiLU-gated MLPs are supported")
+    act_name = getattr(c, "hidden_activation", None) or getattr(c, "hidden_act", "silu")
+    if act_name not in ("silu", "gelu_pytorch_tanh"):
+        raise ValueError(f"unsupported gated-MLP activation {act_name}")
+    gemma = getattr(c, "model_type", "") == "gemma"     # zero-centred norm gains, embeddings times sqrt(hidden)
     cfg = dict(vocab=c.vocab_size, hidden=c.hidden_size, layers=c.num_hidden_layers, heads=c.num_attention_heads,
                kv_heads=c.num_key_value_heads, head_dim=head_dim, ffn=c.intermediate_size, rope_theta=float(rope_theta),
                rms_eps=float(c.rms_norm_eps), qk_norm=int(hasattr(core.layers[0].self_attn, "q_norm")), pooling=int(pooling),
-               normalize=int(bool(normalize)), head=2 if score_token is not None else 0)
+               normalize=int(bool(normalize)), head=2 if score_token is not None else 0,
+               act=int(act_name == "gelu_pytorch_tanh"), norm_plus_one=int(gemma),
+               embed_scale=float(c.hidden_size ** 0.5) if gemma else 1.0)
     p16, p32 = [_np16(core.embed_tokens.weight)], []
     for lyr in core.layers:
         a, m = lyr.self_attn, lyr.mlp
