@@ -1448,12 +1448,12 @@ __global__ __launch_bounds__(256) void k_qknorm_rope(half_t* qkv, int M, int T, 
     }
 }
 
-// act[m][f] = act_fn(gu[m][f]) * gu[m][F + f];  act_fn = SiLU (0) or tanh-GELU (1: gemma's gelu_pytorch_tanh)
+// act[m][f] = act_fn(gu[m][f]) * gu[m][F + f];  act_fn = SiLU (0) or tanh-GELU (1: gemma's gelu_pytorch_tanh).
+// grid (ceil(F / 8 / 256), rows): no index division on the per-chunk path.
 __global__ __launch_bounds__(256) void k_swiglu(const half_t* gu, long long M, int F, int act_kind, half_t* act) {
-    const long long nch = M * (F >> 3);
-    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long long)gridDim.x * 256) {
-        const long long m = c / (F >> 3);
-        const int fc = (int)(c - m * (F >> 3));
+    const int fc = blockIdx.x * 256 + threadIdx.x;
+    if (fc >= (F >> 3)) return;
+    for (long long m = blockIdx.y; m < M; m += gridDim.y) {
         const h8 g = *(const h8*)(gu + m * 2 * F + fc * 8);
         const h8 u = *(const h8*)(gu + m * 2 * F + F + fc * 8);
         h8 o;
@@ -2059,7 +2059,8 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
         std::swap(px, py);
         hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, woff, c.rms_eps, M, H, d->n);
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
-        hipLaunchKernelGGL(k_swiglu, dim3(1024), dim3(256), 0, st, d->gu, (long long)M, F, c.act, d->act);
+        hipLaunchKernelGGL(k_swiglu, dim3(((F >> 3) + 255) / 256, M < 32768 ? M : 32768), dim3(256), 0, st, d->gu, (long long)M, F, c.act,
+                           d->act);
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->act, Wdn, nullptr, px, py, Mp, H, F, st));
         std::swap(px, py);
     }
