@@ -140,6 +140,29 @@ def rerank_p50(args):
                  "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of logits"}
 
 
+def embed_rate(args):
+    """Chunk-embedding throughput of the embed loop (src/load_data.py:120-128,151: batches of 100 chunks) on a
+    BERT-base-shaped embedder (bge-base: CLS + L2), 512-token chunks, seeded random weights: BASELINE configs[3]."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_rerank import random_encoder, flops
+    enc, cfg = random_encoder("bert-base", head=0)
+    rng = np.random.default_rng(98)
+    ids = rng.integers(5, cfg["vocab"], size=(100, 512)).astype(np.int32)
+    mask = np.ones_like(ids)
+    enc.forward(ids, mask)
+    ts = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        enc.forward(ids, mask)
+        ts.append(time.perf_counter() - t0)
+    enc.close()
+    p50 = float(np.median(ts))
+    return {"model_shape": "bert-base", "batch": 100, "tokens": 512, "ms_per_batch": round(p50 * 1e3, 3),
+            "chunks_per_s": round(100 / p50, 1), "tflops": round(flops(cfg, 100, 512) / p50 / 1e12, 1),
+            "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of embeddings"}
+
+
 def main():
     args = parse()
     import torch
@@ -239,9 +262,10 @@ def main():
         if rank == 0:
             print(f"verify ok: bucket of {E} batches through all-gather + merge", file=sys.stderr)
     index.set_option("profile", 0)
-    rr_ms, rr_info = (None, None)
+    rr_ms, rr_info, emb_info = (None, None, None)
     if rank == 0 and not args.no_rerank:
         rr_ms, rr_info = rerank_p50(args)
+        emb_info = embed_rate(args)
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -277,6 +301,7 @@ def main():
                              "exact_reruns_last_batch": stats["exact_reruns"], "path": stats["path"]},
             "rerank_p50_ms": None if rr_ms is None else round(rr_ms, 3),
             "rerank": rr_info,
+            "embed": emb_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
