@@ -12,7 +12,7 @@ def main():
     ap.add_argument("--shapes", default="51200x2304x768,51200x768x768,51200x3072x768,51200x768x3072")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", type=int, default=1)
-    ap.add_argument("--kind", type=int, default=0, help="0 auto, 1 DMA 128x256, 2 256x256, 3 128x128")
+    ap.add_argument("--kind", type=int, default=0, help="0 auto, 5 DMA 128x256 (16x16x32 MFMA), 1 DMA 128x256 (32x32x16), 2 256x256, 3 128x128")
     a = ap.parse_args()
     L = _ffi.lib()
     L.vf_debug_gemm.restype = ctypes.c_int
