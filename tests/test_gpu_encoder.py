@@ -331,6 +331,7 @@ def _hf_qwen3(hidden, layers, heads, kv_heads, head_dim, ffn, vocab=800, seed=3,
     ("gqa-dh64", 256, 2, 4, 2, 64, 512, 3, 48, False),
     ("gqa-dh128-leftpad", 512, 3, 4, 1, 128, 1024, 4, 100, True),
     ("mha-dh128-long", 256, 2, 2, 2, 128, 768, 2, 300, False),
+    ("gqa-dh128-2000", 256, 2, 4, 2, 128, 512, 1, 2000, False),   # beyond 512 tokens: RoPE table, 32 key tiles
 ])
 def test_decoder_embedder_matches_hf_fp32(vf, name, hidden, layers, heads, kv_heads, head_dim, ffn, b, t, left_pad):
     """last_token_pool embeddings of a random Qwen3-architecture model against HF fp32 on the CPU (same weights,
@@ -459,7 +460,7 @@ def _hf_gemma(hidden, layers, heads, kv_heads, head_dim, ffn, vocab=800, seed=5,
     return m
 
 
-@pytest.mark.parametrize("b,t,left_pad", [(3, 100, True), (2, 300, False)])
+@pytest.mark.parametrize("b,t,left_pad", [(3, 100, True), (2, 300, False), (2, 1100, True)])
 def test_gemma_style_decoder_matches_hf_fp32(vf, b, t, left_pad):
     """The configured re-ranker's architecture (config/example.yaml:9, bge-reranker-v2-gemma = gemma): head dim 256
     (Q tile in LDS, 32-key tiles), multi-query attention, (1 + w) RMSNorm, embeddings x sqrt(hidden), tanh-GELU gate;
