@@ -57,6 +57,7 @@ def _batch(rng, b, t, vocab, pad_id=0, ragged=True):
     ("small-odd-t", 256, 3, 4, 1024, 5, 100),
     ("bge-base-shape", 768, 12, 12, 3072, 4, 128),
     ("single-query", 768, 3, 12, 3072, 1, 40),     # <= 64 tokens with ffn >= 2048: the split-K FFN-down kernel
+    ("large-batch", 768, 2, 12, 3072, 32, 512),    # 16384 rows: every GEMM takes the 128x256 DMA / 16x16x32 kernel
 ])
 def test_embedding_encoder_matches_torch_fp32(vf, name, hidden, layers, heads, ffn, b, t):
     import torch
