@@ -494,3 +494,23 @@ def test_gemma_style_decoder_matches_hf_fp32(vf, b, t, left_pad):
     got_logit = sc.forward(ids, mask)
     sc.close()
     assert np.abs(got_logit - want_logit).max() < 2e-2 * max(1.0, float(np.abs(want_logit).max())), (got_logit, want_logit)
+
+
+def test_decoder_embedder_drop_in(vf):
+    """HipDecoderEmbeddings (decoder model as `embedding_function`): batch-independent, unit-norm, and usable by the
+    FaissRetriever exactly like the encoder embedder."""
+    model = _hf_qwen3(256, 2, 4, 2, 64, 512)
+    tok = _StubLLMTokenizer()
+    emb = vf.HipDecoderEmbeddings(tok, vf.HipDecoder.from_hf(model, pooling=2, normalize=True), max_length=64, batch_size=7,
+                                  query_instruction="query: ")
+    docs = [f"filing {i} reports revenue item {i % 13} for segment {i % 5} in year {2015 + i % 9}" for i in range(60)]
+    vecs = np.asarray(emb.embed_documents(docs), np.float32)
+    assert vecs.shape == (60, 256) and np.abs(np.linalg.norm(vecs, axis=1) - 1.0).max() < 1e-3
+    one = np.asarray(vf.HipDecoderEmbeddings(tok, emb.decoder, max_length=64, batch_size=1).embed_documents(docs[:5]), np.float32)
+    assert np.abs(one - vecs[:5]).max() < 3e-3                     # batching / padding width do not change an embedding
+    q = np.asarray(emb.embed_query(docs[17]), np.float32)
+    assert q.shape == (256,) and not np.allclose(q, vecs[17], atol=1e-3)      # the instruction prefix is applied to queries
+    fr = vf.FaissRetriever(vecs.tolist(), emb)
+    I, D = fr.invoke([docs[3], docs[40]], 5)
+    assert I.shape == (2, 5) and np.all(np.diff(D, axis=1) <= 0)
+    emb.decoder.close()

@@ -22,7 +22,7 @@ from .faiss_retriever import FaissRetriever  # noqa: F401
 from .retrieval import get_embeddings, last_token_pool, select_top_chunks, select_top_chunks_batch  # noqa: F401
 from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_rank, time_scores  # noqa: F401
 from .sharded import ShardedRetriever, shard_bounds  # noqa: F401
-from .encoder import (HipDecoder, HipDecoderModel, HipEmbeddings, HipEncoder, HipLLMReranker, HipModel,  # noqa: F401
+from .encoder import (HipDecoder, HipDecoderEmbeddings, HipDecoderModel, HipEmbeddings, HipEncoder, HipLLMReranker, HipModel,  # noqa: F401
                       HipReranker, build_llm_reranker_inputs, pack_hf_decoder_weights, pack_hf_weights)
 from .rank import rank_chunk  # noqa: F401
 from .ensemble import EnsembleRetriever  # noqa: F401

@@ -356,6 +356,46 @@ class HipDecoderModel:
         raise NotImplementedError("use get_embeddings(..., pooling='last_token'): hidden states are not exported")
 
 
+class HipDecoderEmbeddings:
+    """``HuggingFaceEmbeddings``-shaped embedder over a decoder-only model (``embed_query`` / ``embed_documents`` /
+    ``embed_queries``): last_token_pool + L2 normalisation, left padding (the reference's tokenizer setting for its
+    decoder embedder, continuous_retrieval.py:55-60).  ``query_instruction`` is prepended to queries only (instruction-tuned
+    embedders such as Qwen3-Embedding expect one); documents are embedded as given."""
+
+    def __init__(self, tokenizer, decoder: HipDecoder, max_length: int = 512, batch_size: int = 16, query_instruction: str = ""):
+        if decoder.cfg.get("head", 0) != 0 or decoder.cfg.get("pooling", 2) != 2:
+            raise ValueError("HipDecoderEmbeddings needs a decoder built with pooling=2 (last token) and no scoring head")
+        self.tokenizer, self.decoder = tokenizer, decoder
+        self.max_length, self.batch_size, self.query_instruction = max_length, batch_size, query_instruction
+        self.pad_id = getattr(tokenizer, "pad_token_id", None) or 0
+
+    def _embed(self, texts):
+        out = []
+        for i in range(0, len(texts), self.batch_size):
+            rows = [list(self.tokenizer(t, return_tensors=None, truncation=True, max_length=self.max_length)["input_ids"])
+                    for t in texts[i:i + self.batch_size]]
+            width = max(len(r) for r in rows)
+            ids = np.full((len(rows), width), self.pad_id, np.int32)
+            mask = np.zeros((len(rows), width), np.int32)
+            for j, r in enumerate(rows):                      # left padding: every row ends in a real token
+                ids[j, width - len(r):] = r
+                mask[j, width - len(r):] = 1
+            e = self.decoder.forward(ids, mask)
+            if not self.decoder.cfg.get("normalize", 0):
+                e = e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-12)
+            out.append(e)
+        return np.vstack(out) if out else np.zeros((0, self.decoder.hidden), np.float32)
+
+    def embed_documents(self, texts):
+        return self._embed(list(texts)).tolist()
+
+    def embed_query(self, text):
+        return self._embed([self.query_instruction + text])[0].tolist()
+
+    def embed_queries(self, texts):
+        return self._embed([self.query_instruction + t for t in texts]).tolist()
+
+
 DEFAULT_RERANK_PROMPT = ("Given a query A and a passage B, determine whether the passage contains an answer to the query by "
                          "providing a prediction of either 'Yes' or 'No'.")
 
