@@ -187,3 +187,22 @@ def test_e4m3_decode_matches_torch():
     assert np.array_equal(ref[fin].view(np.uint32), got[fin].view(np.uint32))
     assert np.array_equal(got[fin].astype(np.float16).astype(np.float32), got[fin])
     assert np.nanmax(np.abs(got)) == 448.0 and got[1] == 2.0 ** -9
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """oracle/vf_oracle.c built with -fsanitize=address,undefined and driven over ragged / empty / k > n / fp16 inputs
+    (oracle/sanitize_check.c): the sanitizers abort on any finding."""
+    import os, shutil, subprocess
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "sanitize_check")
+    cmd = ["gcc", "-O1", "-g", "-mavx2", "-mfma", "-mf16c", "-ffp-contract=off", "-fopenmp", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=all", "-o", exe, os.path.join(src, "sanitize_check.c"), os.path.join(src, "vf_oracle.c"), "-lm"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in (b.stderr or "").lower():
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, env={**os.environ, "OMP_NUM_THREADS": "4",
+                                                                    "ASAN_OPTIONS": "detect_leaks=1"}, timeout=300)
+    assert r.returncode == 0 and "sanitize_check ok" in r.stdout, (r.stdout, r.stderr[-2000:])
