@@ -262,10 +262,17 @@ def main():
         if rank == 0:
             print(f"verify ok: bucket of {E} batches through all-gather + merge", file=sys.stderr)
     index.set_option("profile", 0)
+    # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
     rr_ms, rr_info, emb_info = (None, None, None)
     if rank == 0 and not args.no_rerank:
-        rr_ms, rr_info = rerank_p50(args)
-        emb_info = embed_rate(args)
+        try:
+            rr_ms, rr_info = rerank_p50(args)
+        except Exception as e:  # noqa: BLE001
+            rr_info = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            emb_info = embed_rate(args)
+        except Exception as e:  # noqa: BLE001
+            emb_info = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -304,7 +311,11 @@ def main():
             "embed": emb_info,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     index.close()
     if dist.is_initialized():
