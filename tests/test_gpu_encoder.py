@@ -253,7 +253,7 @@ def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):
     assert got == want and 0 < len(got) <= 10 and len(set(got)) == len(got)
 
 
-@pytest.mark.parametrize("kind", [1, 2, 3, 5])
+@pytest.mark.parametrize("kind", [1, 2, 3, 5, 6])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_kernels_match_torch(vf, kind, epi):
     """Every GEMM kernel (1 = LDS-DMA 128x256 with two workgroups per CU, 2 = 256x256, 3 = register-staged 128x128) x every

@@ -691,16 +691,19 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma_tn(const half_t* __res
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int swz16(int row) { return (0x6C >> (2 * ((row >> 2) & 3))) & 3; }   // 0b01'10'11'00 -> 0, 3, 2, 1
 
-template <int EPI>
+template <int EPI, int BN>
 __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                           const float* __restrict__ bias, const half_t* __restrict__ R,
                                                           half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 slots x [A 128x32 | W 256x32] fp16
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 slots x [A 128x32 | W BNx32] fp16
+    constexpr int NTW = BN / 32;            // 16-column MFMA tiles per wave (wave tile 64 x BN/2): 8 or 4
+    constexpr int WJ = BN / 64;             // W-tile DMA instructions per wave per stage: 4 or 2
+    constexpr int SLOT = (DBM + BN) * 64;   // bytes per LDS slot: 24 KB or 16 KB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 1, wc = wid & 1;   // MFMA 16x16x32: row / col lane & 15, k-block lane >> 4
     int mt_idx, nt_idx;
     {   // XCD-contiguous, n-major groups of 8 m-tiles (64 workgroups resident per XCD)
-        const int Mt = M / DBM, Nt = N / DBN, nwg = Mt * Nt;
+        const int Mt = M / DBM, Nt = N / BN, nwg = Mt * Nt;
         const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
         const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
         constexpr int GM = 8;
@@ -709,11 +712,11 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
         nt_idx = r / gm;
         mt_idx = g * GM + (r - nt_idx * gm);
     }
-    const long long m0 = (long long)mt_idx * DBM, n0 = (long long)nt_idx * DBN;
+    const long long m0 = (long long)mt_idx * DBM, n0 = (long long)nt_idx * BN;
     // one DMA instruction fills 16 rows x 64 B; the A tile is 8 of them (wave w: rows [32w, 32w+32)), the W tile 16
     // (wave w: rows [64w, 64w+64)).  lane l -> row l >> 2 of the 16, physical chunk l & 3.
     const half_t* a_src[2];
-    const half_t* w_src[4];
+    const half_t* w_src[WJ];
     const int drow = lane >> 2, dpc = lane & 3;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -721,64 +724,65 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
         a_src[j] = A + (m0 + row) * K + (dpc ^ swz16(row)) * 8;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wid * 64 + j * 16 + drow;
+    for (int j = 0; j < WJ; ++j) {
+        const int row = wid * (BN / 4) + j * 16 + drow;
         w_src[j] = W + (n0 + row) * K + (dpc ^ swz16(row)) * 8;
     }
     auto stage = [&](int slot, int kt) {
-        char* abase = smem + slot * DSLOT + (wid * 32) * 64;
-        char* wbase = smem + slot * DSLOT + 8192 + (wid * 64) * 64;
+        char* abase = smem + slot * SLOT + (wid * 32) * 64;
+        char* wbase = smem + slot * SLOT + 8192 + (wid * (BN / 4)) * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * DBK),
                                              (__attribute__((address_space(3))) void*)(abase + j * 1024), 16, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * DBK),
                                              (__attribute__((address_space(3))) void*)(wbase + j * 1024), 16, 0, 0);
     };
-    f4v acc[4][8];   // wave tile 64 x 128 = 4 x 8 MFMA tiles of 16 x 16
+    f4v acc[4][NTW];   // wave tile 64 x BN/2 = 4 x NTW MFMA tiles of 16 x 16
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < NTW; ++b)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
     const int pc = (kb ^ swz16(r15)) * 16;  // tile offsets are multiples of 16 rows: they do not change (row >> 2) & 3
     const char* a_row = smem + (wr * 64 + r15) * 64 + pc;
-    const char* w_row = smem + 8192 + (wc * 128 + r15) * 64 + pc;
+    const char* w_row = smem + 8192 + (wc * (BN / 2) + r15) * 64 + pc;
     const int nk = K / DBK;
     stage(0, 0);
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const int nslot = slot == 2 ? 0 : slot + 1;
         stage(nslot, kt + 1 < nk ? kt + 1 : nk - 1);            // past the end: re-reads the last tile (unused)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // stage kt landed (this wave's DMA)
+        if (BN == 256) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage kt landed (this wave's DMA: 2 + WJ stay in flight)
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // ... and every wave's
-        const char* ab = a_row + slot * DSLOT;
-        const char* wb = w_row + slot * DSLOT;
-        {   // BK = 32 is ONE k-step of the 16x16x32 MFMA: 4 + 8 fragment reads, 32 MFMAs
-            h8 af[4], wf[8];
+        const char* ab = a_row + slot * SLOT;
+        const char* wb = w_row + slot * SLOT;
+        {   // BK = 32 is ONE k-step of the 16x16x32 MFMA: 4 + NTW fragment reads, 4 * NTW MFMAs
+            h8 af[4], wf[NTW];
 #pragma unroll
             for (int t = 0; t < 4; ++t) af[t] = *(const h8*)(ab + t * 16 * 64);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) wf[t] = *(const h8*)(wb + t * 16 * 64);
+            for (int t = 0; t < NTW; ++t) wf[t] = *(const h8*)(wb + t * 16 * 64);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
         }
         slot = nslot;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the trailing dummy stage before LDS is reused
     __syncthreads();
-    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [128][256] fp16 image (64 KB of the 72), then 16-byte
+    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [128][BN] fp16 image (inside the three slots), then 16-byte
     // row chunks out (residual added in fp32 on the vector side)
     half_t* Es = (half_t*)smem;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-        const int col = wc * 128 + nt * 16 + r15;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int col = wc * (BN / 2) + nt * 16 + r15;
         const float bv = bias ? bias[n0 + col] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -787,14 +791,14 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
                 const int row = wr * 64 + mt * 16 + 4 * kb + reg;
                 float v = acc[mt][nt][reg] + bv;
                 if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                Es[row * DBN + col] = (half_t)v;
+                Es[row * BN + col] = (half_t)v;
             }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = tid + DTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
-        h8 o = *(const h8*)(Es + row * DBN + cc * 8);
+    for (int i = 0; i < BN / 16; ++i) {
+        const int c = tid + DTHREADS * i, row = c / (BN / 8), cc = c % (BN / 8);  // BN / 8 chunks of 8 halves per row
+        h8 o = *(const h8*)(Es + row * BN + cc * 8);
         const long long off = (m0 + row) * N + n0 + cc * 8;
         if (EPI == EPI_BIAS_RESIDUAL) {
             const h8 r = *(const h8*)(R + off);
@@ -1624,11 +1628,14 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
@@ -1807,7 +1814,7 @@ template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st, int force_kind = 0) {
     // Tile choice (VF_GEMM_KIND overrides for A/B runs: 5 = DMA 128x256 with 16x16x32 MFMAs (the default large-problem
-    // kernel), 1 = the same with 32x32x16 MFMAs, 2 = 256x256, 3 = 128x128):
+    // kernel), 6 = its 128-wide instance, 1 = 128x256 with 32x32x16 MFMAs, 2 = 256x256, 3 = 128x128):
     //  * 128 x 256 DMA tiles, two workgroups per CU, when they give at least VF_GEMM_DMA_MIN_WGS workgroups
     //    (16x16x32 MFMAs: 4 % faster in isolation, 6 % on the 100-pair forward than the 32x32x16 form);
     //  * 128 x 128 register-staged tiles for everything smaller (micro-batches of 8 pairs, single queries).
@@ -1819,7 +1826,17 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     const bool dma_ok = M % DBM == 0 && N % DBN == 0 && K % DBK == 0;
     const bool big_ok = M % LBM == 0 && N % LBN == 0;
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
-        hipLaunchKernelGGL(k_gemm_dma16_tn<EPI>, dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
+        hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
+        return hipGetLastError();
+    }
+    // The same kernel with 128-wide N tiles (48 KB LDS, three workgroups per CU).  Measured on the mid-size problems it
+    // was meant for (decoder residual products, 8..32-pair micro-batches): equal or up to 6 % SLOWER than the
+    // register-staged 128 x 128 kernel below, so it is off unless asked for (kind 6 / VF_GEMM_DMA128_MIN_WGS).
+    static const long long dma128_min = getenv("VF_GEMM_DMA128_MIN_WGS") ? atoll(getenv("VF_GEMM_DMA128_MIN_WGS")) : (1ll << 60);
+    if (M % DBM == 0 && N % 128 == 0 && K % DBK == 0 &&
+        (kind == 6 || (kind == 0 && (long long)(M / DBM) * (N / 128) >= dma128_min))) {
+        hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 128>), dim3((N / 128) * (M / DBM)), dim3(DTHREADS), 3 * (DBM + 128) * 64, st, A, W, bias,
+                           R, C, M, N, K);
         return hipGetLastError();
     }
     if (dma_ok && kind == 1) {
@@ -2224,6 +2241,7 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     if (er != hipSuccess) return -1;
     if (M % 128 || N % 128 || K % 64) return -2;
     if ((kind == 1 || kind == 5) && (M % DBM || N % DBN)) return -2;
+    if (kind == 6 && (M % DBM || N % 128)) return -2;
     if (kind == 2 && (M % LBM || N % LBN)) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
