@@ -201,7 +201,7 @@ def main():
         e = i % E
         return ids[e * args.batch:(e + 1) * args.batch], sc[e * args.batch:(e + 1) * args.batch]
     if exchange:
-        g_blob = torch.empty(world * E * args.batch * args.k * 12, dtype=torch.uint8, device=device)
+        g_blob = torch.empty(world * vf.packed_part_bytes(E * args.batch, args.k), dtype=torch.uint8, device=device)
         m_ids = torch.empty((E * args.batch, args.k), dtype=torch.int64, device=device)
         m_sc = torch.empty((E * args.batch, args.k), dtype=torch.float32, device=device)
     merged = [None]

@@ -99,13 +99,26 @@ from oracle import canonical as C   # tests may use the oracle as the checker / 
 
 class OracleShard:   # stands in for DenseIndex on a box without a GPU
     def __init__(self, rows, off): self.rows, self.off = rows, off
-    def search_device(self, q, k):
+    def search_device(self, q, k, out_ids=None, out_scores=None):
         i, s = C.search(self.rows, q.numpy(), k, id_offset=self.off)
-        return torch.from_numpy(i), torch.from_numpy(s)
+        if out_ids is None:
+            return torch.from_numpy(i), torch.from_numpy(s)
+        out_ids.copy_(torch.from_numpy(i)); out_scores.copy_(torch.from_numpy(s))
+        return out_ids, out_scores
 
 def merge(ids, sc, k):
     i, s = C.merge_topk(ids.numpy(), sc.numpy(), k)
     return torch.from_numpy(i), torch.from_numpy(s)
+
+def packed_merge(blob, nparts, nq, k):
+    # NumPy stand-in for vf_merge_topk_packed_device: parts at the library's 16-byte padded stride
+    from veritasfi_amd.index import packed_part_bytes
+    raw = blob.numpy()
+    stride = packed_part_bytes(nq, k)
+    assert raw.size == nparts * stride and stride % 16 == 0
+    ids = np.stack([raw[g * stride: g * stride + nq * k * 8].view(np.int64).reshape(nq, k) for g in range(nparts)])
+    sc = np.stack([raw[g * stride + nq * k * 8: g * stride + nq * k * 12].view(np.float32).reshape(nq, k) for g in range(nparts)])
+    return merge(torch.from_numpy(ids), torch.from_numpy(sc), k)
 
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["VF_PORT"],
                         rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
@@ -114,11 +127,15 @@ rng = np.random.default_rng(5)
 corpus = rng.standard_normal((5001, 64)).astype(np.float32).astype(np.float16)
 q = torch.from_numpy(np.random.default_rng(6).standard_normal((7, 64)).astype(np.float32))
 lo, hi = shard_bounds(corpus.shape[0], world, rank)
-sr = ShardedRetriever(OracleShard(corpus[lo:hi], lo), merge_fn=merge)
-ids, sc = sr.search(q, 50)
-fi, fs = C.search(corpus, q.numpy(), 50)
-assert np.array_equal(ids.numpy(), fi), "ids differ from unsharded"
-assert np.array_equal(sc.numpy().view(np.uint32), fs.view(np.uint32)), "scores differ from unsharded"
+# both exchange forms: the default packed single-collective branch (NumPy merge standing in for the HIP kernel; nq*k
+# odd on purpose: part strides are padded to 16 bytes) and the two-collective merge_fn branch
+for K, kw in ((51, dict(packed_merge_fn=packed_merge)), (50, dict(merge_fn=merge))):
+    sr = ShardedRetriever(OracleShard(corpus[lo:hi], lo), **kw)
+    assert sr._packed == ("packed_merge_fn" in kw)
+    ids, sc = sr.search(q, K)
+    fi, fs = C.search(corpus, q.numpy(), K)
+    assert np.array_equal(ids.numpy(), fi), "ids differ from unsharded"
+    assert np.array_equal(sc.numpy().view(np.uint32), fs.view(np.uint32)), "scores differ from unsharded"
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -164,7 +181,9 @@ def test_corpus_file_roundtrip_on_cpu(tmp_path):
         cf.read_header(str(bad))
     with pytest.raises(ValueError):
         with cf.CorpusWriter(str(tmp_path / "x.vfc"), 8) as w:
+            w.append(np.zeros((2, 8), np.float16))
             w.append(np.zeros((2, 9), np.float16))
+    assert not os.path.exists(str(tmp_path / "x.vfc")), "a writer left on an exception must not leave a valid-looking file"
 
 
 def test_embed_loop_to_corpus_file(tmp_path):
@@ -187,3 +206,13 @@ def test_embed_loop_to_corpus_file(tmp_path):
     assert np.array_equal(np.asarray(cf.external_ids(p)), np.arange(1000, 1250))
     with pytest.raises(ValueError):
         cf.embed_to_file(str(tmp_path / "e.vfc"), [], Emb())
+
+    class Failing(Emb):
+        def embed_documents(self, texts):
+            if len(Failing.calls) >= 1:
+                raise RuntimeError("encoder died")
+            return super().embed_documents(texts)
+    Failing.calls = []
+    with pytest.raises(RuntimeError):
+        cf.embed_to_file(str(tmp_path / "f.vfc"), texts, Failing(), batch_size=100)
+    assert not os.path.exists(str(tmp_path / "f.vfc")), "a failed embed loop must not leave a truncated corpus file"

@@ -199,6 +199,30 @@ def test_certificate_repairs_on_hostile_data(vf, oracle):
     _assert_exact(oracle, c_sorted, q, 100, ids, sc)
 
 
+def test_certificate_bound_holds_on_halfway_point_query(vf, oracle):
+    """tests/adversarial.py: the true best match is understated by 3.8e-4 (> 2^-12 + ..., < 2^-11 + ...) and is not
+    among the re-scored rows.  The library must notice (uncertified) and repair; with the round-1 constant it returned
+    a top-100 without the best row."""
+    import adversarial as ADV
+    c = ADV.build_case(oracle)
+    assert not c["victim_rescored"] and c["ck_k"] > c["A"] + c["eps_old"]
+    with vf.DenseIndex(c["corpus"]) as ix:
+        ids, sc = ix.search(c["query"], 100)
+        st = ix.stats()
+    print("half-way query stats", st)
+    assert st["path"] == 1
+    _assert_exact(oracle, c["corpus"], c["query"], 100, ids, sc)
+    assert ids[0, 0] == c["victim"]
+    assert st["uncertified"] == 1 and st["exact_reruns"] == 1
+    # the same corpus under benign queries still certifies (the wider eps costs no re-runs on ordinary data)
+    q = np.random.default_rng(3).standard_normal((32, 768)).astype(np.float32)
+    with vf.DenseIndex(c["corpus"]) as ix:
+        ids, sc = ix.search(q, 100)
+        st = ix.stats()
+    _assert_exact(oracle, c["corpus"], q, 100, ids, sc)
+    assert st["exact_reruns"] == 0
+
+
 def test_sharding_invariance_and_merge(vf, oracle):
     """Per-shard search + merge == unsharded search, bit for bit, uneven shards."""
     import torch
@@ -498,3 +522,109 @@ def test_index_from_corpus_file_matches_in_memory(vf, oracle, tmp_path):
         vf.DenseIndex.from_file(p)
     with pytest.raises(RuntimeError, match="cannot open"):
         vf.DenseIndex.from_file(str(tmp_path / "missing.vfc"))
+
+
+# ---- BASELINE configs[2] at full size: the bench's own 10M x 768 fp16 corpus ------------------------------------------
+def test_c3_10m_subset(vf, oracle):
+    """The corpus bench.py times (same per-chunk seeds, built on the GPU), 64 queries through the fused scan; 8 of them
+    are checked bit for bit against the oracle run over the host copy in 2.5M-row pieces (oracle.merge_topk joins the
+    pieces, as the sharded path would).  No candidate buffer may overflow."""
+    import torch
+    import bench
+    n, d, nq, k = 10_000_000, 768, 64, 100
+    dev = torch.device("cuda", 0)
+    corpus = bench.make_shard(torch, 0, n, d, dev, "f16")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
+    with vf.DenseIndex(corpus) as ix:
+        ids, sc = ix.search_device(q, k)
+        st = ix.stats()
+    torch.cuda.synchronize()
+    print("C3 stats", st)
+    assert st["path"] == 1 and st["overflowed"] == 0 and st["n_queries"] == nq
+    ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+    for r in range(nq):
+        assert_ranked(ids[r], sc[r])
+    pick = [0, 9, 18, 27, 36, 45, 54, 63]
+    qh = q[pick].cpu().numpy()
+    piece = 2_500_000
+    parts_i, parts_s = [], []
+    for a in range(0, n, piece):
+        rows = corpus[a:a + piece].cpu().numpy()          # 3.8 GB of host memory at a time
+        i, s = oracle.search(rows, qh, k, id_offset=a)
+        parts_i.append(i); parts_s.append(s)
+        del rows
+    wi, ws = oracle.merge_topk(np.stack(parts_i), np.stack(parts_s), k)
+    assert np.array_equal(ids[pick], wi)
+    assert np.array_equal(_bits(sc[pick]), _bits(ws))
+
+
+# ---- BASELINE configs[4] shape: fp8-e4m3 rows, d = 1024, B = 1024 queries, k = 1000 -------------------------------------
+def test_c5_shape(vf, oracle):
+    from oracle import ref_numpy as R
+    n, d, nq, k = 200_000, 1024, 1024, 1000
+    codes = _e4m3_codes(n, d, 41)
+    rows16 = R.decode_e4m3(codes).astype(np.float16)
+    q = np.random.default_rng(42).standard_normal((nq, d)).astype(np.float32)
+    ix = vf.DenseIndex.from_e4m3(codes)
+    try:
+        got_i, got_s = ix.search(q, k)
+        st = ix.stats()
+    finally:
+        ix.close()
+    print("C5 stats", st)
+    assert st["path"] == 1 and st["n_queries"] == nq
+    want_i, want_s = oracle.search(rows16, q, k)
+    bad = np.nonzero((got_i != want_i).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {nq} queries differ, first {bad[:5].tolist()}"
+    assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+
+
+# ---- N > 1 on ONE GPU: two fresh processes, real shards, the default packed exchange ------------------------------------
+_WORLD2_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["VF_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import veritasfi_amd as vf
+from oracle import canonical as C   # checker only
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["VF_PORT"], rank=rank, world_size=world)
+torch.cuda.set_device(0)
+rng = np.random.default_rng(7)
+corpus = rng.standard_normal((60_001, 256)).astype(np.float32).astype(np.float16)
+for nq, k in ((7, 51), (64, 100)):          # nq * k odd: part strides are padded to 16 bytes
+    q = np.random.default_rng(8 + nq).standard_normal((nq, 256)).astype(np.float32)
+    lo, hi = vf.shard_bounds(corpus.shape[0], world, rank)
+    with vf.DenseIndex(corpus[lo:hi], id_offset=lo) as ix:
+        sr = vf.ShardedRetriever(ix)        # DEFAULT constructor: packed blob, one all-gather, HIP merge
+        assert sr._packed and sr.world == world
+        ids, sc = sr.search(torch.from_numpy(q).cuda(), k)
+        torch.cuda.synchronize()
+        assert ix.stats()["path"] == 1      # each shard ran the fused scan
+    fi, fs = C.search(corpus, q, k)
+    assert np.array_equal(ids.cpu().numpy(), fi), "ids differ from the unsharded oracle"
+    assert np.array_equal(sc.cpu().numpy().view(np.uint32), fs.view(np.uint32)), "score bits differ"
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_packed_world2(vf, tmp_path):
+    """ShardedRetriever's default branch with world = 2: two child processes share the one GPU (gloo carries the blob
+    through the host; RCCL refuses two ranks on one device), each holds a real DenseIndex shard, and the merged result
+    must equal the unsharded oracle bit for bit on every rank."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w2.py"
+    script.write_text(_WORLD2_WORKER)
+    port = str(31000 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", VF_PORT=port, VF_ROOT=root, OMP_NUM_THREADS="8")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)

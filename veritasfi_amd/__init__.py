@@ -17,7 +17,7 @@ Drop-in names (same signatures as the reference):
 * ``ShardedRetriever``                   -- row-sharded multi-GPU search
 """
 from .index import (DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device,  # noqa: F401
-                    merge_topk_packed_device, packed_result_buffer)
+                    merge_topk_packed_device, packed_part_bytes, packed_result_buffer)
 from .faiss_retriever import FaissRetriever  # noqa: F401
 from .retrieval import get_embeddings, last_token_pool, select_top_chunks, select_top_chunks_batch  # noqa: F401
 from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_rank, time_scores  # noqa: F401

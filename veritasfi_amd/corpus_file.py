@@ -8,6 +8,7 @@ only its row shard from disk into HBM (``vf_index_create_from_file``).  Layout: 
 from __future__ import annotations
 
 import ctypes
+import os
 import struct
 
 import numpy as np
@@ -46,6 +47,18 @@ class CorpusWriter:
             self._ids.append(ids)
         self.n += rows.shape[0]
 
+    def abort(self) -> None:
+        """Leave on an error: the header is NOT written (the file keeps its zeroed first 64 bytes, which no reader
+        accepts) and the partial file is removed."""
+        if self._f is None:
+            return
+        self._f.close()
+        self._f = None
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+
     def close(self) -> None:
         if self._f is None:
             return
@@ -59,8 +72,11 @@ class CorpusWriter:
     def __enter__(self):
         return self
 
-    def __exit__(self, *a):
-        self.close()
+    def __exit__(self, exc_type, *a):
+        if exc_type is not None:
+            self.abort()
+        else:
+            self.close()
 
 
 def write(path: str, rows, ids=None, e4m3: bool = False) -> None:
@@ -123,7 +139,9 @@ def embed_to_file(path: str, texts, embedder, batch_size: int = 100, dtype=np.fl
         if w is None:
             raise ValueError("no texts to embed")
         n = w.n
-    finally:
+    except BaseException:
         if w is not None:
-            w.close()
+            w.abort()  # a failed embed loop must not leave a truncated file that validates
+        raise
+    w.close()
     return n

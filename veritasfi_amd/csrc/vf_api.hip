@@ -421,13 +421,14 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     if (!ix || !name) return fail(VF_EINVAL, "vf_index_set_option: null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     const std::string s(name);
-    if (s == "force_path") ix->force_path = value;
-    else if (s == "sample_rows") ix->sample_rows = value;
-    else if (s == "margin") ix->margin = value;
-    else if (s == "cap") ix->cap_opt = value;
-    else if (s == "waves") ix->waves_opt = value;
-    else if (s == "scan_g") ix->scan_g = value;
-    else if (s == "refresh_every") ix->refresh_every = value;
+    auto in_range = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+    if (s == "force_path") { if (!in_range(-1, 2)) return fail(VF_EINVAL, "force_path must be -1 (auto), 0, 1 or 2"); ix->force_path = value; }
+    else if (s == "sample_rows") { if (!in_range(1, 64)) return fail(VF_EINVAL, "sample_rows must be in [1, 64]"); ix->sample_rows = value; }
+    else if (s == "margin") { if (!in_range(-1, 2048)) return fail(VF_EINVAL, "margin must be -1 (auto) or in [0, 2048]"); ix->margin = value; }
+    else if (s == "cap") { if (!in_range(0, 16384)) return fail(VF_EINVAL, "cap must be in [0, 16384]"); ix->cap_opt = value; }
+    else if (s == "waves") { if (!in_range(0, 8 * 1024)) return fail(VF_EINVAL, "waves must be in [0, 8192]"); ix->waves_opt = value; }
+    else if (s == "scan_g") { if (!in_range(0, 4)) return fail(VF_EINVAL, "scan_g must be in [0, 4]"); ix->scan_g = value; }
+    else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
     else return fail(VF_EINVAL, "vf_index_set_option: unknown option " + s);
@@ -443,8 +444,11 @@ static int exact_search(vf_index* ix, Slot& s, const float* qn_dev, int nq, int 
     const int dt = ix->dtype;
     const int64_t chunk = kSmallN;
     const int64_t nchunks = ix->n == 0 ? 1 : (ix->n + chunk - 1) / chunk;
-    if (nchunks > 1 && (int64_t)k * 2 * 8 > 160 * 1024)
-        return fail(VF_EUNSUPPORTED, "exact chunked search supports k <= 10240 when n > 16384");
+    if (nchunks > 1) {  // k_merge_topk sorts next_pow2(2k) 8-byte keys in LDS
+        int64_t P = 1;
+        while (P < 2 * (int64_t)k) P <<= 1;
+        if (P * 8 > 160 * 1024) return fail(VF_EUNSUPPORTED, "exact chunked search supports k <= 8192 when n > 16384");
+    }
     VF_TRY(s.dense_s.ensure((size_t)nq * chunk * sizeof(float)));
     if (nchunks == 1) {
         const float* cn = ix->cn_cache;
@@ -509,6 +513,7 @@ static FusedPlan make_plan(const vf_index* ix, int k) {
     // k' = k + margin, rounded up to a multiple of 32 (whole re-score rounds of 32 row groups)
     const int margin = ix->margin >= 0 ? (int)ix->margin : std::max(24, k / 4);
     p.kprime = ix->margin >= 0 ? k + margin : (k + margin + 31) / 32 * 32;
+    p.kprime = std::min(p.kprime, 4096);  // k_final ranks into a fixed 4096-entry LDS array (k <= kMaxKFused = 2048)
     int cap = kMaxCap;
     while (cap < 4 * p.kprime && cap < 16384) cap <<= 1;
     if (ix->cap_opt > 0) { cap = 1; while (cap < ix->cap_opt) cap <<= 1; cap = std::min(cap, 16384); }
@@ -519,9 +524,12 @@ static FusedPlan make_plan(const vf_index* ix, int k) {
     p.grid = (int)wgs;
     p.total_waves = p.grid * (kScanThreads / 64);
     p.samp = (int)std::max<int64_t>(1, ix->sample_rows);
-    // |approx - canonical| bound (DESIGN.md "Exactness certificate"): fp16 query rounding 2^-12,
-    // fp16 corpus rounding 2^-12 when the corpus was fp32, fp16 subnormal floor, two fp32 dot products.
-    const double u16 = 1.0 / 4096.0;
+    // |approx - canonical| bound (DESIGN.md "Exactness certificate").  fp16 has an 11-bit significand, so
+    // round-to-nearest moves an element by at most 2^-11 of its magnitude: rounding the normalised query moves the
+    // dot product by <= 2^-11 * sum|q_j c_j| <= 2^-11 (Cauchy-Schwarz, both vectors of unit norm); rounding an fp32
+    // corpus row to fp16 adds the same again.  Then the fp16 subnormal floor (2^-25 per element against a unit
+    // vector: sqrt(d) * 2^-24 covers it twice) and the two fp32 dot products (d * 2^-24 each).
+    const double u16 = 1.0 / 2048.0;
     p.eps = (float)(u16 * (ix->dtype == VF_DTYPE_F32 ? 2.0 : 1.0) + sqrt((double)ix->d) * ldexp(1.0, -24) +
                     2.0 * ix->d * ldexp(1.0, -24) + 1e-6);
     return p;
@@ -542,6 +550,8 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     if (s.pending) return fail(VF_EINVAL, "vf_index_search_begin: slot already has a pending search");
     const int path = select_path(ix, k);
     if (path < 0) return fail(VF_EUNSUPPORTED, "forced fused path is not possible for this n / k / d");
+    if (path != 1 && ix->n > kSmallN && k > 8192)  // checked before anything is enqueued (k_merge_topk's LDS sort)
+        return fail(VF_EUNSUPPORTED, "exact chunked search supports k <= 8192 when n > 16384");
     VF_TRY(ensure_slot(s));
     VF_HIP(hipEventRecord(s.ev_in, user));
     VF_HIP(hipStreamWaitEvent(s.stream, s.ev_in, 0));

@@ -97,6 +97,9 @@ hipError_t launch_merge_topk_packed(const void* parts, int nparts, int nq, int k
                                     hipStream_t s);
 hipError_t launch_fuse_rank(const float* a, const float* b, int n, float* out, long long* order,
                             hipStream_t s);
+// bytes of one packed per-shard result [ids nq*k int64][scores nq*k fp32], padded to 16 so that every part of an
+// all-gathered buffer keeps its int64 ids 8-byte aligned (nq*k odd would otherwise put part 1 on a 4-byte boundary)
+inline long long packed_part_bytes(int nq, int k) { return ((long long)nq * k * 12 + 15) / 16 * 16; }
 size_t scan_lds_bytes(int dp, int qn_tile);
 int scan_stage_cap(int dp, int qn_tile);
 hipError_t scan_configure();   // sets max dynamic LDS on the scan kernels (once per process/device)

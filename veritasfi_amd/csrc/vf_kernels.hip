@@ -375,7 +375,7 @@ hipError_t launch_merge_topk(const long long* ids_parts, const float* score_part
 
 hipError_t launch_merge_topk_packed(const void* parts, int nparts, int nq, int k, long long* ids, float* scores,
                                     hipStream_t s) {
-    const long long stride = (long long)nq * k * 12;
+    const long long stride = packed_part_bytes(nq, k);
     return launch_merge_impl((const char*)parts, (const char*)parts + (long long)nq * k * 8, stride, stride, nparts, nq, k,
                              ids, scores, s);
 }

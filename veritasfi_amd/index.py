@@ -218,13 +218,19 @@ def merge_topk_device(ids_parts, score_parts, k: int):
     return ids, sc
 
 
+def packed_part_bytes(nq: int, k: int) -> int:
+    """Bytes of one packed per-shard result: [ids nq*k int64][scores nq*k fp32], padded to a multiple of 16 so that
+    every part of an all-gathered buffer keeps its int64 ids aligned (the library computes the same stride)."""
+    return (nq * k * 12 + 15) // 16 * 16
+
+
 def packed_result_buffer(nq: int, k: int, device):
-    """One contiguous device blob [ids nq*k int64][scores nq*k fp32] plus the two typed views into it: a shard
-    writes its search result through the views and ships the blob with a single all-gather."""
+    """One contiguous device blob [ids nq*k int64][scores nq*k fp32][pad to 16 B] plus the two typed views into it:
+    a shard writes its search result through the views and ships the blob with a single all-gather."""
     import torch
-    blob = torch.empty(nq * k * 12, dtype=torch.uint8, device=device)
+    blob = torch.zeros(packed_part_bytes(nq, k), dtype=torch.uint8, device=device)
     ids = blob[: nq * k * 8].view(torch.int64).view(nq, k)
-    scores = blob[nq * k * 8:].view(torch.float32).view(nq, k)
+    scores = blob[nq * k * 8: nq * k * 12].view(torch.float32).view(nq, k)
     return blob, ids, scores
 
 

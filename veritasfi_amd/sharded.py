@@ -25,11 +25,16 @@ def shard_bounds(n: int, world: int, rank: int):
 
 
 class ShardedRetriever:
-    """local_index: object with ``search_device(q, k) -> (ids, scores)`` returning GLOBAL ids
-    (a DenseIndex built with id_offset = shard start).  merge_fn: ([G,nq,k] ids, [G,nq,k] scores, k)
-    -> ([nq,k], [nq,k]); defaults to the HIP merge kernel."""
+    """local_index: object with ``search_device(q, k, out_ids, out_scores) -> (ids, scores)`` returning GLOBAL ids
+    (a DenseIndex built with id_offset = shard start).
 
-    def __init__(self, local_index, group=None, merge_fn=None):
+    Default exchange (``merge_fn is None``): the shard writes its result into ONE packed blob
+    (``index.packed_result_buffer``), ONE ``all_gather_into_tensor`` moves every rank's blob and
+    ``packed_merge_fn(all_blobs, world, nq, k)`` merges the parts in place -- by default the HIP kernel behind
+    ``vf_merge_topk_packed_device``.  ``merge_fn`` (two typed all-gathers + ``merge_fn([G,nq,k] ids, [G,nq,k]
+    scores, k)``) is kept for callers that bring their own merge."""
+
+    def __init__(self, local_index, group=None, merge_fn=None, packed_merge_fn=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -39,6 +44,21 @@ class ShardedRetriever:
         self._packed = merge_fn is None  # default: packed single-collective exchange + HIP merge
         self._bufs = {}
         self.merge_fn = merge_fn
+        if packed_merge_fn is None:
+            from .index import merge_topk_packed_device as packed_merge_fn
+        self.packed_merge_fn = packed_merge_fn
+        # RCCL ("nccl") moves device buffers directly over xGMI.  Any other backend (gloo: the CPU tests and the
+        # one-GPU rehearsal of world > 1) gets the blob through a host copy -- same bytes, same single collective.
+        self._direct = (not dist.is_initialized()) or dist.get_backend(group) == "nccl"
+
+    def _all_gather_blob(self, out, blob):
+        if self._direct or not blob.is_cuda:
+            self.dist.all_gather_into_tensor(out, blob, group=self.group)
+            return
+        import torch
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(h_out, blob.cpu(), group=self.group)
+        out.copy_(h_out)
 
     def search(self, queries, k: int):
         """queries: [nq, d] tensor on this rank's device, identical on every rank."""
@@ -47,19 +67,17 @@ class ShardedRetriever:
             return self.local.search_device(queries, k)
         nq = int(queries.shape[0])
         if self._packed:
-            # production path: the shard writes (ids, scores) into one packed blob, ONE all-gather moves every
-            # rank's blob (nq*k*12 bytes each: 77 KB at nq=64, k=100), the HIP merge reads the parts in place
             key = (nq, k, queries.device)
             if self._bufs.get("key") != key:
-                from .index import packed_result_buffer
+                from .index import packed_part_bytes, packed_result_buffer
                 blob, ids, sc = packed_result_buffer(nq, k, queries.device)
                 self._bufs = {"key": key, "blob": blob, "ids": ids, "sc": sc,
-                              "all": torch.empty(self.world * nq * k * 12, dtype=torch.uint8, device=queries.device)}
+                              "all": torch.empty(self.world * packed_part_bytes(nq, k), dtype=torch.uint8,
+                                                 device=queries.device)}
             b = self._bufs
             self.local.search_device(queries, k, b["ids"], b["sc"])
-            self.dist.all_gather_into_tensor(b["all"], b["blob"], group=self.group)
-            from .index import merge_topk_packed_device
-            return merge_topk_packed_device(b["all"], self.world, nq, k)
+            self._all_gather_blob(b["all"], b["blob"])
+            return self.packed_merge_fn(b["all"], self.world, nq, k)
         ids, scores = self.local.search_device(queries, k)
         # outputs are the rank-order concatenation along dim 0 (the layout every backend accepts);
         # rank order == ascending id range, which the merge relies on
