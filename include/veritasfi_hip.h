@@ -76,6 +76,23 @@ int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int3
 int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
                            int32_t device_id, int64_t id_offset);
 
+/* ---- ONE handle over several devices (single-process serving) -------------------------------------------------
+ * The reference serves from one process (RAGManager singleton, src/utils/ragManager.py:17-30; it builds
+ * EnsembleRetriever -> FaissRetriever(embeddings, fn) at src/utils/ensembleRetriever.py:39-43 and searches at :66,:139).
+ * vf_index_create_sharded splits the rows into contiguous blocks of ceil(n / n_dev), one per listed
+ * device (a device may be listed more than once), and returns a handle every vf_index_* entry point accepts: a search
+ * peer-copies the queries from the home device (device_ids[0]) to every shard, runs the shard searches concurrently,
+ * peer-copies each packed per-shard top-k back and merges them on the home device -- the result is bit-identical to
+ * the single-device one (scores are canonical).  Device-buffer entry points take / return buffers on the HOME device.
+ * vf_index_group adopts indexes the caller built itself (e.g. over device-resident shards); they must be contiguous
+ * row blocks in ascending order (id_offset of each = id_offset + n of the previous) and the group then owns them. */
+int vf_index_create_sharded(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
+                            const int32_t* device_ids, int32_t n_dev);
+int vf_index_create_sharded_from_file(vf_index** out, const char* path, const int32_t* device_ids, int32_t n_dev);
+int vf_index_group(vf_index** out, vf_index** shards, int32_t n_shards);
+/* number of shards of a handle (0 for a plain single-device index) and their devices (first `cap` of them) */
+int vf_index_shards(vf_index* idx, int32_t* n_shards, int32_t* device_ids, int32_t cap);
+
 /* Corpus file (.vfc): 64-byte header {char magic[8]="VFCORPUS"; u32 version=1; u32 dtype; u64 n; u32 d; u32 flags;
  * u8 reserved[32]} + n*d row-major elements (+ int64[n] external ids when flags bit 0 is set).  Stands where the
  * reference pulls every embedding out of Chroma into Python lists at start-up (src/utils/ensembleRetriever.py:39-43,
@@ -139,8 +156,9 @@ int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts,
                          int32_t nq, int32_t k, int64_t* d_ids, float* d_scores, int32_t device_id,
                          void* stream);
 
-/* Same, from ONE all-gathered buffer: part g is the blob [ids nq*k int64][scores nq*k fp32] at byte offset
- * g * nq*k*12 (a rank packs its result that way so that a batch needs a single collective). */
+/* Same, from ONE all-gathered buffer: part g is the blob [ids nq*k int64][scores nq*k fp32][pad] at byte offset
+ * g * S, S = nq*k*12 rounded up to a multiple of 16 (so every part's int64 ids stay aligned; a rank packs its result
+ * that way so that a batch needs a single collective). */
 int vf_merge_topk_packed_device(const void* d_parts, int32_t nparts, int32_t nq, int32_t k, int64_t* d_ids,
                                 float* d_scores, int32_t device_id, void* stream);
 

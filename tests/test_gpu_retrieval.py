@@ -628,3 +628,77 @@ def test_sharded_packed_world2(vf, tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+# ---- ONE handle over several devices (single-process serving): vf_index_create_sharded / vf_index_group ------------------
+def test_single_process_sharded_handle(vf, oracle, tmp_path):
+    """The drop-in form of multi-GPU: FaissRetriever(embeddings, fn, device_ids=[...]) inside one process.  With one GPU
+    on the box the shards all live on device 0 (three of them, uneven: 70001 rows), which exercises the same code:
+    per-shard streams, peer copies of queries and packed results, one merge.  Bit-identical to the unsharded oracle."""
+    import torch
+    c, q = _data(51, 70_001, 256, 37, np.float16)
+    k = 51                                                  # nq * k odd: padded part stride
+    want_i, want_s = oracle.search(c, q, k)
+    with vf.DenseIndex(c, device_ids=[0, 0, 0]) as ix:
+        assert ix.shard_devices() == [0, 0, 0] and ix.n == 70_001
+        i, s = ix.search(q, k)                              # host buffers (FaissRetriever.invoke's call)
+        st = ix.stats()
+        assert np.array_equal(i, want_i) and np.array_equal(_bits(s), _bits(want_s))
+        assert st["path"] == 1 and st["n_queries"] == 37 and st["candidates"] > 0
+        qd = torch.from_numpy(q).cuda()
+        di, ds = ix.search_device(qd, k)                    # device buffers on the home device
+        torch.cuda.synchronize()
+        assert np.array_equal(di.cpu().numpy(), want_i) and np.array_equal(_bits(ds.cpu().numpy()), _bits(want_s))
+        outs = []
+        for step in range(5):                               # two batches in flight, as bench.py --single-process keeps
+            slot = step % 2
+            if step >= 2:
+                ix.search_end(slot)
+            outs.append(ix.search_begin(slot, qd, k))
+        ix.search_end(1); ix.search_end(0)
+        torch.cuda.synchronize()
+        for a, b in outs:
+            assert torch.equal(a, di) and torch.equal(b, ds)
+        with pytest.raises(RuntimeError):
+            ix.search_end(0)
+        with pytest.raises(RuntimeError, match="shards \\* k"):
+            ix.search(q, 6000)
+        ix.set_option("force_path", 2)                      # options reach every shard
+        i2, s2 = ix.search(q[:3], k)
+        assert ix.stats()["path"] == 2 and np.array_equal(i2, want_i[:3]) and np.array_equal(_bits(s2), _bits(want_s[:3]))
+    # fp32 rows, k > rows of a shard, one shard on the small dense path, an empty trailing shard
+    c32 = np.random.default_rng(52).standard_normal((5, 64)).astype(np.float32)
+    q32 = np.random.default_rng(53).standard_normal((2, 64)).astype(np.float32)
+    with vf.DenseIndex(c32, device_ids=[0, 0, 0, 0]) as ix:   # blocks of 2, 2, 1, 0 rows
+        i, s = ix.search(q32, 8)
+    _assert_exact(oracle, c32, q32, 8, i, s)
+    assert (i[:, 5:] == -1).all()
+    # the reference's class with the extra keyword, and the file loader
+    class Emb:
+        def embed_query(self, text): return q[int(text)].tolist()
+    fr = vf.FaissRetriever(c.astype(np.float32).tolist()[:20_000], Emb(), device_ids=[0, 0])
+    I, D = fr.invoke(["3", "5"], k=10)
+    wi, ws = oracle.search(c[:20_000].astype(np.float32), q[[3, 5]], 10)
+    assert np.array_equal(I, wi) and np.array_equal(_bits(D), _bits(ws))
+    fr.index.close()
+    from veritasfi_amd import corpus_file as cf
+    p = str(tmp_path / "c.vfc")
+    cf.write(p, c)
+    with vf.DenseIndex.from_file(p, device_ids=[0, 0, 0, 0, 0]) as ix:
+        i, s = ix.search(q, k)
+    assert np.array_equal(i, want_i) and np.array_equal(_bits(s), _bits(want_s))
+    # adopting device-resident shards (what bench.py --single-process builds)
+    cd = torch.from_numpy(c).cuda()
+    cuts = [0, 30_000, 30_100, 70_001]
+    parts = [vf.DenseIndex(cd[a:b], id_offset=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    with vf.DenseIndex.group(parts) as ix:
+        i, s = ix.search(q, k)
+    assert np.array_equal(i, want_i) and np.array_equal(_bits(s), _bits(want_s))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        a = vf.DenseIndex(cd[:100]); b = vf.DenseIndex(cd[100:300], id_offset=50)
+        try:
+            vf.DenseIndex.group([a, b])
+        finally:
+            a.close(); b.close()
+    with pytest.raises(RuntimeError):
+        vf.DenseIndex(c[:10], device_ids=[0, 99])

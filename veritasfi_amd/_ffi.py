@@ -53,6 +53,10 @@ SIGNATURES = {
     "vf_device_count": (ctypes.c_int, [p_i32]),
     "vf_index_create": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, c_i32, c_i64]),
     "vf_index_create_device": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, c_i32, c_i64]),
+    "vf_index_create_sharded": (ctypes.c_int, [ctypes.POINTER(vp), vp, c_i64, c_i32, c_i32, p_i32, c_i32]),
+    "vf_index_create_sharded_from_file": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_char_p, p_i32, c_i32]),
+    "vf_index_group": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), c_i32]),
+    "vf_index_shards": (ctypes.c_int, [vp, p_i32, p_i32, c_i32]),
     "vf_corpus_file_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "vf_index_create_from_file": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_char_p, c_i64, c_i64, c_i32, c_i64]),
     "vf_index_search": (ctypes.c_int, [vp, vp, c_i32, c_i32, vp, vp]),

@@ -104,6 +104,19 @@ struct Slot {
     hipStream_t user_stream = nullptr;
 };
 
+// per-slot state of a group search: one feed stream / staging set per shard, on the shard's device
+struct GroupSlot {
+    std::vector<hipStream_t> feed;       // [G] on shard g's device: query copy -> shard search -> result copy home
+    std::vector<hipEvent_t> ev;          // [G] result of shard g has landed in `all` on the home device
+    std::vector<DevBuf> dq, blob;        // [G] queries / packed result [ids | scores] on shard g's device
+    DevBuf all;                          // home device: G packed parts, the merge kernel's input
+    hipEvent_t ev_in = nullptr;          // home device: the caller's stream at _begin time
+    bool pending = false;
+    int nq = 0, k = 0;
+    int64_t* d_ids = nullptr; float* d_scores = nullptr;
+    hipStream_t user = nullptr;
+};
+
 }  // namespace
 
 struct vf_index {
@@ -128,6 +141,12 @@ struct vf_index {
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
     int64_t prof_launches = 0, prof_bytes = 0;
+    // host-buffer entry (vf_index_search): per-handle device staging, grown on demand, reused across calls
+    DevBuf st_q, st_ids, st_sc;
+    // ---- group handle (vf_index_create_sharded / vf_index_group): the corpus is row-sharded over `shards`, one per
+    // device; this handle owns them.  device = the HOME device: queries arrive there and the merged result lands there.
+    std::vector<vf_index*> shards;
+    GroupSlot gslots[kSlots];
 };
 
 // flags / candidate counts are written by k_final straight into host-mapped pinned memory
@@ -193,8 +212,27 @@ static int ensure_slot(Slot& s) {
 
 static void destroy_index(vf_index* ix) {
     if (!ix) return;
+    if (!ix->shards.empty()) {  // group handle: per-slot staging on every shard's device, then the shards themselves
+        for (int i = 0; i < kSlots; ++i) {
+            GroupSlot& gs = ix->gslots[i];
+            for (size_t g = 0; g < ix->shards.size(); ++g) {
+                (void)hipSetDevice(ix->shards[g]->device);
+                (void)hipDeviceSynchronize();
+                if (g < gs.dq.size()) gs.dq[g].release();
+                if (g < gs.blob.size()) gs.blob[g].release();
+                if (g < gs.feed.size() && gs.feed[g]) (void)hipStreamDestroy(gs.feed[g]);
+                if (g < gs.ev.size() && gs.ev[g]) (void)hipEventDestroy(gs.ev[g]);
+            }
+            (void)hipSetDevice(ix->device);
+            gs.all.release();
+            if (gs.ev_in) (void)hipEventDestroy(gs.ev_in);
+        }
+        for (vf_index* sh : ix->shards) destroy_index(sh);
+        ix->shards.clear();
+    }
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
+    ix->st_q.release(); ix->st_ids.release(); ix->st_sc.release();
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = ix->slots[i];
         DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.hist_coarse, &s.cand, &s.flags, &s.counts, &s.dense_s,
@@ -392,16 +430,24 @@ extern "C" int vf_index_profile(vf_index* ix, double* scan_ms_total, int64_t* sc
                                 int64_t* scan_bytes_per_launch) {
     if (!ix) return fail(VF_EINVAL, "vf_index_profile: null handle");
     std::lock_guard<std::mutex> g(ix->mu);
-    if (scan_ms_total) *scan_ms_total = ix->prof_scan_ms;
-    if (scan_launches) *scan_launches = ix->prof_launches;
-    if (pipeline_ms_total) *pipeline_ms_total = ix->prof_pipe_ms;
-    if (scan_bytes_per_launch) *scan_bytes_per_launch = ix->prof_bytes;
+    double sm = ix->prof_scan_ms, pm = ix->prof_pipe_ms;
+    int64_t nl = ix->prof_launches, nb = ix->prof_bytes;
+    for (vf_index* sh : ix->shards) {  // group: totals over the shards (equal blocks: bytes per launch of the first)
+        std::lock_guard<std::mutex> lk(sh->mu);
+        sm += sh->prof_scan_ms; pm += sh->prof_pipe_ms; nl += sh->prof_launches;
+        if (nb == 0) nb = sh->prof_bytes;
+    }
+    if (scan_ms_total) *scan_ms_total = sm;
+    if (scan_launches) *scan_launches = nl;
+    if (pipeline_ms_total) *pipeline_ms_total = pm;
+    if (scan_bytes_per_launch) *scan_bytes_per_launch = nb;
     return VF_OK;
 }
 
 // debug: copy the wall-clock stamps of slot's last main scan (option debug bit 7) to host
 extern "C" int vf_index_debug_read(vf_index* ix, int32_t slot, unsigned long long* out, int64_t n_words) {
     if (!ix || !out || slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_debug_read: bad argument");
+    if (!ix->shards.empty()) return vf_index_debug_read(ix->shards[0], slot, out, n_words);
     std::lock_guard<std::mutex> g(ix->mu);
     Slot& s = ix->slots[slot];
     const size_t bytes = std::min<size_t>(s.dbg.bytes, (size_t)n_words * 8);
@@ -419,6 +465,7 @@ extern "C" int vf_index_slots(vf_index* ix, int32_t* out) {
 
 extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value) {
     if (!ix || !name) return fail(VF_EINVAL, "vf_index_set_option: null argument");
+    for (vf_index* sh : ix->shards) VF_TRY(vf_index_set_option(sh, name, value));  // a group forwards to every shard
     std::lock_guard<std::mutex> g(ix->mu);
     const std::string s(name);
     auto in_range = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
@@ -703,62 +750,292 @@ static int check_search_args(vf_index* ix, const void* q, int nq, int k, const v
     return VF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Group handle: ONE process, several devices (the reference's serve path is a single process: RAGManager singleton,
+// src/utils/ragManager.py:17-30, building EnsembleRetriever -> FaissRetriever at ensembleRetriever.py:39-43).  Rows are
+// split into contiguous blocks, one vf_index per device; a search copies the queries from the home
+// device to every shard over xGMI peer copies, runs all shard searches concurrently (each on its own device streams),
+// copies the packed per-shard top-k back to the home device and merges them there with k_merge_topk.  No host thread
+// per device and no RCCL communicator are needed: the exchange is G small peer-to-peer copies (77 KB each at nq = 64,
+// k = 100), which is what an all-gather over point-to-point xGMI links amounts to for one receiver.
+// ------------------------------------------------------------------------------------------------
+static int group_ensure_slot(vf_index* ix, GroupSlot& gs) {
+    const size_t G = ix->shards.size();
+    if (gs.feed.size() == G) return VF_OK;
+    gs.feed.assign(G, nullptr); gs.ev.assign(G, nullptr);
+    gs.dq.resize(G); gs.blob.resize(G);
+    for (size_t g = 0; g < G; ++g) {
+        VF_HIP(hipSetDevice(ix->shards[g]->device));
+        VF_HIP(hipStreamCreateWithFlags(&gs.feed[g], hipStreamNonBlocking));
+        VF_HIP(hipEventCreateWithFlags(&gs.ev[g], hipEventDisableTiming));
+    }
+    VF_HIP(hipSetDevice(ix->device));
+    VF_HIP(hipEventCreateWithFlags(&gs.ev_in, hipEventDisableTiming));
+    return VF_OK;
+}
+
+static int group_begin(vf_index* ix, int slot_id, const float* d_queries, int nq, int k, int64_t* d_ids, float* d_scores,
+                       hipStream_t user) {
+    GroupSlot& gs = ix->gslots[slot_id];
+    if (gs.pending) return fail(VF_EINVAL, "vf_index_search_begin: slot already has a pending search");
+    const size_t G = ix->shards.size();
+    if ((size_t)G * k > 16384) return fail(VF_EUNSUPPORTED, "sharded search: shards * k > 16384");
+    VF_TRY(group_ensure_slot(ix, gs));
+    gs.nq = nq; gs.k = k; gs.d_ids = d_ids; gs.d_scores = d_scores; gs.user = user;
+    if (nq == 0 || k == 0) { gs.pending = true; return VF_OK; }
+    const size_t qbytes = (size_t)nq * ix->d * sizeof(float);
+    const size_t part = (size_t)packed_part_bytes(nq, k);
+    VF_HIP(hipSetDevice(ix->device));
+    VF_TRY(gs.all.ensure(G * part));
+    VF_HIP(hipEventRecord(gs.ev_in, user));
+    size_t started = 0;
+    int rc = VF_OK;
+    for (size_t g = 0; g < G && rc == VF_OK; ++g) {
+        vf_index* sh = ix->shards[g];
+        hipError_t e = hipSetDevice(sh->device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(gs.feed[g], gs.ev_in, 0);
+        if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("sharded search: ") + hipGetErrorString(e)); break; }
+        if ((rc = gs.dq[g].ensure(qbytes)) != VF_OK || (rc = gs.blob[g].ensure(part)) != VF_OK) break;
+        e = hipMemcpyPeerAsync(gs.dq[g].p, sh->device, d_queries, ix->device, qbytes, gs.feed[g]);
+        if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("sharded search: query peer copy: ") + hipGetErrorString(e)); break; }
+        std::lock_guard<std::mutex> lk(sh->mu);
+        rc = begin_impl(sh, slot_id, gs.dq[g].as<float>(), nq, k, (int64_t*)gs.blob[g].p,
+                        (float*)((char*)gs.blob[g].p + (size_t)nq * k * 8), gs.feed[g]);
+        if (rc == VF_OK) ++started; else sh->slots[slot_id].pending = false;
+    }
+    if (rc != VF_OK) {  // let the shards that did start finish, then report
+        const std::string keep = g_err;
+        for (size_t g = 0; g < started; ++g) {
+            (void)hipSetDevice(ix->shards[g]->device);
+            std::lock_guard<std::mutex> lk(ix->shards[g]->mu);
+            (void)end_impl(ix->shards[g], slot_id);
+        }
+        g_err = keep;
+        return rc;
+    }
+    gs.pending = true;
+    return VF_OK;
+}
+
+static int group_end(vf_index* ix, int slot_id) {
+    GroupSlot& gs = ix->gslots[slot_id];
+    if (!gs.pending) return fail(VF_EINVAL, "vf_index_search_end: slot has no pending search");
+    gs.pending = false;
+    vf_search_stats tot{};
+    tot.n_queries = gs.nq;
+    if (gs.nq == 0 || gs.k == 0) { ix->stats = tot; return VF_OK; }
+    const size_t G = ix->shards.size();
+    const size_t part = (size_t)packed_part_bytes(gs.nq, gs.k);
+    int rc = VF_OK;
+    for (size_t g = 0; g < G; ++g) {  // every shard is ended even after a failure: no slot may stay pending
+        vf_index* sh = ix->shards[g];
+        (void)hipSetDevice(sh->device);
+        int r;
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            r = end_impl(sh, slot_id);  // waits for the shard, certifies, repairs; feed[g] is ordered after the result
+            if (r == VF_OK) {
+                const vf_search_stats& st = sh->stats;
+                tot.path = std::max(tot.path, st.path);
+                tot.candidates += st.candidates; tot.max_candidates = std::max(tot.max_candidates, st.max_candidates);
+                tot.uncertified += st.uncertified; tot.overflowed += st.overflowed; tot.exact_reruns += st.exact_reruns;
+            }
+        }
+        if (r == VF_OK) {
+            hipError_t e = hipMemcpyPeerAsync((char*)gs.all.p + g * part, ix->device, gs.blob[g].p, sh->device, part, gs.feed[g]);
+            if (e == hipSuccess) e = hipEventRecord(gs.ev[g], gs.feed[g]);
+            if (e != hipSuccess) r = fail(VF_EHIP, std::string("sharded search: result peer copy: ") + hipGetErrorString(e));
+        }
+        if (r != VF_OK && rc == VF_OK) rc = r;
+    }
+    if (rc != VF_OK) return rc;
+    VF_HIP(hipSetDevice(ix->device));
+    VF_HIP(scan_configure());
+    for (size_t g = 0; g < G; ++g) VF_HIP(hipStreamWaitEvent(gs.user, gs.ev[g], 0));
+    // parts are in ascending id-range order (shard order), which the merge's tie rule relies on
+    VF_HIP(launch_merge_topk_packed(gs.all.p, (int)G, gs.nq, gs.k, (long long*)gs.d_ids, gs.d_scores, gs.user));
+    ix->stats = tot;
+    return VF_OK;
+}
+
+static int search_begin_locked(vf_index* ix, int slot, const float* d_queries, int nq, int k, int64_t* d_ids,
+                               float* d_scores, hipStream_t stream) {
+    if (!ix->shards.empty()) return group_begin(ix, slot, d_queries, nq, k, d_ids, d_scores, stream);
+    VF_HIP(hipSetDevice(ix->device));
+    int rc = begin_impl(ix, slot, d_queries, nq, k, d_ids, d_scores, stream);
+    if (rc != VF_OK) ix->slots[slot].pending = false;
+    return rc;
+}
+
+static int search_end_locked(vf_index* ix, int slot) {
+    if (!ix->shards.empty()) return group_end(ix, slot);
+    VF_HIP(hipSetDevice(ix->device));
+    return end_impl(ix, slot);
+}
+
+static bool slot_pending(const vf_index* ix, int slot) {
+    return ix->shards.empty() ? ix->slots[slot].pending : ix->gslots[slot].pending;
+}
+
 extern "C" int vf_index_search_begin(vf_index* ix, int32_t slot, const float* d_queries, int32_t nq, int32_t k,
                                      int64_t* d_ids, float* d_scores, void* stream) {
     VF_TRY(check_search_args(ix, d_queries, nq, k, d_ids, d_scores));
     if (slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_search_begin: bad slot");
     std::lock_guard<std::mutex> g(ix->mu);
-    VF_HIP(hipSetDevice(ix->device));
-    int rc = begin_impl(ix, slot, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
-    if (rc != VF_OK) ix->slots[slot].pending = false;
-    return rc;
+    return search_begin_locked(ix, slot, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
 }
 
 extern "C" int vf_index_search_end(vf_index* ix, int32_t slot) {
     if (!ix) return fail(VF_EINVAL, "vf_index_search_end: null handle");
     if (slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_search_end: bad slot");
     std::lock_guard<std::mutex> g(ix->mu);
-    VF_HIP(hipSetDevice(ix->device));
-    return end_impl(ix, slot);
+    return search_end_locked(ix, slot);
+}
+
+static int search_device_locked(vf_index* ix, const float* d_queries, int nq, int k, int64_t* d_ids, float* d_scores,
+                                hipStream_t stream) {
+    if (slot_pending(ix, 0)) return fail(VF_EINVAL, "vf_index_search_device: slot 0 busy (begin without end)");
+    VF_TRY(search_begin_locked(ix, 0, d_queries, nq, k, d_ids, d_scores, stream));
+    return search_end_locked(ix, 0);
 }
 
 extern "C" int vf_index_search_device(vf_index* ix, const float* d_queries, int32_t nq, int32_t k, int64_t* d_ids,
                                       float* d_scores, void* stream) {
     VF_TRY(check_search_args(ix, d_queries, nq, k, d_ids, d_scores));
     std::lock_guard<std::mutex> g(ix->mu);
-    VF_HIP(hipSetDevice(ix->device));
-    if (ix->slots[0].pending) return fail(VF_EINVAL, "vf_index_search_device: slot 0 busy (begin without end)");
-    int rc = begin_impl(ix, 0, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
-    if (rc != VF_OK) { ix->slots[0].pending = false; return rc; }
-    return end_impl(ix, 0);
+    return search_device_locked(ix, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
 }
 
+// Host buffers in and out: what FaissRetriever.invoke hands over (NumPy arrays, src/utils/faissRetriever.py:34-38).
+// The device staging lives in the handle and is reused from call to call (no hipMalloc / hipFree per request); the
+// handle's mutex is held for the whole call, so concurrent request threads take turns on it.
 extern "C" int vf_index_search(vf_index* ix, const float* queries, int32_t nq, int32_t k, int64_t* out_ids,
                                float* out_scores) {
     VF_TRY(check_search_args(ix, queries, nq, k, out_ids, out_scores));
     if (nq == 0 || k == 0) return VF_OK;
+    std::lock_guard<std::mutex> g(ix->mu);
     VF_HIP(hipSetDevice(ix->device));
-    float* dq = nullptr; int64_t* di = nullptr; float* ds = nullptr;
+    const size_t qb = (size_t)nq * ix->d * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t), sb = (size_t)nq * k * sizeof(float);
+    VF_TRY(ix->st_q.ensure(qb));
+    VF_TRY(ix->st_ids.ensure(ib));
+    VF_TRY(ix->st_sc.ensure(sb));
+    VF_HIP(hipMemcpy(ix->st_q.p, queries, qb, hipMemcpyHostToDevice));
+    VF_TRY(search_device_locked(ix, ix->st_q.as<float>(), nq, k, ix->st_ids.as<int64_t>(), ix->st_sc.as<float>(), nullptr));
+    VF_HIP(hipSetDevice(ix->device));
+    VF_HIP(hipStreamSynchronize(nullptr));
+    VF_HIP(hipMemcpy(out_ids, ix->st_ids.p, ib, hipMemcpyDeviceToHost));
+    VF_HIP(hipMemcpy(out_scores, ix->st_sc.p, sb, hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+// Take ownership of per-device indexes (built with id_offset = first row of their block, in ascending block order)
+// and present them as one index.  home = shards[0]'s device.
+static int make_group(vf_index** out, std::vector<vf_index*>& shards) {
+    vf_index* grp = new (std::nothrow) vf_index();
+    if (!grp) return fail(VF_ENOMEM, "vf_index_group: host allocation failed");
+    grp->device = shards[0]->device;
+    grp->d = shards[0]->d; grp->dp = shards[0]->dp; grp->dtype = shards[0]->dtype; grp->id_offset = shards[0]->id_offset;
+    grp->n_cu = shards[0]->n_cu;
+    grp->n = 0;
+    for (vf_index* sh : shards) grp->n += sh->n;
+    grp->shards = shards;
+    // peer access home <-> shard devices where the platform offers it (copies fall back to staging otherwise)
+    for (vf_index* sh : shards) {
+        if (sh->device == grp->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, grp->device, sh->device) == hipSuccess && can) {
+            (void)hipSetDevice(grp->device);
+            (void)hipDeviceEnablePeerAccess(sh->device, 0);
+        }
+        if (hipDeviceCanAccessPeer(&can, sh->device, grp->device) == hipSuccess && can) {
+            (void)hipSetDevice(sh->device);
+            (void)hipDeviceEnablePeerAccess(grp->device, 0);
+        }
+        (void)hipGetLastError();  // "already enabled" is not an error
+    }
+    (void)hipSetDevice(grp->device);
+    *out = grp;
+    return VF_OK;
+}
+
+extern "C" int vf_index_group(vf_index** out, vf_index** shards, int32_t n_shards) {
+    if (!out || !shards || n_shards <= 0) return fail(VF_EINVAL, "vf_index_group: bad argument");
+    *out = nullptr;
+    std::vector<vf_index*> v(shards, shards + n_shards);
+    int64_t next = v[0] ? v[0]->id_offset : 0;
+    for (vf_index* sh : v) {
+        if (!sh || !sh->shards.empty()) return fail(VF_EINVAL, "vf_index_group: null or nested shard");
+        if (sh->d != v[0]->d || sh->dtype != v[0]->dtype) return fail(VF_EINVAL, "vf_index_group: shards differ in d / dtype");
+        if (sh->id_offset != next) return fail(VF_EINVAL, "vf_index_group: shards must be contiguous row blocks in ascending order");
+        next += sh->n;
+    }
+    return make_group(out, v);
+}
+
+static int check_devices(const int32_t* device_ids, int32_t n_dev, const char* who) {
+    if (!device_ids || n_dev <= 0 || n_dev > 64) return fail(VF_EINVAL, std::string(who) + ": bad device list");
+    int ndev = 0;
+    VF_HIP(hipGetDeviceCount(&ndev));
+    for (int i = 0; i < n_dev; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(VF_EINVAL, std::string(who) + ": bad device id");
+    return VF_OK;
+}
+
+static void shard_block(int64_t n, int n_dev, int g, int64_t* lo, int64_t* hi) {  // SURVEY.md 8e partitioning
+    const int64_t per = (n + n_dev - 1) / n_dev;
+    *lo = std::min<int64_t>(n, (int64_t)g * per);
+    *hi = std::min<int64_t>(n, *lo + per);
+}
+
+extern "C" int vf_index_create_sharded(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
+                                       const int32_t* device_ids, int32_t n_dev) {
+    if (!out) return fail(VF_EINVAL, "vf_index_create_sharded: null out");
+    *out = nullptr;
+    VF_TRY(check_devices(device_ids, n_dev, "vf_index_create_sharded"));
+    if (n < 0 || d <= 0 || (n > 0 && !rows)) return fail(VF_EINVAL, "vf_index_create_sharded: bad rows/n/d");
+    if (dtype != VF_DTYPE_F32 && dtype != VF_DTYPE_F16 && dtype != VF_DTYPE_FP8_E4M3)
+        return fail(VF_EINVAL, "vf_index_create_sharded: unknown dtype");
+    const size_t esz = dtype == VF_DTYPE_F32 ? 4 : (dtype == VF_DTYPE_F16 ? 2 : 1);
+    std::vector<vf_index*> shards;
     int rc = VF_OK;
-    auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (di) (void)hipFree(di); if (ds) (void)hipFree(ds); };
-    hipError_t e;
-    if ((e = hipMalloc((void**)&dq, (size_t)nq * ix->d * sizeof(float))) != hipSuccess ||
-        (e = hipMalloc((void**)&di, (size_t)nq * k * sizeof(int64_t))) != hipSuccess ||
-        (e = hipMalloc((void**)&ds, (size_t)nq * k * sizeof(float))) != hipSuccess) {
-        cleanup();
-        return fail(VF_ENOMEM, std::string("hipMalloc(search buffers): ") + hipGetErrorString(e));
+    for (int g = 0; g < n_dev && rc == VF_OK; ++g) {
+        int64_t lo, hi;
+        shard_block(n, n_dev, g, &lo, &hi);
+        vf_index* sh = nullptr;
+        rc = create_impl(&sh, (const char*)rows + (size_t)lo * d * esz, false, hi - lo, d, dtype, device_ids[g], lo);
+        if (rc == VF_OK) shards.push_back(sh);
     }
-    e = hipMemcpy(dq, queries, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { cleanup(); return fail(VF_EHIP, std::string("hipMemcpy(queries): ") + hipGetErrorString(e)); }
-    rc = vf_index_search_device(ix, dq, nq, k, di, ds, nullptr);
-    if (rc == VF_OK) {
-        e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess) e = hipMemcpy(out_ids, di, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(out_scores, ds, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(VF_EHIP, std::string("copy results: ") + hipGetErrorString(e));
-    }
-    cleanup();
+    if (rc == VF_OK) rc = make_group(out, shards);
+    if (rc != VF_OK) { const std::string keep = g_err; for (vf_index* sh : shards) destroy_index(sh); g_err = keep; }
     return rc;
+}
+
+extern "C" int vf_index_create_sharded_from_file(vf_index** out, const char* path, const int32_t* device_ids, int32_t n_dev) {
+    if (!out || !path) return fail(VF_EINVAL, "vf_index_create_sharded_from_file: null argument");
+    *out = nullptr;
+    VF_TRY(check_devices(device_ids, n_dev, "vf_index_create_sharded_from_file"));
+    int64_t n = 0;
+    VF_TRY(vf_corpus_file_info(path, &n, nullptr, nullptr, nullptr));
+    std::vector<vf_index*> shards;
+    int rc = VF_OK;
+    for (int g = 0; g < n_dev && rc == VF_OK; ++g) {
+        int64_t lo, hi;
+        shard_block(n, n_dev, g, &lo, &hi);
+        vf_index* sh = nullptr;
+        rc = vf_index_create_from_file(&sh, path, lo, hi, device_ids[g], lo);
+        if (rc == VF_OK) shards.push_back(sh);
+    }
+    if (rc == VF_OK) rc = make_group(out, shards);
+    if (rc != VF_OK) { const std::string keep = g_err; for (vf_index* sh : shards) destroy_index(sh); g_err = keep; }
+    return rc;
+}
+
+extern "C" int vf_index_shards(vf_index* ix, int32_t* n_shards, int32_t* device_ids, int32_t cap) {
+    if (!ix || !n_shards) return fail(VF_EINVAL, "vf_index_shards: null argument");
+    const int G = (int)ix->shards.size();
+    *n_shards = G;
+    for (int g = 0; g < G && g < cap && device_ids; ++g) device_ids[g] = ix->shards[g]->device;
+    return VF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

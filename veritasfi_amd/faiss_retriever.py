@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 class FaissRetriever:
     """Exact cosine retriever; the corpus lives in HBM, search runs as hand-written gfx950 kernels."""
 
-    def __init__(self, embeddings, embedding_fn, device_id: int = 0):
+    def __init__(self, embeddings, embedding_fn, device_id: int = 0, device_ids=None):
         # reference :13-24: np.array(embeddings) -> astype('float32') -> normalize_L2 -> IndexFlatIP.add
         self.embeddings = embedding_fn
         embeddings = np.array(embeddings)
@@ -26,7 +26,8 @@ class FaissRetriever:
             raise ValueError("embeddings must be a 2-D array-like [n, d]")
         dimension = embeddings.shape[1]
         x = embeddings if embeddings.dtype == np.float16 else embeddings.astype("float32")
-        self.index = DenseIndex(x, device_id=device_id)
+        # device_ids=[0..7]: the corpus is row-sharded over those GPUs behind the same handle (one process, no torchrun)
+        self.index = DenseIndex(x, device_id=device_id, device_ids=device_ids)
         logger.info(f"Building HIP dense index with {len(embeddings)} vectors of dimension {dimension}")
 
     def invoke(self, querys: list, k: int):

@@ -18,16 +18,51 @@ def _is_torch_tensor(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
 
+def _dev_array(device_ids):
+    ids = [int(x) for x in device_ids]
+    if not ids:
+        raise ValueError("device_ids must name at least one device")
+    return (_ffi.c_i32 * len(ids))(*ids), ids
+
+
 class DenseIndex:
-    def __init__(self, rows, device_id: int = 0, id_offset: int = 0):
+    def __init__(self, rows, device_id: int = 0, id_offset: int = 0, device_ids=None):
         """rows: [n, d] float32 / float16 ndarray (copied to HBM) or a CUDA torch tensor (borrowed).
         FP8: a torch.float8_e4m3fn tensor (CPU or CUDA), or a uint8 ndarray / tensor of OCP e4m3 codes passed with
-        ``DenseIndex.from_e4m3``; the bytes stay fp8 in HBM (scanned as fp8, converted exactly in registers)."""
+        ``DenseIndex.from_e4m3``; the bytes stay fp8 in HBM (scanned as fp8, converted exactly in registers).
+        device_ids=[...]: ONE handle over several GPUs in this process (``vf_index_create_sharded``): host rows are
+        split into contiguous blocks, one per listed device; every search method works on it unchanged, device
+        buffers live on the home device ``device_ids[0]``."""
         L = _ffi.lib()
         self._h = _ffi.vp()
         self._keepalive = None
         self.device_id = int(device_id)
+        self.device_ids = None
         e4m3 = getattr(self, "_e4m3", False)
+        if device_ids is not None:
+            if _is_torch_tensor(rows):
+                import torch
+                if rows.dtype == getattr(torch, "float8_e4m3fn", None):
+                    rows, e4m3 = rows.view(torch.uint8), True
+                rows = rows.cpu().numpy()   # the sharded constructor distributes HOST rows (DenseIndex.group adopts device shards)
+            rows = np.asarray(rows)
+            if rows.ndim != 2:
+                raise ValueError("rows must be [n, d]")
+            if e4m3:
+                if rows.dtype != np.uint8:
+                    raise TypeError("e4m3 rows must be uint8 codes")
+                dt = _ffi.VF_DTYPE_FP8_E4M3
+            elif rows.dtype == np.float16:
+                dt = _ffi.VF_DTYPE_F16
+            else:
+                rows, dt = rows.astype(np.float32, copy=False), _ffi.VF_DTYPE_F32
+            rows = np.ascontiguousarray(rows)
+            arr, ids = _dev_array(device_ids)
+            self.n, self.d, self.id_offset = int(rows.shape[0]), int(rows.shape[1]), 0
+            self.device_id, self.device_ids = ids[0], ids
+            _ffi.check(L.vf_index_create_sharded(ctypes.byref(self._h), rows.ctypes.data, self.n, self.d, dt, arr, len(ids)),
+                       "vf_index_create_sharded")
+            return
         if _is_torch_tensor(rows):
             import torch
             if rows.dtype == getattr(torch, "float8_e4m3fn", None):
@@ -71,18 +106,27 @@ class DenseIndex:
                                      self.id_offset), "vf_index_create")
 
     @classmethod
-    def from_file(cls, path: str, rank: int = 0, world: int = 1, device_id: int = 0):
+    def from_file(cls, path: str, rank: int = 0, world: int = 1, device_id: int = 0, device_ids=None):
         """Rows of this rank's shard of a corpus file (veritasfi_amd/corpus_file.py), streamed disk -> HBM by the
-        library; returned ids are file row numbers (id_offset = the shard's first row)."""
+        library; returned ids are file row numbers (id_offset = the shard's first row).  device_ids=[...]: the whole
+        file, one block per listed device, behind one handle (single-process multi-GPU)."""
         from .sharded import shard_bounds
         n, d, dt, has = _ffi.c_i64(0), _ffi.c_i32(0), _ffi.c_i32(0), _ffi.c_i32(0)
         L = _ffi.lib()
         _ffi.check(L.vf_corpus_file_info(path.encode(), ctypes.byref(n), ctypes.byref(d), ctypes.byref(dt),
                                          ctypes.byref(has)), "vf_corpus_file_info")
-        lo, hi = shard_bounds(n.value, world, rank)
         self = cls.__new__(cls)
         self._h = _ffi.vp()
         self._keepalive = None
+        self.device_ids = None
+        if device_ids is not None:
+            arr, ids = _dev_array(device_ids)
+            self.device_id, self.device_ids, self.id_offset = ids[0], ids, 0
+            self.n, self.d = int(n.value), int(d.value)
+            _ffi.check(L.vf_index_create_sharded_from_file(ctypes.byref(self._h), path.encode(), arr, len(ids)),
+                       "vf_index_create_sharded_from_file")
+            return self
+        lo, hi = shard_bounds(n.value, world, rank)
         self.device_id, self.id_offset = int(device_id), int(lo)
         self.n, self.d = int(hi - lo), int(d.value)
         _ffi.check(L.vf_index_create_from_file(ctypes.byref(self._h), path.encode(), lo, hi, self.device_id, lo),
@@ -90,11 +134,30 @@ class DenseIndex:
         return self
 
     @classmethod
-    def from_e4m3(cls, codes, device_id: int = 0, id_offset: int = 0):
+    def group(cls, shards):
+        """Adopt per-device indexes (contiguous row blocks in ascending order, each built with id_offset = its first
+        row) as ONE handle (``vf_index_group``).  The group owns them: the given objects are emptied."""
+        shards = list(shards)
+        L = _ffi.lib()
+        arr = (_ffi.vp * len(shards))(*[s._h for s in shards])
+        self = cls.__new__(cls)
+        self._h = _ffi.vp()
+        _ffi.check(L.vf_index_group(ctypes.byref(self._h), arr, len(shards)), "vf_index_group")
+        self._keepalive = [s._keepalive for s in shards]   # borrowed device rows stay alive with the group
+        self.device_ids = [s.device_id for s in shards]
+        self.device_id, self.id_offset = shards[0].device_id, shards[0].id_offset
+        self.n, self.d = sum(s.n for s in shards), shards[0].d
+        for s in shards:
+            s._h = _ffi.vp()
+            s._keepalive = None
+        return self
+
+    @classmethod
+    def from_e4m3(cls, codes, device_id: int = 0, id_offset: int = 0, device_ids=None):
         """codes: [n, d] uint8 OCP-e4m3 bytes (ndarray, CPU or CUDA tensor)."""
         self = cls.__new__(cls)
         self._e4m3 = True
-        self.__init__(codes, device_id=device_id, id_offset=id_offset)
+        self.__init__(codes, device_id=device_id, id_offset=id_offset, device_ids=device_ids)
         return self
 
     # -- host buffers ------------------------------------------------------------------------------
@@ -149,6 +212,13 @@ class DenseIndex:
         return int(out.value)
 
     # -- misc --------------------------------------------------------------------------------------
+    def shard_devices(self) -> list:
+        """Devices of the shards behind this handle ([] for a plain single-device index)."""
+        n = _ffi.c_i32(0)
+        devs = (_ffi.c_i32 * 64)()
+        _ffi.check(_ffi.lib().vf_index_shards(self._h, ctypes.byref(n), devs, 64), "vf_index_shards")
+        return [int(devs[i]) for i in range(min(int(n.value), 64))]
+
     def stats(self) -> dict:
         st = _ffi.SearchStats()
         _ffi.check(_ffi.lib().vf_index_stats(self._h, ctypes.byref(st)), "vf_index_stats")
