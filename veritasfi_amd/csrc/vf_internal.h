@@ -59,6 +59,7 @@ struct ScanArgs {
 
 struct FinalArgs {
     const u32* cnt; const u64* cand; int cap;
+    int top_cap, sel_cap;    // LDS areas of k_final (set by launch_final)
     const int* tau_bin;      // final thresholds of the scan (validity check)
     const void* rows_orig; int orig_dtype; long long orig_row_elems;  // exact rows for rescoring (VF_DTYPE_*)
     const float* norm;       // canonical norms [n]
@@ -90,7 +91,7 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
 // test hook: the scan's hardware e4m3 -> fp16 conversion over `count` codes (device pointers)
 hipError_t launch_debug_cvt_e4m3(const unsigned char* in, float* out, int count, hipStream_t s);
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
-hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s);
+hipError_t launch_final(FinalArgs a, int nq, hipStream_t s);
 hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,
                              int k, long long* ids, float* scores, hipStream_t s);
 hipError_t launch_merge_topk_packed(const void* parts, int nparts, int nq, int k, long long* ids, float* scores,

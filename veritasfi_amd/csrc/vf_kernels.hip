@@ -1050,18 +1050,18 @@ hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_final: per query.  Rank the candidates by approximate score, re-score the best k' with the
-// CANONICAL fp32 arithmetic (bit-identical to oracle/vf_oracle.c), rank by (canonical desc, id asc),
-// write k results and the exactness certificate:
+// k_final: per query.  Keep the candidates at or above the scan's final threshold, take the best k' of them by
+// approximate score, re-score those with the CANONICAL fp32 arithmetic (bit-identical to oracle/vf_oracle.c), rank
+// by (canonical desc, id asc), write k results and the exactness certificate:
 //   every row not re-scored has approx <= A (A = approx of the k'-th candidate), hence canonical
 //   <= A + eps; if canonical_k > A + eps no such row can enter the top k  =>  result is exact.
-// Ranking is by counting (rank = number of larger keys; keys are unique): O(n^2 / threads) compares
-// against LDS-broadcast keys but NO barriers inside, which beats a bitonic network at n ~ 1-2k
-// (a 1024-thread bitonic sort of 2048 keys costs 66 barriers, ~100 us measured).  n > 4096 (hostile
-// data) falls back to the bitonic sort.
+// LDS holds only the survivors (<= sel_cap, typically 1.2-2 x k') and the ranked k': 12 KB at k = 100, 46 KB at
+// k = 1000 -- the candidate list itself (up to 16384 per query) is read once from global memory.  Ranking is by
+// counting (rank = number of larger keys; keys are unique): O(n^2 / threads) compares against LDS-broadcast keys
+// but NO barriers inside.  If the threshold turns out not to be a valid bound and the list does not fit the
+// survivor area, the query is flagged and recomputed by the exact path (hostile data only).
 // ------------------------------------------------------------------------------------------------
-constexpr int kFinalThreads = 512;
-constexpr int kRankMaxN = 4096;
+constexpr int kFinalThreads = 256;
 
 // out[r] = the key of rank r (descending) for every r < limit; keys[0..n) unique, in LDS.
 __device__ __forceinline__ void rank_select_desc(const u64* keys, int n, u64* out, int limit, int tid) {
@@ -1097,44 +1097,98 @@ __device__ __forceinline__ void rank_select_desc(const u64* keys, int n, u64* ou
     }
 }
 
-// Canonical cosine of one corpus row against the (already normalised) query, by one 16-lane group:
-// lane l owns partial sum l (elements l, l+16, ...), then the fixed tree.  All of a batch's loads are
-// issued UNCONDITIONALLY (index clamped, value masked afterwards) with the dtype a template
-// parameter: a per-element runtime condition around a load makes hipcc branch around each one and
-// wait vmcnt(0) per element -- 48 serialized round trips per row, 18 us measured.
+// Canonical cosine of one corpus row against the (already normalised) query by TWO lanes: lane half h owns the
+// partial sums acc[8h .. 8h+7] (elements j with (j & 15) in that range, in ascending j: the oracle's order), then
+// the fixed tree.  A lane streams its 8 elements of every 16-element block with one 16-byte load (fp16 rows; two
+// for fp32 rows, one 8-byte load for fp8 rows), kBlk blocks in flight at once; all loads are issued
+// UNCONDITIONALLY (block index clamped, contribution masked): a runtime condition around a load makes hipcc
+// branch around each one and wait vmcnt(0) per element.  qs = the query vector in LDS (broadcast reads).
+template <int DT> struct RowVec;
+template <> struct RowVec<VF_DTYPE_F16> { typedef uint4 type; };
+template <> struct RowVec<VF_DTYPE_FP8_E4M3> { typedef uint2 type; };
+template <> struct RowVec<VF_DTYPE_F32> { struct type { uint4 a, b; }; };
+
 template <int DT>
-__device__ __forceinline__ float rescore_row(const void* rows, long long base, int d, const float* qv, float nm,
-                                             int l) {
-    float acc = 0.0f;
-    const float inv = canon_inv(nm);
-    for (int j0 = l; j0 < d; j0 += 16 * 48) {
-        float cv[48];
+__device__ __forceinline__ void decode8(const typename RowVec<DT>::type& v, float (&x)[8]) {
+    if constexpr (DT == VF_DTYPE_F16) {
+        const h8 hv = __builtin_bit_cast(h8, v);
 #pragma unroll
-        for (int u = 0; u < 48; ++u) {
-            const int j = j0 + 16 * u;
-            const long long idx = base + (j < d ? j : d - 1);
-            cv[u] = DT == VF_DTYPE_F16 ? (float)((const _Float16*)rows)[idx]
-                    : DT == VF_DTYPE_FP8_E4M3 ? (float)((const unsigned char*)rows)[idx]   // raw code; decoded below
-                                              : ((const float*)rows)[idx];
-        }
+        for (int e = 0; e < 8; ++e) x[e] = (float)hv[e];
+    } else if constexpr (DT == VF_DTYPE_FP8_E4M3) {
+        const h8 hv = cvt8_e4m3(v.x, v.y);   // the scan's own conversion (pinned against the oracle's table)
 #pragma unroll
-        for (int u = 0; u < 48; ++u) {
-            const int j = j0 + 16 * u;
-            const float qq = qv[j < d ? j : d - 1];
-            const float cx = DT == VF_DTYPE_FP8_E4M3 ? e4m3_to_float((u32)cv[u]) : cv[u];
-            const float t = __builtin_fmaf(qq, cx * inv, acc);
-            acc = j < d ? t : acc;
-        }
+        for (int e = 0; e < 8; ++e) x[e] = (float)hv[e];
+    } else {
+        x[0] = __uint_as_float(v.a.x); x[1] = __uint_as_float(v.a.y); x[2] = __uint_as_float(v.a.z); x[3] = __uint_as_float(v.a.w);
+        x[4] = __uint_as_float(v.b.x); x[5] = __uint_as_float(v.b.y); x[6] = __uint_as_float(v.b.z); x[7] = __uint_as_float(v.b.w);
     }
-    return group16_tree(acc);
+}
+
+template <int DT>
+__device__ __forceinline__ float rescore_pair(const void* rows, long long row, int d, const float* qs, float nm, int h) {
+    constexpr int ESZ = DT == VF_DTYPE_F32 ? 4 : (DT == VF_DTYPE_F16 ? 2 : 1);
+    constexpr int kBlk = DT == VF_DTYPE_F32 ? 8 : 16;   // 16-element blocks in flight per lane
+    typedef typename RowVec<DT>::type vec_t;
+    const float inv = canon_inv(nm);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    const char* base = (const char*)rows + row * (long long)d * ESZ;
+    const int nblk = d >> 4;
+    if ((((long long)d * ESZ) & 15) == 0) {
+        for (int b0 = 0; b0 < nblk; b0 += kBlk) {
+            vec_t v[kBlk];
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) {
+                const int b = b0 + u < nblk ? b0 + u : nblk - 1;
+                v[u] = *(const vec_t*)(base + ((long long)b * 16 + 8 * h) * ESZ);
+            }
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) {
+                const bool live = b0 + u < nblk;
+                const int b = live ? b0 + u : nblk - 1;
+                float x[8];
+                decode8<DT>(v[u], x);
+                const float4 q0 = *(const float4*)(qs + b * 16 + 8 * h), q1 = *(const float4*)(qs + b * 16 + 8 * h + 4);
+                const float qq[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = __builtin_fmaf(qq[e], x[e] * inv, acc[e]);
+                    acc[e] = live ? t : acc[e];
+                }
+            }
+        }
+    } else {  // rows that are not 16-byte aligned (odd d): element loads, same order
+        for (int b = 0; b < nblk; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = b * 16 + 8 * h + e;
+                acc[e] = __builtin_fmaf(qs[j], load_elem(rows, DT, row * (long long)d + j) * inv, acc[e]);
+            }
+    }
+    // tail block (d % 16 elements): element j = 16 nblk + 8 h + e exists while j < d
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = nblk * 16 + 8 * h + e;
+        if (j < d) acc[e] = __builtin_fmaf(qs[j], load_elem(rows, DT, row * (long long)d + j) * inv, acc[e]);
+    }
+    // canonical tree: s8[l] = acc[l] + acc[l + 8] needs the partner half's sums; then 4, 2, 1 in-lane
+    float s8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s8[e] = acc[e] + __shfl_xor(acc[e], 1);
+    const float s4[4] = {s8[0] + s8[4], s8[1] + s8[5], s8[2] + s8[6], s8[3] + s8[7]};
+    return (s4[0] + s4[2]) + (s4[1] + s4[3]);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    u64* ck = (u64*)smem_raw;                 // [cap] candidate keys
-    u64* top = ck + a.cap;                    // [4096] ranked approx keys, then ranked canonical keys
-    u64* rk = ck;                             // re-scored keys (unordered): reuses ck once `top` is built
-    float* qs = (float*)(top + 4096);         // [d] this query's canonical normalised vector
+    u64* top = (u64*)smem_raw;                // [top_cap] ranked approx keys, then ranked canonical keys
+    u64* sel = top + a.top_cap;               // [sel_cap] survivors of the threshold pre-filter
+    u64* rk = sel;                            // re-scored keys (unordered): reuses sel once `top` is built
+    float* qs = (float*)(sel + a.sel_cap);    // [d] this query's canonical normalised vector (+ 4 spare words)
+    u32* lh = (u32*)(qs + ((a.d + 3) & ~3));  // [kHistBins] histogram of the candidates' score bins
+    u32& s_nsel = lh[kHistBins];              // all LDS is dynamic: the kernel may be given the full 160 KB
+    int& s_bin = *(int*)(lh + kHistBins + 1);
     const int q = blockIdx.x, tid = threadIdx.x;
     unsigned long long* dbg = (a.dbg && tid == 0) ? a.dbg + (long long)q * 8 : nullptr;
     if (dbg) dbg[0] = wall_clock64();
@@ -1142,62 +1196,50 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     const int n = n_raw < (u32)a.cap ? (int)n_raw : a.cap;
     const int m = n < a.kprime ? n : a.kprime;
     const u64* cq = a.cand + (long long)q * a.cap;
-    // Pre-filter by the scan's final threshold: if at least k' candidates sit at or above tau (i.e. tau
-    // is a valid bound -- normally it is, and tight), nothing below it can be among the best k', so only
-    // the survivors (typically 1.2-2 x k') are ranked instead of every candidate the scan ever kept.
-    u64* sel = (u64*)(qs + ((a.d + 1) & ~1));  // [4096] + counter, when the LDS budget allows (see launch_final)
-    u32& s_nsel = *(u32*)(sel + 4096);
-    const bool can_sel = (size_t)a.cap * 8 + 2 * 4096 * 8 + ((size_t)a.d + 1) * 4 + 16 <= 160 * 1024;
-    bool ranked = false;
-    if (can_sel && n > a.kprime) {
-        if (tid == 0) s_nsel = 0u;
-        __syncthreads();
-        const int tbin = a.tau_bin[q];
-        for (int i = tid; i < n; i += kFinalThreads) {
-            const u64 kv = cq[i];
-            if (bin_of_x(bin_x(unorderkey((u32)(kv >> 32)))) >= tbin) {
-                const u32 sl = atomicAdd(&s_nsel, 1u);
-                if (sl < 4096u) sel[sl] = kv;
-            }
-        }
-        __syncthreads();
-        const int ns = (int)s_nsel;
-        if (ns >= a.kprime && ns <= 4096) {
-            rank_select_desc(sel, ns, top, m, tid);
-            ranked = true;
+    const int tbin = a.tau_bin[q];
+    for (int j = tid; j < a.d; j += kFinalThreads) qs[j] = a.qn[(long long)q * a.d + j];
+    for (int b = tid; b < kHistBins; b += kFinalThreads) lh[b] = 0u;
+    if (tid == 0) { s_nsel = 0u; s_bin = 0; }
+    __syncthreads();
+    // Select by the list's OWN histogram: the highest bin b* with >= m candidates at or above it; everything below
+    // b* cannot be among the best m.  (The scan's final threshold is usually the same bin, but it may be looser --
+    // small corpora, stale refreshes -- and is only needed for the completeness check at the end.)
+    for (int i = tid; i < n; i += kFinalThreads) atomicAdd(&lh[bin_of_x(bin_x(unorderkey((u32)(cq[i] >> 32))))], 1u);
+    __syncthreads();
+    if (tid < 64) {
+        const int nb = wave_tau_from_lds(lh, m > 0 ? m : 1, tid);
+        if (tid == 0) s_bin = nb > 0 ? nb : 0;
+    }
+    __syncthreads();
+    const int sbin = s_bin;
+    for (int i = tid; i < n; i += kFinalThreads) {
+        const u64 kv = cq[i];
+        if (bin_of_x(bin_x(unorderkey((u32)(kv >> 32)))) >= sbin) {
+            const u32 sl = atomicAdd(&s_nsel, 1u);
+            if (sl < (u32)a.sel_cap) sel[sl] = kv;
         }
     }
-    if (ranked) {
-    } else if (n <= kRankMaxN) {
-        for (int i = tid; i < n; i += kFinalThreads) ck[i] = cq[i];
-        __syncthreads();
-        rank_select_desc(ck, n, top, m, tid);
-    } else {
-        const int P = next_pow2(n);
-        for (int i = tid; i < P; i += kFinalThreads) ck[i] = i < n ? cq[i] : 0ull;
-        __syncthreads();
-        bitonic_sort_desc(ck, P, tid, kFinalThreads);
-        for (int i = tid; i < m; i += kFinalThreads) top[i] = ck[i];
+    __syncthreads();
+    const int ns = (int)s_nsel;
+    if (ns > a.sel_cap) {  // more than sel_cap candidates share the boundary bin (hostile data): exact path
+        for (int i = tid; i < a.k; i += kFinalThreads) { a.out_ids[(long long)q * a.k + i] = -1; a.out_scores[(long long)q * a.k + i] = -FLT_MAX; }
+        if (tid == 0) { a.flags[q] = n_raw > (u32)a.cap ? 2 : 1; a.cand_count_out[q] = n_raw; }
+        return;
     }
+    rank_select_desc(sel, ns, top, m, tid);
     __syncthreads();
     if (dbg) dbg[1] = wall_clock64();
     const float approx_floor = m > 0 ? unorderkey((u32)(top[m - 1] >> 32)) : -INFINITY;
-    // canonical re-score: one 16-lane group per row, all of a row's loads in flight at once
-    const int g = tid >> 4, l = tid & 15;
-    // the query vector is staged in LDS when it fits next to the candidate keys (it does unless cap = 16384)
-    const bool q_in_lds = (size_t)a.cap * 8 + 4096 * 8 + (size_t)a.d * 4 <= 160 * 1024;
-    if (q_in_lds) {
-        for (int j = tid; j < a.d; j += kFinalThreads) qs[j] = a.qn[(long long)q * a.d + j];
-        __syncthreads();
-    }
-    const float* qv = q_in_lds ? qs : a.qn + (long long)q * a.d;
-    for (int i = g; i < m; i += kFinalThreads / 16) {
-        const u32 row = (u32)top[i];
-        const long long rbase = (long long)row * a.orig_row_elems;
-        const float acc = a.orig_dtype == VF_DTYPE_F16       ? rescore_row<VF_DTYPE_F16>(a.rows_orig, rbase, a.d, qv, a.norm[row], l)
-                          : a.orig_dtype == VF_DTYPE_FP8_E4M3 ? rescore_row<VF_DTYPE_FP8_E4M3>(a.rows_orig, rbase, a.d, qv, a.norm[row], l)
-                                                              : rescore_row<VF_DTYPE_F32>(a.rows_orig, rbase, a.d, qv, a.norm[row], l);
-        if (l == 0) rk[i] = ((u64)orderkey(acc) << 32) | (u64)(0xFFFFFFFFu - row);
+    // canonical re-score: two lanes per row, a block of 128 rows at a time
+    const int pr = tid >> 1, h = tid & 1;
+    for (int i0 = 0; i0 < m; i0 += kFinalThreads / 2) {
+        const int i = i0 + pr;
+        const u32 row = (u32)top[i < m ? i : m - 1];   // idle pairs shadow the last row (whole wave stays converged)
+        const float nm = a.norm[row];
+        const float acc = a.orig_dtype == VF_DTYPE_F16       ? rescore_pair<VF_DTYPE_F16>(a.rows_orig, row, a.d, qs, nm, h)
+                          : a.orig_dtype == VF_DTYPE_FP8_E4M3 ? rescore_pair<VF_DTYPE_FP8_E4M3>(a.rows_orig, row, a.d, qs, nm, h)
+                                                              : rescore_pair<VF_DTYPE_F32>(a.rows_orig, row, a.d, qs, nm, h);
+        if (h == 0 && i < m) rk[i] = ((u64)orderkey(acc) << 32) | (u64)(0xFFFFFFFFu - row);
     }
     __syncthreads();
     if (dbg) dbg[2] = wall_clock64();
@@ -1220,7 +1262,6 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
         if (n_raw > (u32)a.cap) flag = 2;
         else if ((long long)m < a.n_rows) {  // some row was not re-scored: need the certificate
             // (1) the final tau must be a valid bound: >= kprime candidates at or above it
-            const int tbin = a.tau_bin[q];
             if (tbin > 0 && (m < a.kprime || bin_of_x(bin_x(approx_floor)) < tbin)) flag = 1;
             // (2) the k-th canonical score must clear every row that was not re-scored
             if (a.k > m) flag = 1;
@@ -1236,11 +1277,13 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     }
 }
 
-hipError_t launch_final(const FinalArgs& a, int nq, hipStream_t s) {
+hipError_t launch_final(FinalArgs a, int nq, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
-    size_t lds = (size_t)a.cap * 8 + 4096 * 8;
-    if (lds + (size_t)a.d * 4 <= 160 * 1024) lds += ((size_t)a.d + 1) * 4;       // query vector
-    if (lds + 4096 * 8 + 16 <= 160 * 1024) lds += 4096 * 8 + 16;                  // pre-filter survivors + counter
+    a.top_cap = (a.kprime + 1) & ~1;
+    int sc = 1024;
+    while (sc < 3 * a.kprime && sc < 4096) sc <<= 1;   // survivors are typically 1.2-2 x k'
+    a.sel_cap = sc > a.top_cap ? sc : a.top_cap;
+    const size_t lds = ((size_t)a.top_cap + a.sel_cap) * 8 + ((size_t)a.d + 4 + kHistBins + 4) * 4;
     hipLaunchKernelGGL(k_final, dim3(nq), dim3(kFinalThreads), lds, s, a);
     return hipGetLastError();
 }
