@@ -702,3 +702,58 @@ def test_single_process_sharded_handle(vf, oracle, tmp_path):
             a.close(); b.close()
     with pytest.raises(RuntimeError):
         vf.DenseIndex(c[:10], device_ids=[0, 99])
+
+
+# ---- wide scan (k_scan_wide): more than 128 queries share one read of the shard ---------------------------------------
+@pytest.mark.parametrize("n,d,nq,k,kind", [
+    (60_000, 768, 130, 100, "f16"),      # one 256-query tile, padded
+    (90_001, 1024, 700, 10, "fp8"),      # three tiles, ragged row count
+    (50_000, 768, 1024, 100, "fp8"),     # four tiles (one workgroup per CU), fp8 rows with dp = 768
+    (120_000, 256, 1500, 50, "f16"),     # two passes (1024 + 476)
+    (40_000, 384, 300, 20, "f16"),       # dp = 384: 6 chunks per tile
+    (70_000, 1024, 256, 1000, "f16"),    # large k on the wide path
+    (30_000, 640, 200, 10, "fp8"),       # fp8 with dp = 640 (not a multiple of 256): falls back to 64-query passes
+])
+def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
+    from oracle import ref_numpy as R
+    q = np.random.default_rng(62).standard_normal((nq, d)).astype(np.float32)
+    if kind == "fp8":
+        codes = _e4m3_codes(n, d, 61)
+        rows16 = R.decode_e4m3(codes).astype(np.float16)
+        ix = vf.DenseIndex.from_e4m3(codes)
+    else:
+        rows16 = np.random.default_rng(61).standard_normal((n, d)).astype(np.float32).astype(np.float16)
+        ix = vf.DenseIndex(rows16)
+    try:
+        got_i, got_s = ix.search(q, k)
+        st = ix.stats()
+        ix.set_option("wide", 0)                            # the 64-query passes on the same handle: identical answer
+        ref_i, ref_s = ix.search(q[:70], k)
+    finally:
+        ix.close()
+    print("wide stats", (n, d, nq, k, kind), st)
+    assert st["path"] == 1 and st["overflowed"] == 0
+    want_i, want_s = oracle.search(rows16, q, k)
+    bad = np.nonzero((got_i != want_i).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {nq} queries differ, first {bad[:5].tolist()}"
+    assert np.array_equal(_bits(got_s), _bits(want_s))
+    assert np.array_equal(ref_i, want_i[:70]) and np.array_equal(_bits(ref_s), _bits(want_s[:70]))
+    assert st["exact_reruns"] <= max(1, nq // 16), st
+
+
+def test_wide_scan_hostile_data(vf, oracle):
+    """Duplicates and a score-sorted corpus under 200 queries: stage flushes, overflow to the global lists, repairs."""
+    rng = np.random.default_rng(63)
+    n, d, nq = 40_000, 256, 200
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    hot = (q[0] + 0.05 * rng.standard_normal(d)).astype(np.float32)
+    base[rng.choice(n, 400, replace=False)] = hot
+    c = base.astype(np.float16)
+    sims = oracle.cosine(q[1:2], c.astype(np.float32))[0]
+    for corpus in (c, c[np.argsort(sims, kind="stable")]):
+        with vf.DenseIndex(corpus) as ix:
+            ids, sc = ix.search(q, 100)
+            st = ix.stats()
+        print("wide hostile stats", st)
+        _assert_exact(oracle, corpus, q, 100, ids, sc)

@@ -136,7 +136,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0;
+            refresh_every = 128, debug = 0, wide_opt = 1;  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
@@ -476,6 +476,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "waves") { if (!in_range(0, 8 * 1024)) return fail(VF_EINVAL, "waves must be in [0, 8192]"); ix->waves_opt = value; }
     else if (s == "scan_g") { if (!in_range(0, 4)) return fail(VF_EINVAL, "scan_g must be in [0, 4]"); ix->scan_g = value; }
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
+    else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
     else return fail(VF_EINVAL, "vf_index_set_option: unknown option " + s);
@@ -591,6 +592,77 @@ static int select_path(const vf_index* ix, int k) {
     return fused_possible(ix, k) ? 1 : 2;
 }
 
+// ---- wide passes (k_scan_wide): up to 1024 queries share ONE read of the shard --------------------------------------
+constexpr int kWideMinQueries = 129;   // below this the 64-query HBM-bound passes are faster (2 of them at most)
+constexpr int kWideMaxQueries = 1024;  // 4 query tiles of 256 per pass: one workgroup per CU
+constexpr int kWideTile = 256;
+
+static bool wide_possible(const vf_index* ix, int nq) {
+    if (ix->wide_opt == 0 || nq < (ix->wide_opt > 1 ? (int)ix->wide_opt : kWideMinQueries)) return false;
+    // a register stage is 2 k-chunks of fp8 rows / 1 of fp16 rows and a tile alternates two stages
+    return ix->dp % (ix->dtype == VF_DTYPE_FP8_E4M3 ? 256 : 128) == 0;
+}
+
+static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_queries, int nb, int k, int64_t* d_ids,
+                     float* d_scores, int flag_off, float* qn_b, bool timed, hipStream_t st, int slot_id) {
+    const int qtot = (nb + kWideTile - 1) / kWideTile * kWideTile;
+    const int J = qtot / kWideTile;
+    const int RG = std::max(1, ix->n_cu / J);
+    FusedPlan p = p0;
+    if (p.kprime > 256) p.cap = 16384;   // k ~ 1000: ~k' (1 + ln(n / sample)) candidates per query
+    const int samp = J >= 2 ? 64 : 32;   // sample rows per row group = samp * 8: 32768 / 65536 rows in all
+    const size_t slen = (size_t)RG * samp * 8;
+    VF_TRY(s.qimg.ensure((size_t)ix->dp * qtot * 2));
+    VF_TRY(s.s0.ensure((size_t)qtot * slen * sizeof(float)));
+    VF_TRY(s.cnt.ensure((size_t)qtot * kCntStride * sizeof(u32)));
+    VF_TRY(s.tau.ensure((size_t)qtot * sizeof(int)));
+    VF_TRY(s.hist.ensure((size_t)qtot * kHistBins * sizeof(u32)));
+    VF_TRY(s.hist_coarse.ensure((size_t)qtot * 64 * sizeof(u32)));
+    VF_TRY(s.cand.ensure((size_t)qtot * p.cap * sizeof(u64)));
+    if (s.wgbase_n != ix->n || s.wgbase_grid != -RG) {   // negative grid tag: the row-group table of the wide scan
+        std::vector<long long> base(RG);
+        for (int w = 0; w < RG; ++w) base[w] = ix->n * (long long)w / RG;
+        VF_TRY(s.wgbase.ensure((size_t)RG * sizeof(long long)));
+        VF_HIP(hipMemcpyAsync(s.wgbase.p, base.data(), (size_t)RG * sizeof(long long), hipMemcpyHostToDevice, st));
+        VF_HIP(hipStreamSynchronize(st));
+        s.wgbase_n = ix->n; s.wgbase_grid = -RG;
+    }
+    VF_HIP(launch_prep_queries(d_queries, nb, ix->d, ix->dp, qtot, qn_b, s.qimg.as<_Float16>(), st));
+    const bool f8 = ix->dtype == VF_DTYPE_FP8_E4M3;
+    ScanArgs a{};
+    a.rows = (const char*)ix->rows_scan; a.inv_scan = ix->inv_scan; a.qimg = s.qimg.as<_Float16>();
+    a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * (f8 ? 1 : 2);
+    a.total_waves = RG * 8; a.samp = samp;
+    a.s0 = s.s0.as<float>(); a.wg_base = s.wgbase.as<long long>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>();
+    a.hist = s.hist.as<u32>(); a.hist_coarse = s.hist_coarse.as<u32>(); a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
+    a.stage_cap = 2048; a.dbg = nullptr; a.debug = (int)ix->debug;
+    a.refresh_every = (int)std::min<int64_t>(256, std::max<int64_t>(1, ix->refresh_every)); a.nq = nb;
+    a.qn_total = qtot; a.jtiles = J; a.rgroups = RG;
+    if (ix->n / RG < (int64_t)samp * 8)   // sample slots no wave writes must read as empty (NaN)
+        VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qtot * slen * sizeof(float), st));
+    VF_HIP(launch_scan_wide(a, kModeSample, f8, st));
+    VF_HIP(launch_sel0(a, qtot, st));
+    for (int o = 0; o < kSlots; ++o)
+        if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
+    if (timed) VF_HIP(hipEventRecord(s.ev_t[0], st));
+    VF_HIP(launch_scan_wide(a, kModeMain, f8, st));
+    VF_HIP(hipEventRecord(s.ev_scan, st));
+    if (timed) {
+        VF_HIP(hipEventRecord(s.ev_t[1], st));
+        const int64_t sampled = std::min<int64_t>(ix->n, (int64_t)RG * std::min<int64_t>((int64_t)samp * 8, ix->n / RG));
+        ix->prof_bytes = (ix->n - sampled) * ((int64_t)ix->d * (f8 ? 1 : 2) + 4);
+    }
+    FinalArgs f{};
+    f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.tau_bin = a.tau_bin; f.rows_orig = ix->rows_orig;
+    f.orig_dtype = ix->dtype; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
+    f.d = ix->d; f.k = k; f.kprime = p.kprime; f.eps = p.eps; f.n_rows = ix->n; f.id_offset = ix->id_offset;
+    f.out_ids = (long long*)d_ids; f.out_scores = d_scores;
+    f.flags = s.d_flags + flag_off; f.cand_count_out = s.d_counts + flag_off;
+    f.dbg = nullptr;
+    VF_HIP(launch_final(f, nb, st));
+    return VF_OK;
+}
+
 static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq, int k, int64_t* d_ids,
                       float* d_scores, hipStream_t user) {
     Slot& s = ix->slots[slot_id];
@@ -624,6 +696,18 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     }
 
     const FusedPlan p = make_plan(ix, k);
+    if (wide_possible(ix, nq)) {
+        s.timed = ix->profile;
+        if (s.timed) VF_HIP(hipEventRecord(s.ev_t[2], st));
+        for (int b0 = 0; b0 < nq; b0 += kWideMaxQueries) {
+            const int nb = std::min(kWideMaxQueries, nq - b0);
+            VF_TRY(wide_pass(ix, s, p, d_queries + (size_t)b0 * ix->d, nb, k, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k,
+                             b0, s.qn.as<float>() + (size_t)b0 * ix->d, s.timed && b0 == 0, st, slot_id));
+        }
+        if (s.timed) VF_HIP(hipEventRecord(s.ev_t[3], st));
+        VF_HIP(hipEventRecord(s.ev_done, st));
+        return VF_OK;
+    }
     VF_TRY(s.s0.ensure((size_t)kMaxBatch * p.total_waves * p.samp * sizeof(float)));
     VF_TRY(s.cnt.ensure((size_t)kMaxBatch * kCntStride * sizeof(u32)));
     VF_TRY(s.tau.ensure(kMaxBatch * sizeof(int)));

@@ -53,6 +53,8 @@ struct ScanArgs {
     int kprime;              // k + margin: the threshold keeps >= kprime rows above it
     int refresh_every;       // recompute tau when a query's count crosses a multiple of this
     int nq;                  // real queries (<= QN); padded queries never pass
+    // wide scan (k_scan_wide): queries in the global image, 256-query tiles per pass, row groups
+    int qn_total, jtiles, rgroups;
     unsigned long long* dbg; // optional [grid][8 waves][4] wall-clock stamps (debug bit 7), else null
     int debug;               // bit 0: timing experiment -- seed tau so that nothing passes (results invalid)
 };
@@ -90,6 +92,8 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
                        int rows_are_fp8, hipStream_t s);
 // test hook: the scan's hardware e4m3 -> fp16 conversion over `count` codes (device pointers)
 hipError_t launch_debug_cvt_e4m3(const unsigned char* in, float* out, int count, hipStream_t s);
+hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s);
+size_t scan_wide_lds_bytes(int stage_cap);
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
 hipError_t launch_final(FinalArgs a, int nq, hipStream_t s);
 hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,
