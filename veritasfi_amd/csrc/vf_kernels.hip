@@ -858,61 +858,86 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 //
 // With more than ~100 queries per pass the contraction is MFMA-bound, not HBM-bound (2*nq/elt
 // FLOP per byte), so the shard must be read ONCE per as many queries as the accumulators hold instead of once per
-// 64.  A workgroup (8 waves) owns a 256-query tile jt and a row group rg; a wave owns 32 rows of each 256-row
-// super-tile and all 256 queries: 8 accumulator tiles of 32x32 (128 VGPRs).  The k dimension is walked in chunks of
-// 64 elements:
+// 64.  A workgroup of FOUR waves -- one per SIMD, so that each wave may use the whole 512-entry register file --
+// owns a 256-query tile jt and a row group rg; a wave owns 64 rows (two MFMA row tiles) of each 256-row super-tile
+// and all 256 queries: 2 x 8 accumulator tiles of 32x32 (256 accumulator registers).  Every query fragment read
+// from LDS feeds two MFMAs, which keeps the LDS array at a quarter of its bandwidth.  The k dimension is walked in
+// chunks of 64 elements:
 //   * corpus rows go HBM -> registers directly as in k_scan (each byte is used by exactly one wave; fp8 codes are
-//     converted to fp16 in registers), prefetched TWO chunks ahead through three register stages;
-//   * the query chunk [8 k-groups][256 queries][8 halves] = 32 KB is shared by the 8 waves: global (L2-resident
+//     converted to fp16 in registers), two register stages, a stage ahead;
+//   * the query chunk [8 k-groups][256 queries][8 halves] = 32 KB is shared by the waves: global (L2-resident
 //     image) -> registers -> LDS, one chunk ahead, three LDS buffers so that ONE barrier per chunk suffices
 //     (the buffer written in iteration c was last read in iteration c - 2).
 // Epilogue, candidate stage, threshold refresh and histograms are k_scan's, over 256 queries; the stage is flushed
-// to the global lists whenever it is half full (k = 1000 yields ~40 candidates per wave tile).
+// to the global lists whenever it is half full (k = 1000 yields ~40 candidates per 32-row tile).
 // Grid: block b -> jt = (b / 8) % J, rg = b % 8 + 8 * (b / (8 J)): the J workgroups that scan the same rows for
 // different query tiles have equal b % 8 (one XCD under round-robin placement: their row reads share that L2;
 // speed only) and are adjacent in dispatch order.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWideQ = 256, kWideNT = kWideQ / kQueryTile, kWideKC = 64, kWideRows = 256;
+constexpr int kWideThreads = 512, kWideWaves = kWideThreads / 64, kWideM = kWideRows / kWideWaves / kRowTile;   // row tiles per wave (1)
 constexpr int kWideBuf = (kWideKC / 8) * kWideQ * 16;   // 32 KB per query chunk
 constexpr int kWideCtl = 16 + 3 * kWideQ * 4;            // stage_cnt | tau_lds[256] | qcnt[256] | qbase[256]
+constexpr int kSampWaves = kScanThreads / 64;            // sample rows per row group = samp * 8 (k_sel0's slot map)
 
-// One register stage of corpus data = kWideDC(F8) consecutive 64-element chunks of this lane's row: fp8 rows 2 chunks
-// (2 x 32 B per lane = 16 VGPRs), fp16 rows 1 chunk (64 B per lane = 16 VGPRs).  Chunk kc, MFMA step i, lane half h
+// One register stage of corpus data = DC consecutive 64-element chunks of this lane's two rows: fp8 rows 2 chunks
+// (2 x 32 B per row), fp16 rows 1 chunk (64 B per row): 32 VGPRs either way.  Chunk kc, MFMA step i, lane half h
 // covers elements kc*64 + (4h + i)*8 .. +8 -- the k-group order of the query chunk in LDS.
-template <int F8> struct WideStage { uint4 w[4]; };
+template <int F8> struct WideStage { uint4 w[kWideM][4]; };
 template <int F8> __device__ __forceinline__ constexpr int wide_dc() { return F8 ? 2 : 1; }
 
 template <int F8>
-__device__ __forceinline__ void wide_issue_a(WideStage<F8>& st, const char* rows, long long row_bytes, long long row, int unit, int h) {
-    if constexpr (F8 != 0) {
-        const char* p = rows + row * row_bytes + (long long)unit * 128 + h * 32;
-        st.w[0] = *(const uint4*)p;
-        st.w[1] = *(const uint4*)(p + 16);
-        st.w[2] = *(const uint4*)(p + 64);
-        st.w[3] = *(const uint4*)(p + 80);
-    } else {
-        const char* p = rows + row * row_bytes + (long long)unit * 128 + h * 64;
+__device__ __forceinline__ void wide_issue_a(WideStage<F8>& st, const char* rows, long long row_bytes, const long long (&row)[kWideM],
+                                             int unit, int h) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st.w[i] = *(const uint4*)(p + i * 16);
+    for (int m = 0; m < kWideM; ++m) {
+        if constexpr (F8 != 0) {
+            const char* p = rows + row[m] * row_bytes + (long long)unit * 128 + h * 32;
+            st.w[m][0] = *(const uint4*)p;
+            st.w[m][1] = *(const uint4*)(p + 16);
+            st.w[m][2] = *(const uint4*)(p + 64);
+            st.w[m][3] = *(const uint4*)(p + 80);
+        } else {
+            const char* p = rows + row[m] * row_bytes + (long long)unit * 128 + h * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st.w[m][i] = *(const uint4*)(p + i * 16);
+        }
     }
 }
 
-// 32 MFMAs: chunk `cc` (0 .. DC-1) of the stage against the query chunk at lds_lane
-template <int F8>
-__device__ __forceinline__ void wide_compute(f16v (&acc)[kWideNT], const WideStage<F8>& st, int cc, const char* lds_lane) {
+// 32 x kWideM MFMAs: chunk `CC` (0 .. DC-1) of the stage against the query chunk at lds_lane
+template <int F8, int CC>
+__device__ __forceinline__ void wide_compute(f16v (&acc)[kWideM][kWideNT], const WideStage<F8>& st, const char* lds_lane) {
+    // 32 (k-step, query tile) pairs.  The query fragments are read from LDS TWO pairs ahead of the MFMAs that use
+    // them (one wave per SIMD: nobody else would cover an LDS round trip), pinned with sched_group_barrier:
+    // [2 reads] then per pair [2 MFMAs][1 read].
+    auto frag_at = [&](int sn) { return *(const h8*)(lds_lane + (sn / kWideNT) * (kWideQ * 16) + (sn % kWideNT) * (kQueryTile * 16)); };
+    h8 bq[3];
+    bq[0] = frag_at(0);
+    bq[1] = frag_at(1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        h8 afrag;
-        if constexpr (F8 != 0) {
-            const uint4 w = cc ? st.w[2 + (i >> 1)] : st.w[i >> 1];
-            afrag = (i & 1) ? cvt8_e4m3(w.z, w.w) : cvt8_e4m3(w.x, w.y);
-        } else {
-            afrag = __builtin_bit_cast(h8, st.w[i]);
+        h8 afrag[kWideM];
+#pragma unroll
+        for (int m = 0; m < kWideM; ++m) {
+            if constexpr (F8 != 0) {
+                const uint4 w = st.w[m][2 * CC + (i >> 1)];
+                afrag[m] = (i & 1) ? cvt8_e4m3(w.z, w.w) : cvt8_e4m3(w.x, w.y);
+            } else {
+                afrag[m] = __builtin_bit_cast(h8, st.w[m][i]);
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < kWideNT; ++nt) {
-            const h8 b = *(const h8*)(lds_lane + i * (kWideQ * 16) + nt * (kQueryTile * 16));
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, b, acc[nt], 0, 0, 0);
+            const int sidx = i * kWideNT + nt;
+#pragma unroll
+            for (int m = 0; m < kWideM; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[m], bq[sidx % 3], acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, kWideM, 0);
+            if (sidx + 2 < 4 * kWideNT) {
+                bq[(sidx + 2) % 3] = frag_at(sidx + 2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
     }
 }
@@ -929,9 +954,8 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
     const u32 nst = staged < (u32)a.stage_cap ? staged : (u32)a.stage_cap;
     if (tid < kWideQ) qcnt[tid] = 0u;
     __syncthreads();
-    const u32 R = (u32)a.refresh_every;
-    const u32 published = (staged / R) * R;   // complete blocks were published by the wave that completed them
-    for (u32 i = tid; i < nst; i += kScanThreads) {
+    const u32 published = staged & ~((u32)a.refresh_every - 1u);   // complete blocks were published by whoever completed them
+    for (u32 i = tid; i < nst; i += kWideThreads) {
         const uint4 e = ent[i];
         const u32 q = e.z & 0xFFu;
         if (e.w != 1u) continue;
@@ -950,7 +974,7 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
         qbase[tid] = c ? atomicAdd(a.cnt + ((long long)jt * kWideQ + tid) * kCntStride, c) : 0u;
     }
     __syncthreads();
-    for (u32 i = tid; i < nst; i += kScanThreads) {
+    for (u32 i = tid; i < nst; i += kWideThreads) {
         const uint4 e = ent[i];
         if (e.w >= 2u) {
             const u32 q = e.z & 0xFFu;
@@ -963,9 +987,12 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
     __syncthreads();
 }
 
+// epilogue of ONE 32-row tile (rows t0 .. t0+31) against the 256 queries
+constexpr int kWideLaneList = 12;   // passing scores a lane notes per round (of its 128 per tile); + 4 mask words = 64 B per lane
+
 template <int MODE>
 __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[kWideNT], float inv_lane, long long t0,
-                                              long long hi, long long s0_slot, int jt, int lane, char* ctl, bool sync_tau) {
+                                              long long hi, long long s0_slot, int jt, int lane, char* ctl, uint2* lane_list, bool sync_tau) {
     const int r31 = lane & 31, h = lane >> 5;
     auto inv_of = [&](int reg) {
         const int r0 = (reg & 3) + 8 * (reg >> 2);
@@ -975,7 +1002,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     };
     const int qg0 = jt * kWideQ;   // first global query of this workgroup's tile
     if (MODE == kModeSample) {
-        const long long s0_stride = (long long)a.rgroups * a.samp * (kScanThreads / 64);
+        const long long s0_stride = (long long)a.rgroups * a.samp * kSampWaves;
 #pragma unroll
         for (int nt = 0; nt < kWideNT; ++nt) {
             const int q = qg0 + nt * kQueryTile + r31;
@@ -988,87 +1015,101 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         return;
     }
     int* tau_lds = (int*)(ctl + 16);
-    if (sync_tau) {   // one wave per tile folds the global thresholds into the workgroup's copy
+    if (sync_tau) {   // one wave per super-tile folds the global thresholds into the workgroup's copy
 #pragma unroll
         for (int nt = 0; nt < kWideNT; ++nt) {
             const int tg = __hip_atomic_load(a.tau_bin + qg0 + nt * kQueryTile + r31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane < 32) atomicMax(tau_lds + nt * kQueryTile + lane, tg);
         }
     }
-    u32 mask[kWideNT];
-    u32 any = 0u;
+    u32* stage_cnt = (u32*)ctl;
+    uint4* stage_ent = (uint4*)(ctl + kWideCtl);
+    const u32 Rm1 = (u32)a.refresh_every - 1u;   // refresh_every is a power of two on this path
+    bool need = false;
+    u32 myslot = 0u;
+    int myq = 0;
+    // Rounds of (pass 1, pass 2); one round unless a lane has more than kWideLaneList passing scores (a loose seed's
+    // first tiles, hostile data): round r handles each lane's passing scores number L r .. L r + L - 1.
+    float* lane_sc = (float*)lane_list;                       // [kWideLaneList] passing scores of this round, in (nt, reg) order
+    u32* lane_mk = (u32*)(lane_sc + kWideLaneList);           // [4] which of the 128 scores passed (bit 16 (nt & 1) + reg of word nt >> 1)
+    // the thresholds are read ONCE per tile: other waves raise them concurrently, and every round must see the same
+    // set of passing scores (a score's ordinal in that set is what ties the rounds together)
+    float tb[kWideNT];
 #pragma unroll
     for (int nt = 0; nt < kWideNT; ++nt) {
         const int ql = nt * kQueryTile + r31;
         const int t = tau_lds[ql];
-        const float tb = (qg0 + ql) < a.nq ? (t <= 0 ? -INFINITY : (float)t) : INFINITY;
-        u32 mk = 0u;
+        tb[nt] = (qg0 + ql) < a.nq ? (t <= 0 ? -INFINITY : (float)t) : INFINITY;
+    }
+    for (u32 done = 0u;; done += (u32)kWideLaneList) {
+        // Pass 1, straight-line over this lane's 128 scores: a passing score is NOTED -- its value in the lane's
+        // private LDS list, its position as a bit -- and nothing else happens here, so the 128 unrolled blocks stay
+        // three instructions each, need no per-block constants in registers and pin nothing across the MFMA loop.
+        u32 cnt = 0u;
+        u32 mk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float x = bin_x(acc[nt][reg] * inv_of(reg));   // rows past the end carry a NaN inverse norm: never pass
-            mk |= (x >= tb) ? (1u << reg) : 0u;
+        for (int nt = 0; nt < kWideNT; ++nt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float sc = acc[nt][reg] * inv_of(reg);   // rows past the end carry a NaN inverse norm: never pass
+                if (bin_x(sc) >= tb[nt]) {
+                    const u32 o = cnt - done;
+                    if (o < (u32)kWideLaneList) lane_sc[o] = sc;
+                    mk[nt >> 1] |= 1u << ((nt & 1) * 16 + reg);
+                    ++cnt;
+                }
+            }
         }
-        mask[nt] = mk;
-        any |= mk;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (__ballot(any != 0u) == 0ull) return;
-    u32* stage_cnt = (u32*)ctl;
-    uint4* stage_ent = (uint4*)(ctl + kWideCtl);
-    u32 c = 0u;
-    int firstq = 0;
+        if (done == 0u && __ballot(cnt != 0u) == 0ull) return;
 #pragma unroll
-    for (int nt = kWideNT - 1; nt >= 0; --nt) {
-        c += (u32)__popc(mask[nt]);
-        if (mask[nt]) firstq = nt * kQueryTile + r31;
-    }
-    const u32 R = (u32)a.refresh_every;
-    u32 slot = 0;
-    bool need = false;
-    if (c > 0) {
-        slot = atomicAdd(stage_cnt, c);
-        need = (slot / R) != ((slot + c) / R);
-    }
-    const u32 slot_end = slot + c;
-#pragma unroll
-    for (int nt = 0; nt < kWideNT; ++nt) {
-        if (mask[nt] == 0u) continue;
-        const int ql = nt * kQueryTile + r31;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            if (mask[nt] & (1u << reg)) {
-                const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const float sc = acc[nt][reg] * inv_of(reg);
-                const u32 bin = (u32)bin_of_x(bin_x(sc));
-                const u32 key = orderkey(sc), row = (u32)(t0 + rr);
+        for (int w = 0; w < 4; ++w) lane_mk[w] = mk[w];
+        // Pass 2, dynamic loops (the code exists once): walk the set bits in the same order, claim a stage slot per
+        // noted score; the candidate that claims the last slot of a block of R publishes that block and refreshes
+        // one threshold (below).
+        u32 idx = 0u;
+        for (int w = 0; w < 4; ++w) {
+            u32 mw = lane_mk[w];
+            while (mw) {
+                const int bpos = __builtin_ctz(mw);
+                mw &= mw - 1u;
+                const u32 o = idx - done;
+                ++idx;
+                if (o >= (u32)kWideLaneList) continue;   // another round's (also covers idx < done: o wraps)
+                const float sc = lane_sc[o];
+                const int ql = (2 * w + (bpos >> 4)) * kQueryTile + r31, reg = bpos & 15;
+                const u32 row = (u32)(t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
+                const u32 slot = atomicAdd(stage_cnt, 1u);
                 if (slot < (u32)a.stage_cap) {
                     stage_ent[slot] = make_uint4(row, key, (u32)ql | (bin << 8), 1u);
-                } else {  // stage full between two flushes (hostile data): append straight to the global list
+                } else {   // stage full (the first tiles after a loose seed, or hostile data): straight to the global list
                     const long long gq = qg0 + ql;
                     const u32 gs = atomicAdd(a.cnt + gq * kCntStride, 1u);
                     if (gs < (u32)a.cap) a.cand[gq * a.cap + gs] = ((u64)key << 32) | (u64)row;
                     atomicAdd(a.hist + gq * kHistBins + bin, 1u);
                     atomicAdd(a.hist_coarse + gq * 64 + (bin >> 5), 1u);
                 }
-                ++slot;
+                if ((slot & Rm1) == Rm1) { need = true; myslot = slot; myq = ql; }
             }
         }
+        if (__ballot(cnt > done + (u32)kWideLaneList) == 0ull) break;
     }
-    const unsigned long long m = __ballot(need);
-    if (m) {
+    unsigned long long m = __ballot(need);
+    while (m) {
         const int leader = __ffsll((long long)m) - 1;
-        const u32 blk = (u32)__shfl((int)slot_end, leader) / R - 1u;
-        const int qq = qg0 + __shfl(firstq, leader);
+        m &= m - 1ull;
+        const u32 blk0 = (u32)__shfl((int)myslot, leader) & ~Rm1;   // first entry of the completed block
+        const int qq = qg0 + __shfl(myq, leader);
         const int nb = wave_tau_two_level(a.hist_coarse + qq * 64, a.hist + (long long)qq * kHistBins, a.kprime, lane);
         if (lane == 0 && nb > 0) {
             atomicMax(a.tau_bin + qq, nb);
             atomicMax(tau_lds + (qq - qg0), nb);
         }
-        for (u32 j = (u32)lane; j < R; j += 64u) {
-            const u32 idx = blk * R + j;
+        for (u32 j = (u32)lane; j <= Rm1; j += 64u) {
+            const u32 idx = blk0 + j;
             if (idx >= (u32)a.stage_cap) break;
             const uint4 en = stage_ent[idx];
-            if (en.w == 1u) {
+            if (en.w == 1u) {   // claimed-but-unwritten entries read w == 0: skipped, the histogram under-counts (safe)
                 const u32 bin = en.z >> 8;
                 const long long gq = qg0 + (en.z & 0xFFu);
                 if (bin < (u32)kHistBins) {
@@ -1081,9 +1122,8 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
 }
 
 template <int MODE, int F8>
-__global__ __launch_bounds__(kScanThreads) void k_scan_wide(ScanArgs a) {
+__global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WAVES = kScanThreads / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
     const int J = a.jtiles;
@@ -1091,56 +1131,60 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_wide(ScanArgs a) {
     const int rg = ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * J));
     if (rg >= a.rgroups) return;   // grid is padded to a multiple of 8 J; whole workgroups leave before any barrier
     const long long Ra = a.n * rg / a.rgroups, Rb = a.n * (rg + 1) / a.rgroups;
-    const long long swg = (long long)a.samp * WAVES;
+    const long long swg = (long long)a.samp * kSampWaves;
     const long long Rs = (Ra + swg < Rb) ? Ra + swg : Rb;
     const long long lo = MODE == kModeSample ? Ra : Rs;
     const long long hi = MODE == kModeSample ? Rs : Rb;
     const int nst = (int)((hi - lo + kWideRows - 1) / kWideRows);
     const int NCH = a.dp >> 6;
-    const int C = nst * NCH;
     char* ctl = smem + 3 * kWideBuf;
     {
         uint4* z = (uint4*)ctl;
         const int nz = kWideCtl / 16 + (MODE == kModeMain ? a.stage_cap : 0);
-        for (int i = tid; i < nz; i += kScanThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < nz; i += kWideThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
     if (MODE == kModeMain && tid < kWideQ) ((int*)(ctl + 16))[tid] = a.tau_bin[jt * kWideQ + tid];
-    if (C == 0) return;
+    if (nst == 0) return;
     constexpr int DC = wide_dc<F8>();
     const int UN = NCH / DC;           // register stages per tile; even (launch requires dp % 256 == 0 for fp8, % 128 for fp16)
     WideStage<F8> A0, A1;
     uint4 rb0, rb1, rb2, rb3;
-    // query-chunk copy: thread t moves 16-byte units t + 512 v (v = 0..3) of the 32 KB chunk [8 k-groups][256 q][8]
+    // query-chunk copy: thread t moves the 16-byte units t + 512 v (v = 0..3) of the 32 KB chunk [8 k-groups][256 q][8]:
+    // k-group rows (t >> 8) + 2 v, query t & 255
+    static_assert(kWideThreads == 512, "the query-chunk copy is written for 512 threads");
     const long long qn8 = (long long)a.qn_total * 8;   // halves per k-group row of the global image
-    const _Float16* bsrc = a.qimg + ((long long)(tid >> 8) * a.qn_total + jt * kWideQ + (tid & 255)) * 8;
+    const _Float16* bsrc = a.qimg + ((long long)(tid >> 8) * a.qn_total + (long long)jt * kWideQ + (tid & 255)) * 8;
 #define VF_ISSUE_B(KC)                                                        \
     do {                                                                      \
         const _Float16* p_ = bsrc + (long long)(KC) * 8 * qn8;                \
-        rb0 = *(const uint4*)(p_);                                            \
-        rb1 = *(const uint4*)(p_ + 2 * qn8);                                  \
-        rb2 = *(const uint4*)(p_ + 4 * qn8);                                  \
-        rb3 = *(const uint4*)(p_ + 6 * qn8);                                  \
+        rb0 = *(const uint4*)(p_);           rb1 = *(const uint4*)(p_ + 2 * qn8); \
+        rb2 = *(const uint4*)(p_ + 4 * qn8); rb3 = *(const uint4*)(p_ + 6 * qn8); \
     } while (0)
 #define VF_WRITE_B(BUF)                                                       \
     do {                                                                      \
         uint4* d_ = (uint4*)(smem + (BUF) * kWideBuf) + tid;                  \
-        d_[0] = rb0; d_[kScanThreads] = rb1; d_[2 * kScanThreads] = rb2; d_[3 * kScanThreads] = rb3; \
+        d_[0] = rb0; d_[512] = rb1; d_[1024] = rb2; d_[1536] = rb3;           \
     } while (0)
-    const u32 row0 = (u32)lo + (u32)(wid * kRowTile + r31), hi32m1 = (u32)(hi - 1);
-    auto rowof = [&](int st) {
-        const u32 r = row0 + (u32)st * kWideRows;
-        return (long long)(r < hi32m1 ? r : hi32m1);
+    const u32 row0 = (u32)lo + (u32)(wid * (kWideM * kRowTile) + r31), hi32m1 = (u32)(hi - 1);
+    auto rows_of = [&](int st, long long (&r)[kWideM]) {
+#pragma unroll
+        for (int m = 0; m < kWideM; ++m) {
+            const u32 x = row0 + (u32)st * kWideRows + (u32)(m * kRowTile);
+            r[m] = (long long)(x < hi32m1 ? x : hi32m1);
+        }
     };
     const char* lds_lane0 = smem + ((4 * h) * kWideQ + r31) * 16;
-    f16v acc[kWideNT];
+    f16v acc[kWideM][kWideNT];
 #pragma unroll
-    for (int nt = 0; nt < kWideNT; ++nt)
+    for (int m = 0; m < kWideM; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+        for (int nt = 0; nt < kWideNT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
     // flat chunk counter state: buffer being read (br), chunk-in-tile of the chunk being computed (kc)
     int br = 0, kc = 0;
-    // One chunk: queries of chunk c + 1 -> LDS (buffer last read in iteration c - 2), fetch chunk c + 2's, 32 MFMAs
+    // One chunk: queries of chunk c + 1 -> LDS (buffer last read in iteration c - 2), fetch chunk c + 2's, 64 MFMAs
     // on chunk c, ONE barrier.
 #define VF_CHUNK(STG, CC)                                                     \
     do {                                                                      \
@@ -1149,20 +1193,21 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_wide(ScanArgs a) {
         const int kn_ = kc + 2 < NCH ? kc + 2 : kc + 2 - NCH;                 \
         VF_ISSUE_B(kn_);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                    \
-        wide_compute<F8>(acc, STG, CC, lds_lane0 + br * kWideBuf);            \
+        wide_compute<F8, CC>(acc, STG, lds_lane0 + br * kWideBuf);            \
         __syncthreads();                                                      \
         br = bw_;                                                             \
         kc = kc + 1 == NCH ? 0 : kc + 1;                                      \
     } while (0)
-    wide_issue_a<F8>(A0, a.rows, a.row_bytes, rowof(0), 0, h);
+    long long myrow[kWideM], nxrow[kWideM];
+    rows_of(0, myrow);
+    wide_issue_a<F8>(A0, a.rows, a.row_bytes, myrow, 0, h);
     VF_ISSUE_B(0);
     VF_WRITE_B(0);
     VF_ISSUE_B(1);
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
-        const long long myrow = rowof(st);
-        const long long t0 = lo + (long long)st * kWideRows + wid * kRowTile;
-        float inv_lane = 0.0f;
+        const long long t0 = lo + (long long)st * kWideRows + wid * (kWideM * kRowTile);
+        float inv_lane[kWideM];
         for (int u = 0; u < UN; u += 2) {
             wide_issue_a<F8>(A1, a.rows, a.row_bytes, myrow, u + 1, h);
             __builtin_amdgcn_sched_barrier(0);
@@ -1170,19 +1215,33 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_wide(ScanArgs a) {
             if constexpr (DC == 2) VF_CHUNK(A0, 1);
             if (u + 2 < UN) wide_issue_a<F8>(A0, a.rows, a.row_bytes, myrow, u + 2, h);
             else {
-                // 1 / norm of this lane's row; rows past the part's end get NaN: their scores compare false
-                inv_lane = (t0 + r31 < hi) ? a.inv_scan[t0 + r31] : __builtin_nanf("");
-                wide_issue_a<F8>(A0, a.rows, a.row_bytes, rowof(st + 1 < nst ? st + 1 : st), 0, h);
+                // 1 / norm of this lane's rows; rows past the part's end get NaN: their scores compare false
+#pragma unroll
+                for (int m = 0; m < kWideM; ++m)
+                    inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
+                rows_of(st + 1 < nst ? st + 1 : st, nxrow);
+                wide_issue_a<F8>(A0, a.rows, a.row_bytes, nxrow, 0, h);
             }
             __builtin_amdgcn_sched_barrier(0);
             VF_CHUNK(A1, 0);
             if constexpr (DC == 2) VF_CHUNK(A1, 1);
         }
-        wide_epilogue<MODE>(a, acc, inv_lane, t0, hi, (long long)rg * swg + (t0 - lo), jt, lane, ctl, (st & (WAVES - 1)) == wid);
+        // The epilogue's per-lane constants (row offsets, query ids, LDS addresses) must not be hoisted out of the tile
+        // loop by LICM: kept live across the MFMA loop they push accumulators into scratch.  Opaque copies pin them here.
+        int lane_e = lane, jt_e = jt;
+        char* ctl_e = ctl;
+        asm volatile("" : "+v"(lane_e), "+s"(jt_e));
 #pragma unroll
-        for (int nt = 0; nt < kWideNT; ++nt)
+        for (int m = 0; m < kWideM; ++m) {
+            myrow[m] = nxrow[m];
+            wide_epilogue<MODE>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, (long long)rg * swg + (t0 + m * kRowTile - lo), jt_e,
+                                lane_e, ctl_e, (uint2*)(ctl_e + kWideCtl + (size_t)a.stage_cap * 16 + (size_t)tid * ((kWideLaneList + 4) * 4)),
+                                m == 0 && (st & (kWideWaves - 1)) == wid);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+            for (int nt = 0; nt < kWideNT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+        }
         if (MODE == kModeMain) {
             __syncthreads();
             if (*(const u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
@@ -1194,13 +1253,15 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_wide(ScanArgs a) {
 #undef VF_ISSUE_B
 }
 
-size_t scan_wide_lds_bytes(int stage_cap) { return (size_t)3 * kWideBuf + kWideCtl + (size_t)stage_cap * 16; }
+size_t scan_wide_lds_bytes(int stage_cap) {
+    return (size_t)3 * kWideBuf + kWideCtl + (size_t)stage_cap * 16 + (stage_cap ? (size_t)kWideThreads * (kWideLaneList + 4) * 4 : 0);
+}
 
 hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s) {
     const int grid = 8 * a.jtiles * ((a.rgroups + 7) / 8);
     const size_t lds = scan_wide_lds_bytes(mode == kModeMain ? a.stage_cap : 0);
 #define VF_WCASE(MODEV, F8V) \
-    if (mode == MODEV && (rows_are_fp8 != 0) == (F8V != 0)) { hipLaunchKernelGGL((k_scan_wide<MODEV, F8V>), dim3(grid), dim3(kScanThreads), lds, s, a); return hipGetLastError(); }
+    if (mode == MODEV && (rows_are_fp8 != 0) == (F8V != 0)) { hipLaunchKernelGGL((k_scan_wide<MODEV, F8V>), dim3(grid), dim3(kWideThreads), lds, s, a); return hipGetLastError(); }
     VF_WCASE(kModeSample, 0) VF_WCASE(kModeSample, 1) VF_WCASE(kModeMain, 0) VF_WCASE(kModeMain, 1)
 #undef VF_WCASE
     return hipErrorInvalidValue;
@@ -1550,6 +1611,11 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     const int m = n < a.kprime ? n : a.kprime;
     const u64* cq = a.cand + (long long)q * a.cap;
     const int tbin = a.tau_bin[q];
+    if (n_raw > (u32)a.cap) {   // overflowed list: not every slot need be written -- nothing here can be trusted, exact path
+        for (int i = tid; i < a.k; i += kFinalThreads) { a.out_ids[(long long)q * a.k + i] = -1; a.out_scores[(long long)q * a.k + i] = -FLT_MAX; }
+        if (tid == 0) { a.flags[q] = 2; a.cand_count_out[q] = n_raw; }
+        return;
+    }
     for (int j = tid; j < a.d; j += kFinalThreads) qs[j] = a.qn[(long long)q * a.d + j];
     for (int b = tid; b < kHistBins; b += kFinalThreads) lh[b] = 0u;
     if (tid == 0) { s_nsel = 0u; s_bin = 0; }
@@ -1587,7 +1653,8 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     const int pr = tid >> 1, h = tid & 1;
     for (int i0 = 0; i0 < m; i0 += kFinalThreads / 2) {
         const int i = i0 + pr;
-        const u32 row = (u32)top[i < m ? i : m - 1];   // idle pairs shadow the last row (whole wave stays converged)
+        u32 row = (u32)top[i < m ? i : m - 1];   // idle pairs shadow the last row (whole wave stays converged)
+        row = (long long)row < a.n_rows ? row : (u32)(a.n_rows - 1);   // never index the corpus with a value the scan did not produce
         const float nm = a.norm[row];
         const float acc = a.orig_dtype == VF_DTYPE_F16       ? rescore_pair<VF_DTYPE_F16>(a.rows_orig, row, a.d, qs, nm, h)
                           : a.orig_dtype == VF_DTYPE_FP8_E4M3 ? rescore_pair<VF_DTYPE_FP8_E4M3>(a.rows_orig, row, a.d, qs, nm, h)
