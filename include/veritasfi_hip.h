@@ -193,7 +193,8 @@ typedef struct vf_encoder_config {
 int vf_encoder_weight_sizes(const vf_encoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
 int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg, const void* w_fp16, int64_t n_fp16,
                       const float* w_fp32, int64_t n_fp32, int32_t device_id);
-/* ids / mask / type_ids (may be NULL) [b, t] int32 host, t % 32 == 0, t <= 512 (pad with mask 0);
+/* ids / mask / type_ids (may be NULL) [b, t] int32 host, t % 32 == 0, t <= 8192 and within the position table (pad with
+ * mask 0; up to 512 tokens K / V stay resident in LDS, longer sequences -- bge-m3's 8192 -- stream them);
  * t_valid = columns the tokenizer produced (<= t; the rest is alignment padding the caller added: the
  * unmasked-mean and last-token poolings count only the first t_valid columns);
  * out [b, hidden] (head 0) or [b] (head 1) fp32 host. */

@@ -77,9 +77,10 @@ def test_embedding_encoder_matches_torch_fp32(vf, name, hidden, layers, heads, f
     err = np.abs(got - ref).max()
     herr = np.abs(hs - ref_h)[mask.astype(bool)]
     print(name, "cos", cos.min(), "max|d emb|", err, "hidden mean/max err", herr.mean(), herr.max())
-    # tolerance: fp16 activations through `layers` post-LN blocks; LN outputs are O(1)
-    assert cos.min() > 0.9995 and err < 4e-3
-    assert herr.mean() < 6e-3 and herr.max() < 8e-2
+    # tolerance: fp16 activations through `layers` post-LN blocks; LN outputs are O(1).  Measured on MI355X (round 1):
+    # max |d emb| 2.3e-4, hidden mean 1.0e-3 / max 1.3e-2 at 12 layers -- asserted at ~3x that
+    assert cos.min() > 0.99999 and err < 8e-4
+    assert herr.mean() < 3e-3 and herr.max() < 4e-2
 
 
 def test_pooling_variants(vf):
@@ -141,7 +142,7 @@ def test_reranker_matches_torch_fp32(vf, hidden, layers, heads, ffn, b, t):
     rr.close()
     print("reranker logits", ref[:4], got[:4], np.abs(ref - got).max())
     assert got.shape == (b,)
-    assert np.abs(ref - got).max() < 2e-2 * max(1.0, np.abs(ref).max())
+    assert np.abs(ref - got).max() < 2.5e-3 * max(1.0, np.abs(ref).max())   # measured 7e-4
     assert np.array_equal(np.argsort(-ref), np.argsort(-got)) or np.abs(ref - got).max() < np.min(np.diff(np.sort(ref)))
 
 
@@ -514,3 +515,67 @@ def test_decoder_embedder_drop_in(vf):
     I, D = fr.invoke([docs[3], docs[40]], 5)
     assert I.shape == (2, 5) and np.all(np.diff(D, axis=1) <= 0)
     emb.decoder.close()
+
+
+# ---- the reference's CONFIGURED models: bge-m3 (XLM-R-large: hidden 1024, 16 heads, 24 layers, 8192 tokens;
+#      config/example.yaml:3, src/utils/ragManager.py:50) and bge-reranker-large (BASELINE configs[4]) ---------------------
+def _hf_xlmr_embedder(hidden, layers, heads, ffn, max_pos, vocab=1200, seed=7):
+    import torch
+    from transformers import XLMRobertaConfig, XLMRobertaModel
+    torch.manual_seed(seed)
+    cfg = XLMRobertaConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ffn,
+                           vocab_size=vocab, max_position_embeddings=max_pos, type_vocab_size=1, pad_token_id=1)
+    return XLMRobertaModel(cfg, add_pooling_layer=False).eval().half().float()
+
+
+def test_xlmr_large_shape_embedder_and_reranker(vf):
+    """hidden 1024 / 16 heads / 24 layers / ffn 4096 -- the shape of bge-m3 and bge-reranker-large."""
+    import torch
+    rng = np.random.default_rng(11)
+    ids, mask = _batch(rng, 3, 96, 1200, pad_id=1)
+    emb = _hf_xlmr_embedder(1024, 24, 16, 4096, 514)
+    with torch.no_grad():
+        ref = emb(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state[:, 0].numpy()
+    ref = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    enc = vf.HipEncoder.from_hf(emb, pooling=0, normalize=True)
+    got = enc.forward(ids, mask)
+    enc.close()
+    cos, err = np.sum(got * ref, axis=1).min(), np.abs(got - ref).max()
+    print("xlmr-large embedder: cos", cos, "max|d|", err)
+    assert got.shape == (3, 1024) and cos > 0.99999 and err < 1.5e-3      # measured 3e-4 .. 5e-4 (24 post-LN layers in fp16)
+    rr = _hf_xlmr_cls(1024, 24, 16, 4096)
+    with torch.no_grad():
+        want = rr(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits.view(-1).numpy()
+    h = vf.HipEncoder.from_hf(rr)
+    sc = h.forward(ids, mask)
+    h.close()
+    print("xlmr-large re-ranker logits", want, sc)
+    assert np.abs(sc - want).max() < 3e-3 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("b,t,hidden,layers,heads,ffn", [(2, 1024, 256, 2, 4, 1024), (1, 8192, 128, 2, 2, 512), (2, 2000, 1024, 2, 16, 4096)])
+def test_long_sequences_take_the_streaming_attention(vf, b, t, hidden, layers, heads, ffn):
+    """t > 512 (bge-m3 accepts 8192 tokens): K / V no longer fit LDS whole, the encoder switches to the streaming
+    attention kernel.  Ragged masks, RoBERTa position ids up to the end of an 8194-entry table."""
+    import torch
+    rng = np.random.default_rng(12)
+    ids, mask = _batch(rng, b, t, 1200, pad_id=1)
+    m = _hf_xlmr_embedder(hidden, layers, heads, ffn, 8194)
+    with torch.no_grad():
+        ref_h = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state.numpy()
+    ref = ref_h[:, 0] / np.linalg.norm(ref_h[:, 0], axis=1, keepdims=True)
+    enc = vf.HipEncoder.from_hf(m, pooling=0, normalize=True)
+    got = enc.forward(ids, mask)
+    hs = enc.hidden_states(ids, mask)
+    enc.close()
+    herr = np.abs(hs - ref_h)[mask.astype(bool)]
+    print("long sequence", (b, t, hidden), "cos", np.sum(got * ref, axis=1).min(), "max|d emb|", np.abs(got - ref).max(),
+          "hidden mean/max", herr.mean(), herr.max())
+    assert np.sum(got * ref, axis=1).min() > 0.99999 and np.abs(got - ref).max() < 1.5e-3
+    assert herr.mean() < 2e-3 and herr.max() < 4e-2
+    with pytest.raises(RuntimeError, match="position table"):
+        short = vf.HipEncoder.from_hf(_hf_xlmr_embedder(128, 1, 2, 512, 514), pooling=0, normalize=True)
+        try:
+            short.forward(np.ones((1, 1024), np.int64), np.ones((1, 1024), np.int64))
+        finally:
+            short.close()

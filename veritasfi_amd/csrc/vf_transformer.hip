@@ -1648,6 +1648,8 @@ static hipError_t configure_once() {
 
 
 constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
+constexpr int kEncResidentT = 512;   // longest sequence whose K / V^T fit the resident-attention kernel's LDS
+constexpr int kEncMaxT = 8192;       // longest sequence the encoder takes (streaming attention beyond kEncResidentT)
 
 struct vf_encoder {
     vf_encoder_config cfg{};
@@ -1880,7 +1882,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
                     *b2n = g2 + H;
         VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
         static const bool att_stream = getenv("VF_ATT_STREAM") != nullptr;  // A/B switch: streaming kernel on the BERT path
-        if (att_stream) {
+        // Sequences longer than 512 tokens (bge-m3 = XLM-R-large with an 8194-entry position table: config/example.yaml:3,
+        // src/utils/ragManager.py:50) cannot keep K and V^T of a head resident in LDS: they take the streaming kernel
+        // (64-key tiles through LDS, online softmax), which has no length limit.
+        if (att_stream || T > kEncResidentT) {
             hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
                                sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads, 0.125f, e->ctx, H);
         } else {
@@ -1920,7 +1925,7 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_encoder_forward: negative sizes");
     if (b == 0) return VF_OK;
     if (!ids || !mask || !out) return fail(VF_EINVAL, "vf_encoder_forward: null buffer");
-    if (t == 0 || t % 32 != 0 || t > 512) return fail(VF_EINVAL, "vf_encoder_forward: t must be a multiple of 32 in [32, 512] (pad with mask 0)");
+    if (t == 0 || t % 32 != 0 || t > kEncMaxT) return fail(VF_EINVAL, "vf_encoder_forward: t must be a multiple of 32 in [32, 8192] (pad with mask 0)");
     if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_encoder_forward: t_valid must be in [1, t]");
     if (t > e->cfg.max_pos - (e->cfg.roberta_pad_idx >= 0 ? e->cfg.roberta_pad_idx + 1 : 0))
         return fail(VF_EINVAL, "vf_encoder_forward: t exceeds the position table");
@@ -1973,7 +1978,9 @@ extern "C" int vf_encoder_forward_hidden(vf_encoder* e, const int32_t* ids, cons
     if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_encoder_forward_hidden: negative sizes");
     if (b == 0) return VF_OK;
     if (!ids || !mask || !out_hidden) return fail(VF_EINVAL, "vf_encoder_forward_hidden: null buffer");
-    if (t == 0 || t % 32 != 0 || t > 512) return fail(VF_EINVAL, "vf_encoder_forward_hidden: t must be a multiple of 32 in [32, 512]");
+    if (t == 0 || t % 32 != 0 || t > kEncMaxT) return fail(VF_EINVAL, "vf_encoder_forward_hidden: t must be a multiple of 32 in [32, 8192]");
+    if (t > e->cfg.max_pos - (e->cfg.roberta_pad_idx >= 0 ? e->cfg.roberta_pad_idx + 1 : 0))
+        return fail(VF_EINVAL, "vf_encoder_forward_hidden: t exceeds the position table");
     std::lock_guard<std::mutex> g(e->mu);
     VFT_HIP(hipSetDevice(e->device));
     int rc = enc_ensure_ws(e, b, t);

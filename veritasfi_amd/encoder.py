@@ -79,7 +79,7 @@ def pack_hf_weights(model, pooling=POOL_CLS, normalize=True):
 
 
 class HipEncoder:
-    """Handle over ``vf_encoder_*``.  ``forward`` takes int token ids / mask [b, t] (any t <= 512)."""
+    """Handle over ``vf_encoder_*``.  ``forward`` takes int token ids / mask [b, t] (any t <= 8192 within the model's position table)."""
 
     def __init__(self, cfg: dict, w16: np.ndarray, w32: np.ndarray, device_id: int = 0):
         L = _ffi.lib()
@@ -108,8 +108,8 @@ class HipEncoder:
         mask = np.asarray(mask, dtype=np.int32)
         b, t = ids.shape
         tp = max(32, -(-t // 32) * 32)
-        if tp > 512:
-            raise ValueError("sequences longer than 512 tokens are not supported")
+        if tp > 8192:
+            raise ValueError("sequences longer than 8192 tokens are not supported")
         def pad(a):
             if a is None:
                 return None
