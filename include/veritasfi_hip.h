@@ -214,8 +214,10 @@ int vf_encoder_destroy(vf_encoder* enc);
  * Qwen3-Embedding with last_token_pool -- get_embeddings in experiments/retriever/step3_mul.py:181-209 (model :384),
  * continuous_retrieval.py:127-152 -- and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225:
  * score = logits[:, -1, yes_loc]).  Pre-norm layer: x += Wo attn(rope(qnorm(q)), rope(knorm(k)), v) ; x += Wdown
- * (silu(Wgate n) * Wup n), n = RMSNorm(x); causal grouped-query attention; final RMSNorm.  fp16 weights and
- * activations, fp32 accumulation / norms / softmax.  head_dim 64, 128 or 256 (gemma), t <= 2048. */
+ * (silu(Wgate n) * Wup n), n = RMSNorm(x); causal grouped-query attention; final RMSNorm.  fp16 weights and GEMM
+ * operands; the RESIDUAL STREAM x is fp32 (the reference runs these models in the checkpoint's wider dtype,
+ * step3_mul.py:62-64: a residual beyond the fp16 range must not overflow), fp32 accumulation / norms / softmax.
+ * head_dim 64, 128 or 256 (gemma), t <= 2048. */
 typedef struct vf_decoder vf_decoder;
 typedef struct vf_decoder_config {
     int32_t vocab, hidden, layers, heads, kv_heads, head_dim, ffn;
@@ -239,6 +241,10 @@ int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg, const void
  * (what HF does when no position_ids are passed); out [b, hidden] (head 0) or [b] (head 2) fp32 host. */
 int vf_decoder_forward(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
                        float* out);
+/* last_hidden_state [b, t, hidden] fp32 host (after the final RMSNorm), for callers that pool themselves -- the
+ * reference's generic route outputs.last_hidden_state -> last_token_pool (experiments/retriever/step3_mul.py:203-207). */
+int vf_decoder_forward_hidden(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
+                              float* out_hidden);
 int vf_decoder_destroy(vf_decoder* dec);
 
 /* re-ranker = encoder with head == 1 */

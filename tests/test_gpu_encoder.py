@@ -579,3 +579,77 @@ def test_long_sequences_take_the_streaming_attention(vf, b, t, hidden, layers, h
             short.forward(np.ones((1, 1024), np.int64), np.ones((1, 1024), np.int64))
         finally:
             short.close()
+
+
+# ---- decoder family: fp32 residual stream + exported hidden states (reference loads these models in the checkpoint's
+#      wider dtype, step3_mul.py:62-64, and pools outputs.last_hidden_state itself, :203-207) -------------------------------
+def test_decoder_hidden_states_and_generic_get_embeddings_route(vf):
+    import torch
+    from veritasfi_amd.retrieval import get_embeddings, last_token_pool
+    model = _hf_qwen3(256, 2, 4, 2, 64, 512)
+    rng = np.random.default_rng(31)
+    b, t = 3, 80
+    ids = rng.integers(5, 800, size=(b, t)).astype(np.int64)
+    mask = np.ones((b, t), np.int64)
+    mask[1, :17] = 0                                          # left padding, as the reference's tokenizer pads
+    mask[2, :40] = 0
+    with torch.no_grad():
+        ref = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state.numpy()
+    dec = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    hs = dec.hidden_states(ids, mask)
+    assert hs.shape == (b, t, 256) and hs.dtype == np.float32
+    err = np.abs(hs - ref)[mask.astype(bool)]
+    print("decoder hidden states: mean/max err", err.mean(), err.max(), "ref absmax", np.abs(ref).max())
+    assert err.mean() < 3e-3 and err.max() < 5e-2
+    # HF-signature callable: the reference's own pooling code runs on the exported states and agrees with the GPU pooling
+    m = vf.HipDecoderModel(dec)
+    out = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+    pooled_host = last_token_pool(out.last_hidden_state, torch.from_numpy(mask)).numpy()
+    pooled_gpu = dec.forward(ids, mask)
+    assert np.abs(pooled_host - pooled_gpu).max() < 5e-3 * np.abs(pooled_gpu).max()
+
+    class Tok:
+        padding_side = "left"
+        def __call__(self, texts, padding=True, truncation=True, return_tensors="pt", max_length=None):
+            r = [int(x) for x in texts]
+            return {"input_ids": torch.from_numpy(ids[r]), "attention_mask": torch.from_numpy(mask[r])}
+
+    class HiddenOnly:                                           # hides .pooled: forces the generic hidden-state route
+        def __init__(self, mm): self.mm = mm
+        def __call__(self, **kw): return self.mm(**kw)
+    slow = get_embeddings(["0", "1", "2"], HiddenOnly(m), Tok(), "cpu", batch_size=2, pooling="last_token")
+    fast = get_embeddings(["0", "1", "2"], m, Tok(), "cpu", batch_size=2, pooling="last_token")
+    assert np.abs(slow - fast).max() < 5e-3 * np.abs(fast).max()
+    dec.close()
+
+
+def test_decoder_residual_beyond_fp16_range(vf):
+    """A model whose residual stream leaves the fp16 range (|x| > 65504): layer 0's down-projection is scaled up so that
+    the MLP writes ~1e5 into the stream (the 'massive activation' pattern of real checkpoints).  With the stream kept
+    in fp32 the embeddings still match HF fp32; an fp16 stream turns them into inf / NaN."""
+    import torch
+    from veritasfi_amd.retrieval import last_token_pool
+    model = _hf_qwen3(256, 3, 4, 2, 64, 512)
+    with torch.no_grad():
+        for lin, f in ((model.layers[0].mlp.up_proj, 300.0), (model.layers[0].mlp.down_proj, 4000.0)):
+            lin.weight.mul_(f)
+            lin.weight.copy_(lin.weight.half().float())     # still fp16-representable (|w| < 400)
+    rng = np.random.default_rng(32)
+    ids = rng.integers(5, 800, size=(2, 64)).astype(np.int64)
+    mask = np.ones((2, 64), np.int64)
+    peak = []
+    hook = model.layers[1].register_forward_pre_hook(lambda mod, args: peak.append(float(args[0].abs().max())))
+    with torch.no_grad():
+        hs = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state
+    hook.remove()
+    want = last_token_pool(hs, torch.from_numpy(mask)).numpy()
+    print("residual peak entering layer 1:", peak[0])
+    assert peak[0] > 65504.0, "the construction must push the residual stream past the fp16 range"
+    dec = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    got = dec.forward(ids, mask)
+    dec.close()
+    assert np.isfinite(got).all()
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    print("beyond-fp16 residual: cos", cos, "rel", rel)
+    assert cos.min() > 0.999 and rel < 3e-2

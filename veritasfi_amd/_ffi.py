@@ -88,6 +88,7 @@ SIGNATURES = {
     "vf_decoder_weight_sizes": (ctypes.c_int, [vp, p_i64, p_i64]),
     "vf_decoder_create": (ctypes.c_int, [ctypes.POINTER(vp), vp, vp, c_i64, vp, c_i64, c_i32]),
     "vf_decoder_forward": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, c_i32, vp]),
+    "vf_decoder_forward_hidden": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp]),
     "vf_decoder_destroy": (ctypes.c_int, [vp]),
 }
 

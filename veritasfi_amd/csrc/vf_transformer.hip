@@ -54,6 +54,12 @@ static int fail(int code, const std::string& msg) { return vf::set_error(code, m
                                      std::to_string(__LINE__) + ")");                                     \
     } while (0)
 
+#define VFT_TRY(expr)               \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != VF_OK) return _rc; \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------------------
@@ -180,7 +186,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float*
 // per K-tile).  LDS rows padded to 144 B: ds_read_b128 fragment reads are conflict-free.
 // Requires M % 128 == 0 (buffers are padded), N % 128 == 0, K % 64 == 0.
 // ------------------------------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+// EPI_RESIDUAL_F32: C and R are FP32 buffers, C = R + acc (+ bias): the decoder family's residual stream is kept in fp32 (the
+// reference runs those models in the checkpoint's wider dtype: experiments/retriever/step3_mul.py:62-64), only the
+// GEMM operands are fp16.
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 = 3 };
 
 // exact-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far
 // below the fp16 precision of the stored activation): one rcp, one exp, five FMAs instead of libm's erff.
@@ -306,7 +315,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
                 float v = acc[mt][nt][reg] + bv;
                 if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
                 if (EPI == EPI_BIAS_RESIDUAL) v += (float)R[m * N + n];
-                C[m * N + n] = (half_t)v;
+                if (EPI == EPI_RESIDUAL_F32) ((float*)C)[m * N + n] = v + ((const float*)R)[m * N + n];
+                else C[m * N + n] = (half_t)v;
             }
     }
 }
@@ -777,6 +787,25 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the trailing dummy stage before LDS is reused
     __syncthreads();
+    if constexpr (EPI == EPI_RESIDUAL_F32) {
+        // fp32 residual stream: straight from the accumulators (16 lanes cover 64 contiguous bytes of a row; an fp32
+        // image of the tile would not fit the three operand slots)
+        const float* R32 = (const float*)R;
+        float* C32 = (float*)C;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const long long col = n0 + wc * (BN / 2) + nt * 16 + r15;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long long off = (m0 + wr * 64 + mt * 16 + 4 * kb + reg) * N + col;
+                    C32[off] = acc[mt][nt][reg] + bv + R32[off];
+                }
+        }
+        return;
+    }
     // epilogue through LDS: fp16(acc + bias [+GELU]) into a [128][BN] fp16 image (inside the three slots), then 16-byte
     // row chunks out (residual added in fp32 on the vector side)
     half_t* Es = (half_t*)smem;
@@ -1480,42 +1509,45 @@ __global__ __launch_bounds__(256) void k_attention_stream256(const half_t* __res
 // :384) and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225).  GEMMs and the streaming
 // attention are the kernels above; these are the small row kernels around them (half a wave per row, 16-byte chunks).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_rows(const int* ids, const half_t* table, int M, int H, float scale, half_t* out) {
+// token embeddings (times the model's embedding scale) into the FP32 residual stream
+__global__ __launch_bounds__(256) void k_gather_rows(const int* ids, const half_t* table, int M, int H, float scale, float* out) {
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
     const h8* src = (const h8*)(table + (long long)ids[row] * H);
-    h8* dst = (h8*)(out + (long long)row * H);
+    float4* dst = (float4*)(out + (long long)row * H);
     for (int c = l32; c < (H >> 3); c += 32) {
-        h8 v = src[c];
-        if (scale != 1.0f) {   // gemma: embeddings times sqrt(hidden)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
-        }
-        dst[c] = v;
+        const h8 v = src[c];   // gemma: embeddings times sqrt(hidden)
+        dst[2 * c] = make_float4((float)v[0] * scale, (float)v[1] * scale, (float)v[2] * scale, (float)v[3] * scale);
+        dst[2 * c + 1] = make_float4((float)v[4] * scale, (float)v[5] * scale, (float)v[6] * scale, (float)v[7] * scale);
     }
 }
 
 // y = x * rsqrt(mean(x^2) + eps) * (w + woff)   (woff = 1 for gemma's zero-centred gains; fp32 statistics; chunks are
-// re-read in the second pass)
-__global__ __launch_bounds__(256) void k_rmsnorm(const half_t* x, const float* w, float woff, float eps, int M, int H, half_t* y) {
+// re-read in the second pass).  x is the fp32 residual stream; y is fp16 (the next GEMM's operand) or fp32 (exported
+// hidden states).
+template <typename TOUT>
+__global__ __launch_bounds__(256) void k_rmsnorm(const float* x, const float* w, float woff, float eps, int M, int H, TOUT* y) {
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
-    const h8* src = (const h8*)(x + (long long)row * H);
-    const int nch = H >> 3;
+    const float4* src = (const float4*)(x + (long long)row * H);
+    const int nch = H >> 2;
     float q = 0.f;
     for (int c = l32; c < nch; c += 32) {
-        const h8 a = src[c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q += (float)a[e] * (float)a[e];
+        const float4 a = src[c];
+        q += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
     }
     const float r = rsqrtf(half_wave_sum(q) / H + eps);
-    h8* dst = (h8*)(y + (long long)row * H);
+    const float4* wv = (const float4*)w;
     for (int c = l32; c < nch; c += 32) {
-        const h8 a = src[c];
-        h8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] * r * (w[c * 8 + e] + woff));
-        dst[c] = o;
+        const float4 a = src[c], g = wv[c];
+        const float o0 = a.x * r * (g.x + woff), o1 = a.y * r * (g.y + woff), o2 = a.z * r * (g.z + woff), o3 = a.w * r * (g.w + woff);
+        if constexpr (sizeof(TOUT) == 4) {
+            ((float4*)(y + (long long)row * H))[c] = make_float4(o0, o1, o2, o3);
+        } else {
+            h4 o;
+            o[0] = (half_t)o0; o[1] = (half_t)o1; o[2] = (half_t)o2; o[3] = (half_t)o3;
+            ((h4*)(y + (long long)row * H))[c] = o;
+        }
     }
 }
 
@@ -1636,6 +1668,8 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
@@ -1827,6 +1861,16 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     static const long long dma_min = getenv("VF_GEMM_DMA_MIN_WGS") ? atoll(getenv("VF_GEMM_DMA_MIN_WGS")) : 384;
     const bool dma_ok = M % DBM == 0 && N % DBN == 0 && K % DBK == 0;
     const bool big_ok = M % LBM == 0 && N % LBN == 0;
+    if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: the default large kernel or the 128 x 128 one
+        if (dma_ok && (long long)(M / DBM) * (N / DBN) >= dma_min && kind != 3) {
+            hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
+            return hipGetLastError();
+        }
+        const dim3 grid32((N / GBN) * (M / GBM));
+        hipLaunchKernelGGL(k_gemm_tn<EPI>, grid32, dim3(256), (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t), st, A, W, bias, R, C, M, N, K);
+        return hipGetLastError();
+    }
+    else {
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
         hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
@@ -1854,6 +1898,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     const size_t lds = (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t);
     hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
     return hipGetLastError();
+    }
 }
 
 // ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
@@ -2032,9 +2077,11 @@ struct vf_decoder {
     size_t o_embed = 0, o_layers = 0, layer16 = 0, o_head_row = 0;  // fp16 offsets (elements)
     size_t f_layers = 0, layer32 = 0, f_final = 0;                   // fp32 offsets
     int cap_tokens = 0, cap_b = 0, rope_T = 0;
-    half_t *x = nullptr, *y = nullptr, *n = nullptr, *qkv = nullptr, *ctx = nullptr, *gu = nullptr, *act = nullptr;
+    float *x = nullptr, *y = nullptr;   // the residual stream, FP32 (ping-pong)
+    half_t *n = nullptr, *qkv = nullptr, *ctx = nullptr, *gu = nullptr, *act = nullptr;
     int *d_ids = nullptr, *d_mask = nullptr, *d_flag = nullptr;
     float* d_out = nullptr;
+    float* d_hidden = nullptr;   // [cap_tokens, H] fp32 final hidden states (vf_decoder_forward_hidden)
     float2* rope = nullptr;
     std::mutex mu;
 };
@@ -2077,9 +2124,10 @@ extern "C" int vf_decoder_weight_sizes(const vf_decoder_config* cfg, int64_t* n_
 }
 
 static void dec_free_ws(vf_decoder* d) {
-    void* p[] = {d->x, d->y, d->n, d->qkv, d->ctx, d->gu, d->act, d->d_ids, d->d_mask, d->d_out, d->rope};
+    void* p[] = {d->x, d->y, d->n, d->qkv, d->ctx, d->gu, d->act, d->d_ids, d->d_mask, d->d_out, d->rope, d->d_hidden};
     for (void* q : p) if (q) (void)hipFree(q);
-    d->x = d->y = d->n = d->qkv = d->ctx = d->gu = d->act = nullptr;
+    d->x = d->y = nullptr; d->d_hidden = nullptr;
+    d->n = d->qkv = d->ctx = d->gu = d->act = nullptr;
     d->d_ids = d->d_mask = nullptr; d->d_out = nullptr; d->rope = nullptr;
     d->cap_tokens = d->cap_b = d->rope_T = 0;
 }
@@ -2137,8 +2185,9 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     dec_free_ws(d);
     const vf_decoder_config& c = d->cfg;
     const size_t H = c.hidden, F = c.ffn, QKV = dec_qd(c) + 2 * dec_kd(c), QD = dec_qd(c), Mp = tokens;
-    VFT_HIP(hipMalloc((void**)&d->x, Mp * H * 2));
-    VFT_HIP(hipMalloc((void**)&d->y, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&d->x, Mp * H * 4));
+    VFT_HIP(hipMalloc((void**)&d->y, Mp * H * 4));
+    VFT_HIP(hipMalloc((void**)&d->d_hidden, Mp * H * 4));
     VFT_HIP(hipMalloc((void**)&d->n, Mp * H * 2));
     VFT_HIP(hipMalloc((void**)&d->qkv, Mp * QKV * 2));
     VFT_HIP(hipMalloc((void**)&d->ctx, Mp * QD * 2));
@@ -2149,8 +2198,8 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     VFT_HIP(hipMalloc((void**)&d->d_out, (size_t)B * (c.head == 2 ? 1 : H) * 4));
     VFT_HIP(hipMalloc((void**)&d->rope, (size_t)kDecMaxT * (c.head_dim / 2) * sizeof(float2)));
     // padded rows are read by the GEMMs: keep them finite
-    VFT_HIP(hipMemset(d->x, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(d->y, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(d->x, 0, Mp * H * 4));
+    VFT_HIP(hipMemset(d->y, 0, Mp * H * 4));
     VFT_HIP(hipMemset(d->n, 0, Mp * H * 2));
     VFT_HIP(hipMemset(d->qkv, 0, Mp * QKV * 2));
     VFT_HIP(hipMemset(d->ctx, 0, Mp * QD * 2));
@@ -2163,30 +2212,14 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     return VF_OK;
 }
 
-// ids / mask [b, t] int32 host (t % 32 == 0, t <= 2048; right- or left-padded with mask 0); t_valid = columns the
-// tokenizer produced.  out: [b, hidden] fp32 (head 0) or [b] fp32 (head 2).
-extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
-                                  int32_t t_valid, float* out) {
-    if (!d) return fail(VF_EINVAL, "vf_decoder_forward: null handle");
-    if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_decoder_forward: negative sizes");
-    if (b == 0) return VF_OK;
-    if (!ids || !mask || !out) return fail(VF_EINVAL, "vf_decoder_forward: null buffer");
-    if (t == 0 || t % 32 != 0 || t > kDecMaxT) return fail(VF_EINVAL, "vf_decoder_forward: t must be a multiple of 32 in [32, 2048] (pad with mask 0)");
-    if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_decoder_forward: t_valid must be in [1, t]");
-    std::lock_guard<std::mutex> g(d->mu);
-    VFT_HIP(hipSetDevice(d->device));
-    int rc = dec_ensure_ws(d, b, t);
-    if (rc != VF_OK) return rc;
+// The layers: ids / mask already in d->d_ids / d->d_mask.  Returns the final residual stream (fp32, device) in *xfinal.
+static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float** xfinal) {
     const vf_decoder_config& c = d->cfg;
     const int H = c.hidden, F = c.ffn, DH = c.head_dim, QD = (int)dec_qd(c), KD = (int)dec_kd(c), QKV = QD + 2 * KD;
     const int M = b * t, Mp = (M + 255) / 256 * 256;
-    hipStream_t st = nullptr;
-    const size_t ntok = (size_t)b * t;
-    VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
-    VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gather_rows, dim3((M + 7) / 8), dim3(256), 0, st, d->d_ids, d->w16 + d->o_embed, M, H,
                        c.embed_scale > 0.f ? c.embed_scale : 1.0f, d->x);
-    half_t *px = d->x, *py = d->y;
+    float *px = d->x, *py = d->y;   // residual stream in fp32; GEMM operands (d->n, d->ctx, d->act) in fp16
     const float scale = 1.0f / sqrtf((float)DH);
     const float woff = c.norm_plus_one ? 1.0f : 0.0f;
     const dim3 agrid((t + 127) / 128, c.heads, b);
@@ -2195,7 +2228,7 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
         const half_t *Wqkv = W, *Wo = Wqkv + (size_t)QKV * H, *Wgu = Wo + (size_t)H * QD, *Wdn = Wgu + (size_t)2 * F * H;
         const float* P = d->w32 + d->f_layers + (size_t)l * d->layer32;
         const float *ln1 = P, *ln2 = P + H, *qn = P + 2 * H, *kn = qn + DH;
-        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, woff, c.rms_eps, M, H, d->n);
+        hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, woff, c.rms_eps, M, H, d->n);
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st));
         const int units = M * (c.heads + c.kv_heads);
         hipLaunchKernelGGL(k_qknorm_rope, dim3((units + 256 / (DH / 8) - 1) / (256 / (DH / 8))), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
@@ -2210,16 +2243,50 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
             hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
                                t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
         }
-        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->ctx, Wo, nullptr, px, py, Mp, H, QD, st));
+        VFT_HIP(gemm<EPI_RESIDUAL_F32>(d->ctx, Wo, nullptr, (const half_t*)px, (half_t*)py, Mp, H, QD, st));
         std::swap(px, py);
-        hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, woff, c.rms_eps, M, H, d->n);
+        hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, woff, c.rms_eps, M, H, d->n);
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
         hipLaunchKernelGGL(k_swiglu, dim3(((F >> 3) + 255) / 256, M < 32768 ? M : 32768), dim3(256), 0, st, d->gu, (long long)M, F, c.act,
                            d->act);
-        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(d->act, Wdn, nullptr, px, py, Mp, H, F, st));
+        VFT_HIP(gemm<EPI_RESIDUAL_F32>(d->act, Wdn, nullptr, (const half_t*)px, (half_t*)py, Mp, H, F, st));
         std::swap(px, py);
     }
-    hipLaunchKernelGGL(k_rmsnorm, dim3((M + 7) / 8), dim3(256), 0, st, px, d->w32 + d->f_final, woff, c.rms_eps, M, H, d->n);
+    VFT_HIP(hipGetLastError());
+    *xfinal = px;
+    return VF_OK;
+}
+
+static int dec_check_call(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, const void* out, const char* who) {
+    if (!d) return fail(VF_EINVAL, std::string(who) + ": null handle");
+    if (b < 0 || t < 0) return fail(VF_EINVAL, std::string(who) + ": negative sizes");
+    if (b > 0 && (!ids || !mask || !out)) return fail(VF_EINVAL, std::string(who) + ": null buffer");
+    if (b > 0 && (t == 0 || t % 32 != 0 || t > kDecMaxT))
+        return fail(VF_EINVAL, std::string(who) + ": t must be a multiple of 32 in [32, 2048] (pad with mask 0)");
+    return VF_OK;
+}
+
+// ids / mask [b, t] int32 host (t % 32 == 0, t <= 2048; right- or left-padded with mask 0); t_valid = columns the
+// tokenizer produced.  out: [b, hidden] fp32 (head 0) or [b] fp32 (head 2).
+extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
+                                  int32_t t_valid, float* out) {
+    VFT_TRY(dec_check_call(d, ids, mask, b, t, out, "vf_decoder_forward"));
+    if (b == 0) return VF_OK;
+    if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_decoder_forward: t_valid must be in [1, t]");
+    std::lock_guard<std::mutex> g(d->mu);
+    VFT_HIP(hipSetDevice(d->device));
+    int rc = dec_ensure_ws(d, b, t);
+    if (rc != VF_OK) return rc;
+    const vf_decoder_config& c = d->cfg;
+    const int H = c.hidden, M = b * t;
+    hipStream_t st = nullptr;
+    const size_t ntok = (size_t)b * t;
+    VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
+    VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
+    float* px = nullptr;
+    VFT_TRY(dec_layers_device(d, b, t, st, &px));
+    const float woff = c.norm_plus_one ? 1.0f : 0.0f;
+    hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3((M + 7) / 8), dim3(256), 0, st, px, d->w32 + d->f_final, woff, c.rms_eps, M, H, d->n);
     int all_last = 0;
     if (c.pooling == 2 || c.head == 2) {
         hipLaunchKernelGGL(k_all_last_set, dim3(1), dim3(64), 0, st, d->d_mask, b, t, t_valid, d->d_flag);
@@ -2236,6 +2303,33 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
     }
     VFT_HIP(hipGetLastError());
     VFT_HIP(hipMemcpyAsync(out, d->d_out, (size_t)b * (c.head == 2 ? 1 : H) * 4, hipMemcpyDeviceToHost, st));
+    VFT_HIP(hipStreamSynchronize(st));
+    return VF_OK;
+}
+
+// last_hidden_state [b, t, hidden] fp32 host: the final RMSNorm of the fp32 residual stream, what HF's model(**inputs)
+// returns and the reference's generic route pools itself (experiments/retriever/step3_mul.py:203-207:
+// outputs.last_hidden_state -> last_token_pool).
+extern "C" int vf_decoder_forward_hidden(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
+                                         float* out_hidden) {
+    VFT_TRY(dec_check_call(d, ids, mask, b, t, out_hidden, "vf_decoder_forward_hidden"));
+    if (b == 0) return VF_OK;
+    std::lock_guard<std::mutex> g(d->mu);
+    VFT_HIP(hipSetDevice(d->device));
+    int rc = dec_ensure_ws(d, b, t);
+    if (rc != VF_OK) return rc;
+    const vf_decoder_config& c = d->cfg;
+    const int H = c.hidden, M = b * t;
+    hipStream_t st = nullptr;
+    const size_t ntok = (size_t)b * t;
+    VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
+    VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
+    float* px = nullptr;
+    VFT_TRY(dec_layers_device(d, b, t, st, &px));
+    hipLaunchKernelGGL(k_rmsnorm<float>, dim3((M + 7) / 8), dim3(256), 0, st, px, d->w32 + d->f_final, c.norm_plus_one ? 1.0f : 0.0f,
+                       c.rms_eps, M, H, d->d_hidden);
+    VFT_HIP(hipGetLastError());
+    VFT_HIP(hipMemcpyAsync(out_hidden, d->d_hidden, ntok * H * 4, hipMemcpyDeviceToHost, st));
     VFT_HIP(hipStreamSynchronize(st));
     return VF_OK;
 }

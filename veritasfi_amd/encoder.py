@@ -327,6 +327,24 @@ class HipDecoder:
                    "vf_decoder_forward")
         return out[:, 0] if self.out_dim == 1 else out
 
+    def hidden_states(self, ids, mask) -> np.ndarray:
+        """last_hidden_state [b, t, hidden] float32 (after the final RMSNorm), as HF's ``model(**inputs)`` returns it."""
+        ids = np.asarray(ids, dtype=np.int32)
+        mask = np.asarray(mask, dtype=np.int32)
+        b, t = ids.shape
+        tp = max(32, -(-t // 32) * 32)
+        if tp > 2048:
+            raise ValueError("sequences longer than 2048 tokens are not supported")
+        if tp != t:
+            pi, pm = np.zeros((b, tp), np.int32), np.zeros((b, tp), np.int32)
+            pi[:, :t], pm[:, :t] = ids, mask
+            ids, mask = pi, pm
+        ids, mask = np.ascontiguousarray(ids), np.ascontiguousarray(mask)
+        out = np.empty((b, tp, self.hidden), dtype=np.float32)
+        _ffi.check(_ffi.lib().vf_decoder_forward_hidden(self._h, ids.ctypes.data, mask.ctypes.data, b, tp, out.ctypes.data),
+                   "vf_decoder_forward_hidden")
+        return out[:, :t]
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _ffi.lib().vf_decoder_destroy(self._h)
@@ -340,8 +358,8 @@ class HipDecoder:
 
 
 class HipDecoderModel:
-    """HF-signature callable for get_embeddings (``pooled`` fast path only: the pooling the reference applies to a
-    decoder embedder is last_token_pool, computed on the GPU)."""
+    """HF-signature callable for get_embeddings: ``model(**inputs).last_hidden_state`` (the reference's generic route,
+    step3_mul.py:203-207) and the ``pooled`` fast path (last_token_pool on the GPU, no [b, t, hidden] copy-back)."""
 
     def __init__(self, decoder: HipDecoder):
         self.decoder = decoder
@@ -352,8 +370,10 @@ class HipDecoderModel:
         ids, mask, _ = _tok_arrays({"input_ids": input_ids, "attention_mask": attention_mask, "token_type_ids": None})
         return self.decoder.forward(ids, mask)
 
-    def __call__(self, **kw):
-        raise NotImplementedError("use get_embeddings(..., pooling='last_token'): hidden states are not exported")
+    def __call__(self, input_ids=None, attention_mask=None, **_):
+        import torch
+        ids, mask, _tt = _tok_arrays({"input_ids": input_ids, "attention_mask": attention_mask, "token_type_ids": None})
+        return types.SimpleNamespace(last_hidden_state=torch.from_numpy(self.decoder.hidden_states(ids, mask)))
 
 
 class HipDecoderEmbeddings:
