@@ -43,6 +43,7 @@ typedef _Float16 half_t;
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 static int fail(int code, const std::string& msg) { return vf::set_error(code, msg); }
 
@@ -203,6 +204,26 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float erf_abs = 1.0f - poly * t * __expf(-z * z);
     const float erf_x = x < 0.f ? -erf_abs : erf_abs;
     return 0.5f * x * (1.0f + erf_x);
+}
+// The same arithmetic on TWO values at once: the multiplies / FMAs are written on 2-vectors so that they issue as
+// v_pk_mul_f32 / v_pk_fma_f32 (one slot for two lanes' worth of work); rcp and exp2 stay scalar.  The epilogue of the
+// 256 x 256 kernel is VALU-bound (one workgroup per CU: nothing else runs under it), so issue slots are what it costs.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v gelu_erf2(f2v x) {
+    const f2v ax = {fabsf(x[0]), fabsf(x[1])};
+    const f2v z = ax * 0.70710678118654752f;
+    const f2v d = z * 0.3275911f + 1.0f;
+    const f2v t = {__frcp_rn(d[0]), __frcp_rn(d[1])};
+    f2v poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    const f2v q = z * (z * -1.4426950408889634f);            // -z^2 * log2(e)
+    const f2v e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f2v erf_abs = 1.0f - poly * t * e;
+    const f2v half_x = x * 0.5f;
+    // 0.5 x (1 + sign(x) erf|x|) = 0.5 x + 0.5 |x| erf|x|
+    return half_x + (ax * 0.5f) * erf_abs;
 }
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
 
@@ -698,7 +719,6 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma_tn(const half_t* __res
 // operands from LDS).  Lane (r = lane & 15, kb = lane >> 4) reads rows r of a 16-row tile at k-block kb, so the chunk
 // swizzle is re-derived for that map: physical chunk = c ^ f(row), f = {0, 3, 2, 1}[(row >> 2) & 3], which gives every
 // ds_read_b128 lane group ({0-3, 12-15, 20-27} ...) 16 distinct 16-byte slots.
-typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int swz16(int row) { return (0x6C >> (2 * ((row >> 2) & 3))) & 3; }   // 0b01'10'11'00 -> 0, 3, 2, 1
 
 template <int EPI, int BN>
@@ -828,6 +848,195 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
     for (int i = 0; i < BN / 16; ++i) {
         const int c = tid + DTHREADS * i, row = c / (BN / 8), cc = c % (BN / 8);  // BN / 8 chunks of 8 halves per row
         h8 o = *(const h8*)(Es + row * BN + cc * 8);
+        const long long off = (m0 + row) * N + n0 + cc * 8;
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const h8 r = *(const h8*)(R + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+        }
+        *(h8*)(C + off) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm8p_tn: 256 x 256 x 64 tiles, 8 waves (2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles,
+// 128 accumulator VGPRs), ONE workgroup per CU, LDS-DMA staging with a counted vmcnt and raw barriers --
+// the "8-phase" schedule of the CDNA GEMM playbook, derived here for this operand layout:
+//
+//  * a K-tile (64 deep) is FOUR half-tiles of 16 KB (128 rows x 128 B), in the order they are first needed:
+//      g % 4 = 0  A_m0: A rows {0..63, 128..191}   (each wave's first 64 rows)
+//              1  B_n0: W rows {64 wc + 0..31}      (each wave's first 32 columns)
+//              2  B_n1: W rows {64 wc + 32..63}
+//              3  A_m1: A rows {64..127, 192..255}
+//    two K-tiles of LDS (128 KB) + a 16 KB dump slot for the stage instructions past the end of K;
+//  * a K-tile is FOUR phases of 16 MFMAs per wave, one 64 x 32 quadrant of the wave tile each, in the order
+//    (m0,n0) (m0,n1) (m1,n1) (m1,n0); phase 0 reads A_m0 + B_n0 from LDS (12 ds_read_b128), phase 1 B_n1 (4),
+//    phase 2 A_m1 (8), phase 3 nothing (B_n0 is still in registers);
+//  * phase P (counted over the whole K loop) issues the DMA of half-tile P + 6: its slot was last read in phase
+//    P - 2; it waits, with vmcnt(6), until half-tiles <= P + 2 of this wave's own DMA have landed (3 half-tiles
+//    = 6 instructions stay in flight);
+//  * waves 4..7 (the partner of wave w on its SIMD is wave w + 4) run ONE barrier behind waves 0..3: while one
+//    half reads LDS / issues DMA, the other half issues its 16 MFMAs, so each SIMD's matrix pipe always has work.
+//    With the one-barrier stagger a half-tile read in phase P was waited for by every wave in phase P - 1 or
+//    earlier (the +1 in "P + 2" above), and the slot written in phase P was read no later than phase P - 2.
+//  LDS rows are 128 B = 8 chunks of 16 B; chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7) (the DMA lanes
+//  fetch the matching logical chunk): a ds_read_b128 lane group of the 16x16x32 operand read (8 rows at k-block kb,
+//  8 rows at kb + 1) then touches 16 distinct 16-byte slots of the 256-byte bank row.
+//  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128.
+// ------------------------------------------------------------------------------------------------
+constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLDS = 2 * 4 * PSLOT + PSLOT;
+
+template <int EPI>
+__global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                          half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: [2 K-tiles][4 half-tiles][16 KB] + dump
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
+    int mt_idx, nt_idx;
+    {   // XCD-contiguous, n-major groups of 4 m-tiles
+        const int Mt = M / PBM, Nt = N / PBN, nwg = Mt * Nt;
+        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        constexpr int GM = 4;
+        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
+        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+        nt_idx = r / gm;
+        mt_idx = g * GM + (r - nt_idx * gm);
+    }
+    const long long m0 = (long long)mt_idx * PBM, n0 = (long long)nt_idx * PBN;
+    // ---- staging: wave w issues DMA instructions 2w, 2w+1 of every half-tile: LDS rows 16 w + 8 j + (lane >> 3)
+    const half_t* src[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = 16 * wid + 8 * j + (lane >> 3);          // LDS row of the half-tile
+        const int lc = (lane & 7) ^ ((i >> 1) & 7);            // logical 16-byte chunk this lane fetches
+        const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
+        const int bn0 = (i >> 5) * 64 + (i & 31), bn1 = bn0 + 32;
+        src[0][j] = A + (m0 + am0) * K + lc * 8;
+        src[1][j] = W + (n0 + bn0) * K + lc * 8;
+        src[2][j] = W + (n0 + bn1) * K + lc * 8;
+        src[3][j] = A + (m0 + am1) * K + lc * 8;
+    }
+    const int nk = K / PBK, G = 4 * nk;   // K-tiles, half-tiles
+    auto stage = [&](int g) {             // g: half-tile counted over the whole K loop (wave-uniform)
+        const int s = g & 3;
+        const int kt = g < G ? (g >> 2) : nk - 1;                                // past the end: re-read the last K-tile ...
+        const int slot = g < G ? ((g >> 2) & 1) * 4 + s : 8;                     // ... into the dump slot
+        char* dst = smem + slot * PSLOT + (16 * wid) * 128;
+        const half_t* s0 = s == 0 ? src[0][0] : s == 1 ? src[1][0] : s == 2 ? src[2][0] : src[3][0];
+        const half_t* s1 = s == 0 ? src[0][1] : s == 1 ? src[1][1] : s == 2 ? src[2][1] : src[3][1];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (long long)kt * PBK),
+                                         (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + (long long)kt * PBK),
+                                         (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+    };
+    f4v acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+    // fragment addresses inside a half-tile: row = (wave's 64 / 32 rows) + tile * 16 + r15; chunk (4 ks + kb) ^ ((r15 >> 1) & 7)
+    const int swz = (r15 >> 1) & 7;
+    const int a_off = (wr * 64 + r15) * 128, b_off = (wc * 32 + r15) * 128;
+    const int c0 = ((0 + kb) ^ swz) * 16, c1 = ((4 + kb) ^ swz) * 16;   // k-steps 0 and 1
+    h8 Af[4][2], B0f[2][2], B1f[2][2];
+#define VFT_READ_A(SLOTBASE)                                                              \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+        Af[t][0] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c0);                       \
+        Af[t][1] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c1);                       \
+    }
+#define VFT_READ_B(DSTF, SLOTBASE)                                                         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                        \
+        DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
+        DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
+    }
+#define VFT_QUAD(MQ, NQ, BF)                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[t][ks], BF[u][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
+#define VFT_PHASE_HEAD(G)                                                                  \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
+    __builtin_amdgcn_s_barrier();                                                          \
+    stage(G);
+#define VFT_PHASE_MID()                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    __builtin_amdgcn_s_barrier();                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    __builtin_amdgcn_s_setprio(1);
+#define VFT_PHASE_TAIL()                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 6; ++g) stage(g);
+    if (wr == 1) {   // waves 4..7 run one barrier behind; the other half reads half-tiles 0 and 1 right after this barrier
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 12 issued, 8 may still fly: half-tiles 0, 1 of this wave landed
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * (4 * PSLOT);
+        const int g0 = 4 * kt + 6;
+        // phase 0: quadrant (m0, n0); reads B_n0 then A_m0
+        VFT_PHASE_HEAD(g0)
+        VFT_READ_B(B0f, base + 1 * PSLOT)
+        VFT_READ_A(base + 0 * PSLOT)
+        VFT_PHASE_MID()
+        VFT_QUAD(0, 0, B0f)
+        VFT_PHASE_TAIL()
+        // phase 1: quadrant (m0, n1); reads B_n1
+        VFT_PHASE_HEAD(g0 + 1)
+        VFT_READ_B(B1f, base + 2 * PSLOT)
+        VFT_PHASE_MID()
+        VFT_QUAD(0, 1, B1f)
+        VFT_PHASE_TAIL()
+        // phase 2: quadrant (m1, n1); reads A_m1
+        VFT_PHASE_HEAD(g0 + 2)
+        VFT_READ_A(base + 3 * PSLOT)
+        VFT_PHASE_MID()
+        VFT_QUAD(1, 1, B1f)
+        VFT_PHASE_TAIL()
+        // phase 3: quadrant (m1, n0); nothing to read
+        VFT_PHASE_HEAD(g0 + 3)
+        VFT_PHASE_MID()
+        VFT_QUAD(1, 0, B0f)
+        VFT_PHASE_TAIL()
+    }
+#undef VFT_READ_A
+#undef VFT_READ_B
+#undef VFT_QUAD
+#undef VFT_PHASE_HEAD
+#undef VFT_PHASE_MID
+#undef VFT_PHASE_TAIL
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
+    __syncthreads();
+    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [256][256] fp16 image (the two K-tile buffers), then
+    // 16-byte row chunks out (residual added in fp32 on the vector side)
+    half_t* Es = (half_t*)smem;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int col = wc * 64 + ni * 16 + r15;
+        const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg += 2) {
+                const int row = wr * 128 + mi * 16 + 4 * kb + reg;
+                f2v v = {acc[mi][ni][reg] + bv, acc[mi][ni][reg + 1] + bv};
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf2(v);
+                Es[row * PBN + col] = (half_t)v[0];
+                Es[(row + 1) * PBN + col] = (half_t)v[1];
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
+        h8 o = *(const h8*)(Es + row * PBN + cc * 8);
         const long long off = (m0 + row) * N + n0 + cc * 8;
         if (EPI == EPI_BIAS_RESIDUAL) {
             const h8 r = *(const h8*)(R + off);
@@ -1668,6 +1877,9 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1871,6 +2083,14 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         return hipGetLastError();
     }
     else {
+    // 256 x 256 8-phase tiles (one workgroup per CU) once they fill the chip 1.5 times over; measured against the
+    // 128 x 256 DMA kernel at M = 51200: 225 / 79 / 265 / 246 us vs 278 / 79 / 296 / 295 us (QKV / out / FFN-up / FFN-down
+    // shapes of a 768-wide encoder; the vendor library: 210 / 66 / 234 / 217)
+    static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K);
+        return hipGetLastError();
+    }
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
         hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
@@ -2343,7 +2563,8 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     if (M % 128 || N % 128 || K % 64) return -2;
     if ((kind == 1 || kind == 5) && (M % DBM || N % DBN)) return -2;
     if (kind == 6 && (M % DBM || N % 128)) return -2;
-    if (kind == 2 && (M % LBM || N % LBN)) return -2;
+    if ((kind == 2 || kind == 7) && (M % LBM || N % LBN)) return -2;
+    if (kind == 7 && K < 128) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;
