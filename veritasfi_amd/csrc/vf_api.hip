@@ -87,7 +87,7 @@ struct Slot {
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
     DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
-    DevBuf dbg, wgbase;
+    DevBuf dbg, wgbase, tilecnt;
     int64_t wgbase_n = -1; int wgbase_grid = -1;
     DevBuf dense_s, cn_tmp, parts_ids, parts_sc, run_ids, run_sc, qsel; // exact-path scratch
     int* h_flags = nullptr;      // pinned, [max batches * 64]
@@ -136,7 +136,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0, wide_opt = 1;  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
+            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1;  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
@@ -236,7 +236,7 @@ static void destroy_index(vf_index* ix) {
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = ix->slots[i];
         DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.hist_coarse, &s.cand, &s.flags, &s.counts, &s.dense_s,
-                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg, &s.wgbase};
+                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg, &s.wgbase, &s.tilecnt};
         for (DevBuf* b : bufs) b->release();
         if (s.h_flags) (void)hipHostFree(s.h_flags);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
@@ -476,6 +476,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "waves") { if (!in_range(0, 8 * 1024)) return fail(VF_EINVAL, "waves must be in [0, 8192]"); ix->waves_opt = value; }
     else if (s == "scan_g") { if (!in_range(0, 4)) return fail(VF_EINVAL, "scan_g must be in [0, 4]"); ix->scan_g = value; }
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
+    else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
@@ -715,6 +716,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     VF_TRY(s.hist.ensure((size_t)kMaxBatch * kHistBins * sizeof(u32)));
     VF_TRY(s.hist_coarse.ensure((size_t)kMaxBatch * 64 * sizeof(u32)));
     VF_TRY(s.cand.ensure((size_t)kMaxBatch * p.cap * sizeof(u64)));
+    VF_TRY(s.tilecnt.ensure((size_t)p.grid * sizeof(u32)));
     s.timed = ix->profile;
     if (s.timed) VF_HIP(hipEventRecord(s.ev_t[2], st));
     if (s.wgbase_n != ix->n || s.wgbase_grid != p.grid) {  // first row of every scan workgroup (k_sel0 maps sample slots back to rows)
@@ -735,6 +737,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         a.s0 = s.s0.as<float>(); a.wg_base = s.wgbase.as<long long>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>(); a.hist = s.hist.as<u32>();
         a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
         a.hist_coarse = s.hist_coarse.as<u32>(); a.stage_cap = scan_stage_cap(ix->dp, qt);
+        a.tile_cnt = ix->steal_opt ? s.tilecnt.as<u32>() : nullptr; a.scan_grid = p.grid;
         a.dbg = nullptr;
         if (ix->debug & 128) { VF_TRY(s.dbg.ensure((size_t)p.total_waves * 4 * sizeof(u64))); a.dbg = s.dbg.as<u64>(); }
         a.refresh_every = (int)std::min<int64_t>(256, std::max<int64_t>(1, ix->refresh_every)); a.nq = nb; a.debug = (int)ix->debug;

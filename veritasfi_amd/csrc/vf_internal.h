@@ -53,6 +53,8 @@ struct ScanArgs {
     int kprime;              // k + margin: the threshold keeps >= kprime rows above it
     int refresh_every;       // recompute tau when a query's count crosses a multiple of this
     int nq;                  // real queries (<= QN); padded queries never pass
+    u32* tile_cnt;           // [grid] pool counters: tiles claimed from the shared tail of each workgroup's row range (k_sel0 zeroes them); null = no stealing
+    int scan_grid;           // workgroups of the main scan (k_sel0 resets that many counters)
     // wide scan (k_scan_wide): queries in the global image, 256-query tiles per pass, row groups
     int qn_total, jtiles, rgroups;
     unsigned long long* dbg; // optional [grid][8 waves][4] wall-clock stamps (debug bit 7), else null

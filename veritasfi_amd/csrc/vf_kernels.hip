@@ -727,15 +727,40 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     const int lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
     const long long grid = gridDim.x;
-    const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
     const long long swg = (long long)a.samp * WAVES;
-    const long long Rs = (Ra + swg < Rb) ? Ra + swg : Rb;
-    const long long lo = MODE == kModeSample ? Ra : Rs;
-    const long long hi = MODE == kModeSample ? Rs : Rb;
-    const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);  // per workgroup: < 2^31 / 32 rows
+    // row range of workgroup v's part in this mode: the sample part is the first swg rows of its range, the main part the rest
+    long long lo, hi;
+    int ntiles;
+    auto part_of = [&](long long v, long long& plo, long long& phi) {
+        const long long Ra = a.n * v / grid, Rb = a.n * (v + 1) / grid;
+        const long long Rs = (Ra + swg < Rb) ? Ra + swg : Rb;
+        plo = MODE == kModeSample ? Ra : Rs;
+        phi = MODE == kModeSample ? Rs : Rb;
+    };
+    part_of(blockIdx.x, lo, hi);
+    ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);  // per workgroup: < 2^31 / 32 rows
+    // Main mode with a.tile_cnt: the LAST kPoolDiv-th of every range is a POOL that any workgroup may take tiles from
+    // (global counters, set to 0 by k_sel0); the first part is the owner's alone (LDS counter: a global atomic per
+    // tile on every tile measured 10 % slower -- its latency sits in the in-order memory queue ahead of the prefetch).
+    constexpr int kPoolDiv = 12;
+    const bool pooled = MODE == kModeMain && a.tile_cnt != nullptr;
+    auto pool_of = [&](long long v, long long& plo, long long& phi) {
+        part_of(v, plo, phi);
+        const int nt_v = (int)((phi - plo + kRowTile - 1) / kRowTile);
+        plo += (long long)(nt_v - nt_v / kPoolDiv) * kRowTile;   // the pool: tiles [nt - nt / 12, nt)
+        if (plo > phi) plo = phi;
+    };
+    if (pooled) {
+        const int nloc = ntiles - ntiles / kPoolDiv;
+        hi = lo + (long long)nloc * kRowTile < hi ? lo + (long long)nloc * kRowTile : hi;
+        ntiles = nloc;
+    }
     const int SS = (a.dp >> 6) / G;
     char* ctl = smem + (size_t)a.dp * QN * 2;
     u32* next_tile = (u32*)(ctl + 4);
+    // When a workgroup's own part is exhausted its waves take tiles from the pool with the most tiles left (their own
+    // first, as a rule), so that the launch ends when the corpus does, not when the slowest CU does.
+    u32* const own_cnt = next_tile;
 
     // Two register stages (A0, A1), one flat sequence of supersteps over (tile, ss).  The prefetch of
     // the next step is issued UNCONDITIONALLY before the current one is consumed (past the end it
@@ -746,9 +771,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     stage_t A0[F8 ? 2 * G : 4 * G], A1[F8 ? 2 * G : 4 * G];
     EpiRegs<NT> epi;
     int cur_tile = wid, claimed = 0x7fffffff, tiles_done = 0;
-    const bool active = cur_tile < ntiles;
+    bool active = cur_tile < ntiles;
     // row index of this lane in `tile`, clamped into the part (32-bit: a shard has < 2^32 rows)
-    const u32 lo32 = (u32)lo + (u32)r31, hi32m1 = (u32)(hi - 1);
+    u32 lo32 = (u32)lo + (u32)r31, hi32m1 = (u32)(hi - 1);
     auto rowof = [&](int tile) {
         const u32 r = lo32 + (u32)tile * kRowTile;
         return (long long)(r < hi32m1 ? r : hi32m1);
@@ -773,6 +798,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
                                   ? a.dbg + ((long long)blockIdx.x * WAVES + wid) * 4 : nullptr;
     if (dbg) dbg[0] = wall_clock64();
 
+    u32* seg_cnt = own_cnt;          // the tile counter of the range this wave is working on
+    long long s0_base = (long long)blockIdx.x * swg;
+    for (;;) {   // one iteration per row range ("segment"): the workgroup's own, then stolen ones (main mode)
     if (active) {
         f16v acc[NT];
 #pragma unroll
@@ -783,9 +811,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
         const int pairs = SS >> 1;
         while (true) {
             const long long t0 = lo + (long long)cur_tile * kRowTile;
-            {   // one claim per wave (LDS atomic); the result is consumed at the tile's end
+            {   // one claim per wave (LDS atomic, or an L2 atomic in main mode); the result is consumed at the tile's end
                 int v_ = 0;
-                if (lane == 0) v_ = (int)atomicAdd(next_tile, 1u);
+                if (lane == 0) v_ = (int)atomicAdd(seg_cnt, 1u);
                 claimed = __builtin_amdgcn_readfirstlane(v_);
             }
             const long long myrow = rowof(cur_tile);
@@ -806,7 +834,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
             VF_ISSUE(A0, a.rows, a.row_bytes, rowof(more ? claimed : cur_tile), 0, h);
             __builtin_amdgcn_sched_barrier(0);
             VF_COMPUTE(acc, A1, lds_lane, SS - 1);
-            tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, (long long)blockIdx.x * swg + (t0 - lo), lane, ctl);
+            tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, s0_base + (t0 - lo), lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -815,6 +843,44 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
             if (!more) break;
             cur_tile = claimed;
         }
+    }
+    if (!pooled) break;
+    // ---- steal: the range with the most unclaimed tiles (lane l looks at ranges 4l .. 4l+3; counters only grow, so a
+    // stale read over-estimates what is left and at worst costs a failed claim)
+    {
+        int best_left = 0, best_v = -1;
+        for (int v0 = 0; v0 < (int)grid; v0 += 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = v0 + lane * 4 + j;
+                if (v < (int)grid) {
+                    long long plo, phi;
+                    pool_of(v, plo, phi);
+                    const int nt_v = (int)((phi - plo + kRowTile - 1) / kRowTile);
+                    const int c = (int)__hip_atomic_load(a.tile_cnt + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int left = nt_v - c;
+                    if (left > best_left) { best_left = left; best_v = v; }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const int ol = __shfl_xor(best_left, off), ov = __shfl_xor(best_v, off);
+            if (ol > best_left || (ol == best_left && ov > best_v)) { best_left = ol; best_v = ov; }
+        }
+        if (best_left <= 0) break;   // nothing left anywhere: the wave is done
+        const int v = __builtin_amdgcn_readfirstlane(best_v);
+        pool_of(v, lo, hi);
+        ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
+        lo32 = (u32)lo + (u32)r31; hi32m1 = (u32)(hi - 1);
+        seg_cnt = a.tile_cnt + v;
+        s0_base = 0;
+        int t_ = 0;
+        if (lane == 0) t_ = (int)atomicAdd(seg_cnt, 1u);
+        cur_tile = __builtin_amdgcn_readfirstlane(t_);
+        active = cur_tile < ntiles;
+        if (active) VF_ISSUE(A0, a.rows, a.row_bytes, rowof(cur_tile), 0, h);
+    }
     }
     if (dbg) { dbg[1] = wall_clock64(); }
     if (MODE == kModeMain) {
@@ -1456,6 +1522,9 @@ __global__ __launch_bounds__(1024) void k_sel0(ScanArgs a) {
         a.cnt[q * kCntStride] = lcnt;
         a.tau_bin[q] = (q < a.nq && !(a.debug & 1)) ? tb : kHistBins;
     }
+    // the main scan's pool counters (tiles any workgroup may claim from the tail of every range) start at 0
+    if (q == 0 && a.tile_cnt)
+        for (int i = tid; i < a.scan_grid; i += 1024) a.tile_cnt[i] = 0u;
 }
 
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s) {
