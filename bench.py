@@ -185,9 +185,12 @@ def main():
     device = torch.device("cuda", local)
     # VF_BENCH_FORCE_EXCHANGE=1 runs the all-gather + merge even with one rank (rehearsal of the N>1 path)
     exchange = world > 1 or os.environ.get("VF_BENCH_FORCE_EXCHANGE") == "1"
+    # NOTE: the process group is created WITHOUT device_id=.  Eager binding (device_id=device) before the corpus is
+    # allocated made every later scan 25 % slower on this stack (0.39 -> 0.49 ms per launch at 1.25M rows, same box,
+    # same binary; profiles/r02b_pg_init_order.log): the allocations made after an eagerly bound communicator exists
+    # read slower.  Lazy initialisation (communicator created at the first collective) leaves them alone.
     if world > 1 or (exchange and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=device)
-
+        dist.init_process_group("nccl")
     devs = None
     if args.single_process:
         assert world == 1, "--single-process runs without torchrun"
@@ -256,7 +259,7 @@ def main():
             torch.cuda.synchronize(dv)
         torch.cuda.synchronize()
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(device_ids=[local])
             torch.cuda.synchronize()
 
     run(args.warmup)
@@ -367,7 +370,7 @@ def main():
         print(json.dumps(line), flush=True)
     index.close()
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 
