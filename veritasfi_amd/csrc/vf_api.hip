@@ -661,6 +661,7 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     f.out_ids = (long long*)d_ids; f.out_scores = d_scores;
     f.flags = s.d_flags + flag_off; f.cand_count_out = s.d_counts + flag_off;
     f.dbg = nullptr;
+    if (ix->debug & 256) { VF_TRY(s.dbg.ensure((size_t)qtot * 8 * sizeof(u64))); f.dbg = s.dbg.as<u64>(); }
     VF_HIP(launch_final(f, nb, st));
     return VF_OK;
 }

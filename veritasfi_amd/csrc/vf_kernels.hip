@@ -1672,12 +1672,13 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     u32* lh = (u32*)(qs + ((a.d + 3) & ~3));  // [kHistBins] histogram of the candidates' score bins
     u32& s_nsel = lh[kHistBins];              // all LDS is dynamic: the kernel may be given the full 160 KB
     int& s_bin = *(int*)(lh + kHistBins + 1);
+    u32& s_minkey = lh[kHistBins + 2];        // smallest approximate key among the survivors
     const int q = blockIdx.x, tid = threadIdx.x;
     unsigned long long* dbg = (a.dbg && tid == 0) ? a.dbg + (long long)q * 8 : nullptr;
     if (dbg) dbg[0] = wall_clock64();
     const u32 n_raw = a.cnt[q * kCntStride];
     const int n = n_raw < (u32)a.cap ? (int)n_raw : a.cap;
-    const int m = n < a.kprime ? n : a.kprime;
+    const int mwant = n < a.kprime ? n : a.kprime;   // how many of the best candidates must be re-scored
     const u64* cq = a.cand + (long long)q * a.cap;
     const int tbin = a.tau_bin[q];
     if (n_raw > (u32)a.cap) {   // overflowed list: not every slot need be written -- nothing here can be trusted, exact path
@@ -1687,26 +1688,41 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
     }
     for (int j = tid; j < a.d; j += kFinalThreads) qs[j] = a.qn[(long long)q * a.d + j];
     for (int b = tid; b < kHistBins; b += kFinalThreads) lh[b] = 0u;
-    if (tid == 0) { s_nsel = 0u; s_bin = 0; }
+    if (tid == 0) { s_nsel = 0u; s_bin = 0; s_minkey = 0xFFFFFFFFu; }
     __syncthreads();
-    // Select by the list's OWN histogram: the highest bin b* with >= m candidates at or above it; everything below
-    // b* cannot be among the best m.  (The scan's final threshold is usually the same bin, but it may be looser --
-    // small corpora, stale refreshes -- and is only needed for the completeness check at the end.)
-    for (int i = tid; i < n; i += kFinalThreads) atomicAdd(&lh[bin_of_x(bin_x(unorderkey((u32)(cq[i] >> 32))))], 1u);
+    // Select by the list's OWN histogram, in FINE bins: 16 per threshold bin, counted from the scan's final threshold
+    // (every candidate sits at or just below it; nearly all of a k = 1000 list falls into ~40 threshold bins, so a
+    // histogram at that resolution would serialise its LDS atomics on those few words and leave ~100 candidates in the
+    // boundary bin to be ranked).  The highest fine bin b* with >= m candidates at or above it splits the list: the
+    // survivors (m plus the handful that share b*) are ALL re-scored -- no approximate ranking is needed at all; A, the
+    // certificate's "best score a row that was not re-scored can have", is the smallest survivor.
+    const float fscale = tbin > 0 ? 16.0f : 1.0f, forig = tbin > 0 ? (float)tbin : 0.0f;
+    auto fine_bin = [&](u64 kv) {
+        const float x = (bin_x(unorderkey((u32)(kv >> 32))) - forig) * fscale;
+        const int fb = (int)floorf(x) + 1;   // bin 0 is for what lies BELOW the origin only (entries kept under an earlier, looser threshold)
+        return fb < 0 ? 0 : (fb > kHistBins - 1 ? kHistBins - 1 : fb);
+    };
+    for (int i = tid; i < n; i += kFinalThreads) atomicAdd(&lh[fine_bin(cq[i])], 1u);
     __syncthreads();
     if (tid < 64) {
-        const int nb = wave_tau_from_lds(lh, m > 0 ? m : 1, tid);
+        const int nb = wave_tau_from_lds(lh, mwant > 0 ? mwant : 1, tid);
         if (tid == 0) s_bin = nb > 0 ? nb : 0;
     }
     __syncthreads();
     const int sbin = s_bin;
+    u32 mymin = 0xFFFFFFFFu;
     for (int i = tid; i < n; i += kFinalThreads) {
         const u64 kv = cq[i];
-        if (bin_of_x(bin_x(unorderkey((u32)(kv >> 32)))) >= sbin) {
+        if (fine_bin(kv) >= sbin) {
             const u32 sl = atomicAdd(&s_nsel, 1u);
             if (sl < (u32)a.sel_cap) sel[sl] = kv;
+            const u32 ak = (u32)(kv >> 32);
+            mymin = ak < mymin ? ak : mymin;
         }
     }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { const u32 o = (u32)__shfl_xor((int)mymin, off); mymin = o < mymin ? o : mymin; }
+    if ((tid & 63) == 0) atomicMin(&s_minkey, mymin);
     __syncthreads();
     const int ns = (int)s_nsel;
     if (ns > a.sel_cap) {  // more than sel_cap candidates share the boundary bin (hostile data): exact path
@@ -1714,32 +1730,45 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
         if (tid == 0) { a.flags[q] = n_raw > (u32)a.cap ? 2 : 1; a.cand_count_out[q] = n_raw; }
         return;
     }
-    rank_select_desc(sel, ns, top, m, tid);
-    __syncthreads();
     if (dbg) dbg[1] = wall_clock64();
-    const float approx_floor = m > 0 ? unorderkey((u32)(top[m - 1] >> 32)) : -INFINITY;
-    // canonical re-score: two lanes per row, a block of 128 rows at a time
+    const float approx_floor = ns > 0 ? unorderkey(s_minkey) : -INFINITY;
+    // canonical re-score of every survivor: two lanes per row, a block of 128 rows at a time.  The key of row i replaces
+    // its approximate key in place (sel[i] is read by the pair that writes it).
     const int pr = tid >> 1, h = tid & 1;
-    for (int i0 = 0; i0 < m; i0 += kFinalThreads / 2) {
+    for (int i0 = 0; i0 < ns; i0 += kFinalThreads / 2) {
         const int i = i0 + pr;
-        u32 row = (u32)top[i < m ? i : m - 1];   // idle pairs shadow the last row (whole wave stays converged)
+        u32 row = (u32)sel[i < ns ? i : ns - 1];   // idle pairs shadow the last row (whole wave stays converged)
         row = (long long)row < a.n_rows ? row : (u32)(a.n_rows - 1);   // never index the corpus with a value the scan did not produce
         const float nm = a.norm[row];
         const float acc = a.orig_dtype == VF_DTYPE_F16       ? rescore_pair<VF_DTYPE_F16>(a.rows_orig, row, a.d, qs, nm, h)
                           : a.orig_dtype == VF_DTYPE_FP8_E4M3 ? rescore_pair<VF_DTYPE_FP8_E4M3>(a.rows_orig, row, a.d, qs, nm, h)
                                                               : rescore_pair<VF_DTYPE_F32>(a.rows_orig, row, a.d, qs, nm, h);
-        if (h == 0 && i < m) rk[i] = ((u64)orderkey(acc) << 32) | (u64)(0xFFFFFFFFu - row);
+        __builtin_amdgcn_wave_barrier();   // every pair of this wave has read its row id before any pair overwrites a slot
+        if (h == 0 && i < ns) rk[i] = ((u64)orderkey(acc) << 32) | (u64)(0xFFFFFFFFu - row);
     }
     __syncthreads();
     if (dbg) dbg[2] = wall_clock64();
-    rank_select_desc(rk, m, top, m, tid);  // top now holds the canonical ranking
+    // rank by (canonical desc, id asc): counting for short lists, an LDS bitonic network beyond 256 keys (counting is
+    // O(n^2 / threads): 60 us at n = 1280; the network's 66 barriers cost ~10 us with four waves)
+    const u64* ranked;
+    if (ns <= 256) {
+        rank_select_desc(rk, ns, top, ns < a.top_cap ? ns : a.top_cap, tid);
+        ranked = top;
+    } else {
+        const int P = next_pow2(ns);   // <= sel_cap (a power of two)
+        for (int i = ns + tid; i < P; i += kFinalThreads) rk[i] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc(rk, P, tid, kFinalThreads);
+        ranked = rk;
+    }
     __syncthreads();
     if (dbg) dbg[3] = wall_clock64();
+    const int m = ns;   // rows re-scored
     for (int i = tid; i < a.k; i += kFinalThreads) {
         long long id = -1;
         float sc = -FLT_MAX;
         if (i < m) {
-            const u64 kv = top[i];
+            const u64 kv = ranked[i];
             id = a.id_offset + (long long)(0xFFFFFFFFu - (u32)kv);
             sc = unorderkey((u32)(kv >> 32));
         }
@@ -1751,11 +1780,11 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
         if (n_raw > (u32)a.cap) flag = 2;
         else if ((long long)m < a.n_rows) {  // some row was not re-scored: need the certificate
             // (1) the final tau must be a valid bound: >= kprime candidates at or above it
-            if (tbin > 0 && (m < a.kprime || bin_of_x(bin_x(approx_floor)) < tbin)) flag = 1;
+            if (tbin > 0 && (mwant < a.kprime || bin_of_x(bin_x(approx_floor)) < tbin)) flag = 1;
             // (2) the k-th canonical score must clear every row that was not re-scored
             if (a.k > m) flag = 1;
             else if (flag == 0) {
-                const float ck_k = unorderkey((u32)(top[a.k - 1] >> 32));
+                const float ck_k = unorderkey((u32)(ranked[a.k - 1] >> 32));
                 if (!(ck_k > approx_floor + a.eps)) flag = 1;
             }
         }
