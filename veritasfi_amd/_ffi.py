@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libveritasfi_hip.so")
+LIB_PATH = os.environ.get("VF_LIB_PATH") or os.path.join(_HERE, "lib", "libveritasfi_hip.so")   # VF_LIB_PATH: A/B builds
 
 VF_OK = 0
 VF_DTYPE_F32, VF_DTYPE_F16, VF_DTYPE_FP8_E4M3 = 0, 1, 2

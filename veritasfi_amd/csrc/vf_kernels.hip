@@ -941,7 +941,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 // speed only) and are adjacent in dispatch order.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWideQ = 256, kWideNT = kWideQ / kQueryTile, kWideKC = 64, kWideRows = 256;
-constexpr int kWideThreads = 512, kWideWaves = kWideThreads / 64, kWideM = kWideRows / kWideWaves / kRowTile;   // row tiles per wave (1)
+#ifndef VF_WIDE_THREADS
+#define VF_WIDE_THREADS 512
+#endif
+constexpr int kWideThreads = VF_WIDE_THREADS, kWideWaves = kWideThreads / 64, kWideM = kWideRows / kWideWaves / kRowTile;   // row tiles per wave: 1 (8 waves) or 2 (4 waves)
 constexpr int kWideBuf = (kWideKC / 8) * kWideQ * 16;   // 32 KB per query chunk
 constexpr int kWideCtl = 16 + 3 * kWideQ * 4;            // stage_cnt | tau_lds[256] | qcnt[256] | qbase[256]
 constexpr int kSampWaves = kScanThreads / 64;            // sample rows per row group = samp * 8 (k_sel0's slot map)
@@ -972,16 +975,19 @@ __device__ __forceinline__ void wide_issue_a(WideStage<F8>& st, const char* rows
 }
 
 // 32 x kWideM MFMAs: chunk `CC` (0 .. DC-1) of the stage against the query chunk at lds_lane
+// 32 x kWideM MFMAs: chunk CC (0 .. DC-1) of the stage against the query chunk at lds_lane.
+// The query fragments run through a 4-deep register ring that is carried ACROSS chunks: fragment s of this chunk sits in
+// bq[s % 4] (32 fragments per chunk, so the ring position is the same at every chunk start); while pair s computes, the
+// read of fragment s + 3 is issued -- for the last three pairs from the NEXT chunk's buffer (next_lane), which is
+// already visible (it was written two chunks ago).  Pinned with sched_group_barrier: per pair [kWideM MFMAs][1 read].
 template <int F8, int CC>
-__device__ __forceinline__ void wide_compute(f16v (&acc)[kWideM][kWideNT], const WideStage<F8>& st, const char* lds_lane) {
-    // 32 (k-step, query tile) pairs.  The query fragments are read from LDS TWO pairs ahead of the MFMAs that use
-    // them (one wave per SIMD: nobody else would cover an LDS round trip), pinned with sched_group_barrier:
-    // [2 reads] then per pair [2 MFMAs][1 read].
-    auto frag_at = [&](int sn) { return *(const h8*)(lds_lane + (sn / kWideNT) * (kWideQ * 16) + (sn % kWideNT) * (kQueryTile * 16)); };
-    h8 bq[3];
-    bq[0] = frag_at(0);
-    bq[1] = frag_at(1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+__device__ __forceinline__ void wide_compute(f16v (&acc)[kWideM][kWideNT], const WideStage<F8>& st, const char* lds_lane,
+                                             const char* next_lane, h8 (&bq)[4]) {
+    auto frag_at = [&](int sn) {
+        const char* base = sn < 4 * kWideNT ? lds_lane : next_lane;
+        const int s2 = sn < 4 * kWideNT ? sn : sn - 4 * kWideNT;
+        return *(const h8*)(base + (s2 / kWideNT) * (kWideQ * 16) + (s2 % kWideNT) * (kQueryTile * 16));
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         h8 afrag[kWideM];
@@ -998,12 +1004,10 @@ __device__ __forceinline__ void wide_compute(f16v (&acc)[kWideM][kWideNT], const
         for (int nt = 0; nt < kWideNT; ++nt) {
             const int sidx = i * kWideNT + nt;
 #pragma unroll
-            for (int m = 0; m < kWideM; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[m], bq[sidx % 3], acc[m][nt], 0, 0, 0);
+            for (int m = 0; m < kWideM; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[m], bq[sidx % 4], acc[m][nt], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, kWideM, 0);
-            if (sidx + 2 < 4 * kWideNT) {
-                bq[(sidx + 2) % 3] = frag_at(sidx + 2);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
+            bq[(sidx + 3) % 4] = frag_at(sidx + 3);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
     }
 }
@@ -1054,7 +1058,7 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
 }
 
 // epilogue of ONE 32-row tile (rows t0 .. t0+31) against the 256 queries
-constexpr int kWideLaneList = 12;   // passing scores a lane notes per round (of its 128 per tile); + 4 mask words = 64 B per lane
+constexpr int kWideLaneList = 12;   // passing scores a lane notes per round (of its 128 per 32-row tile); + 4 mask words = 64 B per lane
 
 template <int MODE>
 __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[kWideNT], float inv_lane, long long t0,
@@ -1215,12 +1219,32 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
     constexpr int DC = wide_dc<F8>();
     const int UN = NCH / DC;           // register stages per tile; even (launch requires dp % 256 == 0 for fp8, % 128 for fp16)
     WideStage<F8> A0, A1;
+    // query-chunk copy: the 32 KB chunk [8 k-groups][256 q][8 halves] is 2048 units of 16 bytes; thread t moves units
+    // t + kWideThreads v: k-group row (t >> 8) + (kWideThreads / 256) v, query t & 255
+    // (named registers, not an array: an array here was demoted to scratch memory by the compiler)
+    constexpr int GSTEP = kWideThreads / 256;      // k-group rows between a thread's consecutive units
     uint4 rb0, rb1, rb2, rb3;
-    // query-chunk copy: thread t moves the 16-byte units t + 512 v (v = 0..3) of the 32 KB chunk [8 k-groups][256 q][8]:
-    // k-group rows (t >> 8) + 2 v, query t & 255
-    static_assert(kWideThreads == 512, "the query-chunk copy is written for 512 threads");
+#if VF_WIDE_THREADS == 256
+    uint4 rb4, rb5, rb6, rb7;
+#endif
     const long long qn8 = (long long)a.qn_total * 8;   // halves per k-group row of the global image
     const _Float16* bsrc = a.qimg + ((long long)(tid >> 8) * a.qn_total + (long long)jt * kWideQ + (tid & 255)) * 8;
+#if VF_WIDE_THREADS == 256
+#define VF_ISSUE_B(KC)                                                        \
+    do {                                                                      \
+        const _Float16* p_ = bsrc + (long long)(KC) * 8 * qn8;                \
+        rb0 = *(const uint4*)(p_);           rb1 = *(const uint4*)(p_ + qn8);     \
+        rb2 = *(const uint4*)(p_ + 2 * qn8); rb3 = *(const uint4*)(p_ + 3 * qn8); \
+        rb4 = *(const uint4*)(p_ + 4 * qn8); rb5 = *(const uint4*)(p_ + 5 * qn8); \
+        rb6 = *(const uint4*)(p_ + 6 * qn8); rb7 = *(const uint4*)(p_ + 7 * qn8); \
+    } while (0)
+#define VF_WRITE_B(BUF)                                                       \
+    do {                                                                      \
+        uint4* d_ = (uint4*)(smem + (BUF) * kWideBuf) + tid;                  \
+        d_[0] = rb0; d_[256] = rb1; d_[512] = rb2; d_[768] = rb3;             \
+        d_[1024] = rb4; d_[1280] = rb5; d_[1536] = rb6; d_[1792] = rb7;       \
+    } while (0)
+#else
 #define VF_ISSUE_B(KC)                                                        \
     do {                                                                      \
         const _Float16* p_ = bsrc + (long long)(KC) * 8 * qn8;                \
@@ -1232,6 +1256,8 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
         uint4* d_ = (uint4*)(smem + (BUF) * kWideBuf) + tid;                  \
         d_[0] = rb0; d_[512] = rb1; d_[1024] = rb2; d_[1536] = rb3;           \
     } while (0)
+#endif
+    static_assert(GSTEP == 1 || GSTEP == 2, "256 or 512 threads");
     const u32 row0 = (u32)lo + (u32)(wid * (kWideM * kRowTile) + r31), hi32m1 = (u32)(hi - 1);
     auto rows_of = [&](int st, long long (&r)[kWideM]) {
 #pragma unroll
@@ -1250,18 +1276,24 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
             for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
     // flat chunk counter state: buffer being read (br), chunk-in-tile of the chunk being computed (kc)
     int br = 0, kc = 0;
-    // One chunk: queries of chunk c + 1 -> LDS (buffer last read in iteration c - 2), fetch chunk c + 2's, 64 MFMAs
-    // on chunk c, ONE barrier.
+    h8 bq[4];
+    // One chunk c: queries of chunk c + 2 -> LDS (the buffer read in chunk c - 1: every wave finished with it before the
+    // last barrier), fetch chunk c + 3's into registers, 32 MFMAs on chunk c while the fragment ring runs on into
+    // chunk c + 1's buffer (written during chunk c - 1, visible since the last barrier), ONE barrier.
+#ifndef VF_WIDE_EXP
+#define VF_WIDE_EXP 0   /* timing experiments (results invalid): bit 0 no query-chunk traffic, bit 1 no corpus loads, bit 2 no barrier */
+#endif
 #define VF_CHUNK(STG, CC)                                                     \
     do {                                                                      \
-        const int bw_ = br == 2 ? 0 : br + 1;                                 \
-        VF_WRITE_B(bw_);                                                      \
-        const int kn_ = kc + 2 < NCH ? kc + 2 : kc + 2 - NCH;                 \
-        VF_ISSUE_B(kn_);                                                      \
+        const int b1_ = br == 2 ? 0 : br + 1;          /* buffer of chunk c + 1 */ \
+        const int b2_ = b1_ == 2 ? 0 : b1_ + 1;        /* buffer of chunk c + 2 (= the one chunk c - 1 used) */ \
+        if (!(VF_WIDE_EXP & 1)) { VF_WRITE_B(b2_); }                          \
+        int kn_ = kc + 3; kn_ = kn_ >= NCH ? kn_ - NCH : kn_; kn_ = kn_ >= NCH ? kn_ - NCH : kn_; \
+        if (!(VF_WIDE_EXP & 1)) { VF_ISSUE_B(kn_); }                          \
         __builtin_amdgcn_sched_barrier(0);                                    \
-        wide_compute<F8, CC>(acc, STG, lds_lane0 + br * kWideBuf);            \
-        __syncthreads();                                                      \
-        br = bw_;                                                             \
+        wide_compute<F8, CC>(acc, STG, lds_lane0 + br * kWideBuf, lds_lane0 + b1_ * kWideBuf, bq); \
+        if (!(VF_WIDE_EXP & 4)) __syncthreads();                              \
+        br = b1_;                                                             \
         kc = kc + 1 == NCH ? 0 : kc + 1;                                      \
     } while (0)
     long long myrow[kWideM], nxrow[kWideM];
@@ -1270,16 +1302,27 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
     VF_ISSUE_B(0);
     VF_WRITE_B(0);
     VF_ISSUE_B(1);
+    VF_WRITE_B(1);
+    VF_ISSUE_B(2 < NCH ? 2 : 2 - NCH);
     __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) bq[s_] = *(const h8*)(lds_lane0 + (s_ / kWideNT) * (kWideQ * 16) + (s_ % kWideNT) * (kQueryTile * 16));
+    bq[3] = bq[2];
     for (int st = 0; st < nst; ++st) {
         const long long t0 = lo + (long long)st * kWideRows + wid * (kWideM * kRowTile);
         float inv_lane[kWideM];
         for (int u = 0; u < UN; u += 2) {
-            wide_issue_a<F8>(A1, a.rows, a.row_bytes, myrow, u + 1, h);
+            if (!(VF_WIDE_EXP & 2)) wide_issue_a<F8>(A1, a.rows, a.row_bytes, myrow, u + 1, h);
             __builtin_amdgcn_sched_barrier(0);
             VF_CHUNK(A0, 0);
             if constexpr (DC == 2) VF_CHUNK(A0, 1);
-            if (u + 2 < UN) wide_issue_a<F8>(A0, a.rows, a.row_bytes, myrow, u + 2, h);
+            if (VF_WIDE_EXP & 2) {
+                if (u + 2 >= UN) {
+#pragma unroll
+                    for (int m = 0; m < kWideM; ++m) inv_lane[m] = 1.0f;
+                    rows_of(st + 1 < nst ? st + 1 : st, nxrow);
+                }
+            } else if (u + 2 < UN) wide_issue_a<F8>(A0, a.rows, a.row_bytes, myrow, u + 2, h);
             else {
                 // 1 / norm of this lane's rows; rows past the part's end get NaN: their scores compare false
 #pragma unroll
