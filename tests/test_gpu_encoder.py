@@ -199,8 +199,10 @@ def test_encoder_errors(vf):
     with pytest.raises((RuntimeError, ValueError)):
         vf.HipEncoder(bad, w16, w32)
     e = vf.HipEncoder(cfg, w16, w32)
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="position table"):       # 600 tokens against a 512-entry position table
         e.forward(np.zeros((1, 600), np.int64), np.ones((1, 600), np.int64))
+    with pytest.raises(ValueError):                                  # beyond the 8192-token limit of the encoder path
+        e.forward(np.zeros((1, 8200), np.int64), np.ones((1, 8200), np.int64))
     e.close()
 
 

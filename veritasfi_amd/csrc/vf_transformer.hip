@@ -859,6 +859,73 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemm_skinny: C[M <= 64, N] = A[., K] . W[N, K]^T + bias (+ epilogue) for ONE short sequence (a query string:
+// src/utils/faissRetriever.py:33 embeds one per request).  Such a product is a weight stream: a workgroup owns 16 output
+// columns (N / 16 workgroups: 48 .. 192), its eight waves split K into eighths and stream their slice of W straight
+// into MFMA 16x16x32 B operands (16 rows x 64 contiguous bytes per instruction), the activations (L2-resident) into A
+// operands (a batch of 6 k-steps in flight); the fp32 partial tiles meet in LDS, the epilogue writes M x 16 halves.  No split-K hand-off between
+// workgroups, no padding rows computed beyond the next multiple of 16.  Requires N % 16 == 0, K % 256 == 0; A has at
+// least 64 rows (the workspace is padded and zero-filled).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSkinnyWaves = 8, kSkinnyBatch = 6;
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                                   const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                                   half_t* __restrict__ C, int M, int N, int K) {
+    __shared__ float red[kSkinnyWaves][MT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r15 = lane & 15, kb = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int steps = K >> 5, per = steps / kSkinnyWaves;   // k-steps of 32; per wave (K % 256 == 0)
+    const half_t* wp = W + (long long)(n0 + r15) * K + kb * 8 + (long long)wid * per * 32;
+    const half_t* ap = A + (long long)r15 * K + kb * 8 + (long long)wid * per * 32;
+    f4v acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    for (int s0 = 0; s0 < per; s0 += kSkinnyBatch) {
+        h8 bf[kSkinnyBatch], af[kSkinnyBatch][MT];
+#pragma unroll
+        for (int u = 0; u < kSkinnyBatch; ++u) {        // all loads of the batch in flight at once; the tail is clamped
+            const int s = s0 + u < per ? s0 + u : per - 1;
+            bf[u] = *(const h8*)(wp + s * 32);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[u][t] = *(const h8*)(ap + (long long)t * 16 * K + s * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < kSkinnyBatch; ++u) {
+            if (s0 + u < per) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][t], bf[u], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wid][t * 16 + 4 * kb + reg][r15] = acc[t][reg];
+    __syncthreads();
+    // thread -> row tid >> 2, columns 4 (tid & 3) .. + 3   (the first 4 * 16 MT threads have a row)
+    const int row = tid >> 2, c0 = (tid & 3) * 4;
+    if (row < M && row < MT * 16) {
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kSkinnyWaves; ++w) v += red[w][row][c0 + e];
+            v += bias ? bias[n0 + c0 + e] : 0.f;
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            if (EPI == EPI_BIAS_RESIDUAL) v += (float)R[(long long)row * N + n0 + c0 + e];
+            o[e] = (half_t)v;
+        }
+        *(h4*)(C + (long long)row * N + n0 + c0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_gemm8p_tn: 256 x 256 x 64 tiles, 8 waves (2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles,
 // 128 accumulator VGPRs), ONE workgroup per CU, LDS-DMA staging with a counted vmcnt and raw barriers --
 // the "8-phase" schedule of the CDNA GEMM playbook, derived here for this operand layout:
@@ -1915,6 +1982,12 @@ struct vf_encoder {
     // split-K GEMM (forwards of <= kSplitMaxRows tokens): fp32 slabs [kSplitMax][kSplitMaxRows][max(3H, F)] + tile counters
     float* sk_part = nullptr;
     unsigned* sk_cnt = nullptr;
+    // Small forwards (one query string: faissRetriever.py:33) are ~90 dependent launches of a few microseconds each and
+    // run host-bound when launched one by one: they are captured once per shape into a hipGraph and replayed.
+    struct GraphKey { int B, T, Tv, tt, pooling, normalize; bool operator==(const GraphKey& o) const { return B == o.B && T == o.T && Tv == o.Tv && tt == o.tt && pooling == o.pooling && normalize == o.normalize; } };
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t gstream = nullptr;
     std::mutex mu;
 };
 
@@ -1939,7 +2012,13 @@ extern "C" int vf_encoder_weight_sizes(const vf_encoder_config* cfg, int64_t* n_
     return VF_OK;
 }
 
+static void enc_drop_graphs(vf_encoder* e) {
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
+}
+
 static void enc_free_ws(vf_encoder* e) {
+    enc_drop_graphs(e);   // captured launches hold the workspace pointers
     void* p[] = {e->x, e->y, e->qkv, e->ctx, e->hbuf, e->d_ids, e->d_mask, e->d_tt, e->d_pos, e->d_out, e->d_hidden};
     for (void* q : p) if (q) (void)hipFree(q);
     e->x = e->y = e->qkv = e->ctx = e->hbuf = nullptr;
@@ -1953,6 +2032,7 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     enc_free_ws(e);
+    if (e->gstream) (void)hipStreamDestroy(e->gstream);
     if (e->w16) (void)hipFree(e->w16);
     if (e->w32) (void)hipFree(e->w32);
     if (e->d_flag) (void)hipFree(e->d_flag);
@@ -2121,6 +2201,19 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     }
 }
 
+template <int EPI>
+static hipError_t gemm_skinny(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int Mvalid, int N,
+                              int K, hipStream_t st) {
+    const dim3 grid(N / 16), block(kSkinnyWaves * 64);
+    switch ((Mvalid + 15) >> 4) {   // 16-row tiles that hold real rows
+    case 1: hipLaunchKernelGGL((k_gemm_skinny<EPI, 1>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
+    case 2: hipLaunchKernelGGL((k_gemm_skinny<EPI, 2>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
+    case 3: hipLaunchKernelGGL((k_gemm_skinny<EPI, 3>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
+    default: hipLaunchKernelGGL((k_gemm_skinny<EPI, 4>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
+    }
+    return hipGetLastError();
+}
+
 // ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
 static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, hipStream_t st) {
     const vf_encoder_config& c = e->cfg;
@@ -2128,6 +2221,8 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     const int Ms = (M + 63) / 64 * 64;
     static const bool no_splitk = getenv("VF_NO_SPLITK") != nullptr;  // A/B switch
     const bool small = !no_splitk && Ms <= kSplitMaxRows && H % 64 == 0 && F % 64 == 0;
+    static const bool no_skinny = getenv("VF_NO_SKINNY") != nullptr;  // A/B switch
+    const bool skinny = !no_skinny && M <= 64 && H % 256 == 0 && F % 256 == 0;   // one short sequence: weight-streaming GEMMs
     hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
@@ -2145,7 +2240,8 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
         const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F, *g2 = b2 + H,
                     *b2n = g2 + H;
-        VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
+        if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, M, 3 * H, H, st));
+        else VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
         static const bool att_stream = getenv("VF_ATT_STREAM") != nullptr;  // A/B switch: streaming kernel on the BERT path
         // Sequences longer than 512 tokens (bge-m3 = XLM-R-large with an 8194-entry position table: config/example.yaml:3,
         // src/utils/ragManager.py:50) cannot keep K and V^T of a head resident in LDS: they take the streaming kernel
@@ -2157,10 +2253,14 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
                                e->ctx);
         }
-        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
+        if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
+        else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
-        VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
-        if (small && F >= 2048) {
+        if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, M, F, H, st));
+        else VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
+        if (skinny) {
+            VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, M, H, F, st));
+        } else if (small && F >= 2048) {
             // a single short sequence: the long-K product (K = ffn) is split over K across the chip (1.17 -> 1.00 ms per
             // forward); the K = hidden products are not (the split's extra dependent memory round trips cost more than
             // 12 short K-steps), nor anything from 256 tokens up (measured slower)
@@ -2206,12 +2306,40 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     int rc = enc_ensure_ws(e, b, t);
     if (rc != VF_OK) return rc;
     const size_t n = (size_t)b * t;
+    const int out_dim = e->cfg.head == 1 ? 1 : e->cfg.hidden;
+    static const bool no_graph = getenv("VF_NO_GRAPH") != nullptr;   // A/B switch
+    if (!no_graph && n <= 256 && e->cfg.pooling != 2) {   // (last-token pooling reads a flag back mid-forward: not capturable)
+        if (!e->gstream) VFT_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
+        hipStream_t gs = e->gstream;
+        const vf_encoder::GraphKey key{b, t, t_valid, type_ids != nullptr, e->cfg.pooling, e->cfg.normalize};
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : e->graphs) if (g.key == key) { exec = g.exec; break; }
+        VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, gs));
+        VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, gs));
+        if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, gs));
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            VFT_HIP(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
+            rc = enc_forward_device(e, b, t, t_valid, type_ids != nullptr, gs);
+            const hipError_t ce = hipStreamEndCapture(gs, &graph);
+            if (rc != VF_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) return fail(VF_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) return fail(VF_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+            if (e->graphs.size() >= 32) enc_drop_graphs(e);   // bounded cache: request shapes are few (t = 32, 64, ...)
+            e->graphs.push_back({key, exec});
+        }
+        VFT_HIP(hipGraphLaunch(exec, gs));
+        VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, gs));
+        VFT_HIP(hipStreamSynchronize(gs));
+        return VF_OK;
+    }
     VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, nullptr));
     VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, nullptr));
     if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, nullptr));
     rc = enc_forward_device(e, b, t, t_valid, type_ids != nullptr, nullptr);
     if (rc != VF_OK) return rc;
-    const int out_dim = e->cfg.head == 1 ? 1 : e->cfg.hidden;
     VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
     VFT_HIP(hipStreamSynchronize(nullptr));
     return VF_OK;
