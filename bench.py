@@ -124,13 +124,15 @@ def cpu_baseline(args):
     return out
 
 
-def rerank_p50(args):
+def rerank_p50(args, shape=None):
     """p50 latency of scoring top-100 candidates (100 pairs x 512 tokens) with a cross-encoder of the given
-    shape and seeded random weights (no checkpoints offline): BASELINE configs[3].  Each rank runs a replica."""
+    shape and seeded random weights (no checkpoints offline): BASELINE configs[3] (xlmr-base = bge-reranker-base) and
+    configs[4] (xlmr-large = bge-reranker-large).  Each rank runs a replica."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from bench_rerank import random_encoder, flops
-    enc, cfg = random_encoder(args.rerank_shape, head=1)
+    shape = shape or args.rerank_shape
+    enc, cfg = random_encoder(shape, head=1, vocab=32000 if shape == "xlmr-large" else None)
     rng = np.random.default_rng(99)
     ids = rng.integers(5, cfg["vocab"], size=(args.rerank_pairs, args.rerank_tokens)).astype(np.int32)
     mask = np.ones_like(ids)
@@ -143,7 +145,7 @@ def rerank_p50(args):
     enc.close()
     p50 = float(np.median(ts))
     tf = flops(cfg, args.rerank_pairs, args.rerank_tokens) / p50 / 1e9
-    return p50, {"model_shape": args.rerank_shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens,
+    return p50, {"model_shape": shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens,
                  "tflops": round(tf, 1), "bound": "mfma", "peak_tflops": 2500.0, "frac": round(tf / 2500.0, 4),
                  "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of logits",
                  "what": "median of 12 HipEncoder.forward calls on pre-tokenised ids (tokenisation is not timed)"}
@@ -170,6 +172,35 @@ def embed_rate(args):
     return {"model_shape": "bert-base", "batch": 100, "tokens": 512, "ms_per_batch": round(p50 * 1e3, 3),
             "chunks_per_s": round(100 / p50, 1), "tflops": round(flops(cfg, 100, 512) / p50 / 1e12, 1),
             "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of embeddings"}
+
+
+def request_latency(args):
+    """Per-request call shapes of the reference: one embed_query forward (src/utils/faissRetriever.py:33: one query string)
+    and FaissRetriever.invoke's search (src/utils/ensembleRetriever.py:64-66: N ~ 1e4 chunks, d = 1024, nq <= 4,
+    k = 2048), host buffers in and out; p50 of 40 calls."""
+    import numpy as np
+    import veritasfi_amd as vf
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_rerank import random_encoder
+
+    def p50(fn, n=40):
+        fn(); fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+        return round(float(np.median(ts)), 4)
+
+    rng = np.random.default_rng(0)
+    out = {}
+    enc, cfg = random_encoder("bert-base", head=0)
+    ids = rng.integers(5, cfg["vocab"], size=(1, 32)).astype(np.int32)
+    out["embed_query_ms"] = {"model_shape": "bert-base", "tokens": 32, "p50": p50(lambda: enc.forward(ids, np.ones_like(ids)))}
+    enc.close()
+    c = rng.standard_normal((10_000, 1024)).astype(np.float32)
+    q = rng.standard_normal((4, 1024)).astype(np.float32)
+    with vf.DenseIndex(c) as ix:
+        out["invoke_search_ms"] = {"n": 10_000, "d": 1024, "nq": 4, "k": 2048, "p50": p50(lambda: ix.search(q, 2048))}
+    return out
 
 
 def main():
@@ -291,12 +322,22 @@ def main():
             print(f"verify ok: bucket of {E} batches through all-gather + merge", file=sys.stderr)
     index.set_option("profile", 0)
     # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
-    rr_ms, rr_info, emb_info = (None, None, None)
+    rr_ms, rr_info, emb_info, rr_large, lat_info = (None, None, None, None, None)
     if rank == 0 and not args.no_rerank:
         try:
             rr_ms, rr_info = rerank_p50(args)
         except Exception as e:  # noqa: BLE001
             rr_info = {"error": f"{type(e).__name__}: {e}"}
+        if args.rerank_shape != "xlmr-large":
+            try:
+                ms_l, rr_large = rerank_p50(args, "xlmr-large")
+                rr_large["p50_ms"] = round(ms_l, 3)
+            except Exception as e:  # noqa: BLE001
+                rr_large = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            lat_info = request_latency(args)
+        except Exception as e:  # noqa: BLE001
+            lat_info = {"error": f"{type(e).__name__}: {e}"}
         try:
             emb_info = embed_rate(args)
         except Exception as e:  # noqa: BLE001
@@ -359,7 +400,9 @@ def main():
                              "exact_reruns_last_batch": stats["exact_reruns"], "path": stats["path"]},
             "rerank_p50_ms": None if rr_ms is None else round(rr_ms, 3),
             "rerank": rr_info,
+            "rerank_large": rr_large,
             "embed": emb_info,
+            "request_latency": lat_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -10,8 +10,11 @@ import veritasfi_amd as vf
 SHAPES = {"xlmr-base": (768, 12, 12, 3072, 250002), "xlmr-large": (1024, 24, 16, 4096, 250002),
           "bert-base": (768, 12, 12, 3072, 30522)}
 
-def random_encoder(shape, head, seed=0):
+def random_encoder(shape, head, seed=0, vocab=None):
+    """vocab: override the embedding-table size (it does not enter the forward's cost; a small table keeps the host-side
+    generation of random weights short)."""
     H, L, heads, F, V = SHAPES[shape]
+    V = vocab or V
     cfg = dict(vocab=V, hidden=H, layers=L, heads=heads, ffn=F, max_pos=514, type_vocab=1,
                roberta_pad_idx=1 if shape.startswith("xlmr") else -1, pooling=0, normalize=0 if head else 1, head=head,
                ln_eps=1e-5)
