@@ -366,8 +366,18 @@ def main():
             qpass = min(args.batch, 1024)
             flops = 2.0 * qpass * rows_scanned * args.dim
             tf = flops / (avg_ms * 1e-3) / 1e12
+            wtraffic, wsrc = None, None
+            try:
+                wfile = os.path.join("profiles", "pmc_traffic_scan_wide_c5_10Mx1024.json")
+                rec = json.load(open(os.path.join(ROOT, wfile)))
+                w = rec["workload"]
+                if not devs and args.corpus_dtype == "fp8" and (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (args.rows, args.dim, args.batch, args.k, world):
+                    wtraffic = round(rec["hbm_bytes_per_launch"])
+                    wsrc = f"{wfile} (rocprofv3 --pmc passes of this workload, committed; not re-measured in this run)"
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                    "traffic": None, "kernel": "vf::k_scan_wide<main>", "avg_launch_ms": round(avg_ms, 4),
+                    "traffic": wtraffic, "traffic_source": wsrc, "kernel": "vf::k_scan_wide<main>", "avg_launch_ms": round(avg_ms, 4),
                     "flops_per_launch": flops, "queries_per_launch": qpass,
                     "peak_note": "dense fp16 MFMA (rows are converted to fp16 in registers; queries stay fp16 so that the "
                                  "exactness certificate's 2^-11 bound holds -- fp8 queries would need a 2^-4 bound)",
