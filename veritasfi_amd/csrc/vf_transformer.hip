@@ -1149,8 +1149,7 @@ __device__ __forceinline__ void attn_qk(f16v& s, const half_t* Ks, const h8 (&qf
 
 // online-softmax update with the scores of key tile kt (state 0: all keys valid, 1: mixed) and O^T += V^T P^T
 __device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], float& m_run, float& l_run, const half_t* Vt,
-                                                int vt_ld, const float* mb, int kt, int state, int r31, int h) {
-    const float LOG2E = 1.4426950408889634f;
+                                                int vt_ld, const float* mb, int kt, int state, int r31, int h, float LOG2E) {
     // this tile's V^T fragments first (their LDS latency hides under the softmax):
     // k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
     h8 vf[2][2];
@@ -1212,7 +1211,7 @@ __device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], fl
 }
 
 __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask,
-                                                         int T, int H, int vt_ld, half_t* __restrict__ ctx) {
+                                                         int T, int H, int vt_ld, float qs, float ex, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Ks = (half_t*)smem;                   // [T][AKLD]
     half_t* Vt = Ks + (size_t)T * AKLD;           // [64][vt_ld]
@@ -1279,7 +1278,7 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
             for (int ks = 0; ks < 4; ++ks) {
                 h8 v = *(const h8*)(Qg + ks * 16);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * (half_t)0.125f;
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * qs);
                 qf[ks] = v;
             }
         }
@@ -1301,12 +1300,12 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
             const unsigned rest = act & (~1u << kt);      // active tiles after kt
             const int kn = rest ? __builtin_ctz(rest) : kt;
             attn_qk(sB, Ks, qf, kn * 32, r31, h);
-            attn_softmax_pv(sA, o, m_run, l_run, Vt, vt_ld, mb, kt * 32, (mixed >> kt) & 1, r31, h);
+            attn_softmax_pv(sA, o, m_run, l_run, Vt, vt_ld, mb, kt * 32, (mixed >> kt) & 1, r31, h, ex);
             if (!rest) break;
             const unsigned rest2 = act & (~1u << kn);
             const int kn2 = rest2 ? __builtin_ctz(rest2) : kn;
             attn_qk(sA, Ks, qf, kn2 * 32, r31, h);
-            attn_softmax_pv(sB, o, m_run, l_run, Vt, vt_ld, mb, kn * 32, (mixed >> kn) & 1, r31, h);
+            attn_softmax_pv(sB, o, m_run, l_run, Vt, vt_ld, mb, kn * 32, (mixed >> kn) & 1, r31, h, ex);
             if (!rest2) break;
             kt = kn2;
         }
@@ -1321,6 +1320,417 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
                 for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
                 *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
             }
+    }
+}
+
+// weight preparation: the attention kernels take scores in log2 units, so log2(e) / sqrt(dh) is folded into the query
+// projection (rows [0, H) of Wqkv and of its bias) once, when the weights are loaded
+__global__ void k_scale_half(half_t* __restrict__ w, long long n, float s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = (half_t)((float)w[i] * s);
+}
+__global__ void k_scale_float(float* __restrict__ w, long long n, float s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] *= s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_attention2: resident attention, second generation (dh = 64, T % 32 == 0, T <= 512).
+// grid (heads, B), 64 * ceil(T / 64) threads; wave w owns queries [64w, 64w + 64) as two 32-query blocks (a, b) that
+// share every K / V fragment read.  Scores arrive in LOG2 units: the caller has folded log2(e) / sqrt(64) into Q.
+//  * K and V of the (sequence, head) are staged verbatim ([key][64] rows of 128 B) by LDS-DMA, every transfer in
+//    flight at once; the XOR swizzles live in the per-lane SOURCE address.  K: chunk ^ ((key >> 1) & 7) -- the
+//    ds_read_b128 A-operand reads of 32 keys are conflict-free.  V: chunk ^ (((key >> 1) & 1) << 2) -- the 4-key x 16-dh
+//    blocks of ds_read_b64_tr_b16 (which delivers V^T fragments without a transposing staging pass) are.
+//  * S^T = K Q^T with the key on the MFMA row (a lane owns 16 scores of one query), and the running reference maximum
+//    m_ref enters through the matrix pipe as a fifth k-step (A = 1 in slot 0, B = -m_ref in slot 0, m_ref kept
+//    fp16-representable so the product is exact): the scores come out already relative to m_ref and p = exp2(s) needs
+//    no per-element arithmetic.  (As the MFMA's initial accumulator the same bias costs 16 register copies per tile.)
+//  * Lazy maximum (a2_softmax): m_ref moves only when a probability overflows fp16, which the row sum reveals; the
+//    rescale of O, l and the bias fragment is a rare wave-uniform branch.  l is kept per lane (its half of the keys)
+//    and combined once at the end.
+//  * O is staged through LDS (the K region, after a barrier) and stored as whole 128-byte rows.
+// Key padding: additive -30000 on mixed tiles, fully masked tiles skipped (their probabilities underflow to exactly 0
+// either way); a sequence without any valid key keeps every tile.
+// ------------------------------------------------------------------------------------------------
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+constexpr float A2_THR = 8.0f;
+
+__device__ __forceinline__ int a2_koff(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int a2_voff(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 1) << 2)) << 4); }
+
+__device__ __forceinline__ void a2_tr_read(h8& dst, const char* lo, const char* hi) {
+    const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)lo);
+    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)hi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[e] = (half_t)a[e]; dst[4 + e] = (half_t)b[e]; }
+}
+
+// the rare path: move the reference maximum of one query block (first tile: to the tile's maximum; later: up to the
+// maximum of the queries whose scores ran more than A2_THR ahead of it) and bring s, O, l and the bias fragment to the
+// new reference.  m_ref stays representable in fp16, so the bias k-step (1 x -m_ref, fp32 accumulation) subtracts it exactly.
+__device__ __forceinline__ void a2_move_ref(f16v& s, f16v (&o)[2], float& l, float& mref, h8& mq, bool first, int h) {
+    float tmax = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, s[e]);
+    {
+        float lo, hi;
+        halves(tmax, lo, hi);
+        tmax = fmaxf(lo, hi);
+    }
+    const float want = mref + (first ? tmax : (tmax > A2_THR ? tmax : 0.f));
+    const float mnew = (float)(half_t)fminf(fmaxf(want, -60000.f), 60000.f);
+    const float delta = mnew - mref;
+    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+    mref = mnew;
+    l *= alpha;
+    mq[0] = h == 0 ? (half_t)(-mnew) : (half_t)0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        s[e] -= delta;
+        o[0][e] *= alpha;
+        o[1][e] *= alpha;
+    }
+}
+
+// p = exp2(s) -> fp16 B-operand fragments; returns the lane's partial row sum, taken over the ROUNDED probabilities
+// (v_dot2_f32_f16 against (1, 1)), so that O / l is a weighted mean with consistently perturbed weights: a dominant
+// key then reproduces its value row exactly, as it does when the largest probability is exactly 1.  A probability
+// past the fp16 range makes the sum infinite: that is the overflow signal of a2_softmax.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float a2_probs(const f16v& s, h8 (&pf)[2]) {
+    const h2 one2 = {(half_t)1.f, (half_t)1.f};
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+        const h2 p01 = {(half_t)__builtin_amdgcn_exp2f(s[e]), (half_t)__builtin_amdgcn_exp2f(s[e + 1])};
+        const h2 p23 = {(half_t)__builtin_amdgcn_exp2f(s[e + 2]), (half_t)__builtin_amdgcn_exp2f(s[e + 3])};
+        s0 = __builtin_amdgcn_fdot2(p01, one2, s0, false);
+        s1 = __builtin_amdgcn_fdot2(p23, one2, s1, false);
+        pf[e >> 3][e & 7] = p01[0];
+        pf[e >> 3][(e & 7) + 1] = p01[1];
+        pf[e >> 3][(e & 7) + 2] = p23[0];
+        pf[e >> 3][(e & 7) + 3] = p23[1];
+    }
+    return s0 + s1;
+}
+
+// Softmax of one query block's 32-key tile, optimistically: exponentiate against the current reference and look at the
+// result -- a score more than 16 (log2 units) above the reference overflows fp16 and shows up as an infinite sum, the
+// only case that NEEDS a new reference (probabilities up to 2^16 are as precise in fp16 as those below 1; every sum is
+// fp32).  Then, and on the first tile, the reference moves (a2_move_ref) and the tile is exponentiated again.  One
+// ballot per tile instead of a maximum over the scores.
+__device__ __forceinline__ void a2_softmax(f16v& s, h8 (&pf)[2], f16v (&o)[2], float& l, float& mref, h8& mq, bool first, int h) {
+    if (first) a2_move_ref(s, o, l, mref, mq, true, h);
+    float sum = a2_probs(s, pf);
+    if (__ballot(!(sum < 1e30f)) != 0ull) {
+        a2_move_ref(s, o, l, mref, mq, false, h);
+        sum = a2_probs(s, pf);
+    }
+    l += sum;
+}
+
+// One 32-key tile for the wave's two query blocks.  kf: this tile's K fragments (already in registers); kn: filled with
+// the next tile's.  Fragment addresses: K -- key kt*32 + r31, chunk 2 ks + h.  V (transposed read) -- lane 4q + p of its
+// 16-lane group addresses key (base + q), dh chunk 4 mt + 2 (group & 1) + (p >> 1), byte 8 (p & 1).
+// Order: QK^T of block a, then of block b (two separate accumulation chains, so a's scores are complete while b's are
+// still in the matrix pipe and a's softmax runs under them); b's softmax runs under a's P.V.
+__device__ __forceinline__ void a2_tile(const h8 (&kf)[4], h8 (&kn)[4], int kt, int ktn, bool mixed, bool first, const char* Ks,
+                                        const char* Vs, const float* mb, const h8 (&qa)[4], const h8 (&qb)[4], const h8& ones,
+                                        h8& mqa, h8& mqb, f16v (&oa)[2], f16v (&ob)[2], float& la, float& lb, float& mra,
+                                        float& mrb, int lane, int prio) {
+    const int r31 = lane & 31, h = lane >> 5;
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
+    const int k0 = kt * 32;
+    // the two waves of a SIMD take turns at issue priority, tile by tile: left alone the older wave wins every
+    // arbitration, the pair drifts apart by +-20 % and every barrier waits for the slower one
+    if (prio >= 0) {
+        if (prio >= 16 ? (prio & 1) : ((prio ^ kt) & 1)) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    f16v zero;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+    f16v sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, mqa, zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qa[ks], sa, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    f16v sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, mqb, zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qb[ks], sb, 0, 0, 0);
+    // V^T fragments of this tile: k-slot j of half h <-> key 16 st + (j & 3) + 8 (j >> 2) + 4 h
+    h8 vf[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int key = k0 + 16 * st + 4 * h + vq, ch = 4 * mt + 2 * vg + (vp >> 1);
+            a2_tr_read(vf[st][mt], Vs + a2_voff(key, ch) + 8 * (vp & 1), Vs + a2_voff(key + 8, ch) + 8 * (vp & 1));
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kn[ks] = *(const h8*)(Ks + a2_koff(ktn * 32 + r31, 2 * ks + h));
+    if (mixed) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float m = mb[k0 + (e & 3) + 8 * (e >> 2) + 4 * h];
+            sa[e] += m;
+            sb[e] += m;
+        }
+    }
+    h8 pa[2], pb[2];
+    a2_softmax(sa, pa, oa, la, mra, mqa, first, h);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) oa[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pa[st], oa[mt], 0, 0, 0);
+    a2_softmax(sb, pb, ob, lb, mrb, mqb, first, h);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ob[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pb[st], ob[mt], 0, 0, 0);
+}
+
+// 16 bytes per lane global -> LDS (lds: wave-uniform base, lane i lands at base + 16 i), as inline asm ON PURPOSE.  With the
+// builtin the compiler knows an LDS-DMA is pending and, unable to prove that a later LDS read does not alias it, puts
+// s_waitcnt vmcnt(0) in front of every ds_read -- in k_attention2's tile loop that drains the next pair's prefetch at
+// every tile (measured: +45 % loop time).  Here the kernel orders DMA against reads itself (vmcnt(0) + barrier at the
+// chunk boundaries).  M0 is saved and restored around the transfer.
+__device__ __forceinline__ void a2_dma16(const void* g, const char* lds) {
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(base)
+                 : "memory");
+}
+
+// O of one 16-query group of a block: the owning lanes write their 8 x 8 bytes into the wave's 2 KiB staging rows
+// (swizzled like K), then every lane moves 32 bytes of whole rows to global memory
+__device__ __forceinline__ void a2_store_group(const f16v (&o)[2], float inv, int hh, char* Os, half_t* dst_rows, int H, int nrows,
+                                               int lane) {
+    const int r31 = lane & 31, h = lane >> 5;
+    if ((r31 >> 4) == hh) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
+                // dh = 32 mt + 8 g4 + 4 h + e  ->  chunk 4 mt + g4, byte 8 h
+                *(h4*)(Os + a2_koff(r31 & 15, 4 * mt + g4) + 8 * h) = v;
+            }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = lane + 64 * it, row = c >> 3, ch = c & 7;
+        const uint4 v = *(const uint4*)(Os + a2_koff(row, ch));
+        if (row < nrows) *(uint4*)(dst_rows + (long long)row * H + ch * 8) = v;
+    }
+}
+
+// MODE 0: the kernel; 6: diagnostic build that returns the tile loops' shader-clock / 100 MHz ticks instead of O
+// (tools/attention_clock.py)
+template <int MODE>
+__global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int B, int T, int H,
+                                                    int ct, int dbg, half_t* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                  // [T] rows of 128 B, swizzled (a2_koff)
+    char* Vs = smem + (size_t)T * 128;                // [T] rows of 128 B, swizzled (a2_voff)
+    float* mbuf = (float*)(Vs + (size_t)T * 128);     // [2][T] additive masks: this pair's and the next one's
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* Os = (char*)(mbuf + 2 * T) + wid * 2048;    // the wave's O staging rows
+    const int r31 = lane & 31, h = lane >> 5;
+    const int heads = H / ADH, npairs = B * heads, ld = 3 * H;
+    const int wprio = (dbg & 8) ? 16 + (wid >> 2) : (dbg & 6) == 2 ? (wid >> 2) : (dbg & 6) == 4 ? (wid & 1) : -1;
+    const int ntiles = T >> 5, nchunks = (ntiles + ct - 1) / ct;   // ct: tiles per chunk (4, 8 or 16)
+    const unsigned cmask = ct >= 32 ? 0xffffffffu : ((1u << ct) - 1u);
+    const unsigned all_tiles = ntiles >= 32 ? 0xffffffffu : ((1u << ntiles) - 1u);
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
+    unsigned long long tk_start = 0, rt_start = 0;
+    if (MODE == 6) { tk_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
+
+    // 16-byte chunk c of an image <- key c >> 3, source chunk (c & 7) ^ swizzle(key); a wave-instruction fills 1 KiB (8 keys)
+    auto stage_chunk = [&](int p, int g) {
+        const long long prow = (long long)(p / heads) * T;
+        const half_t* Kg = qkv + prow * ld + H + (p % heads) * ADH;
+        const half_t* Vg = Kg + H;
+        const int cper = ct * 256;   // 16-byte pieces per chunk and image
+        const int cend = (g + 1) * cper < T * 8 ? (g + 1) * cper : T * 8;
+        for (int c0 = g * cper + wid * 64; c0 < cend; c0 += nthreads) {
+            const int c = c0 + lane, key = c >> 3, chp = c & 7;
+            const half_t* ks = Kg + (long long)key * ld + ((chp ^ ((key >> 1) & 7)) << 3);
+            const half_t* vs = Vg + (long long)key * ld + ((chp ^ (((key >> 1) & 1) << 2)) << 3);
+            a2_dma16(ks, Ks + c0 * 16);
+            a2_dma16(vs, Vs + c0 * 16);
+        }
+    };
+    auto stage_mask = [&](int p, float* mb) {
+        const long long prow = (long long)(p / heads) * T;
+        for (int t = tid; t < T; t += nthreads) mb[t] = mask[prow + t] ? 0.f : -30000.f;
+    };
+    // tile classes (bit j = 32-key tile j): act = has a valid key, mixed = needs the additive mask; a sequence without
+    // any valid key keeps every tile
+    auto classify = [&](const float* mb, unsigned& act, unsigned& mixed) {
+        act = 0;
+        mixed = 0;
+        for (int j = 0; j < ntiles; ++j) {
+            const int nvalid = __popc((unsigned)__ballot(mb[j * 32 + r31] == 0.f));
+            act |= (nvalid != 0 ? 1u : 0u) << j;
+            mixed |= ((nvalid != 0 && nvalid != 32) ? 1u : 0u) << j;
+        }
+        if (act == 0) act = mixed = all_tiles;
+    };
+    // Q fragments (B operand) of both query blocks: lane (query r31, half h) holds q[8h + j + 16 ks].  A block past the
+    // end of the sequence re-reads the last query (computed, never stored).
+    const int qa0 = wid * 64, qb0 = qa0 + 32;
+    const bool b_valid = qb0 < T;
+    h8 qa[4], qb[4];
+    auto load_q = [&](int p) {
+        const long long prow = (long long)(p / heads) * T;
+        const half_t* Qa = qkv + (prow + qa0 + r31) * ld + (p % heads) * ADH + h * 8;
+        const half_t* Qb = qkv + (prow + (b_valid ? qb0 + r31 : T - 1)) * ld + (p % heads) * ADH + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qa[ks] = *(const h8*)(Qa + ks * 16);
+            qb[ks] = *(const h8*)(Qb + ks * 16);
+        }
+    };
+
+    // ---- first pair: everything in flight at once (and the mask of the second)
+    for (int g = 0; g < nchunks; ++g) stage_chunk(pair, g);
+    stage_mask(pair, mbuf);
+    if (pair + (int)gridDim.x < npairs) stage_mask(pair + gridDim.x, mbuf + T);
+    load_q(pair);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+    unsigned act, mixed;
+    classify(mbuf, act, mixed);
+    // the bias k-step: A = (1, 0, ...) on every key row, B = (-m_ref, 0, ...) per query; both only in the h = 0 lanes
+    h8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (half_t)0.f;
+    ones[0] = h == 0 ? (half_t)1.f : (half_t)0.f;
+    unsigned long long tk_loop = 0, tk_tail = 0;
+
+    // Pair loop.  No vector-memory LOAD with a register destination is pending while tiles run: the wait the compiler
+    // places before such a register's first use is vmcnt(0) -- the counter is in order -- and inside the tile loop
+    // that would drain the LDS-DMA prefetch at every tile.  The next pair's Q fragments and the mask of the pair after
+    // it are therefore loaded in the quiet window at the pair's end (after the closing barrier, nothing else in flight)
+    // and settled there, under the O epilogue.
+    for (int cur = 0;; cur ^= 1) {
+        const int nxt_pair = pair + gridDim.x, nxt2_pair = nxt_pair + gridDim.x;
+        const bool has_next = nxt_pair < npairs;
+        const float* mb = mbuf + cur * T;
+        float* mbn = mbuf + (cur ^ 1) * T;
+        f16v oa[2], ob[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oa[0][e] = oa[1][e] = ob[0][e] = ob[1][e] = 0.f;
+        h8 mqa, mqb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mqa[e] = mqb[e] = (half_t)0.f;
+        float la = 0.f, lb = 0.f, mra = 0.f, mrb = 0.f;
+        bool first = true;
+        unsigned act_n = 0, mixed_n = 0;
+        unsigned long long t0 = 0;
+        if (MODE == 6) t0 = __builtin_amdgcn_s_memtime();
+        // Chunks of ct 32-key tiles.  Within a chunk the tile loop is software-pipelined by hand (a2_tile) and unrolled
+        // by two so the K fragment sets ping-pong.  At a chunk's end every wave has left its keys: after the barrier the
+        // chunk's LDS rows take the NEXT pair's keys (LDS-DMA, in flight under the following chunks; each wait is a
+        // whole chunk of work away from the issue).
+        for (int g = 0; g < nchunks; ++g) {
+            unsigned rest = (act >> (ct * g)) & cmask;
+            if (rest) {
+                int kt = ct * g + __builtin_ctz(rest);
+                rest &= rest - 1;
+                h8 kfA[4], kfB[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kfA[ks] = *(const h8*)(Ks + a2_koff(kt * 32 + r31, 2 * ks + h));
+                while (true) {
+                    int ktn = rest ? ct * g + __builtin_ctz(rest) : kt;
+                    a2_tile(kfA, kfB, kt, ktn, (mixed >> kt) & 1, first, Ks, Vs, mb, qa, qb, ones, mqa, mqb, oa, ob, la, lb, mra, mrb,
+                            lane, wprio);
+                    first = false;
+                    if (!rest) break;
+                    rest &= rest - 1;
+                    kt = ktn;
+                    ktn = rest ? ct * g + __builtin_ctz(rest) : kt;
+                    a2_tile(kfB, kfA, kt, ktn, (mixed >> kt) & 1, false, Ks, Vs, mb, qa, qb, ones, mqa, mqb, oa, ob, la, lb, mra, mrb,
+                            lane, wprio);
+                    if (!rest) break;
+                    rest &= rest - 1;
+                    kt = ktn;
+                }
+            }
+            if (g + 1 < nchunks) {
+                // inner boundary: the transfers issued a chunk ago have landed (the last pair still has to publish the
+                // refills the previous pair issued)
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                __syncthreads();
+                if (has_next) {
+                    if (g == 0) classify(mbn, act_n, mixed_n);      // the next pair's mask: written a pair ago
+                    if (((act_n >> (ct * g)) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, g);
+                }
+            }
+        }
+        unsigned long long t1 = 0;
+        if (MODE == 6) { t1 = __builtin_amdgcn_s_memtime(); tk_loop += t1 - t0; }
+        const int p_b = pair / heads, p_hd = pair % heads;
+        int rmask = 1;
+        if (has_next) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            __syncthreads();                                        // the pair is done in every wave
+            if (nchunks == 1) classify(mbn, act_n, mixed_n);
+            load_q(nxt_pair);                                       // quiet window: nothing else in flight
+            if (nxt2_pair < npairs && tid < T) rmask = mask[(long long)(nxt2_pair / heads) * T + tid];
+        }
+        // ---- O: normalise (the halves' partial row sums combine here), stage 16 queries at a time, store whole rows
+        {
+            float inva, invb;
+            {
+                float lo, hi;
+                halves(la, lo, hi);
+                inva = 1.0f / (lo + hi);
+                halves(lb, lo, hi);
+                invb = 1.0f / (lo + hi);
+            }
+            half_t* dst = ctx + ((long long)p_b * T + qa0) * H + p_hd * ADH;
+            const int nrows = T - qa0;   // >= 32
+            a2_store_group(oa, inva, 0, Os, dst, H, nrows, lane);
+            a2_store_group(oa, inva, 1, Os, dst + 16LL * H, H, nrows - 16, lane);
+            a2_store_group(ob, invb, 0, Os, dst + 32LL * H, H, nrows - 32, lane);
+            a2_store_group(ob, invb, 1, Os, dst + 48LL * H, H, nrows - 48, lane);
+        }
+        if (MODE == 6) {
+            tk_tail += __builtin_amdgcn_s_memtime() - t1;
+            if (!has_next && lane == 0) {
+                unsigned long long* out = (unsigned long long*)(ctx + (long long)B * T * H) + ((long long)blockIdx.x * 8 + wid) * 8;
+                out[0] = 0; out[1] = tk_loop; out[2] = tk_tail;
+                out[3] = __builtin_amdgcn_s_memtime() - tk_start;
+                out[4] = __builtin_amdgcn_s_memrealtime() - rt_start;
+                out[5] = (unsigned long long)(pair / gridDim.x + 1);
+                out[6] = rt_start;
+                out[7] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+        // Settle the window's loads here: a real S_WAITCNT (the builtin), which the compiler's own wait insertion accounts
+        // for -- and BEFORE the loop exit, because the structurised control flow routes the exit through the loop
+        // header's predecessor: a load still pending on the exit path would put the waits back into the tile loop.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        asm volatile("" : "+v"(rmask));       // (keeps the mask's compare-and-select below the wait)
+        if (!has_next) break;
+        if (nxt2_pair < npairs && tid < T) mbuf[cur * T + tid] = rmask ? 0.f : -30000.f;   // read (as mbn) after the next pair's first barrier
+        if (((act_n >> (ct * (nchunks - 1))) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, nchunks - 1);
+        if (nchunks == 1) {   // a single chunk: the refill must land before the next pair starts
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            __syncthreads();
+        }
+        if (MODE == 6) tk_tail += 0;
+        pair = nxt_pair;
+        act = act_n;
+        mixed = mixed_n;
     }
 }
 
@@ -1417,8 +1827,10 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             h8 v = *(const h8*)(Qg + ks * 16);
+            if (scale > 0.f) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
+            }
             qf[ks] = v;
         }
     }
@@ -1428,7 +1840,8 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
-    const float LOG2E = 1.4426950408889634f;
+    // scale <= 0: the caller folded log2(e) / sqrt(DH) into Q (the encoder does, at weight load): scores are in log2 units
+    const float LOG2E = scale > 0.f ? 1.4426950408889634f : 1.0f;
     fetch(0);
     stash(0);
     __syncthreads();
@@ -1950,6 +2363,8 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
@@ -1960,6 +2375,28 @@ static hipError_t configure_once() {
 }
 
 
+// k_attention2 launcher: persistent workgroups, as many as stay co-resident (LDS: K, V, two masks, O staging; registers:
+// two waves per SIMD), each walking (sequence, head) pairs blockIdx.x, + gridDim.x, ...
+template <int MODE>
+static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, int heads, half_t* ctx, hipStream_t st) {
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    const int waves = (T + 63) / 64;
+    const size_t lds = (size_t)T * 256 + (size_t)T * 8 + (size_t)waves * 2048;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8 / waves) per_cu = 8 / waves;
+    if (per_cu < 1) per_cu = 1;
+    const int npairs = B * heads;
+    const int grid = npairs < n_cu * per_cu ? npairs : n_cu * per_cu;
+    static const int ct = [] { const char* e = getenv("VF_ATT_CHUNK"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 16) ? v : 4; }();
+    static const int dbg = [] { const char* e = getenv("VF_ATT_DBG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, dbg, ctx);
+}
+
 constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
 constexpr int kEncResidentT = 512;   // longest sequence whose K / V^T fit the resident-attention kernel's LDS
 constexpr int kEncMaxT = 8192;       // longest sequence the encoder takes (streaming attention beyond kEncResidentT)
@@ -1969,6 +2406,7 @@ struct vf_encoder {
     int device = 0;
     half_t* w16 = nullptr;   // all fp16 matrices
     float* w32 = nullptr;    // all fp32 vectors (biases, LayerNorm)
+    bool q_folded = true;    // log2(e) / sqrt(dh) folded into the query projection (k_scale_half at load)
     // fp16 offsets (elements)
     size_t o_word = 0, o_pos = 0, o_type = 0, o_layers = 0, o_head_dense = 0, o_head_out = 0, layer16 = 0;
     // fp32 offsets
@@ -2084,6 +2522,17 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = configure_once();
+    e->q_folded = getenv("VF_ATT_V1") == nullptr;   // A/B switch: the first-generation kernel scales Q itself
+    if (er == hipSuccess && e->q_folded) {
+        const float qs = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(64)
+        for (int l = 0; l < c.layers; ++l) {
+            hipLaunchKernelGGL(k_scale_half, dim3((unsigned)((H * H + 255) / 256)), dim3(256), 0, 0,
+                               e->w16 + e->o_layers + (size_t)l * e->layer16, (long long)(H * H), qs);
+            hipLaunchKernelGGL(k_scale_float, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, 0,
+                               e->w32 + e->f_layers + (size_t)l * e->layer32, (long long)H, qs);
+        }
+        er = hipDeviceSynchronize();
+    }
     if (er != hipSuccess) {
         const std::string msg = std::string("vf_encoder_create: ") + hipGetErrorString(er);
         vf_encoder_destroy(e);
@@ -2248,10 +2697,13 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         // (64-key tiles through LDS, online softmax), which has no length limit.
         if (att_stream || T > kEncResidentT) {
             hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
-                               sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads, 0.125f, e->ctx, H);
+                               sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
+                               e->q_folded ? -1.f : 0.125f, e->ctx, H);
+        } else if (e->q_folded) {
+            launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st);
         } else {
             hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
-                               e->ctx);
+                               0.125f, 1.4426950408889634f, e->ctx);
         }
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
         else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
@@ -2700,4 +3152,34 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st, kind);
     else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st, kind);
     return er == hipSuccess ? 0 : -1;
+}
+
+// Test hook (tools/bench_attention.py, tests/test_gpu_encoder.py): one attention pass over qkv [B*T][3*64*heads]
+// (Q already carrying log2(e) / 8) with the key padding mask [B*T]; kind 1 = first-generation resident kernel,
+// 2 = k_attention2, 3 = streaming kernel.
+extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T, int heads, void* ctx, void* stream, int kind) {
+    hipError_t er = configure_once();
+    if (er != hipSuccess) return -1;
+    if (B <= 0 || heads <= 0 || T <= 0 || T % 32) return -2;
+    if (kind != 3 && T > kEncResidentT) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = heads * ADH;
+    if (kind == 1) {
+        int pad = 8;
+        while ((((T + pad) / 2) & 63) != 4) pad += 8;
+        const int vt_ld = T + pad;
+        const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4 + 64;
+        hipLaunchKernelGGL(k_attention, dim3(heads, B), dim3(ATHREADS), att_lds, st, (const half_t*)qkv, mask, T, H, vt_ld, 1.0f, 1.0f,
+                           (half_t*)ctx);
+    } else if (kind == 2) {
+        launch_attention2<0>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
+    } else if (kind == 26) {
+        launch_attention2<6>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
+    } else if (kind == 3) {
+        hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStreamLds<64>), st,
+                           (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
+    } else {
+        return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
