@@ -2,10 +2,14 @@
 architecture in plain PyTorch fp32 on the CPU (HF BertModel / XLMRobertaForSequenceClassification with
 seeded random weights: no checkpoints exist in this pipeline).  Floating-point path: fp16 weights and
 activations with fp32 accumulation, so the bar is a tolerance, written in each test."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -657,3 +661,50 @@ def test_decoder_residual_beyond_fp16_range(vf):
     rel = np.abs(got - want).max() / np.abs(want).max()
     print("beyond-fp16 residual: cos", cos, "rel", rel)
     assert cos.min() > 0.999 and rel < 3e-2
+
+
+@pytest.mark.parametrize("b,t,heads,ragged,growing,scale", [
+    (6, 512, 12, False, False, 1.0),     # the re-rank shape, full sequences
+    (9, 512, 4, True, False, 1.0),       # ragged lengths, a sequence without valid keys, a single valid key
+    (5, 480, 2, True, True, 1.0),        # odd number of 32-query blocks; key norms grow along the sequence
+    (4, 256, 3, False, True, 3.0),       # scores far past the fp16 range of the first reference: the overflow path
+    (7, 96, 2, True, False, 1.0),
+    (3, 32, 1, False, False, 1.0),
+    (300, 64, 2, True, False, 1.0),      # more pairs than resident workgroups: the persistent loop, single-chunk refills
+    (70, 512, 4, True, True, 2.0),       # 280 pairs on 256 workgroups: next-pair prefetch with skipped chunks
+])
+def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, scale):
+    """k_attention2 (persistent, LDS-DMA prefetch, lazy softmax reference) and the two older kernels against an fp32
+    softmax in torch, through the vf_debug_attention hook.  Rows of padded queries are not compared (HF never reads them)."""
+    import ctypes
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_attention import make_case, reference, run
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_attention.restype = ctypes.c_int
+    L.vf_debug_attention.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_int]
+    dev = torch.device("cuda:0")
+    qkv, mask = make_case(b, t, heads, dev, seed=11, scale=scale, ragged=ragged, growing=growing)
+    rows = min(b, 12)
+    ref = reference(qkv, mask, b, t, heads, rows=rows)
+    valid = mask.reshape(b, t)[:rows].reshape(-1).bool()
+    vmax = float(qkv[:, 2 * heads * 64:].float().abs().max())
+    for kind in (2, 1, 3):
+        ctx = torch.full((b * t, heads * 64), float("nan"), dtype=torch.float16, device=dev)
+        run(L, kind, qkv, mask, b, t, heads, ctx)
+        torch.cuda.synchronize()
+        got = ctx[:rows * t].float()[valid]
+        assert bool(torch.isfinite(got).all()), (kind, "non-finite output")
+        err = float((got - ref[valid]).abs().max())
+        # measured <= 2.5e-4 * max|v| on these cases (fp16 probabilities and outputs); 3x that
+        assert err <= 7.5e-4 * vmax, (kind, err, vmax)
+    # the last pairs too (the persistent kernel's later rounds), kind 2 against kind 3
+    c2 = torch.zeros(b * t, heads * 64, dtype=torch.float16, device=dev)
+    c3 = torch.zeros_like(c2)
+    run(L, 2, qkv, mask, b, t, heads, c2)
+    run(L, 3, qkv, mask, b, t, heads, c3)
+    torch.cuda.synchronize()
+    allv = mask.bool()
+    assert float((c2.float()[allv] - c3.float()[allv]).abs().max()) <= 1.5e-3 * vmax

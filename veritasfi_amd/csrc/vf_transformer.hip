@@ -1346,7 +1346,7 @@ __global__ void k_scale_float(float* __restrict__ w, long long n, float s) {
 //    m_ref enters through the matrix pipe as a fifth k-step (A = 1 in slot 0, B = -m_ref in slot 0, m_ref kept
 //    fp16-representable so the product is exact): the scores come out already relative to m_ref and p = exp2(s) needs
 //    no per-element arithmetic.  (As the MFMA's initial accumulator the same bias costs 16 register copies per tile.)
-//  * Lazy maximum (a2_softmax): m_ref moves only when a probability overflows fp16, which the row sum reveals; the
+//  * Lazy maximum: m_ref moves only when a probability overflows fp16, which the (infinite) row sum reveals; the
 //    rescale of O, l and the bias fragment is a rare wave-uniform branch.  l is kept per lane (its half of the keys)
 //    and combined once at the end.
 //  * O is staged through LDS (the K region, after a barrier) and stored as whole 128-byte rows.
@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void a2_move_ref(f16v& s, f16v (&o)[2], float& l, flo
 // p = exp2(s) -> fp16 B-operand fragments; returns the lane's partial row sum, taken over the ROUNDED probabilities
 // (v_dot2_f32_f16 against (1, 1)), so that O / l is a weighted mean with consistently perturbed weights: a dominant
 // key then reproduces its value row exactly, as it does when the largest probability is exactly 1.  A probability
-// past the fp16 range makes the sum infinite: that is the overflow signal of a2_softmax.
+// past the fp16 range makes the sum infinite: the overflow signal that moves the reference (a2_move_ref).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float a2_probs(const f16v& s, h8 (&pf)[2]) {
     const h2 one2 = {(half_t)1.f, (half_t)1.f};
@@ -1415,79 +1415,88 @@ __device__ __forceinline__ float a2_probs(const f16v& s, h8 (&pf)[2]) {
     return s0 + s1;
 }
 
-// Softmax of one query block's 32-key tile, optimistically: exponentiate against the current reference and look at the
-// result -- a score more than 16 (log2 units) above the reference overflows fp16 and shows up as an infinite sum, the
-// only case that NEEDS a new reference (probabilities up to 2^16 are as precise in fp16 as those below 1; every sum is
-// fp32).  Then, and on the first tile, the reference moves (a2_move_ref) and the tile is exponentiated again.  One
-// ballot per tile instead of a maximum over the scores.
-__device__ __forceinline__ void a2_softmax(f16v& s, h8 (&pf)[2], f16v (&o)[2], float& l, float& mref, h8& mq, bool first, int h) {
-    if (first) a2_move_ref(s, o, l, mref, mq, true, h);
-    float sum = a2_probs(s, pf);
-    if (__ballot(!(sum < 1e30f)) != 0ull) {
-        a2_move_ref(s, o, l, mref, mq, false, h);
-        sum = a2_probs(s, pf);
-    }
-    l += sum;
-}
+// ---- in-wave software pipeline -------------------------------------------------------------------------------
+// Two waves of a SIMD do NOT fill each other's matrix-pipe gaps here (measured: the loop ran as long as its MFMA time
+// plus its VALU time; a wave whose next MFMA waits for the pipe keeps the issue slot).  The overlap has to be inside
+// one wave's instruction stream: the two query blocks run half a tile apart, and each phase issues one block's nine
+// MFMAs (P.V of this tile, then the bias step and QK^T of the next tile) with the OTHER block's softmax spread over
+// the gaps -- two v_exp, one pack, one row-sum step per MFMA.
+//   phase A(i): MFMA  P.V(a, i), QK(a, i+1)      VALU  probabilities(b, i)      then the overflow check of b
+//   phase B(i): MFMA  P.V(b, i), QK(b, i+1)      VALU  probabilities(a, i+1)    then the overflow check of a
+// The key padding mask rides the bias k-step (A = (1, mask_key), B = (-m_ref, 1)): no branch, no per-score arithmetic.
 
-// One 32-key tile for the wave's two query blocks.  kf: this tile's K fragments (already in registers); kn: filled with
-// the next tile's.  Fragment addresses: K -- key kt*32 + r31, chunk 2 ks + h.  V (transposed read) -- lane 4q + p of its
-// 16-lane group addresses key (base + q), dh chunk 4 mt + 2 (group & 1) + (p >> 1), byte 8 (p & 1).
-// Order: QK^T of block a, then of block b (two separate accumulation chains, so a's scores are complete while b's are
-// still in the matrix pipe and a's softmax runs under them); b's softmax runs under a's P.V.
-__device__ __forceinline__ void a2_tile(const h8 (&kf)[4], h8 (&kn)[4], int kt, int ktn, bool mixed, bool first, const char* Ks,
-                                        const char* Vs, const float* mb, const h8 (&qa)[4], const h8 (&qb)[4], const h8& ones,
-                                        h8& mqa, h8& mqb, f16v (&oa)[2], f16v (&ob)[2], float& la, float& lb, float& mra,
-                                        float& mrb, int lane, int prio) {
-    const int r31 = lane & 31, h = lane >> 5;
-    const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
-    const int k0 = kt * 32;
-    // the two waves of a SIMD take turns at issue priority, tile by tile: left alone the older wave wins every
-    // arbitration, the pair drifts apart by +-20 % and every barrier waits for the slower one
-    if (prio >= 0) {
-        if (prio >= 16 ? (prio & 1) : ((prio ^ kt) & 1)) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(0);
+// half of a slice: two scores -> exp2 -> one packed pair -> row-sum step
+#define A2_HALF_SLICE(S, PF, ACC, E)                                                                                   \
+    {                                                                                                                  \
+        const h2 p_ = {(half_t)__builtin_amdgcn_exp2f(S[E]), (half_t)__builtin_amdgcn_exp2f(S[(E) + 1])};             \
+        ACC = __builtin_amdgcn_fdot2(p_, one2, ACC, false);                                                            \
+        PF[(E) >> 3][(E) & 7] = p_[0];                                                                                 \
+        PF[(E) >> 3][((E) & 7) + 1] = p_[1];                                                                           \
     }
+
+// One phase.  MFMA: o += V^T(vf) . P(pv_p) for this tile [4], then (QK) s_next = bias + K(kf) . Q(q) for the next
+// tile [5].  VALU: pr_p = exp2(pr_s), returns the lane's partial row sum.
+template <bool QK>
+__device__ __forceinline__ float a2_phase(f16v (&o)[2], const h8 (&pv_p)[2], const h8 (&vf)[2][2], f16v& s_next, const h8 (&kf)[4],
+                                          const h8 (&q)[4], const h8& ba, const h8& mq, const f16v& pr_s, h8 (&pr_p)[2]) {
+    const h2 one2 = {(half_t)1.f, (half_t)1.f};
+    float s0 = 0.f, s1 = 0.f;
     f16v zero;
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-    f16v sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, mqa, zero, 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pv_p[0], o[0], 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s0, 0)
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], pv_p[0], o[1], 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s1, 2)
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pv_p[1], o[0], 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s0, 4)
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], pv_p[1], o[1], 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s1, 6)
+    if (QK) s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mq, zero, 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s0, 8)
+    if (QK) s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], q[0], s_next, 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s1, 10)
+    if (QK) s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], q[1], s_next, 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s0, 12)
+    if (QK) s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2], q[2], s_next, 0, 0, 0);
+    A2_HALF_SLICE(pr_s, pr_p, s1, 14)
+    if (QK) s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3], q[3], s_next, 0, 0, 0);
+    // one MFMA, two transcendentals, two other vector ops per gap
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qa[ks], sa, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    f16v sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, mqb, zero, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+    return s0 + s1;
+}
+
+// the bias k-step's A operand for key tile kt: (1, mask_key) in the h = 0 lanes (mh[key] = packed {1.0h, 0 or -30000h})
+__device__ __forceinline__ h8 a2_bias_a(const unsigned* mh, int kt, int r31, int h) {
+    const unsigned w = h == 0 ? mh[kt * 32 + r31] : 0u;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v v = {w, 0u, 0u, 0u};
+    h8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+__device__ __forceinline__ void a2_read_k(h8 (&kf)[4], const char* Ks, int kt, int r31, int h) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qb[ks], sb, 0, 0, 0);
-    // V^T fragments of this tile: k-slot j of half h <-> key 16 st + (j & 3) + 8 (j >> 2) + 4 h
-    h8 vf[2][2];
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const h8*)(Ks + a2_koff(kt * 32 + r31, 2 * ks + h));
+}
+
+// V^T fragments of key tile kt: k-slot j of half h <-> key 16 st + (j & 3) + 8 (j >> 2) + 4 h.  Transposed read: lane
+// 4q + p of its 16-lane group addresses key (base + q), dh chunk 4 mt + 2 (group & 1) + (p >> 1), byte 8 (p & 1).
+__device__ __forceinline__ void a2_read_v(h8 (&vf)[2][2], const char* Vs, int kt, int lane) {
+    const int h = lane >> 5, vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int key = k0 + 16 * st + 4 * h + vq, ch = 4 * mt + 2 * vg + (vp >> 1);
+            const int key = kt * 32 + 16 * st + 4 * h + vq, ch = 4 * mt + 2 * vg + (vp >> 1);
             a2_tr_read(vf[st][mt], Vs + a2_voff(key, ch) + 8 * (vp & 1), Vs + a2_voff(key + 8, ch) + 8 * (vp & 1));
         }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kn[ks] = *(const h8*)(Ks + a2_koff(ktn * 32 + r31, 2 * ks + h));
-    if (mixed) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float m = mb[k0 + (e & 3) + 8 * (e >> 2) + 4 * h];
-            sa[e] += m;
-            sb[e] += m;
-        }
-    }
-    h8 pa[2], pb[2];
-    a2_softmax(sa, pa, oa, la, mra, mqa, first, h);
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) oa[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pa[st], oa[mt], 0, 0, 0);
-    a2_softmax(sb, pb, ob, lb, mrb, mqb, first, h);
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) ob[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pb[st], ob[mt], 0, 0, 0);
 }
 
 // 16 bytes per lane global -> LDS (lds: wave-uniform base, lane i lands at base + 16 i), as inline asm ON PURPOSE.  With the
@@ -1529,24 +1538,24 @@ __device__ __forceinline__ void a2_store_group(const f16v (&o)[2], float inv, in
     }
 }
 
-// MODE 0: the kernel; 6: diagnostic build that returns the tile loops' shader-clock / 100 MHz ticks instead of O
-// (tools/attention_clock.py)
+// MODE 0: the kernel; 6: diagnostic build that also appends per-wave clock stamps after ctx (tools/attention_clock.py)
 template <int MODE>
 __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int B, int T, int H,
                                                     int ct, int dbg, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                  // [T] rows of 128 B, swizzled (a2_koff)
     char* Vs = smem + (size_t)T * 128;                // [T] rows of 128 B, swizzled (a2_voff)
-    float* mbuf = (float*)(Vs + (size_t)T * 128);     // [2][T] additive masks: this pair's and the next one's
+    unsigned* mbuf = (unsigned*)(Vs + (size_t)T * 128);   // [2][T] packed {1.0h, mask_h}: this pair's and the next one's
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* Os = (char*)(mbuf + 2 * T) + wid * 2048;    // the wave's O staging rows
     const int r31 = lane & 31, h = lane >> 5;
     const int heads = H / ADH, npairs = B * heads, ld = 3 * H;
-    const int wprio = (dbg & 8) ? 16 + (wid >> 2) : (dbg & 6) == 2 ? (wid >> 2) : (dbg & 6) == 4 ? (wid & 1) : -1;
-    const int ntiles = T >> 5, nchunks = (ntiles + ct - 1) / ct;   // ct: tiles per chunk (4, 8 or 16)
+    const int cts = ct == 16 ? 4 : ct == 8 ? 3 : 2;                  // ct: tiles per chunk (4, 8 or 16) = 1 << cts
+    const int ntiles = T >> 5, nchunks = (ntiles + ct - 1) >> cts;
     const unsigned cmask = ct >= 32 ? 0xffffffffu : ((1u << ct) - 1u);
     const unsigned all_tiles = ntiles >= 32 ? 0xffffffffu : ((1u << ntiles) - 1u);
+    const unsigned MASK_ON = 0x00003c00u, MASK_OFF = 0xf7533c00u;   // {1.0h, 0h} / {1.0h, -30000h}
     int pair = blockIdx.x;
     if (pair >= npairs) return;
     unsigned long long tk_start = 0, rt_start = 0;
@@ -1567,21 +1576,11 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
             a2_dma16(vs, Vs + c0 * 16);
         }
     };
-    auto stage_mask = [&](int p, float* mb) {
-        const long long prow = (long long)(p / heads) * T;
-        for (int t = tid; t < T; t += nthreads) mb[t] = mask[prow + t] ? 0.f : -30000.f;
-    };
-    // tile classes (bit j = 32-key tile j): act = has a valid key, mixed = needs the additive mask; a sequence without
-    // any valid key keeps every tile
-    auto classify = [&](const float* mb, unsigned& act, unsigned& mixed) {
-        act = 0;
-        mixed = 0;
-        for (int j = 0; j < ntiles; ++j) {
-            const int nvalid = __popc((unsigned)__ballot(mb[j * 32 + r31] == 0.f));
-            act |= (nvalid != 0 ? 1u : 0u) << j;
-            mixed |= ((nvalid != 0 && nvalid != 32) ? 1u : 0u) << j;
-        }
-        if (act == 0) act = mixed = all_tiles;
+    // tile classes (bit j = 32-key tile j has a valid key); a sequence without any valid key keeps every tile
+    auto classify = [&](const unsigned* mh) {
+        unsigned act = 0;
+        for (int j = 0; j < ntiles; ++j) act |= (__ballot((mh[j * 32 + r31] >> 16) == 0u) != 0ull ? 1u : 0u) << j;
+        return act ? act : all_tiles;
     };
     // Q fragments (B operand) of both query blocks: lane (query r31, half h) holds q[8h + j + 16 ks].  A block past the
     // end of the sequence re-reads the last query (computed, never stored).
@@ -1601,18 +1600,15 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
 
     // ---- first pair: everything in flight at once (and the mask of the second)
     for (int g = 0; g < nchunks; ++g) stage_chunk(pair, g);
-    stage_mask(pair, mbuf);
-    if (pair + (int)gridDim.x < npairs) stage_mask(pair + gridDim.x, mbuf + T);
+    if (tid < T) {
+        mbuf[tid] = mask[(long long)(pair / heads) * T + tid] ? MASK_ON : MASK_OFF;
+        if (pair + (int)gridDim.x < npairs) mbuf[T + tid] = mask[(long long)((pair + gridDim.x) / heads) * T + tid] ? MASK_ON : MASK_OFF;
+    }
     load_q(pair);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
-    unsigned act, mixed;
-    classify(mbuf, act, mixed);
-    // the bias k-step: A = (1, 0, ...) on every key row, B = (-m_ref, 0, ...) per query; both only in the h = 0 lanes
-    h8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (half_t)0.f;
-    ones[0] = h == 0 ? (half_t)1.f : (half_t)0.f;
+    unsigned act = classify(mbuf);
+    bool last_published = true;            // the pair's last chunk has landed and been published by a barrier
     unsigned long long tk_loop = 0, tk_tail = 0;
 
     // Pair loop.  No vector-memory LOAD with a register destination is pending while tiles run: the wait the compiler
@@ -1623,58 +1619,112 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     for (int cur = 0;; cur ^= 1) {
         const int nxt_pair = pair + gridDim.x, nxt2_pair = nxt_pair + gridDim.x;
         const bool has_next = nxt_pair < npairs;
-        const float* mb = mbuf + cur * T;
-        float* mbn = mbuf + (cur ^ 1) * T;
-        f16v oa[2], ob[2];
+        const unsigned* mh = mbuf + cur * T;
+        const unsigned* mhn = mbuf + (cur ^ 1) * T;
+        unsigned act_n = 0;
+        int g_nb = 0;                      // next inner chunk boundary to run
+        // An inner boundary: every wave has left chunk g (and every LDS read of it has returned); the transfers issued a
+        // chunk ago have landed.  After the barrier the chunk's rows take the NEXT pair's keys (LDS-DMA, in flight under
+        // the following chunks).
+        auto boundary = [&](int g) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            __syncthreads();
+            last_published = true;
+            if (has_next) {
+                if (g == 0) act_n = classify(mhn);                  // the next pair's mask: written a pair ago
+                if (((act_n >> (ct * g)) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, g);
+            }
+        };
+        // reads may run ahead of the boundaries, but not into a last chunk that no barrier of this pair has published yet
+        auto publish_for = [&](int tile) {
+            if (!last_published && (tile >> cts) == nchunks - 1) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+                last_published = true;
+            }
+        };
+        unsigned long long t0 = 0;
+        if (MODE == 6) t0 = __builtin_amdgcn_s_memtime();
+
+        f16v oa[2], ob[2], sa, sb, zero;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oa[0][e] = oa[1][e] = ob[0][e] = ob[1][e] = 0.f;
+        for (int e = 0; e < 16; ++e) oa[0][e] = oa[1][e] = ob[0][e] = ob[1][e] = zero[e] = 0.f;
+        // the bias k-step's B operand: (-m_ref, 1, 0, ...) per query, in the h = 0 lanes
         h8 mqa, mqb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) mqa[e] = mqb[e] = (half_t)0.f;
+        mqa[1] = mqb[1] = h == 0 ? (half_t)1.f : (half_t)0.f;
         float la = 0.f, lb = 0.f, mra = 0.f, mrb = 0.f;
-        bool first = true;
-        unsigned act_n = 0, mixed_n = 0;
-        unsigned long long t0 = 0;
-        if (MODE == 6) t0 = __builtin_amdgcn_s_memtime();
-        // Chunks of ct 32-key tiles.  Within a chunk the tile loop is software-pipelined by hand (a2_tile) and unrolled
-        // by two so the K fragment sets ping-pong.  At a chunk's end every wave has left its keys: after the barrier the
-        // chunk's LDS rows take the NEXT pair's keys (LDS-DMA, in flight under the following chunks; each wait is a
-        // whole chunk of work away from the issue).
-        for (int g = 0; g < nchunks; ++g) {
-            unsigned rest = (act >> (ct * g)) & cmask;
-            if (rest) {
-                int kt = ct * g + __builtin_ctz(rest);
-                rest &= rest - 1;
-                h8 kfA[4], kfB[4];
+        h8 pa[2], pb[2], vf[2][2], kf[4], ba;
+
+        // ---- prologue of the pipeline: scores of the first active tile for both blocks, references, a's probabilities
+        unsigned rest = act;
+        int t = __builtin_ctz(rest);
+        rest &= rest - 1;
+        int tn = rest ? __builtin_ctz(rest) : -1;
+        publish_for(t);
+        a2_read_k(kf, Ks, t, r31, h);
+        ba = a2_bias_a(mh, t, r31, h);
+        a2_read_v(vf, Vs, t, lane);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mqa, zero, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mqb, zero, 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kfA[ks] = *(const h8*)(Ks + a2_koff(kt * 32 + r31, 2 * ks + h));
-                while (true) {
-                    int ktn = rest ? ct * g + __builtin_ctz(rest) : kt;
-                    a2_tile(kfA, kfB, kt, ktn, (mixed >> kt) & 1, first, Ks, Vs, mb, qa, qb, ones, mqa, mqb, oa, ob, la, lb, mra, mrb,
-                            lane, wprio);
-                    first = false;
-                    if (!rest) break;
-                    rest &= rest - 1;
-                    kt = ktn;
-                    ktn = rest ? ct * g + __builtin_ctz(rest) : kt;
-                    a2_tile(kfB, kfA, kt, ktn, (mixed >> kt) & 1, false, Ks, Vs, mb, qa, qb, ones, mqa, mqb, oa, ob, la, lb, mra, mrb,
-                            lane, wprio);
-                    if (!rest) break;
-                    rest &= rest - 1;
-                    kt = ktn;
-                }
-            }
-            if (g + 1 < nchunks) {
-                // inner boundary: the transfers issued a chunk ago have landed (the last pair still has to publish the
-                // refills the previous pair issued)
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-                __syncthreads();
-                if (has_next) {
-                    if (g == 0) classify(mbn, act_n, mixed_n);      // the next pair's mask: written a pair ago
-                    if (((act_n >> (ct * g)) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, g);
-                }
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qa[ks], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qb[ks], sb, 0, 0, 0);
         }
+        if (tn >= 0) {
+            publish_for(tn);
+            a2_read_k(kf, Ks, tn, r31, h);
+            ba = a2_bias_a(mh, tn, r31, h);
+        }
+        a2_move_ref(sa, oa, la, mra, mqa, true, h);
+        a2_move_ref(sb, ob, lb, mrb, mqb, true, h);
+        la += a2_probs(sa, pa);
+        // ---- steady state: here pa(t), sb(t), vf(t) are ready, and kf / ba hold tile tn
+        while (tn >= 0) {
+            rest &= rest - 1;
+            const int tn2 = rest ? __builtin_ctz(rest) : -1;
+            // phase A: P.V(a, t), QK(a, tn)  ||  probabilities(b, t)
+            float sum = a2_phase<true>(oa, pa, vf, sa, kf, qa, ba, mqa, sb, pb);
+            if (__ballot(!(sum < 1e30f)) != 0ull) {
+                a2_move_ref(sb, ob, lb, mrb, mqb, false, h);
+                sum = a2_probs(sb, pb);
+            }
+            lb += sum;
+            // phase B: P.V(b, t), QK(b, tn)  ||  probabilities(a, tn); then the fragment reads of the tiles ahead
+            publish_for(tn);
+            if (tn2 >= 0) publish_for(tn2);
+            sum = a2_phase<true>(ob, pb, vf, sb, kf, qb, ba, mqb, sa, pa);
+            a2_read_v(vf, Vs, tn, lane);
+            if (tn2 >= 0) {
+                a2_read_k(kf, Ks, tn2, r31, h);
+                ba = a2_bias_a(mh, tn2, r31, h);
+            }
+            if (__ballot(!(sum < 1e30f)) != 0ull) {
+                a2_move_ref(sa, oa, la, mra, mqa, false, h);
+                sum = a2_probs(sa, pa);
+            }
+            la += sum;
+            // chunk boundaries between tile t and tile tn
+            while (g_nb < (tn >> cts)) boundary(g_nb++);
+            t = tn;
+            tn = tn2;
+        }
+        // ---- drain: P.V(a, t) || probabilities(b, t), then P.V(b, t)
+        {
+            float sum = a2_phase<false>(oa, pa, vf, sa, kf, qa, ba, mqa, sb, pb);
+            if (__ballot(!(sum < 1e30f)) != 0ull) {
+                a2_move_ref(sb, ob, lb, mrb, mqb, false, h);
+                sum = a2_probs(sb, pb);
+            }
+            lb += sum;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) ob[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pb[st], ob[mt], 0, 0, 0);
+        }
+        while (g_nb < nchunks - 1) boundary(g_nb++);
         unsigned long long t1 = 0;
         if (MODE == 6) { t1 = __builtin_amdgcn_s_memtime(); tk_loop += t1 - t0; }
         const int p_b = pair / heads, p_hd = pair % heads;
@@ -1682,7 +1732,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         if (has_next) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             __syncthreads();                                        // the pair is done in every wave
-            if (nchunks == 1) classify(mbn, act_n, mixed_n);
+            if (nchunks == 1) act_n = classify(mhn);
             load_q(nxt_pair);                                       // quiet window: nothing else in flight
             if (nxt2_pair < npairs && tid < T) rmask = mask[(long long)(nxt2_pair / heads) * T + tid];
         }
@@ -1721,16 +1771,16 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         asm volatile("" : "+v"(rmask));       // (keeps the mask's compare-and-select below the wait)
         if (!has_next) break;
-        if (nxt2_pair < npairs && tid < T) mbuf[cur * T + tid] = rmask ? 0.f : -30000.f;   // read (as mbn) after the next pair's first barrier
+        if (nxt2_pair < npairs && tid < T) mbuf[cur * T + tid] = rmask ? MASK_ON : MASK_OFF;   // read (as mhn) after a barrier of the next pair
         if (((act_n >> (ct * (nchunks - 1))) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, nchunks - 1);
+        last_published = false;
         if (nchunks == 1) {   // a single chunk: the refill must land before the next pair starts
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
+            last_published = true;
         }
-        if (MODE == 6) tk_tail += 0;
         pair = nxt_pair;
         act = act_n;
-        mixed = mixed_n;
     }
 }
 
