@@ -31,7 +31,7 @@ for npw in sorted(set(raw[:, 5].tolist())):
 npairs = rec[:, 5]
 clk = rec[:, 3] / rec[:, 4] * 100e6
 print(f"waves {len(rec)}  in-kernel clock {np.median(clk)/1e9:.3f} GHz   kernel span per wave {np.median(rec[:,4])/100:.1f} us  pairs per workgroup {npairs.min():.0f}-{npairs.max():.0f}")
-for name, col in (("pair head (mask, classify)", 0), ("tile loops", 1), ("tail (O, next Q)", 2)):
+for name, col in (("  of the tail: closing barrier", 0), ("tile loops", 1), ("tail (O, next Q)", 2)):
     per = rec[:, col] / npairs
     print(f"{name:28s} per pair: median {np.median(per):8.0f} cycles = {np.median(per)/np.median(clk)*1e6:6.2f} us   p10 {np.percentile(per,10):8.0f} p90 {np.percentile(per,90):8.0f}")
 print(f"cycles per 32-key tile (64 queries): {np.median(rec[:,1]/npairs)/(T//32):.0f}")

@@ -1336,22 +1336,31 @@ __global__ void k_scale_float(float* __restrict__ w, long long n, float s) {
 
 // ------------------------------------------------------------------------------------------------
 // k_attention2: resident attention, second generation (dh = 64, T % 32 == 0, T <= 512).
-// grid (heads, B), 64 * ceil(T / 64) threads; wave w owns queries [64w, 64w + 64) as two 32-query blocks (a, b) that
-// share every K / V fragment read.  Scores arrive in LOG2 units: the caller has folded log2(e) / sqrt(64) into Q.
-//  * K and V of the (sequence, head) are staged verbatim ([key][64] rows of 128 B) by LDS-DMA, every transfer in
-//    flight at once; the XOR swizzles live in the per-lane SOURCE address.  K: chunk ^ ((key >> 1) & 7) -- the
-//    ds_read_b128 A-operand reads of 32 keys are conflict-free.  V: chunk ^ (((key >> 1) & 1) << 2) -- the 4-key x 16-dh
-//    blocks of ds_read_b64_tr_b16 (which delivers V^T fragments without a transposing staging pass) are.
-//  * S^T = K Q^T with the key on the MFMA row (a lane owns 16 scores of one query), and the running reference maximum
-//    m_ref enters through the matrix pipe as a fifth k-step (A = 1 in slot 0, B = -m_ref in slot 0, m_ref kept
-//    fp16-representable so the product is exact): the scores come out already relative to m_ref and p = exp2(s) needs
-//    no per-element arithmetic.  (As the MFMA's initial accumulator the same bias costs 16 register copies per tile.)
+// PERSISTENT workgroups (as many as stay co-resident: one per CU at T = 512), 64 * ceil(T / 64) threads, each walking
+// (sequence, head) pairs blockIdx.x, + gridDim.x, ...; wave w owns queries [64w, 64w + 64) as two 32-query blocks (a, b)
+// that share every K / V fragment read.  Scores arrive in LOG2 units: the caller has folded log2(e) / sqrt(64) into Q.
+//  * K and V of the pair are staged verbatim ([key][64] rows of 128 B) by LDS-DMA; the XOR swizzles live in the
+//    per-lane SOURCE address.  K: chunk ^ ((key >> 1) & 7) -- the ds_read_b128 A-operand reads of 32 keys are
+//    conflict-free.  V: chunk ^ (((key >> 1) & 1) << 2) -- the 4-key x 16-dh blocks of ds_read_b64_tr_b16 (which
+//    delivers V^T fragments without a transposing staging pass) are.
+//  * Next-pair prefetch: the key range is cut into chunks of 128 keys; once every wave has left a chunk (one barrier per
+//    chunk) its LDS rows are refilled with the NEXT pair's keys, so staging runs under the tile loop instead of in front
+//    of it.  Fully masked chunks are neither staged nor visited.  (a2_dma16 and the pair loop say what it takes to keep
+//    the compiler's own s_waitcnt vmcnt(0) out of the tile loop.)
+//  * S^T = K Q^T with the key on the MFMA row (a lane owns 16 scores of one query).  The running reference maximum
+//    m_ref AND the key padding mask enter through the matrix pipe as a fifth k-step (A = (1, mask_key), B = (-m_ref, 1),
+//    m_ref kept fp16-representable so the products are exact): the scores come out already masked and relative to
+//    m_ref, and p = exp2(s) needs no per-element arithmetic.  (As the MFMA's initial accumulator the same bias costs 16
+//    register copies per tile.)
 //  * Lazy maximum: m_ref moves only when a probability overflows fp16, which the (infinite) row sum reveals; the
 //    rescale of O, l and the bias fragment is a rare wave-uniform branch.  l is kept per lane (its half of the keys)
 //    and combined once at the end.
-//  * O is staged through LDS (the K region, after a barrier) and stored as whole 128-byte rows.
-// Key padding: additive -30000 on mixed tiles, fully masked tiles skipped (their probabilities underflow to exactly 0
-// either way); a sequence without any valid key keeps every tile.
+//  * In-wave software pipeline (a2_phase): the two query blocks run half a tile apart; each phase issues one block's
+//    nine MFMAs with the other block's softmax in the gaps.
+//  * O is staged 16 queries at a time through the wave's own 2 KiB of LDS and stored as whole 128-byte rows.
+// Cost anatomy (tools/attention_clock.py, tools/ubench/issue_cost.hip): the loop is bound by vector ISSUE, not by the
+// matrix pipe -- v_exp_f32 13.9 cycles, v_dot2c 7.5, v_cvt_pk 4, an MFMA's issue 8 of its 32 -- about 800 cycles per
+// (64 queries x 32 keys) against 576 of MFMA time.
 // ------------------------------------------------------------------------------------------------
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr float A2_THR = 8.0f;
@@ -1541,7 +1550,7 @@ __device__ __forceinline__ void a2_store_group(const f16v (&o)[2], float inv, in
 // MODE 0: the kernel; 6: diagnostic build that also appends per-wave clock stamps after ctx (tools/attention_clock.py)
 template <int MODE>
 __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int B, int T, int H,
-                                                    int ct, int dbg, half_t* __restrict__ ctx) {
+                                                    int ct, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                  // [T] rows of 128 B, swizzled (a2_koff)
     char* Vs = smem + (size_t)T * 128;                // [T] rows of 128 B, swizzled (a2_voff)
@@ -1598,8 +1607,9 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         }
     };
 
-    // ---- first pair: everything in flight at once (and the mask of the second)
-    for (int g = 0; g < nchunks; ++g) stage_chunk(pair, g);
+    // ---- first pair: its first chunk (and the mask of the second pair), waited for; the other chunks are issued right
+    //      behind the barrier and land under the first chunk's tiles (published by the first boundary, or on demand)
+    stage_chunk(pair, 0);
     if (tid < T) {
         mbuf[tid] = mask[(long long)(pair / heads) * T + tid] ? MASK_ON : MASK_OFF;
         if (pair + (int)gridDim.x < npairs) mbuf[T + tid] = mask[(long long)((pair + gridDim.x) / heads) * T + tid] ? MASK_ON : MASK_OFF;
@@ -1607,9 +1617,10 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     load_q(pair);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
+    for (int g = 1; g < nchunks; ++g) stage_chunk(pair, g);
     unsigned act = classify(mbuf);
-    bool last_published = true;            // the pair's last chunk has landed and been published by a barrier
-    unsigned long long tk_loop = 0, tk_tail = 0;
+    int pub_from = 1;                      // chunks >= pub_from are not yet known to have landed (no barrier published them)
+    unsigned long long tk_loop = 0, tk_tail = 0, tk_bar = 0;
 
     // Pair loop.  No vector-memory LOAD with a register destination is pending while tiles run: the wait the compiler
     // places before such a register's first use is vmcnt(0) -- the counter is in order -- and inside the tile loop
@@ -1629,18 +1640,18 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         auto boundary = [&](int g) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             __syncthreads();
-            last_published = true;
+            pub_from = nchunks;
             if (has_next) {
                 if (g == 0) act_n = classify(mhn);                  // the next pair's mask: written a pair ago
-                if (((act_n >> (ct * g)) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, g);
+                if ((act_n >> (ct * g)) & cmask) stage_chunk(nxt_pair, g);
             }
         };
-        // reads may run ahead of the boundaries, but not into a last chunk that no barrier of this pair has published yet
+        // reads may run ahead of the boundaries, but not into a chunk that no barrier has published yet
         auto publish_for = [&](int tile) {
-            if (!last_published && (tile >> cts) == nchunks - 1) {
+            if ((tile >> cts) >= pub_from) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 __syncthreads();
-                last_published = true;
+                pub_from = nchunks;
             }
         };
         unsigned long long t0 = 0;
@@ -1732,6 +1743,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         if (has_next) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             __syncthreads();                                        // the pair is done in every wave
+            if (MODE == 6) tk_bar += __builtin_amdgcn_s_memtime() - t1;
             if (nchunks == 1) act_n = classify(mhn);
             load_q(nxt_pair);                                       // quiet window: nothing else in flight
             if (nxt2_pair < npairs && tid < T) rmask = mask[(long long)(nxt2_pair / heads) * T + tid];
@@ -1757,7 +1769,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
             tk_tail += __builtin_amdgcn_s_memtime() - t1;
             if (!has_next && lane == 0) {
                 unsigned long long* out = (unsigned long long*)(ctx + (long long)B * T * H) + ((long long)blockIdx.x * 8 + wid) * 8;
-                out[0] = 0; out[1] = tk_loop; out[2] = tk_tail;
+                out[0] = tk_bar; out[1] = tk_loop; out[2] = tk_tail;
                 out[3] = __builtin_amdgcn_s_memtime() - tk_start;
                 out[4] = __builtin_amdgcn_s_memrealtime() - rt_start;
                 out[5] = (unsigned long long)(pair / gridDim.x + 1);
@@ -1772,12 +1784,12 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         asm volatile("" : "+v"(rmask));       // (keeps the mask's compare-and-select below the wait)
         if (!has_next) break;
         if (nxt2_pair < npairs && tid < T) mbuf[cur * T + tid] = rmask ? MASK_ON : MASK_OFF;   // read (as mhn) after a barrier of the next pair
-        if (((act_n >> (ct * (nchunks - 1))) & cmask) && !(dbg & 1)) stage_chunk(nxt_pair, nchunks - 1);
-        last_published = false;
+        if ((act_n >> (ct * (nchunks - 1))) & cmask) stage_chunk(nxt_pair, nchunks - 1);
+        pub_from = nchunks - 1;
         if (nchunks == 1) {   // a single chunk: the refill must land before the next pair starts
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
-            last_published = true;
+            pub_from = nchunks;
         }
         pair = nxt_pair;
         act = act_n;
@@ -2436,15 +2448,14 @@ static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, 
         return n;
     }();
     const int waves = (T + 63) / 64;
-    const size_t lds = (size_t)T * 256 + (size_t)T * 8 + (size_t)waves * 2048;
+    const size_t lds = (size_t)T * 256 + (size_t)T * 8 + (size_t)waves * 2048;   // K, V, two masks, O staging
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8 / waves) per_cu = 8 / waves;
     if (per_cu < 1) per_cu = 1;
     const int npairs = B * heads;
     const int grid = npairs < n_cu * per_cu ? npairs : n_cu * per_cu;
     static const int ct = [] { const char* e = getenv("VF_ATT_CHUNK"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 16) ? v : 4; }();
-    static const int dbg = [] { const char* e = getenv("VF_ATT_DBG"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, dbg, ctx);
+    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, ctx);
 }
 
 constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
