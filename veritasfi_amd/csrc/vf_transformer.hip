@@ -2630,6 +2630,17 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
     return VF_OK;
 }
 
+// compute units of the current device (256 on MI355X)
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
 // split count for the small-M kernel: enough workgroups to cover the chip, at least two K-steps per split
 static int pick_splits(int tiles, int K) {
     const int steps = K / SBK;
@@ -2678,6 +2689,8 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // shapes of a 768-wide encoder; the vendor library: 210 / 66 / 234 / 217)
     static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+        // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
+        // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
         hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
     }
