@@ -70,6 +70,31 @@ def test_small_path_bit_exact(vf, oracle, n, d, nq, k, dtype):
         assert np.all(ids[:, n:] == -1) and np.all(sc[:, n:] == -FLT_MAX)
 
 
+@pytest.mark.parametrize("n,d,nq,k", [
+    (10000, 1024, 4, 2048),   # the reference's per-request shape (ensembleRetriever.py:64-66): radix select + 2048-key sort
+    (10000, 64, 5, 1),
+    (16384, 128, 3, 2048),    # largest corpus the select kernel holds in LDS
+    (3000, 96, 2, 1500),      # k = n / 2: last shape that takes the select
+    (3000, 96, 2, 1501),      # ... and the first that takes the full sort
+    (9000, 32, 6, 257),       # k just past a power of two
+])
+def test_small_path_topk_select_with_ties(vf, oracle, n, d, nq, k):
+    """k_topk_rows (radix select of the k-th key, compaction, sort of the selected keys) against the oracle on data full
+    of exact ties: a third of the rows are duplicates of other rows (equal scores: the lower id must win, at the k-th
+    boundary too), some rows are zero, one query is a corpus row (a score of exactly 1)."""
+    c, q = _data(23, n, d, nq, np.float32)
+    rng = np.random.default_rng(5)
+    dup = rng.integers(0, n, size=n // 3)
+    src = rng.integers(0, n, size=n // 3)
+    c[dup] = c[src]
+    c[rng.integers(0, n, size=7)] = 0
+    q[0] = c[n // 2]
+    with vf.DenseIndex(c) as ix:
+        ids, sc = ix.search(q, k)
+        assert ix.stats()["path"] == 0
+    _assert_exact(oracle, c, q, k, ids, sc)
+
+
 def test_empty_and_degenerate(vf, oracle):
     c, q = _data(12, 100, 64, 3, np.float32)
     with vf.DenseIndex(c) as ix:

@@ -233,7 +233,31 @@ __global__ __launch_bounds__(256) void k_dense_dot16(const float* qn, int nq, co
     const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (r >= nrows) return;
     const float* c = cn + r * (long long)d;
-    for (int q = 0; q < nq; ++q) {
+    // four queries per pass over the row: the row is read once per four queries and the four accumulation chains are
+    // independent (each keeps the canonical order: lane l sums j = l, l + 16, ... ascending, then the 16-lane tree)
+    int q = 0;
+    for (; q + 4 <= nq; q += 4) {
+        const float *a0 = qn + (long long)q * d, *a1 = a0 + d, *a2 = a1 + d, *a3 = a2 + d;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        for (int j = l; j < d; j += 16) {
+            const float cj = c[j];
+            s0 = __builtin_fmaf(a0[j], cj, s0);
+            s1 = __builtin_fmaf(a1[j], cj, s1);
+            s2 = __builtin_fmaf(a2[j], cj, s2);
+            s3 = __builtin_fmaf(a3[j], cj, s3);
+        }
+        s0 = group16_tree(s0);
+        s1 = group16_tree(s1);
+        s2 = group16_tree(s2);
+        s3 = group16_tree(s3);
+        if (l == 0) {
+            out[(long long)q * out_stride + r] = s0;
+            out[(long long)(q + 1) * out_stride + r] = s1;
+            out[(long long)(q + 2) * out_stride + r] = s2;
+            out[(long long)(q + 3) * out_stride + r] = s3;
+        }
+    }
+    for (; q < nq; ++q) {
         const float* a = qn + (long long)q * d;
         float acc = 0.0f;
         for (int j = l; j < d; j += 16) acc = __builtin_fmaf(a[j], c[j], acc);
@@ -276,11 +300,96 @@ __global__ __launch_bounds__(1024) void k_sort_rows(const float* scores, long lo
     }
 }
 
+// k_topk_rows: the same result as k_sort_rows (the k best of a score row, ranked, ties to the lower id) without sorting
+// the row.  The reference's per-request search shape is N ~ 1e4, k = 2048 (ensembleRetriever.py:64-66): a full bitonic
+// sort of 16384 keys is 105 LDS passes (146 us, LDS-bandwidth bound); here a radix SELECT finds the k-th largest 64-bit
+// key (8-bit digits from the top; a level is one LDS histogram and one suffix scan; it stops as soon as a digit's bin
+// is taken whole, normally after the four score bytes), the keys >= it are compacted -- exactly k of them, keys are
+// unique -- and only those are sorted (66 passes over 2048 keys, four waves).
+constexpr int kTopkThreads = 256;
+__global__ __launch_bounds__(kTopkThreads) void k_topk_rows(const float* scores, long long score_stride, int n, int k, int Pk,
+                                                             long long id_base, long long* out_ids, float* out_scores,
+                                                             int out_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    u64* keys = (u64*)smem_raw;                    // [n]
+    u64* sel = keys + n;                           // [Pk]
+    unsigned* hist = (unsigned*)(sel + Pk);        // [256]
+    unsigned* wsum = hist + 256;                   // [4] wave totals, [4] digit, [5] above, [6] bin count, [7] compaction cursor
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* s = scores + (long long)q * score_stride;
+    for (int i = tid; i < n; i += kTopkThreads) keys[i] = ((u64)orderkey(s[i]) << 32) | (u64)(0xFFFFFFFFu - (u32)i);
+    const int kk = k < n ? k : n;                  // real results
+    u64 prefix = 0;
+    int need = kk;
+    int shift = 56;
+    for (;; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        const u64 hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        for (int i = tid; i < n; i += kTopkThreads) {
+            const u64 key = keys[i];
+            if ((key & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // inclusive suffix sums over the 256 digits (thread t owns digit t): in-wave scan, then the waves' totals
+        const unsigned c = hist[tid];
+        unsigned sfx = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_down(sfx, o, 64);
+            if (lane + o < 64) sfx += v;
+        }
+        if (lane == 0) wsum[wid] = sfx;
+        __syncthreads();
+        for (int w = wid + 1; w < kTopkThreads / 64; ++w) sfx += wsum[w];
+        if (sfx >= (unsigned)need && sfx - c < (unsigned)need) {   // the digit that holds the need-th largest key
+            wsum[4] = (unsigned)tid;
+            wsum[5] = sfx - c;
+            wsum[6] = c;
+        }
+        __syncthreads();
+        prefix |= (u64)wsum[4] << shift;
+        need -= (int)wsum[5];
+        const bool whole_bin = (int)wsum[6] == need;   // every key of this bin is wanted: its lower digits do not matter
+        if (whole_bin || shift == 0) break;
+    }
+    // keys >= prefix (lower digits zero) with the matched upper digits are exactly the kk best
+    if (tid == 0) wsum[7] = 0;
+    for (int i = kk + tid; i < Pk; i += kTopkThreads) sel[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += kTopkThreads) {
+        const u64 key = keys[i];
+        if (key >= prefix) sel[atomicAdd(&wsum[7], 1u)] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc(sel, Pk, tid, kTopkThreads);
+    for (int i = tid; i < k; i += kTopkThreads) {
+        long long id = -1;
+        float sc = -FLT_MAX;
+        if (i < kk) {
+            const u64 kv = sel[i];
+            id = id_base + (long long)(0xFFFFFFFFu - (u32)kv);
+            sc = unorderkey((u32)(kv >> 32));
+        }
+        out_ids[(long long)q * out_stride + i] = id;
+        out_scores[(long long)q * out_stride + i] = sc;
+    }
+}
+
 hipError_t launch_sort_rows(const float* scores, long long score_stride, int nq, int n, int k, long long id_base,
                             long long* out_ids, float* out_scores, int out_stride, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     int P = 1;
     while (P < n) P <<= 1;
+    int Pk = 1;
+    while (Pk < (k < n ? k : n)) Pk <<= 1;
+    const size_t topk_lds = (size_t)n * 8 + (size_t)Pk * 8 + 256 * 4 + 64;
+    static const bool full_sort = getenv("VF_FULL_SORT") != nullptr;   // A/B switch
+    if (!full_sort && n >= 2 && Pk * 2 <= P && topk_lds <= 160 * 1024) {
+        hipLaunchKernelGGL(k_topk_rows, dim3(nq), dim3(kTopkThreads), topk_lds, s, scores, score_stride, n, k, Pk, id_base, out_ids,
+                           out_scores, out_stride);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_sort_rows, dim3(nq), dim3(1024), (size_t)P * 8, s, scores, score_stride, n, k, id_base,
                        out_ids, out_scores, out_stride);
     return hipGetLastError();
@@ -1870,6 +1979,7 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if (dev >= 0 && dev < 64) done[dev] = true;
