@@ -672,6 +672,9 @@ def test_decoder_residual_beyond_fp16_range(vf):
     (3, 32, 1, False, False, 1.0),
     (300, 64, 2, True, False, 1.0),      # more pairs than resident workgroups: the persistent loop, single-chunk refills
     (70, 512, 4, True, True, 2.0),       # 280 pairs on 256 workgroups: next-pair prefetch with skipped chunks
+    (150, 128, 12, True, False, 1.0),    # 1800 pairs, one chunk per pair: the refill-at-pair-end path, several rounds
+    (110, 256, 6, True, True, 1.0),      # 660 pairs on 512 resident workgroups: two chunks (last chunk published on demand)
+    (30, 384, 12, False, False, 1.0),    # 360 pairs, three chunks, six waves
 ])
 def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, scale):
     """k_attention2 (persistent, LDS-DMA prefetch, lazy softmax reference) and the two older kernels against an fp32
