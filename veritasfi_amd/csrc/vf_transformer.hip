@@ -1115,6 +1115,257 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemm8q_tn: the 8-phase kernel made PERSISTENT, with a seamless pipeline across its tiles.  k_gemm8p_tn spends about
+// half of a K = 768 tile outside its main loop (first DMAs in front, epilogue behind, nothing else on the CU).  Here a
+// workgroup walks tiles blockIdx.x, + gridDim.x, ... and
+//  * the stage sequence simply runs on into the NEXT tile: the last six stage calls of a tile (which k_gemm8p_tn sends to
+//    a dump slot) fetch the next tile's first six half-tiles, so its main loop starts with its pipeline full;
+//  * the MFMA operands are swapped (D = W_frag x A_frag): a lane then owns 4 consecutive COLUMNS of one output row, and the
+//    epilogue packs them (bias / GELU in registers) and moves the tile through 32 KB of LDS -- the two slots the prefetch
+//    does not touch -- in four 64-row passes of 8-byte writes and 16-byte row reads (128 two-byte LDS writes per thread
+//    before);
+//  * the bias of a tile arrives by one LDS-DMA during its main loop; residual rows are loaded up front in the epilogue.
+// All staging goes through inline asm (dma16s): the compiler never sees an LDS-DMA, so it puts no vmcnt(0) in front of the
+// epilogue's LDS traffic; every wait is written here.  vmcnt is in order and counts stores: in the first K-tile after
+// an epilogue the counted waits allow the 16 epilogue stores (younger than the prefetched stages) to stay in flight.
+// Requires M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128; gridDim.x a multiple of 8 or the tile count.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, const char* lds) {
+    // both scalars are wave-uniform by construction; readfirstlane makes that a fact for the register allocator
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds);
+    const unsigned long long a = (unsigned long long)sbase;
+    // (readfirstlane returns int: widen through unsigned, or the low half sign-extends into the high one)
+    const unsigned long long ua = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(ua), "s"(base)
+                 : "memory");
+}
+
+constexpr int QLDS = PLDS + 1024;   // + one tile's bias (256 floats)
+
+// tile of a dispatch index: XCD-contiguous, n-major groups of 4 m-tiles (as k_gemm8p_tn)
+__device__ __forceinline__ void q_tile_of(int orig, int Mt, int Nt, int& mt, int& nt) {
+    const int ntiles = Mt * Nt, xcd = orig & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    constexpr int GM = 4;
+    const int g = p / (GM * Nt), r = p - g * (GM * Nt);
+    const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+    nt = r / gm;
+    mt = g * GM + (r - nt * gm);
+}
+
+// Half-tile g (counted from the current tile's first; S = g & 3 is known at every call site): g >= G runs on into the
+// next tile, or -- without one -- re-reads the last K-tile into the dump slot so that the counted waits keep their meaning.
+// Everything by value: a lambda capturing the loop's variables by reference parks them in scratch memory.
+template <int S>
+__device__ __forceinline__ void q_stage(char* smem, int wid, const half_t* A, const half_t* W, int K, int g, int G, int nk, int ktg,
+                                        bool has_next, int mt_c, int nt_c, int mt_n, int nt_n, unsigned o0, unsigned o1) {
+    const bool cur = g < G, real = cur || has_next;
+    const int kt = cur ? (g >> 2) : (real ? (g >> 2) - nk : nk - 1);
+    const int mt = (cur || !has_next) ? mt_c : mt_n, nt = (cur || !has_next) ? nt_c : nt_n;
+    const int slot = real ? ((ktg + (g >> 2)) & 1) * 4 + S : 8;
+    char* dst = smem + slot * PSLOT + (16 * wid) * 128;
+    const half_t* base = (S == 0 || S == 3) ? A + ((long long)mt * PBM) * K : W + ((long long)nt * PBN) * K;
+    base += (long long)kt * PBK;
+    dma16s(base, o0, dst);
+    dma16s(base, o1, dst + 1024);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                          half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
+    const int Mt = M / PBM, Nt = N / PBN, ntiles = Mt * Nt;
+    float* bias_lds = (float*)(smem + PLDS);
+    // ---- staging: wave w issues DMA instructions 2w, 2w+1 of every half-tile: LDS rows 16 w + 8 j + (lane >> 3).
+    //      Per-lane byte offsets inside a tile's A / W panel; the tile and the K-tile enter through the scalar base.
+    unsigned voff[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = 16 * wid + 8 * j + (lane >> 3);          // LDS row of the half-tile
+        const int lc = (lane & 7) ^ ((i >> 1) & 7);            // logical 16-byte chunk this lane fetches
+        const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
+        const int bn0 = (i >> 5) * 64 + (i & 31), bn1 = bn0 + 32;
+        voff[0][j] = (unsigned)((am0 * K + lc * 8) * 2);
+        voff[1][j] = (unsigned)((bn0 * K + lc * 8) * 2);
+        voff[2][j] = (unsigned)((bn1 * K + lc * 8) * 2);
+        voff[3][j] = (unsigned)((am1 * K + lc * 8) * 2);
+    }
+    const int nk = K / PBK, G = 4 * nk;   // K-tiles, half-tiles of one tile
+    int mt_c, nt_c, mt_n = 0, nt_n = 0;
+    int orig = blockIdx.x;
+    q_tile_of(orig, Mt, Nt, mt_c, nt_c);
+    bool has_next = orig + (int)gridDim.x < ntiles;
+    if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
+    int ktg = 0;   // K-tiles consumed by this workgroup so far: LDS buffer of local K-tile kt is (ktg + kt) & 1
+#define VFQ_STAGE(S_, G_) q_stage<S_>(smem, wid, A, W, K, (G_), G, nk, ktg, has_next, mt_c, nt_c, mt_n, nt_n, voff[S_][0], voff[S_][1]);
+    f4v acc[8][4];
+    // fragment addresses inside a half-tile: row = (wave's 64 / 32 rows) + tile * 16 + r15; chunk (4 ks + kb) ^ ((r15 >> 1) & 7)
+    const int swz = (r15 >> 1) & 7;
+    const int a_off = (wr * 64 + r15) * 128, b_off = (wc * 32 + r15) * 128;
+    const int c0 = ((0 + kb) ^ swz) * 16, c1 = ((4 + kb) ^ swz) * 16;   // k-steps 0 and 1
+    h8 Af[4][2], B0f[2][2], B1f[2][2];
+#define VFQ_READ_A(SLOTBASE)                                                              \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+        Af[t][0] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c0);                       \
+        Af[t][1] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c1);                       \
+    }
+#define VFQ_READ_B(DSTF, SLOTBASE)                                                         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                        \
+        DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
+        DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
+    }
+    // operands swapped (W fragment first): tile (m-tile MQ*4+t, n-tile NQ*2+u) comes out TRANSPOSED -- lane (r15, kb)
+    // holds C[row 16 (MQ*4+t) + r15][cols 16 (NQ*2+u) + 4 kb .. + 3]
+#define VFQ_QUAD(MQ, NQ, BF)                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
+#define VFQ_PHASE_HEAD(S_, G_)                                                             \
+    if (relaxed) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                         \
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                  \
+    __builtin_amdgcn_s_barrier();                                                          \
+    VFQ_STAGE(S_, G_)
+#define VFQ_PHASE_MID()                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    __builtin_amdgcn_s_barrier();                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    __builtin_amdgcn_s_setprio(1);
+#define VFQ_PHASE_TAIL()                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    VFQ_STAGE(0, 0) VFQ_STAGE(1, 1) VFQ_STAGE(2, 2) VFQ_STAGE(3, 3) VFQ_STAGE(0, 4) VFQ_STAGE(1, 5)
+    for (int it = 0;; ++it) {
+        const long long m0 = (long long)mt_c * PBM, n0 = (long long)nt_c * PBN;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+        // waves 4..7 run one barrier behind; the other half reads half-tiles 0 and 1 right after this barrier.  12 DMAs of this
+        // tile are issued: 8 may still fly (+ the 16 stores of the previous tile's epilogue, younger than all of them)
+        if (wr == 1) {
+            if (it > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* base = smem + ((ktg + kt) & 1) * (4 * PSLOT);
+            const int g0 = 4 * kt + 6;
+            const bool relaxed = kt == 0 && it > 0;   // (see the header: the previous epilogue's stores)
+            // phase 0: quadrant (m0, n0); reads B_n0 then A_m0
+            VFQ_PHASE_HEAD(2, g0)
+            if (kt == 0 && wid == 0 && bias) dma16s(bias + n0, (unsigned)lane * 16u, (const char*)bias_lds);
+            VFQ_READ_B(B0f, base + 1 * PSLOT)
+            VFQ_READ_A(base + 0 * PSLOT)
+            VFQ_PHASE_MID()
+            VFQ_QUAD(0, 0, B0f)
+            VFQ_PHASE_TAIL()
+            // phase 1: quadrant (m0, n1); reads B_n1
+            VFQ_PHASE_HEAD(3, g0 + 1)
+            VFQ_READ_B(B1f, base + 2 * PSLOT)
+            VFQ_PHASE_MID()
+            VFQ_QUAD(0, 1, B1f)
+            VFQ_PHASE_TAIL()
+            // phase 2: quadrant (m1, n1); reads A_m1
+            VFQ_PHASE_HEAD(0, g0 + 2)
+            VFQ_READ_A(base + 3 * PSLOT)
+            VFQ_PHASE_MID()
+            VFQ_QUAD(1, 1, B1f)
+            VFQ_PHASE_TAIL()
+            // phase 3: quadrant (m1, n0); nothing to read
+            VFQ_PHASE_HEAD(1, g0 + 3)
+            VFQ_PHASE_MID()
+            VFQ_QUAD(1, 0, B0f)
+            VFQ_PHASE_TAIL()
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+        ktg += nk;
+        // ---- epilogue.  Es: slots 2, 3 of the buffer that holds the (next) K-tile 1 -- the prefetch has filled that
+        // buffer's slots 0, 1 and all of the other buffer, or is still doing so.
+        char* Es = smem + (((ktg + 1) & 1) * 4 + 2) * PSLOT;   // [64 rows][512 B], 16-byte chunk c of row r at c ^ (r & 15)
+        h8 rres[16];
+        if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = tid + PTHREADS * (i & 3), row = (i >> 2) * 64 + (c >> 5), cc = c & 31;
+                rres[i] = *(const h8*)(R + (m0 + row) * N + n0 + cc * 8);
+            }
+        }
+        __builtin_amdgcn_s_barrier();   // every wave has left the main loop: the tile's last LDS reads are done
+        h4 pk[8][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            f4v bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *(const f4v*)(bias_lds + wc * 64 + ni * 16 + 4 * kb);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                f2v v0 = {acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]};
+                f2v v1 = {acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]};
+                if (EPI == EPI_BIAS_GELU) {
+                    v0 = gelu_erf2(v0);
+                    v1 = gelu_erf2(v1);
+                }
+                pk[mi][ni][0] = (half_t)v0[0];
+                pk[mi][ni][1] = (half_t)v0[1];
+                pk[mi][ni][2] = (half_t)v1[0];
+                pk[mi][ni][3] = (half_t)v1[1];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {   // rows [64 p, 64 p + 64) of the tile: waves wr == p >> 1, their m-tiles 4 (p & 1) .. + 3
+            if (wr == (p >> 1)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int row = t * 16 + r15;                        // in the pass
+                        const int chunk = (wc * 8 + ni * 2 + (kb >> 1)) ^ r15;  // 16-byte chunk of the 512-byte row, swizzled
+                        *(h4*)(Es + row * 512 + chunk * 16 + (kb & 1) * 8) = pk[4 * (p & 1) + t][ni];
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;   // 32 chunks of 8 halves per 256-wide row
+                h8 o = *(const h8*)(Es + row * 512 + ((cc ^ (row & 15)) * 16));
+                if (EPI == EPI_BIAS_RESIDUAL) {
+                    const h8 r = rres[p * 4 + i];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+                }
+                *(h8*)(C + (m0 + p * 64 + row) * N + n0 + cc * 8) = o;
+            }
+            __syncthreads();
+        }
+        if (!has_next) break;
+        orig += gridDim.x;
+        mt_c = mt_n;
+        nt_c = nt_n;
+        has_next = orig + (int)gridDim.x < ntiles;
+        if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
+    }
+#undef VFQ_READ_A
+#undef VFQ_READ_B
+#undef VFQ_QUAD
+#undef VFQ_PHASE_HEAD
+#undef VFQ_PHASE_MID
+#undef VFQ_PHASE_TAIL
+#undef VFQ_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused attention.  grid (ceil(T/128), heads, B), 256 threads; wave w handles queries
 // [qb*128 + 32w, +32) of sequence b, head hd; K [T][64] and V^T [64][T] of that (b, head) live in LDS.
 // S^T = K Q^T is computed with the KEY on the MFMA row, so a lane holds 16 key scores of ONE query
@@ -2422,6 +2673,9 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2688,6 +2942,14 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // 128 x 256 DMA kernel at M = 51200: 225 / 79 / 265 / 246 us vs 278 / 79 / 296 / 295 us (QKV / out / FFN-up / FFN-down
     // shapes of a 768-wide encoder; the vendor library: 210 / 66 / 234 / 217)
     static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
+    // ... and of the two 8-phase forms the PERSISTENT one (k_gemm8q_tn) is the default: 209 / 71 / 247 / 237 us on the same four
+    // shapes (bias epilogue), 1.02 - 1.11 x the vendor library; GELU / residual epilogues 331 / 79 + 247 vs 366 / 86 + 254 us
+    // (profiles/r02b_gemm_persistent.log).  VF_GEMM_KIND=7 selects the one-tile-per-workgroup form.
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 8 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+        const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
+        hipLaunchKernelGGL(k_gemm8q_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), QLDS, st, A, W, bias, R, C, M, N, K);
+        return hipGetLastError();
+    }
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
@@ -3217,8 +3479,8 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     if (M % 128 || N % 128 || K % 64) return -2;
     if ((kind == 1 || kind == 5) && (M % DBM || N % DBN)) return -2;
     if (kind == 6 && (M % DBM || N % 128)) return -2;
-    if ((kind == 2 || kind == 7) && (M % LBM || N % LBN)) return -2;
-    if (kind == 7 && K < 128) return -2;
+    if ((kind == 2 || kind == 7 || kind == 8) && (M % LBM || N % LBN)) return -2;
+    if ((kind == 7 || kind == 8) && K < 128) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;
