@@ -2942,10 +2942,14 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // 128 x 256 DMA kernel at M = 51200: 225 / 79 / 265 / 246 us vs 278 / 79 / 296 / 295 us (QKV / out / FFN-up / FFN-down
     // shapes of a 768-wide encoder; the vendor library: 210 / 66 / 234 / 217)
     static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
-    // ... and of the two 8-phase forms the PERSISTENT one (k_gemm8q_tn) is the default: 209 / 71 / 247 / 237 us on the same four
-    // shapes (bias epilogue), 1.02 - 1.11 x the vendor library; GELU / residual epilogues 331 / 79 + 247 vs 366 / 86 + 254 us
-    // (profiles/r02b_gemm_persistent.log).  VF_GEMM_KIND=7 selects the one-tile-per-workgroup form.
-    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 8 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+    // The PERSISTENT 8-phase form (k_gemm8q_tn, VF_GEMM_KIND=8) is an experiment, not the default.  Back to back on the same
+    // operands it wins everywhere (209 / 71 / 247 / 237 us on the four shapes, 1.02 - 1.11 x the vendor library; GELU / residual
+    // epilogues 331 / 79 + 247 vs 366 / 86 + 254 us: profiles/r02b_gemm_persistent.log), but INSIDE the forward, where the
+    // operands were written by the previous kernel and the first loads of a tile hit L2, the one-tile-per-workgroup form
+    // already runs at 328 / 161 / 187 us per layer and the persistent one at 328 / 162 / 184 (XLM-R-large shape: 498 / 258 / 289
+    // vs 508 / 270 / 291): what it hides -- load latency at the tile seams -- is not what the forward waits for, and its
+    // static tile schedule gives up the dispatcher's balancing.  The epilogue still runs on the waves that own the MFMAs.
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && kind == 8) {
         const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
         hipLaunchKernelGGL(k_gemm8q_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), QLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
