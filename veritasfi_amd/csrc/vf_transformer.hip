@@ -885,6 +885,13 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t*
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    // the epilogue's residual (thread -> row tid >> 2, columns 4 (tid & 3) .. + 3) is fetched before the weight stream starts:
+    // loaded after the reduction it costs one more dependent memory round trip per product (10.7 vs 7.5 us measured)
+    h4 rpre = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    if (EPI == EPI_BIAS_RESIDUAL) {
+        const int row = tid >> 2, c0 = (tid & 3) * 4;
+        if (row < M && row < MT * 16) rpre = *(const h4*)(R + (long long)row * N + n0 + c0);
+    }
     for (int s0 = 0; s0 < per; s0 += kSkinnyBatch) {
         h8 bf[kSkinnyBatch], af[kSkinnyBatch][MT];
 #pragma unroll
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t*
             for (int w = 0; w < kSkinnyWaves; ++w) v += red[w][row][c0 + e];
             v += bias ? bias[n0 + c0 + e] : 0.f;
             if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-            if (EPI == EPI_BIAS_RESIDUAL) v += (float)R[(long long)row * N + n0 + c0 + e];
+            if (EPI == EPI_BIAS_RESIDUAL) v += (float)rpre[e];
             o[e] = (half_t)v;
         }
         *(h4*)(C + (long long)row * N + n0 + c0) = o;
