@@ -869,17 +869,26 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
 // ------------------------------------------------------------------------------------------------
 constexpr int kSkinnyWaves = 8, kSkinnyBatch = 6;
 
+// S > 1 (long K, few column tiles: the N = hidden products with K = ffn): S workgroups share a column tile, each taking
+// K / S; their fp32 partial tiles meet in `part` ([S][64][N], agent-scope stores and loads: the XCDs' L2s are not coherent
+// with each other) and the last to arrive (counters[tile]) sums them in split order and runs the epilogue -- the protocol
+// of k_gemm_splitk.  With 48 workgroups each streaming all of A (M x 3072) the product took 15-26 us; with 192 it is one
+// memory round trip per wave.
 template <int EPI, int MT>
 __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                                    const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                                   half_t* __restrict__ C, int M, int N, int K) {
+                                                                   half_t* __restrict__ C, int M, int N, int K, int S,
+                                                                   float* __restrict__ part, unsigned* __restrict__ counters) {
     __shared__ float red[kSkinnyWaves][MT * 16][17];
+    __shared__ unsigned s_old;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r15 = lane & 15, kb = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int steps = K >> 5, per = steps / kSkinnyWaves;   // k-steps of 32; per wave (K % 256 == 0)
-    const half_t* wp = W + (long long)(n0 + r15) * K + kb * 8 + (long long)wid * per * 32;
-    const half_t* ap = A + (long long)r15 * K + kb * 8 + (long long)wid * per * 32;
+    const int tile = blockIdx.x / S, sp = blockIdx.x - tile * S;
+    const int n0 = tile * 16;
+    const int Ks = K / S;                                     // this workgroup's K range: [sp Ks, (sp + 1) Ks)
+    const int steps = Ks >> 5, per = steps / kSkinnyWaves;   // k-steps of 32; per wave (Ks % 256 == 0)
+    const half_t* wp = W + (long long)(n0 + r15) * K + kb * 8 + (long long)sp * Ks + (long long)wid * per * 32;
+    const half_t* ap = A + (long long)r15 * K + kb * 8 + (long long)sp * Ks + (long long)wid * per * 32;
     f4v acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -916,13 +925,41 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t*
     __syncthreads();
     // thread -> row tid >> 2, columns 4 (tid & 3) .. + 3   (the first 4 * 16 MT threads have a row)
     const int row = tid >> 2, c0 = (tid & 3) * 4;
-    if (row < M && row < MT * 16) {
+    const bool has_row = row < M && row < MT * 16;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has_row) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int w = 0; w < kSkinnyWaves; ++w) sum[e] += red[w][row][c0 + e];
+    }
+    if (S > 1) {
+        if (has_row) {
+            float* slab = part + ((long long)sp * 64 + row) * N + n0 + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) __hip_atomic_store(slab + e, sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slab has reached memory before the arrival is counted
+        __syncthreads();
+        if (tid == 0) s_old = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_old != (unsigned)(S - 1)) return;             // not the last split of this column tile
+        if (has_row) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] = 0.f;
+            for (int s2 = 0; s2 < S; ++s2) {                // split order: deterministic
+                const float* src = part + ((long long)s2 * 64 + row) * N + n0 + c0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    if (has_row) {
         h4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < kSkinnyWaves; ++w) v += red[w][row][c0 + e];
+            float v = sum[e];
             v += bias ? bias[n0 + c0 + e] : 0.f;
             if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
             if (EPI == EPI_BIAS_RESIDUAL) v += (float)rpre[e];
@@ -2999,13 +3036,19 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
 
 template <int EPI>
 static hipError_t gemm_skinny(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int Mvalid, int N,
-                              int K, hipStream_t st) {
-    const dim3 grid(N / 16), block(kSkinnyWaves * 64);
+                              int K, hipStream_t st, float* part = nullptr, unsigned* counters = nullptr) {
+    // K split over workgroups when K is long and the column tiles alone leave most of the chip idle (see the kernel)
+    static const bool no_split = getenv("VF_NO_SKINNY_SPLIT") != nullptr;
+    int S = 1;
+    if (part && counters && !no_split && K >= 2048 && N / 16 <= 64 && N / 16 <= 4096)
+        for (int c = 2; c <= kSplitMax; ++c)
+            if (K % (c * 256) == 0 && (N / 16) * c <= 256) S = c;
+    const dim3 grid((N / 16) * S), block(kSkinnyWaves * 64);
     switch ((Mvalid + 15) >> 4) {   // 16-row tiles that hold real rows
-    case 1: hipLaunchKernelGGL((k_gemm_skinny<EPI, 1>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
-    case 2: hipLaunchKernelGGL((k_gemm_skinny<EPI, 2>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
-    case 3: hipLaunchKernelGGL((k_gemm_skinny<EPI, 3>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
-    default: hipLaunchKernelGGL((k_gemm_skinny<EPI, 4>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K); break;
+    case 1: hipLaunchKernelGGL((k_gemm_skinny<EPI, 1>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K, S, part, counters); break;
+    case 2: hipLaunchKernelGGL((k_gemm_skinny<EPI, 2>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K, S, part, counters); break;
+    case 3: hipLaunchKernelGGL((k_gemm_skinny<EPI, 3>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K, S, part, counters); break;
+    default: hipLaunchKernelGGL((k_gemm_skinny<EPI, 4>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K, S, part, counters); break;
     }
     return hipGetLastError();
 }
@@ -3058,7 +3101,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, M, F, H, st));
         else VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
         if (skinny) {
-            VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, M, H, F, st));
+            VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, M, H, F, st, e->sk_part, e->sk_cnt));
         } else if (small && F >= 2048) {
             // a single short sequence: the long-K product (K = ffn) is split over K across the chip (1.17 -> 1.00 ms per
             // forward); the K = hidden products are not (the split's extra dependent memory round trips cost more than
