@@ -720,3 +720,57 @@ def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, 
     torch.cuda.synchronize()
     allv = mask.bool()
     assert float((c2.float()[allv] - c3.float()[allv]).abs().max()) <= 1.5e-3 * vmax
+
+
+@pytest.mark.parametrize("b,tmax,heads,seed", [
+    (40, 512, 4, 1),      # 160 pairs, lengths 32..512: one to four chunks per pair, idle waves on short pairs
+    (90, 512, 4, 2),      # 360 pairs on 256 workgroups: hand-over between pairs of different chunk counts
+    (200, 256, 6, 3),     # two workgroups per CU, one or two chunks
+    (64, 96, 2, 4),
+])
+def test_attention_packed_variable_length(vf, b, tmax, heads, seed):
+    """k_attention2 on PACKED sequences (each sequence its own length, rounded up to 32 rows) against the fp32 softmax
+    of every sequence on its own."""
+    import ctypes
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_attention_packed.restype = ctypes.c_int
+    L.vf_debug_attention_packed.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, tmax + 1, size=b)
+    lens[0] = tmax                       # the longest sequence sizes the workgroup
+    lens[1] = 1
+    l32 = np.maximum(32, -(-lens // 32) * 32)
+    off = np.concatenate([[0], np.cumsum(l32)]).astype(np.int32)
+    rows, H = int(off[-1]), heads * 64
+    g = torch.Generator(device=dev).manual_seed(seed)
+    qkv = torch.randn(rows, 3 * H, device=dev, generator=g)
+    qkv[:, :H] *= 0.125 * 1.4426950408889634
+    qkv = qkv.half()
+    mask_np = np.zeros(rows, np.int32)
+    for i in range(b):
+        mask_np[off[i]:off[i] + lens[i]] = 1
+    mask = torch.from_numpy(mask_np).to(dev)
+    seq_off = torch.from_numpy(off).to(dev)
+    ctx = torch.full((rows, H), float("nan"), dtype=torch.float16, device=dev)
+    rc = L.vf_debug_attention_packed(qkv.data_ptr(), mask.data_ptr(), seq_off.data_ptr(), b, int(l32.max()), heads, ctx.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    worst = 0.0
+    x = qkv.float()
+    for i in list(range(min(b, 12))) + list(range(max(12, b - 12), b)):     # head and tail of the pair list
+        o0, n = int(off[i]), int(lens[i])
+        q = x[o0:o0 + n, :H].reshape(n, heads, 64).transpose(0, 1)
+        k = x[o0:o0 + n, H:2 * H].reshape(n, heads, 64).transpose(0, 1)
+        v = x[o0:o0 + n, 2 * H:].reshape(n, heads, 64).transpose(0, 1)
+        p = torch.softmax(q @ k.transpose(-1, -2) * 0.6931471805599453, dim=-1)
+        ref = (p @ v).transpose(0, 1).reshape(n, H)
+        got = ctx[o0:o0 + n].float()
+        assert bool(torch.isfinite(got).all())
+        worst = max(worst, float((got - ref).abs().max()))
+    vmax = float(x[:, 2 * H:].abs().max())
+    assert worst <= 7.5e-4 * vmax, (worst, vmax)

@@ -1842,10 +1842,14 @@ __device__ __forceinline__ void a2_store_group(const f16v (&o)[2], float inv, in
     }
 }
 
-// MODE 0: the kernel; 6: diagnostic build that also appends per-wave clock stamps after ctx (tools/attention_clock.py)
+// MODE 0: the kernel; 6: diagnostic build that also appends per-wave clock stamps after ctx (tools/attention_clock.py).
+// seq_off != nullptr: PACKED sequences -- sequence b occupies rows [seq_off[b], seq_off[b + 1]) of qkv / mask / ctx (its
+// length rounded up to 32; T is then the longest, which sizes LDS and the workgroup).  Pairs differ in length: a wave
+// whose queries lie past the pair's end sits the pair out but keeps every barrier, and the chunk hand-over below works
+// with the two pairs' own chunk counts.
 template <int MODE>
 __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int B, int T, int H,
-                                                    int ct, half_t* __restrict__ ctx) {
+                                                    int ct, const int* __restrict__ seq_off, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                  // [T] rows of 128 B, swizzled (a2_koff)
     char* Vs = smem + (size_t)T * 128;                // [T] rows of 128 B, swizzled (a2_voff)
@@ -1856,22 +1860,32 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     const int r31 = lane & 31, h = lane >> 5;
     const int heads = H / ADH, npairs = B * heads, ld = 3 * H;
     const int cts = ct == 16 ? 4 : ct == 8 ? 3 : 2;                  // ct: tiles per chunk (4, 8 or 16) = 1 << cts
-    const int ntiles = T >> 5, nchunks = (ntiles + ct - 1) >> cts;
     const unsigned cmask = ct >= 32 ? 0xffffffffu : ((1u << ct) - 1u);
-    const unsigned all_tiles = ntiles >= 32 ? 0xffffffffu : ((1u << ntiles) - 1u);
     const unsigned MASK_ON = 0x00003c00u, MASK_OFF = 0xf7533c00u;   // {1.0h, 0h} / {1.0h, -30000h}
+    constexpr int ALL_PUBLISHED = 1 << 20;
     int pair = blockIdx.x;
     if (pair >= npairs) return;
     unsigned long long tk_start = 0, rt_start = 0;
     if (MODE == 6) { tk_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
 
+    // first row and length of pair p's sequence
+    auto seq_of = [&](int p, long long& row0, int& Tb) {
+        const int b = p / heads;
+        if (seq_off) {
+            const int o0 = seq_off[b], o1 = seq_off[b + 1];
+            row0 = o0;
+            Tb = o1 - o0;
+        } else {
+            row0 = (long long)b * T;
+            Tb = T;
+        }
+    };
     // 16-byte chunk c of an image <- key c >> 3, source chunk (c & 7) ^ swizzle(key); a wave-instruction fills 1 KiB (8 keys)
-    auto stage_chunk = [&](int p, int g) {
-        const long long prow = (long long)(p / heads) * T;
-        const half_t* Kg = qkv + prow * ld + H + (p % heads) * ADH;
+    auto stage_chunk = [&](long long prow, int Tb, int hd, int g) {
+        const half_t* Kg = qkv + prow * ld + H + hd * ADH;
         const half_t* Vg = Kg + H;
         const int cper = ct * 256;   // 16-byte pieces per chunk and image
-        const int cend = (g + 1) * cper < T * 8 ? (g + 1) * cper : T * 8;
+        const int cend = (g + 1) * cper < Tb * 8 ? (g + 1) * cper : Tb * 8;
         for (int c0 = g * cper + wid * 64; c0 < cend; c0 += nthreads) {
             const int c = c0 + lane, key = c >> 3, chp = c & 7;
             const half_t* ks = Kg + (long long)key * ld + ((chp ^ ((key >> 1) & 7)) << 3);
@@ -1881,20 +1895,19 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         }
     };
     // tile classes (bit j = 32-key tile j has a valid key); a sequence without any valid key keeps every tile
-    auto classify = [&](const unsigned* mh) {
+    auto classify = [&](const unsigned* mh, int ntl) {
         unsigned act = 0;
-        for (int j = 0; j < ntiles; ++j) act |= (__ballot((mh[j * 32 + r31] >> 16) == 0u) != 0ull ? 1u : 0u) << j;
-        return act ? act : all_tiles;
+        for (int j = 0; j < ntl; ++j) act |= (__ballot((mh[j * 32 + r31] >> 16) == 0u) != 0ull ? 1u : 0u) << j;
+        return act ? act : (ntl >= 32 ? 0xffffffffu : ((1u << ntl) - 1u));
     };
-    // Q fragments (B operand) of both query blocks: lane (query r31, half h) holds q[8h + j + 16 ks].  A block past the
-    // end of the sequence re-reads the last query (computed, never stored).
+    // Q fragments (B operand) of both query blocks: lane (query r31, half h) holds q[8h + j + 16 ks].  A query past the
+    // end of the sequence re-reads its last one (computed, never stored).
     const int qa0 = wid * 64, qb0 = qa0 + 32;
-    const bool b_valid = qb0 < T;
     h8 qa[4], qb[4];
-    auto load_q = [&](int p) {
-        const long long prow = (long long)(p / heads) * T;
-        const half_t* Qa = qkv + (prow + qa0 + r31) * ld + (p % heads) * ADH + h * 8;
-        const half_t* Qb = qkv + (prow + (b_valid ? qb0 + r31 : T - 1)) * ld + (p % heads) * ADH + h * 8;
+    auto load_q = [&](long long prow, int Tb, int hd) {
+        const int ra = qa0 + r31 < Tb ? qa0 + r31 : Tb - 1, rb = qb0 + r31 < Tb ? qb0 + r31 : Tb - 1;
+        const half_t* Qa = qkv + (prow + ra) * ld + hd * ADH + h * 8;
+        const half_t* Qb = qkv + (prow + rb) * ld + hd * ADH + h * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qa[ks] = *(const h8*)(Qa + ks * 16);
@@ -1902,18 +1915,22 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         }
     };
 
+    long long row0, row0n = 0;
+    int Tb, Tbn = 0;
+    seq_of(pair, row0, Tb);
     // ---- first pair: its first chunk (and the mask of the second pair), waited for; the other chunks are issued right
     //      behind the barrier and land under the first chunk's tiles (published by the first boundary, or on demand)
-    stage_chunk(pair, 0);
-    if (tid < T) {
-        mbuf[tid] = mask[(long long)(pair / heads) * T + tid] ? MASK_ON : MASK_OFF;
-        if (pair + (int)gridDim.x < npairs) mbuf[T + tid] = mask[(long long)((pair + gridDim.x) / heads) * T + tid] ? MASK_ON : MASK_OFF;
+    stage_chunk(row0, Tb, pair % heads, 0);
+    if (tid < Tb) mbuf[tid] = mask[row0 + tid] ? MASK_ON : MASK_OFF;
+    if (pair + (int)gridDim.x < npairs) {
+        seq_of(pair + gridDim.x, row0n, Tbn);
+        if (tid < Tbn) mbuf[T + tid] = mask[row0n + tid] ? MASK_ON : MASK_OFF;
     }
-    load_q(pair);
+    load_q(row0, Tb, pair % heads);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
-    for (int g = 1; g < nchunks; ++g) stage_chunk(pair, g);
-    unsigned act = classify(mbuf);
+    for (int g = 1; g < (((Tb >> 5) + ct - 1) >> cts); ++g) stage_chunk(row0, Tb, pair % heads, g);
+    unsigned act = classify(mbuf, Tb >> 5);
     int pub_from = 1;                      // chunks >= pub_from are not yet known to have landed (no barrier published them)
     unsigned long long tk_loop = 0, tk_tail = 0, tk_bar = 0;
 
@@ -1925,6 +1942,10 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     for (int cur = 0;; cur ^= 1) {
         const int nxt_pair = pair + gridDim.x, nxt2_pair = nxt_pair + gridDim.x;
         const bool has_next = nxt_pair < npairs;
+        const int hd = pair % heads, hdn = nxt_pair % heads;
+        const int nchunks = ((Tb >> 5) + ct - 1) >> cts;            // of this pair
+        const int nchunks_n = has_next ? (((Tbn >> 5) + ct - 1) >> cts) : 0;
+        const bool wact = qa0 < Tb;                                 // this wave has queries in this pair
         const unsigned* mh = mbuf + cur * T;
         const unsigned* mhn = mbuf + (cur ^ 1) * T;
         unsigned act_n = 0;
@@ -1935,10 +1956,10 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         auto boundary = [&](int g) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             __syncthreads();
-            pub_from = nchunks;
+            pub_from = ALL_PUBLISHED;
             if (has_next) {
-                if (g == 0) act_n = classify(mhn);                  // the next pair's mask: written a pair ago
-                if ((act_n >> (ct * g)) & cmask) stage_chunk(nxt_pair, g);
+                if (g == 0) act_n = classify(mhn, Tbn >> 5);        // the next pair's mask: written a pair ago
+                if (g < nchunks_n && ((act_n >> (ct * g)) & cmask)) stage_chunk(row0n, Tbn, hdn, g);
             }
         };
         // reads may run ahead of the boundaries, but not into a chunk that no barrier has published yet
@@ -1946,7 +1967,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
             if ((tile >> cts) >= pub_from) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 __syncthreads();
-                pub_from = nchunks;
+                pub_from = ALL_PUBLISHED;
             }
         };
         unsigned long long t0 = 0;
@@ -1969,56 +1990,59 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         rest &= rest - 1;
         int tn = rest ? __builtin_ctz(rest) : -1;
         publish_for(t);
-        a2_read_k(kf, Ks, t, r31, h);
-        ba = a2_bias_a(mh, t, r31, h);
-        a2_read_v(vf, Vs, t, lane);
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mqa, zero, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mqb, zero, 0, 0, 0);
+        if (tn >= 0) publish_for(tn);
+        if (wact) {
+            a2_read_k(kf, Ks, t, r31, h);
+            ba = a2_bias_a(mh, t, r31, h);
+            a2_read_v(vf, Vs, t, lane);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mqa, zero, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ba, mqb, zero, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qa[ks], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qb[ks], sb, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qa[ks], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qb[ks], sb, 0, 0, 0);
+            }
+            if (tn >= 0) {
+                a2_read_k(kf, Ks, tn, r31, h);
+                ba = a2_bias_a(mh, tn, r31, h);
+            }
+            a2_move_ref(sa, oa, la, mra, mqa, true, h);
+            a2_move_ref(sb, ob, lb, mrb, mqb, true, h);
+            la += a2_probs(sa, pa);
         }
-        if (tn >= 0) {
-            publish_for(tn);
-            a2_read_k(kf, Ks, tn, r31, h);
-            ba = a2_bias_a(mh, tn, r31, h);
-        }
-        a2_move_ref(sa, oa, la, mra, mqa, true, h);
-        a2_move_ref(sb, ob, lb, mrb, mqb, true, h);
-        la += a2_probs(sa, pa);
         // ---- steady state: here pa(t), sb(t), vf(t) are ready, and kf / ba hold tile tn
         while (tn >= 0) {
             rest &= rest - 1;
             const int tn2 = rest ? __builtin_ctz(rest) : -1;
-            // phase A: P.V(a, t), QK(a, tn)  ||  probabilities(b, t)
-            float sum = a2_phase<true>(oa, pa, vf, sa, kf, qa, ba, mqa, sb, pb);
-            if (__ballot(!(sum < 1e30f)) != 0ull) {
-                a2_move_ref(sb, ob, lb, mrb, mqb, false, h);
-                sum = a2_probs(sb, pb);
-            }
-            lb += sum;
-            // phase B: P.V(b, t), QK(b, tn)  ||  probabilities(a, tn); then the fragment reads of the tiles ahead
-            publish_for(tn);
             if (tn2 >= 0) publish_for(tn2);
-            sum = a2_phase<true>(ob, pb, vf, sb, kf, qb, ba, mqb, sa, pa);
-            a2_read_v(vf, Vs, tn, lane);
-            if (tn2 >= 0) {
-                a2_read_k(kf, Ks, tn2, r31, h);
-                ba = a2_bias_a(mh, tn2, r31, h);
+            if (wact) {
+                // phase A: P.V(a, t), QK(a, tn)  ||  probabilities(b, t)
+                float sum = a2_phase<true>(oa, pa, vf, sa, kf, qa, ba, mqa, sb, pb);
+                if (__ballot(!(sum < 1e30f)) != 0ull) {
+                    a2_move_ref(sb, ob, lb, mrb, mqb, false, h);
+                    sum = a2_probs(sb, pb);
+                }
+                lb += sum;
+                // phase B: P.V(b, t), QK(b, tn)  ||  probabilities(a, tn); then the fragment reads of the tiles ahead
+                sum = a2_phase<true>(ob, pb, vf, sb, kf, qb, ba, mqb, sa, pa);
+                a2_read_v(vf, Vs, tn, lane);
+                if (tn2 >= 0) {
+                    a2_read_k(kf, Ks, tn2, r31, h);
+                    ba = a2_bias_a(mh, tn2, r31, h);
+                }
+                if (__ballot(!(sum < 1e30f)) != 0ull) {
+                    a2_move_ref(sa, oa, la, mra, mqa, false, h);
+                    sum = a2_probs(sa, pa);
+                }
+                la += sum;
             }
-            if (__ballot(!(sum < 1e30f)) != 0ull) {
-                a2_move_ref(sa, oa, la, mra, mqa, false, h);
-                sum = a2_probs(sa, pa);
-            }
-            la += sum;
             // chunk boundaries between tile t and tile tn
             while (g_nb < (tn >> cts)) boundary(g_nb++);
             t = tn;
             tn = tn2;
         }
         // ---- drain: P.V(a, t) || probabilities(b, t), then P.V(b, t)
-        {
+        if (wact) {
             float sum = a2_phase<false>(oa, pa, vf, sa, kf, qa, ba, mqa, sb, pb);
             if (__ballot(!(sum < 1e30f)) != 0ull) {
                 a2_move_ref(sb, ob, lb, mrb, mqb, false, h);
@@ -2033,18 +2057,22 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         while (g_nb < nchunks - 1) boundary(g_nb++);
         unsigned long long t1 = 0;
         if (MODE == 6) { t1 = __builtin_amdgcn_s_memtime(); tk_loop += t1 - t0; }
-        const int p_b = pair / heads, p_hd = pair % heads;
         int rmask = 1;
+        long long row0n2 = 0;
+        int Tbn2 = 0;
         if (has_next) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             __syncthreads();                                        // the pair is done in every wave
             if (MODE == 6) tk_bar += __builtin_amdgcn_s_memtime() - t1;
-            if (nchunks == 1) act_n = classify(mhn);
-            load_q(nxt_pair);                                       // quiet window: nothing else in flight
-            if (nxt2_pair < npairs && tid < T) rmask = mask[(long long)(nxt2_pair / heads) * T + tid];
+            if (nchunks == 1) act_n = classify(mhn, Tbn >> 5);
+            load_q(row0n, Tbn, hdn);                                // quiet window: nothing else in flight
+            if (nxt2_pair < npairs) {
+                seq_of(nxt2_pair, row0n2, Tbn2);
+                if (tid < Tbn2) rmask = mask[row0n2 + tid];
+            }
         }
         // ---- O: normalise (the halves' partial row sums combine here), stage 16 queries at a time, store whole rows
-        {
+        if (wact) {
             float inva, invb;
             {
                 float lo, hi;
@@ -2053,8 +2081,8 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
                 halves(lb, lo, hi);
                 invb = 1.0f / (lo + hi);
             }
-            half_t* dst = ctx + ((long long)p_b * T + qa0) * H + p_hd * ADH;
-            const int nrows = T - qa0;   // >= 32
+            half_t* dst = ctx + (row0 + qa0) * H + hd * ADH;
+            const int nrows = Tb - qa0;   // >= 32
             a2_store_group(oa, inva, 0, Os, dst, H, nrows, lane);
             a2_store_group(oa, inva, 1, Os, dst + 16LL * H, H, nrows - 16, lane);
             a2_store_group(ob, invb, 0, Os, dst + 32LL * H, H, nrows - 32, lane);
@@ -2078,16 +2106,22 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         asm volatile("" : "+v"(rmask));       // (keeps the mask's compare-and-select below the wait)
         if (!has_next) break;
-        if (nxt2_pair < npairs && tid < T) mbuf[cur * T + tid] = rmask ? MASK_ON : MASK_OFF;   // read (as mhn) after a barrier of the next pair
-        if ((act_n >> (ct * (nchunks - 1))) & cmask) stage_chunk(nxt_pair, nchunks - 1);
+        if (nxt2_pair < npairs && tid < Tbn2) mbuf[cur * T + tid] = rmask ? MASK_ON : MASK_OFF;   // read (as mhn) after a barrier of the next pair
+        // the pair's last chunk, and the chunks only the next pair has, refill now
+        for (int g = nchunks - 1; g < nchunks_n; ++g)
+            if ((act_n >> (ct * g)) & cmask) stage_chunk(row0n, Tbn, hdn, g);
         pub_from = nchunks - 1;
         if (nchunks == 1) {   // a single chunk: the refill must land before the next pair starts
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
-            pub_from = nchunks;
+            pub_from = ALL_PUBLISHED;
         }
         pair = nxt_pair;
         act = act_n;
+        row0 = row0n;
+        Tb = Tbn;
+        row0n = row0n2;
+        Tbn = Tbn2;
     }
 }
 
@@ -2738,7 +2772,8 @@ static hipError_t configure_once() {
 // k_attention2 launcher: persistent workgroups, as many as stay co-resident (LDS: K, V, two masks, O staging; registers:
 // two waves per SIMD), each walking (sequence, head) pairs blockIdx.x, + gridDim.x, ...
 template <int MODE>
-static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, int heads, half_t* ctx, hipStream_t st) {
+static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, int heads, half_t* ctx, hipStream_t st,
+                              const int* seq_off = nullptr) {
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -2753,7 +2788,7 @@ static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, 
     const int npairs = B * heads;
     const int grid = npairs < n_cu * per_cu ? npairs : n_cu * per_cu;
     static const int ct = [] { const char* e = getenv("VF_ATT_CHUNK"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 16) ? v : 4; }();
-    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, ctx);
+    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, seq_off, ctx);
 }
 
 constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
@@ -3571,5 +3606,16 @@ extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T
     } else {
         return -2;
     }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Test hook: k_attention2 over PACKED sequences -- sequence b in rows [seq_off[b], seq_off[b + 1]) (lengths multiples of 32,
+// at most Tmax <= 512) of qkv [rows][3*64*heads] / mask [rows] / ctx [rows][64*heads]; seq_off is a device array of B + 1 ints.
+extern "C" int vf_debug_attention_packed(const void* qkv, const int* mask, const int* seq_off, int B, int Tmax, int heads, void* ctx,
+                                         void* stream) {
+    hipError_t er = configure_once();
+    if (er != hipSuccess) return -1;
+    if (B <= 0 || heads <= 0 || Tmax <= 0 || Tmax % 32 || Tmax > kEncResidentT || !seq_off) return -2;
+    launch_attention2<0>((const half_t*)qkv, mask, B, Tmax, heads, (half_t*)ctx, (hipStream_t)stream, seq_off);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
