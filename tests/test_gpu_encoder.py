@@ -774,3 +774,52 @@ def test_attention_packed_variable_length(vf, b, tmax, heads, seed):
         worst = max(worst, float((got - ref).abs().max()))
     vmax = float(x[:, 2 * H:].abs().max())
     assert worst <= 7.5e-4 * vmax, (worst, vmax)
+
+
+@pytest.mark.parametrize("kind", ["bert-embedder", "xlmr-reranker"])
+def test_ragged_batch_takes_the_packed_forward_and_matches_torch(vf, kind):
+    """A right-padded ragged batch (24 sequences, 9..256 tokens) runs PACKED (every sequence keeps ceil32(length) rows:
+    vf_debug_packed_forwards counts it) and still matches HF fp32 -- BERT positions (embedder, CLS + L2) and RoBERTa
+    positions (re-ranker logits); a batch that is not ragged enough, and one that is left-padded, take the padded path."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_packed_forwards.restype = ctypes.c_longlong
+    rng = np.random.default_rng(21)
+    b, t = 24, 256
+    lens = rng.integers(9, t + 1, size=b)
+    lens[0], lens[1] = t, 9
+    if kind == "bert-embedder":
+        m = _hf_bert(256, 3, 4, 512)
+        pad_id, lo = 0, 5
+    else:
+        m = _hf_xlmr_cls(256, 3, 4, 512)
+        pad_id, lo = 1, 5
+    ids = rng.integers(lo, 900, size=(b, t)).astype(np.int64)
+    mask = (np.arange(t)[None, :] < lens[:, None]).astype(np.int64)
+    ids[mask == 0] = pad_id
+    with torch.no_grad():
+        if kind == "bert-embedder":
+            ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state[:, 0]
+            ref = torch.nn.functional.normalize(ref, dim=-1).numpy()
+        else:
+            ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits[:, 0].numpy()
+    enc = vf.HipEncoder.from_hf(m)
+    try:
+        n0 = L.vf_debug_packed_forwards()
+        got = enc.forward(ids.astype(np.int32), mask.astype(np.int32))
+        assert L.vf_debug_packed_forwards() == n0 + 1, "the ragged batch did not take the packed path"
+        tol = 8e-4 if kind == "bert-embedder" else 2.5e-3
+        assert float(np.abs(got - ref).max()) < tol, float(np.abs(got - ref).max())
+        # nearly full batch: padded path
+        full = np.ones_like(mask)
+        enc.forward(ids.astype(np.int32), full.astype(np.int32))
+        assert L.vf_debug_packed_forwards() == n0 + 1
+        # left-padded batch: padded path, same answer as HF
+        lmask = mask[:, ::-1].copy()
+        lids = np.where(lmask == 1, rng.integers(lo, 900, size=(b, t)), pad_id)
+        got_l = enc.forward(lids.astype(np.int32), lmask.astype(np.int32))
+        assert L.vf_debug_packed_forwards() == n0 + 1 and np.isfinite(got_l).all()
+    finally:
+        enc.close()

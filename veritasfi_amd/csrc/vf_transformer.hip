@@ -35,6 +35,7 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <atomic>
 #include <vector>
 
 namespace vft {
@@ -2338,12 +2339,14 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pool(const half_t* x, const int* mask, int T, int Tv, int H, int pooling,
                                                int normalize, int all_last_set, int head, const half_t* Wd,
-                                               const float* bd, const half_t* Wp, const float* bp, float* out) {
+                                               const float* bd, const half_t* Wp, const float* bp, float* out,
+                                               const int* seq_off = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* v = (float*)smem;        // [H]
     float* red = v + H;             // [256]
     const int b = blockIdx.x, tid = threadIdx.x;
-    const half_t* xb = x + (long long)b * T * H;
+    // packed sequences (CLS pooling only): sequence b starts at row seq_off[b]
+    const half_t* xb = x + (seq_off ? (long long)seq_off[b] : (long long)b * T) * H;
     int tok = 0;
     if (pooling == 2) {
         if (all_last_set) tok = Tv - 1;
@@ -2809,6 +2812,8 @@ struct vf_encoder {
     int cap_tokens = 0, cap_b = 0;
     half_t *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *hbuf = nullptr;
     int *d_ids = nullptr, *d_mask = nullptr, *d_tt = nullptr, *d_pos = nullptr, *d_flag = nullptr;
+    int* d_seq = nullptr;            // [cap_b + 1] row offsets of the packed (ragged-batch) forward
+    std::vector<int32_t> pk;         // host staging of the packed ids / mask / position ids / type ids / offsets
     float* d_out = nullptr;
     float* d_hidden = nullptr;  // [cap_tokens, H] fp32, for vf_encoder_forward_hidden
     // split-K GEMM (forwards of <= kSplitMaxRows tokens): fp32 slabs [kSplitMax][kSplitMaxRows][max(3H, F)] + tile counters
@@ -2851,10 +2856,10 @@ static void enc_drop_graphs(vf_encoder* e) {
 
 static void enc_free_ws(vf_encoder* e) {
     enc_drop_graphs(e);   // captured launches hold the workspace pointers
-    void* p[] = {e->x, e->y, e->qkv, e->ctx, e->hbuf, e->d_ids, e->d_mask, e->d_tt, e->d_pos, e->d_out, e->d_hidden};
+    void* p[] = {e->x, e->y, e->qkv, e->ctx, e->hbuf, e->d_ids, e->d_mask, e->d_tt, e->d_pos, e->d_out, e->d_hidden, e->d_seq};
     for (void* q : p) if (q) (void)hipFree(q);
     e->x = e->y = e->qkv = e->ctx = e->hbuf = nullptr;
-    e->d_ids = e->d_mask = e->d_tt = e->d_pos = nullptr;
+    e->d_ids = e->d_mask = e->d_tt = e->d_pos = e->d_seq = nullptr;
     e->d_out = nullptr; e->d_hidden = nullptr;
     e->cap_tokens = 0; e->cap_b = 0;
 }
@@ -2951,6 +2956,7 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
     VFT_HIP(hipMalloc((void**)&e->d_mask, Mp * 4));
     VFT_HIP(hipMalloc((void**)&e->d_tt, Mp * 4));
     VFT_HIP(hipMalloc((void**)&e->d_pos, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&e->d_seq, ((size_t)B + 1) * 4));
     VFT_HIP(hipMalloc((void**)&e->d_out, (size_t)B * out_dim * 4));
     VFT_HIP(hipMalloc((void**)&e->d_hidden, Mp * H * 4));
     // padded rows are read by the GEMMs: keep them finite
@@ -3089,15 +3095,18 @@ static hipError_t gemm_skinny(const half_t* A, const half_t* W, const float* bia
 }
 
 // ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
-static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, hipStream_t st) {
+// seq_off != nullptr: PACKED rows (forward_impl's ragged-batch path) -- Mpk rows in all, sequence b in rows
+// [seq_off[b], seq_off[b + 1]), T = the longest; ids / mask / position ids are already packed on the device.
+static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, hipStream_t st, const int* seq_off = nullptr,
+                              int Mpk = 0) {
     const vf_encoder_config& c = e->cfg;
-    const int H = c.hidden, F = c.ffn, M = B * T, Mp = (M + 255) / 256 * 256;
+    const int H = c.hidden, F = c.ffn, M = seq_off ? Mpk : B * T, Mp = (M + 255) / 256 * 256;
     const int Ms = (M + 63) / 64 * 64;
     static const bool no_splitk = getenv("VF_NO_SPLITK") != nullptr;  // A/B switch
     const bool small = !no_splitk && Ms <= kSplitMaxRows && H % 64 == 0 && F % 64 == 0;
     static const bool no_skinny = getenv("VF_NO_SKINNY") != nullptr;  // A/B switch
     const bool skinny = !no_skinny && M <= 64 && H % 256 == 0 && F % 256 == 0;   // one short sequence: weight-streaming GEMMs
-    hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
+    if (!seq_off) hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
                        c.ln_eps, M, H, e->x);
@@ -3125,7 +3134,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
                                sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
                                e->q_folded ? -1.f : 0.125f, e->ctx, H);
         } else if (e->q_folded) {
-            launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st);
+            launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         } else {
             hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
                                0.125f, 1.4426950408889634f, e->ctx);
@@ -3156,10 +3165,14 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     const size_t pool_lds = ((size_t)H * 2 + 256) * sizeof(float);
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), pool_lds, st, e->x, e->d_mask, T, Tv, H, c.pooling, c.normalize, all_last,
                        c.head, e->w16 + e->o_head_dense, e->w32 + e->f_head_bd, e->w16 + e->o_head_out,
-                       e->w32 + e->f_head_bp, e->d_out);
+                       e->w32 + e->f_head_bp, e->d_out, seq_off);
     VFT_HIP(hipGetLastError());
     return VF_OK;
 }
+
+static std::atomic<long long> g_packed_forwards{0};
+// Test hook: how many forwards took the packed (ragged-batch) path in this process.
+extern "C" long long vf_debug_packed_forwards() { return g_packed_forwards.load(std::memory_order_relaxed); }
 
 static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids, int32_t b,
                         int32_t t, int32_t t_valid, int32_t pooling, int32_t normalize, float* out) {
@@ -3211,6 +3224,57 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
         VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, gs));
         VFT_HIP(hipStreamSynchronize(gs));
         return VF_OK;
+    }
+    // Ragged batch (right-padded, CLS pooling or a classification head, resident attention): the rows are PACKED -- every
+    // sequence keeps ceil32(length) rows -- so the GEMMs, LayerNorms and attention only see the tokens that exist.  A row's
+    // output does not depend on its neighbours or its padding (masked keys weigh exactly 0), so this is the same forward
+    // on fewer rows; FlagEmbedding sorts by length for the same reason (the reference's compute_score / encode).
+    static const bool no_pack = getenv("VF_NO_PACKED") != nullptr;   // A/B switch
+    if (!no_pack && e->q_folded && t <= kEncResidentT && b >= 8 && (e->cfg.head == 1 || e->cfg.pooling == 0)) {
+        std::vector<int32_t>& pk = e->pk;
+        pk.resize((size_t)b + 1);
+        long long rows = 0;
+        int tmax = 0;
+        bool ok = true;
+        for (int i = 0; i < b && ok; ++i) {
+            const int32_t* m = mask + (size_t)i * t;
+            int len = 0;
+            while (len < t && m[len]) ++len;
+            for (int j = len; j < t; ++j) if (m[j]) { ok = false; break; }   // not right-padded
+            if (len == 0) ok = false;                                         // a sequence without tokens: the padded path
+            const int l32 = (len + 31) / 32 * 32;
+            pk[i] = (int32_t)rows;
+            rows += l32;
+            tmax = l32 > tmax ? l32 : tmax;
+        }
+        pk[b] = (int32_t)rows;
+        if (ok && rows * 100 <= (long long)n * 85) {   // at least 15 % fewer rows
+            const size_t R = (size_t)rows;
+            pk.resize((size_t)b + 1 + 4 * R);
+            int32_t *off = pk.data(), *pid = off + b + 1, *pmk = pid + R, *ppos = pmk + R, *ptt = ppos + R;
+            const int rp = e->cfg.roberta_pad_idx;
+            for (int i = 0; i < b; ++i) {
+                const int r0 = off[i], l32 = off[i + 1] - off[i];
+                const int32_t *si = ids + (size_t)i * t, *sm = mask + (size_t)i * t;
+                for (int j = 0; j < l32; ++j) {
+                    pid[r0 + j] = si[j];
+                    pmk[r0 + j] = sm[j] != 0;
+                    ppos[r0 + j] = rp >= 0 ? (sm[j] ? j + 1 + rp : rp) : j;      // k_position_ids on a right-padded row
+                    if (type_ids) ptt[r0 + j] = type_ids[(size_t)i * t + j];
+                }
+            }
+            VFT_HIP(hipMemcpyAsync(e->d_seq, off, ((size_t)b + 1) * 4, hipMemcpyHostToDevice, nullptr));
+            VFT_HIP(hipMemcpyAsync(e->d_ids, pid, R * 4, hipMemcpyHostToDevice, nullptr));
+            VFT_HIP(hipMemcpyAsync(e->d_mask, pmk, R * 4, hipMemcpyHostToDevice, nullptr));
+            VFT_HIP(hipMemcpyAsync(e->d_pos, ppos, R * 4, hipMemcpyHostToDevice, nullptr));
+            if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, ptt, R * 4, hipMemcpyHostToDevice, nullptr));
+            rc = enc_forward_device(e, b, tmax, tmax, type_ids != nullptr, nullptr, e->d_seq, (int)rows);
+            if (rc != VF_OK) return rc;
+            g_packed_forwards.fetch_add(1, std::memory_order_relaxed);
+            VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
+            VFT_HIP(hipStreamSynchronize(nullptr));
+            return VF_OK;
+        }
     }
     VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, nullptr));
     VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, nullptr));
