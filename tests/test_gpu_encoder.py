@@ -823,3 +823,48 @@ def test_ragged_batch_takes_the_packed_forward_and_matches_torch(vf, kind):
         assert L.vf_debug_packed_forwards() == n0 + 1 and np.isfinite(got_l).all()
     finally:
         enc.close()
+
+
+@pytest.mark.parametrize("name,hidden,layers,heads,kv_heads,head_dim,ffn,b,t,left_pad", [
+    ("qwen-dh64-right", 256, 2, 4, 2, 64, 512, 12, 160, False),
+    ("qwen-dh128-left", 256, 2, 4, 1, 128, 512, 10, 224, True),
+])
+def test_decoder_ragged_batch_takes_the_packed_forward(vf, name, hidden, layers, heads, kv_heads, head_dim, ffn, b, t, left_pad):
+    """A ragged batch padded on one side runs PACKED through the decoder (rows = sum of ceil32(length), each token keeping
+    its original column as RoPE position) and gives last_token_pool's embeddings of HF fp32; the token-logit head likewise."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    from veritasfi_amd.retrieval import last_token_pool
+    L = _ffi.lib()
+    L.vf_debug_packed_forwards.restype = ctypes.c_longlong
+    model = _hf_qwen3(hidden, layers, heads, kv_heads, head_dim, ffn, causal_lm=True)
+    rng = np.random.default_rng(31)
+    ids = rng.integers(5, 800, size=(b, t)).astype(np.int64)
+    mask = np.ones((b, t), np.int64)
+    for i in range(1, b):                                  # row 0 stays full
+        n_pad = int(rng.integers(t // 4, t - 4))
+        if left_pad:
+            mask[i, :n_pad] = 0
+        else:
+            mask[i, t - n_pad:] = 0
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), output_hidden_states=True)
+        want = last_token_pool(out.hidden_states[-1], torch.from_numpy(mask)).numpy()
+        lengths = mask.sum(1)
+        last = (t - 1) * np.ones(b, np.int64) if left_pad else lengths - 1
+        want_logit = out.logits[torch.arange(b), torch.from_numpy(last), 7].numpy()
+    dec = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    n0 = L.vf_debug_packed_forwards()
+    got = dec.forward(ids, mask)
+    assert L.vf_debug_packed_forwards() == n0 + 1, "the ragged batch did not take the packed path"
+    dec.close()
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    assert cos.min() > 0.9995 and rel < 2e-2, (name, cos, rel)
+    scorer = vf.HipDecoder.from_hf(model, score_token=7)
+    n1 = L.vf_debug_packed_forwards()
+    got_logit = scorer.forward(ids, mask)
+    assert L.vf_debug_packed_forwards() == n1 + 1
+    scorer.close()
+    assert np.abs(got_logit - want_logit).max() < 2e-2 * max(1.0, np.abs(want_logit).max()), (got_logit, want_logit)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=512)
     ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--ragged", type=int, default=0, help="lengths uniform in [ragged, tokens], LEFT-padded (the LLM re-ranker's input form)")
     a = ap.parse_args()
     H, L, NH, KV, DH, F, V = SHAPES[a.shape]
     cfg = dict(vocab=V, hidden=H, layers=L, heads=NH, kv_heads=KV, head_dim=DH, ffn=F, rope_theta=1e6, rms_eps=1e-6,
@@ -40,6 +41,10 @@ def main():
     del w16
     ids = rng.integers(5, V, size=(a.batch, a.tokens)).astype(np.int32)
     mask = np.ones_like(ids)
+    if a.ragged:
+        lens = rng.integers(a.ragged, a.tokens + 1, size=a.batch)
+        lens[0] = a.tokens
+        mask = (np.arange(a.tokens)[None, :] >= (a.tokens - lens)[:, None]).astype(np.int32)
     dec.forward(ids, mask)
     ts = []
     for _ in range(a.iters):
@@ -48,7 +53,8 @@ def main():
     per_tok = 2 * (H * (QD + 2 * KD) + QD * H + 3 * H * F)
     flops = a.batch * L * (T * per_tok + 2 * T * T * QD)      # causal attention: half of 4 T^2 QD
     p50 = float(np.median(ts))
-    print(json.dumps({"shape": a.shape, "batch": a.batch, "tokens": a.tokens, "p50_ms": round(p50, 2), "min_ms": round(min(ts), 2),
+    print(json.dumps({"shape": a.shape, "batch": a.batch, "tokens": a.tokens, "ragged_from": a.ragged, "valid_tokens": int(mask.sum()),
+                      "packed": os.environ.get("VF_NO_PACKED") is None, "p50_ms": round(p50, 2), "min_ms": round(min(ts), 2),
                       "tflops_at_p50": round(flops / p50 / 1e9, 1), "seq_per_s": round(a.batch / p50 * 1e3, 1),
                       "finite": bool(np.isfinite(out).all())}))
     dec.close()

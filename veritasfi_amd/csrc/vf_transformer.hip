@@ -2148,9 +2148,9 @@ struct AttnStreamLds {
 };
 
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
+__global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
                                                            int ld, int heads, int kv_heads, float scale,
-                                                           half_t* __restrict__ ctx, int ctx_ld) {
+                                                           half_t* __restrict__ ctx, int ctx_ld, const int* __restrict__ seq_off = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     AttnStreamLds<DH>& L = *reinterpret_cast<AttnStreamLds<DH>*>(smem);
     constexpr int KS = DH / 16;   // k-steps of a QK^T tile
@@ -2159,7 +2159,10 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
     const int r31 = lane & 31, h = lane >> 5;
     const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
     const int hk = hd / (heads / kv_heads);
-    const long long row0 = (long long)b * T;
+    // packed sequences (seq_off): sequence b occupies rows [seq_off[b], seq_off[b + 1]); the grid is sized for the longest
+    const long long row0 = seq_off ? (long long)seq_off[b] : (long long)b * Targ;
+    const int T = seq_off ? seq_off[b + 1] - seq_off[b] : Targ;
+    if (qb * 128 >= T) return;
     const int q_dim = heads * DH, kv_dim = kv_heads * DH;
     const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
     const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
@@ -2345,14 +2348,16 @@ __global__ __launch_bounds__(256) void k_pool(const half_t* x, const int* mask, 
     float* v = (float*)smem;        // [H]
     float* red = v + H;             // [256]
     const int b = blockIdx.x, tid = threadIdx.x;
-    // packed sequences (CLS pooling only): sequence b starts at row seq_off[b]
-    const half_t* xb = x + (seq_off ? (long long)seq_off[b] : (long long)b * T) * H;
+    // packed sequences (CLS or last-token pooling): sequence b occupies rows [seq_off[b], seq_off[b + 1]), valid tokens first
+    const long long base = seq_off ? (long long)seq_off[b] : (long long)b * T;
+    if (seq_off) { Tv = seq_off[b + 1] - seq_off[b]; all_last_set = 0; }
+    const half_t* xb = x + base * H;
     int tok = 0;
     if (pooling == 2) {
         if (all_last_set) tok = Tv - 1;
         else {
             int c = 0;
-            for (int t = 0; t < Tv; ++t) c += mask[b * T + t] != 0;
+            for (int t = 0; t < Tv; ++t) c += mask[base + t] != 0;
             tok = c > 0 ? c - 1 : 0;
         }
     }
@@ -2426,9 +2431,9 @@ struct AttnStream256Lds {
 };
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attention_stream256(const half_t* __restrict__ qkv, const int* __restrict__ mask, int T,
+__global__ __launch_bounds__(256) void k_attention_stream256(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
                                                               int ld, int heads, int kv_heads, float scale,
-                                                              half_t* __restrict__ ctx, int ctx_ld) {
+                                                              half_t* __restrict__ ctx, int ctx_ld, const int* __restrict__ seq_off = nullptr) {
     constexpr int DH = 256, KT = 32, KS = DH / 16, MT = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     AttnStream256Lds& L = *reinterpret_cast<AttnStream256Lds*>(smem);
@@ -2436,7 +2441,9 @@ __global__ __launch_bounds__(256) void k_attention_stream256(const half_t* __res
     const int r31 = lane & 31, h = lane >> 5;
     const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
     const int hk = hd / (heads / kv_heads);
-    const long long row0 = (long long)b * T;
+    const long long row0 = seq_off ? (long long)seq_off[b] : (long long)b * Targ;   // (packed sequences: see k_attention_stream)
+    const int T = seq_off ? seq_off[b + 1] - seq_off[b] : Targ;
+    if (qb * 128 >= T) return;
     const int q_dim = heads * DH, kv_dim = kv_heads * DH;
     const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
     const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
@@ -2651,7 +2658,7 @@ __global__ void k_rope_table(float theta, int T, int dh, float2* tab) {
 // contiguous per unit and half): no cross-lane traffic for the rotation.  dh in {64, 128}.
 __global__ __launch_bounds__(256) void k_qknorm_rope(half_t* qkv, int M, int T, int ld, int heads, int kv_heads, int dh,
                                                       const float* qw, const float* kw, float eps, int qk_norm,
-                                                      const float2* tab) {
+                                                      const float2* tab, const int* pos_ids = nullptr) {
     const int lpu = dh >> 3;                       // lanes per unit: 16 (dh 128) or 8 (dh 64)
     const int upw = 256 / lpu;                     // units per workgroup
     const int unit = blockIdx.x * upw + threadIdx.x / lpu, j = threadIdx.x % lpu;
@@ -2662,7 +2669,7 @@ __global__ __launch_bounds__(256) void k_qknorm_rope(half_t* qkv, int M, int T, 
     const bool is_q = hh < heads;
     half_t* v = qkv + (long long)tok * ld + (is_q ? hh * dh : heads * dh + (hh - heads) * dh);
     const float* w = is_q ? qw : kw;
-    const int half_dh = dh >> 1, pos = tok % T;
+    const int half_dh = dh >> 1, pos = pos_ids ? pos_ids[tok] : tok % T;   // packed rows carry their own positions
     const h4 lo = *(const h4*)(v + 4 * j), hi = *(const h4*)(v + half_dh + 4 * j);
     float a[4], b[4], q = 0.f;
 #pragma unroll
@@ -2711,15 +2718,18 @@ __global__ __launch_bounds__(256) void k_swiglu(const half_t* gu, long long M, i
 
 // one vocabulary token's logit at the pooled (last) position: out[b] = x[last_b] . row     (the "Yes" score)
 __global__ __launch_bounds__(64) void k_token_logit(const half_t* x, const int* mask, int T, int Tv, int H, int all_last_set,
-                                                    const half_t* row, float* out) {
+                                                    const half_t* row, float* out, const int* seq_off = nullptr) {
     const int b = blockIdx.x, lane = threadIdx.x;
+    // packed sequences: rows [seq_off[b], seq_off[b + 1]), valid tokens first -- the last valid one is the count - 1
+    const long long base = seq_off ? (long long)seq_off[b] : (long long)b * T;
+    if (seq_off) { Tv = seq_off[b + 1] - seq_off[b]; all_last_set = 0; }
     int tok = Tv - 1;
     if (!all_last_set) {
         int c = 0;
-        for (int t = 0; t < Tv; ++t) c += mask[b * T + t] != 0;
+        for (int t = 0; t < Tv; ++t) c += mask[base + t] != 0;
         tok = c > 0 ? c - 1 : 0;
     }
-    const half_t* xr = x + ((long long)b * T + tok) * H;
+    const half_t* xr = x + (base + tok) * H;
     float s = 0.f;
     for (int j = lane; j < H; j += 64) s += (float)xr[j] * (float)row[j];
     s = wave_sum(s);
@@ -3369,6 +3379,8 @@ struct vf_decoder {
     float *x = nullptr, *y = nullptr;   // the residual stream, FP32 (ping-pong)
     half_t *n = nullptr, *qkv = nullptr, *ctx = nullptr, *gu = nullptr, *act = nullptr;
     int *d_ids = nullptr, *d_mask = nullptr, *d_flag = nullptr;
+    int *d_seq = nullptr, *d_pos = nullptr;   // packed (ragged-batch) forward: row offsets [cap_b + 1], RoPE positions [cap_tokens]
+    std::vector<int32_t> pk;                  // its host staging
     float* d_out = nullptr;
     float* d_hidden = nullptr;   // [cap_tokens, H] fp32 final hidden states (vf_decoder_forward_hidden)
     float2* rope = nullptr;
@@ -3413,11 +3425,11 @@ extern "C" int vf_decoder_weight_sizes(const vf_decoder_config* cfg, int64_t* n_
 }
 
 static void dec_free_ws(vf_decoder* d) {
-    void* p[] = {d->x, d->y, d->n, d->qkv, d->ctx, d->gu, d->act, d->d_ids, d->d_mask, d->d_out, d->rope, d->d_hidden};
+    void* p[] = {d->x, d->y, d->n, d->qkv, d->ctx, d->gu, d->act, d->d_ids, d->d_mask, d->d_out, d->rope, d->d_hidden, d->d_seq, d->d_pos};
     for (void* q : p) if (q) (void)hipFree(q);
     d->x = d->y = nullptr; d->d_hidden = nullptr;
     d->n = d->qkv = d->ctx = d->gu = d->act = nullptr;
-    d->d_ids = d->d_mask = nullptr; d->d_out = nullptr; d->rope = nullptr;
+    d->d_ids = d->d_mask = d->d_seq = d->d_pos = nullptr; d->d_out = nullptr; d->rope = nullptr;
     d->cap_tokens = d->cap_b = d->rope_T = 0;
 }
 
@@ -3484,6 +3496,8 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     VFT_HIP(hipMalloc((void**)&d->act, Mp * F * 2));
     VFT_HIP(hipMalloc((void**)&d->d_ids, Mp * 4));
     VFT_HIP(hipMalloc((void**)&d->d_mask, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&d->d_pos, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&d->d_seq, ((size_t)B + 1) * 4));
     VFT_HIP(hipMalloc((void**)&d->d_out, (size_t)B * (c.head == 2 ? 1 : H) * 4));
     VFT_HIP(hipMalloc((void**)&d->rope, (size_t)kDecMaxT * (c.head_dim / 2) * sizeof(float2)));
     // padded rows are read by the GEMMs: keep them finite
@@ -3502,10 +3516,13 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
 }
 
 // The layers: ids / mask already in d->d_ids / d->d_mask.  Returns the final residual stream (fp32, device) in *xfinal.
-static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float** xfinal) {
+// seq_off != nullptr: PACKED rows (vf_decoder_forward's ragged-batch path) -- Mpk rows in all, sequence i in rows
+// [seq_off[i], seq_off[i + 1]) with its valid tokens first, t = the longest; pos = each row's RoPE position.
+static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float** xfinal, const int* seq_off = nullptr, int Mpk = 0,
+                             const int* pos = nullptr) {
     const vf_decoder_config& c = d->cfg;
     const int H = c.hidden, F = c.ffn, DH = c.head_dim, QD = (int)dec_qd(c), KD = (int)dec_kd(c), QKV = QD + 2 * KD;
-    const int M = b * t, Mp = (M + 255) / 256 * 256;
+    const int M = seq_off ? Mpk : b * t, Mp = (M + 255) / 256 * 256;
     hipLaunchKernelGGL(k_gather_rows, dim3((M + 7) / 8), dim3(256), 0, st, d->d_ids, d->w16 + d->o_embed, M, H,
                        c.embed_scale > 0.f ? c.embed_scale : 1.0f, d->x);
     float *px = d->x, *py = d->y;   // residual stream in fp32; GEMM operands (d->n, d->ctx, d->act) in fp16
@@ -3521,16 +3538,16 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st));
         const int units = M * (c.heads + c.kv_heads);
         hipLaunchKernelGGL(k_qknorm_rope, dim3((units + 256 / (DH / 8) - 1) / (256 / (DH / 8))), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
-                           qn, kn, c.rms_eps, c.qk_norm, d->rope);
+                           qn, kn, c.rms_eps, c.qk_norm, d->rope, pos);
         if (DH == 64) {
             hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
-                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
+                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else if (DH == 128) {
             hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
-                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
+                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else {
             hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
-                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD);
+                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         }
         VFT_HIP(gemm<EPI_RESIDUAL_F32>(d->ctx, Wo, nullptr, (const half_t*)px, (half_t*)py, Mp, H, QD, st));
         std::swap(px, py);
@@ -3570,6 +3587,75 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
     const int H = c.hidden, M = b * t;
     hipStream_t st = nullptr;
     const size_t ntok = (size_t)b * t;
+    // Ragged batch, padded on ONE side throughout (the tokenizer's left or right padding), last-token pooling or the
+    // token-logit head: the rows are PACKED -- a sequence keeps ceil32(length) rows, valid tokens first, each carrying its
+    // original column as RoPE position -- and the layers only see the tokens that exist (as the encoder's forward_impl).
+    // The pooled row is the last valid token, which is what last_token_pool (step3_mul.py:181-188) and logits[:, -1]
+    // (stress_test.py:212-225) select on one-sided padding.
+    static const bool no_pack = getenv("VF_NO_PACKED") != nullptr;   // A/B switch
+    if (!no_pack && b >= 4 && (c.pooling == 2 || c.head == 2)) {
+        std::vector<int32_t>& pk = d->pk;
+        pk.assign((size_t)3 * b + 1, 0);
+        int32_t *off = pk.data(), *first = off + b + 1, *lens = first + b;
+        long long rows = 0;
+        int tmax = 0;
+        bool ok = true, all_left = true, all_right = true;
+        for (int i = 0; i < b && ok; ++i) {
+            const int32_t* m = mask + (size_t)i * t;
+            int f = 0;
+            while (f < t && !m[f]) ++f;
+            int e2 = f;
+            while (e2 < t && m[e2]) ++e2;
+            for (int j = e2; j < t; ++j) if (m[j]) { ok = false; break; }   // more than one run of tokens
+            if (e2 == f) ok = false;                                         // no token at all: the padded path
+            all_right = all_right && f == 0;
+            all_left = all_left && e2 == t;
+            const int l32 = (e2 - f + 31) / 32 * 32;
+            off[i] = (int32_t)rows; first[i] = f; lens[i] = e2 - f;
+            rows += l32;
+            tmax = l32 > tmax ? l32 : tmax;
+        }
+        off[b] = (int32_t)rows;
+        if (ok && (all_left || all_right) && rows * 100 <= (long long)ntok * 85) {
+            const size_t R = (size_t)rows;
+            const size_t head = (size_t)3 * b + 1;
+            pk.resize(head + 3 * R);
+            off = pk.data(); first = off + b + 1; lens = first + b;
+            int32_t *pid = pk.data() + head, *pmk = pid + R, *ppos = pmk + R;
+            for (int i = 0; i < b; ++i) {
+                const int r0 = off[i], l32 = off[i + 1] - off[i], f = first[i], n = lens[i];
+                const int32_t* si = ids + (size_t)i * t;
+                for (int j = 0; j < l32; ++j) {
+                    const bool v = j < n;
+                    pid[r0 + j] = si[v ? f + j : f];
+                    pmk[r0 + j] = v;
+                    ppos[r0 + j] = v ? f + j : 0;
+                }
+            }
+            VFT_HIP(hipMemcpyAsync(d->d_seq, off, ((size_t)b + 1) * 4, hipMemcpyHostToDevice, st));
+            VFT_HIP(hipMemcpyAsync(d->d_ids, pid, R * 4, hipMemcpyHostToDevice, st));
+            VFT_HIP(hipMemcpyAsync(d->d_mask, pmk, R * 4, hipMemcpyHostToDevice, st));
+            VFT_HIP(hipMemcpyAsync(d->d_pos, ppos, R * 4, hipMemcpyHostToDevice, st));
+            float* pxp = nullptr;
+            VFT_TRY(dec_layers_device(d, b, tmax, st, &pxp, d->d_seq, (int)rows, d->d_pos));
+            const float woffp = c.norm_plus_one ? 1.0f : 0.0f;
+            hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3(((int)rows + 7) / 8), dim3(256), 0, st, pxp, d->w32 + d->f_final, woffp, c.rms_eps,
+                               (int)rows, H, d->n);
+            if (c.head == 2) {
+                hipLaunchKernelGGL(k_token_logit, dim3(b), dim3(64), 0, st, d->n, d->d_mask, tmax, tmax, H, 0, d->w16 + d->o_head_row,
+                                   d->d_out, d->d_seq);
+            } else {
+                const size_t pool_lds = ((size_t)H * 2 + 256) * sizeof(float);
+                hipLaunchKernelGGL(k_pool, dim3(b), dim3(256), pool_lds, st, d->n, d->d_mask, tmax, tmax, H, c.pooling, c.normalize, 0,
+                                   0, nullptr, nullptr, nullptr, nullptr, d->d_out, d->d_seq);
+            }
+            VFT_HIP(hipGetLastError());
+            VFT_HIP(hipMemcpyAsync(out, d->d_out, (size_t)b * (c.head == 2 ? 1 : H) * 4, hipMemcpyDeviceToHost, st));
+            VFT_HIP(hipStreamSynchronize(st));
+            g_packed_forwards.fetch_add(1, std::memory_order_relaxed);
+            return VF_OK;
+        }
+    }
     VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
     VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
     float* px = nullptr;
