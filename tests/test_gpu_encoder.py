@@ -868,3 +868,31 @@ def test_decoder_ragged_batch_takes_the_packed_forward(vf, name, hidden, layers,
     assert L.vf_debug_packed_forwards() == n1 + 1
     scorer.close()
     assert np.abs(got_logit - want_logit).max() < 2e-2 * max(1.0, np.abs(want_logit).max()), (got_logit, want_logit)
+
+
+@pytest.mark.parametrize("act", ["silu", "gelu_tanh"])
+def test_gated_mlp_gemm_matches_torch(vf, act):
+    """The decoder's fused gate / up product (k_gemm8p_tn's gated epilogue: act(A Wg^T) * (A Wu^T) in one launch) against torch
+    fp32, at a ragged m-tile count and an odd K-tile count."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_gemm.restype = ctypes.c_int
+    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(77)
+    M, F, K = 256 * 17, 3072, 320
+    A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
+    W = (torch.randn(2 * F, K, device=dev, generator=g) * 0.08).half()
+    C = torch.full((M, F), float("nan"), device=dev, dtype=torch.float16)
+    rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), None, None, C.data_ptr(), M, 2 * F, K, 4 if act == "silu" else 5,
+                         torch.cuda.current_stream().cuda_stream, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    gate = A.float() @ W[:F].float().T
+    up = A.float() @ W[F:].float().T
+    ref = (torch.nn.functional.silu(gate) if act == "silu" else torch.nn.functional.gelu(gate, approximate="tanh")) * up
+    err = (C.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert not torch.isnan(C).any() and err < 2e-3 * max(1.0, scale), (err, scale)

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float*
 // EPI_RESIDUAL_F32: C and R are FP32 buffers, C = R + acc (+ bias): the decoder family's residual stream is kept in fp32 (the
 // reference runs those models in the checkpoint's wider dtype: experiments/retriever/step3_mul.py:62-64), only the
 // GEMM operands are fp16.
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 = 3,
+       EPI_GATED_SILU = 4, EPI_GATED_GELU = 5 };   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
 
 // exact-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far
 // below the fp16 precision of the stored activation): one rcp, one exp, five FMAs instead of libm's erff.
@@ -1027,8 +1028,16 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
         const int bn0 = (i >> 5) * 64 + (i & 31), bn1 = bn0 + 32;
         src[0][j] = A + (m0 + am0) * K + lc * 8;
-        src[1][j] = W + (n0 + bn0) * K + lc * 8;
-        src[2][j] = W + (n0 + bn1) * K + lc * 8;
+        if (EPI >= EPI_GATED_SILU) {
+            // gated product: the tile's 256 columns are 128 gate columns and the SAME 128 up columns, laid out so that a wave's
+            // first 32 columns (half-tile B_n0) are gate rows and its second 32 (B_n1) the matching up rows of W
+            const long long gr = (long long)nt_idx * 128 + (i >> 5) * 32 + (i & 31);
+            src[1][j] = W + gr * K + lc * 8;
+            src[2][j] = W + ((long long)(N >> 1) + gr) * K + lc * 8;
+        } else {
+            src[1][j] = W + (n0 + bn0) * K + lc * 8;
+            src[2][j] = W + (n0 + bn1) * K + lc * 8;
+        }
         src[3][j] = A + (m0 + am1) * K + lc * 8;
     }
     const int nk = K / PBK, G = 4 * nk;   // K-tiles, half-tiles
@@ -1126,6 +1135,33 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
     __syncthreads();
+    if (EPI >= EPI_GATED_SILU) {
+        // gated epilogue: out[row][32 wc + 16 ni + r15] = act(gate) * up with gate = acc[.][ni], up = acc[.][ni + 2] (ni = 0, 1),
+        // fp32 throughout (the unfused path rounds both products to fp16 first); a [256][128] fp16 image, then 16-byte chunks
+        half_t* Eg = (half_t*)smem;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = wc * 32 + ni * 16 + r15;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = wr * 128 + mi * 16 + 4 * kb + reg;
+                    const float g = acc[mi][ni][reg], u = acc[mi][ni + 2][reg];
+                    // tanh-GELU = x * sigmoid(2 * 0.7978845608 * (x + 0.044715 x^3));  SiLU = x * sigmoid(x)
+                    const float z = EPI == EPI_GATED_GELU ? 1.5957691216f * (g + 0.044715f * g * g * g) : g;
+                    Eg[row * 128 + col] = (half_t)(g / (1.0f + __expf(-z)) * u);
+                }
+        }
+        __syncthreads();
+        const int NO = N >> 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + PTHREADS * i, row = c >> 4, cc = c & 15;   // 16 chunks of 8 halves per 128-wide row
+            *(h8*)(C + (m0 + row) * NO + (long long)nt_idx * 128 + cc * 8) = *(const h8*)(Eg + row * 128 + cc * 8);
+        }
+        return;
+    }
     // epilogue through LDS: fp16(acc + bias [+GELU]) into a [256][256] fp16 image (the two K-tile buffers), then
     // 16-byte row chunks out (residual added in fp32 on the vector side)
     half_t* Es = (half_t*)smem;
@@ -2764,6 +2800,8 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
@@ -3083,6 +3121,21 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
     return hipGetLastError();
     }
+}
+
+// Gated MLP front half in one launch: C[M][F] = act(A . Wgate^T) * (A . Wup^T), Wgu = [gate rows (F) | up rows (F)] x K.  Returns
+// false when the shape does not fill the 8-phase kernel (the caller then runs the plain product + k_swiglu).
+static bool gemm_gated(const half_t* A, const half_t* Wgu, half_t* C, int M, int F, int K, int act_kind, hipStream_t st, hipError_t* er) {
+    static const bool off = getenv("VF_NO_GATED_GEMM") != nullptr;   // A/B switch
+    const int N = 2 * F;
+    *er = hipSuccess;
+    if (off || M % PBM || N % PBN || F % 128 || K % PBK || K < 2 * PBK || (long long)(M / PBM) * (N / PBN) < 384) return false;
+    if (act_kind == 1)
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K);
+    else
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K);
+    *er = hipGetLastError();
+    return true;
 }
 
 template <int EPI>
@@ -3552,9 +3605,13 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         VFT_HIP(gemm<EPI_RESIDUAL_F32>(d->ctx, Wo, nullptr, (const half_t*)px, (half_t*)py, Mp, H, QD, st));
         std::swap(px, py);
         hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, woff, c.rms_eps, M, H, d->n);
-        VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
-        hipLaunchKernelGGL(k_swiglu, dim3(((F >> 3) + 255) / 256, M < 32768 ? M : 32768), dim3(256), 0, st, d->gu, (long long)M, F, c.act,
-                           d->act);
+        hipError_t ger = hipSuccess;
+        if (!gemm_gated(d->n, Wgu, d->act, Mp, F, H, c.act, st, &ger)) {   // gate / up products and the activation in one launch
+            VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
+            hipLaunchKernelGGL(k_swiglu, dim3(((F >> 3) + 255) / 256, M < 32768 ? M : 32768), dim3(256), 0, st, d->gu, (long long)M, F, c.act,
+                               d->act);
+        }
+        VFT_HIP(ger);
         VFT_HIP(gemm<EPI_RESIDUAL_F32>(d->act, Wdn, nullptr, (const half_t*)px, (half_t*)py, Mp, H, F, st));
         std::swap(px, py);
     }
@@ -3723,6 +3780,10 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;
+    if (epi == EPI_GATED_SILU || epi == EPI_GATED_GELU) {   // W = [gate rows (N / 2) | up rows (N / 2)], C is M x N / 2
+        if (!gemm_gated(a, w, c, M, N / 2, K, epi == EPI_GATED_GELU, st, &er)) return -2;
+        return er == hipSuccess ? 0 : -1;
+    }
     if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st, kind);
     else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st, kind);
     else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st, kind);
