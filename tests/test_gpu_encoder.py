@@ -896,3 +896,29 @@ def test_gated_mlp_gemm_matches_torch(vf, act):
     err = (C.float() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert not torch.isnan(C).any() and err < 2e-3 * max(1.0, scale), (err, scale)
+
+
+@pytest.mark.parametrize("kind", [0, 5, 7])
+def test_fp32_residual_gemm_matches_torch(vf, kind):
+    """out(fp32) = R(fp32) + A . W^T (the decoder's residual products) through every kernel that has the epilogue: the 8-phase
+    kernel (7; also what 0 picks at this size: operands swapped, 16-byte read-modify-writes from registers), the 128 x 256
+    DMA kernel (5)."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_gemm.restype = ctypes.c_int
+    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5 + kind)
+    M, N, K = 256 * 24, 4096, 320
+    A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.08).half()
+    R = torch.randn(M, N, device=dev, generator=g) * 300.0          # a residual stream well beyond fp16's precision at its scale
+    C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32)
+    rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), None, R.data_ptr(), C.data_ptr(), M, N, K, 3, torch.cuda.current_stream().cuda_stream, kind)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = R + A.float() @ W.float().T
+    err = (C - ref).abs().max().item()
+    assert not torch.isnan(C).any() and err < 2e-3, err

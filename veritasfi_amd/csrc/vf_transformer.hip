@@ -1079,7 +1079,9 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
             _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
-                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[t][ks], BF[u][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = EPI == EPI_RESIDUAL_F32                                                     \
+                    ? __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0) \
+                    : __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[t][ks], BF[u][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
 #define VFT_PHASE_HEAD(G)                                                                  \
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
     __builtin_amdgcn_s_barrier();                                                          \
@@ -1135,6 +1137,24 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
     __syncthreads();
+    if (EPI == EPI_RESIDUAL_F32) {
+        // fp32 residual stream (decoder): the MFMA operands were swapped (W fragment first), so a lane holds 4 consecutive
+        // COLUMNS of one row -- out = R + acc as one 16-byte read-modify-write per tile, straight from the registers
+        const float* Rf = (const float*)R;
+        float* Cf = (float*)C;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const long long off = (m0 + wr * 128 + mi * 16 + r15) * N + n0 + wc * 64 + ni * 16 + 4 * kb;
+                const f4v rv = *(const f4v*)(Rf + off);
+                f4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rv[e] + acc[mi][ni][e];
+                *(f4v*)(Cf + off) = o;
+            }
+        return;
+    }
     if (EPI >= EPI_GATED_SILU) {
         // gated epilogue: out[row][32 wc + 16 ni + r15] = act(gate) * up with gate = acc[.][ni], up = acc[.][ni + 2] (ni = 0, 1),
         // fp32 throughout (the unfused path rounds both products to fp16 first); a [256][128] fp16 image, then 16-byte chunks
@@ -2800,6 +2820,7 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
@@ -3061,7 +3082,12 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     static const long long dma_min = getenv("VF_GEMM_DMA_MIN_WGS") ? atoll(getenv("VF_GEMM_DMA_MIN_WGS")) : 384;
     const bool dma_ok = M % DBM == 0 && N % DBN == 0 && K % DBK == 0;
     const bool big_ok = M % LBM == 0 && N % LBN == 0;
-    if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: the default large kernel or the 128 x 128 one
+    if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: 8-phase, the 128 x 256 DMA kernel or the 128 x 128 one
+        static const long long p8f_min = getenv("VF_GEMM_8P_F32_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_F32_MIN_WGS")) : 256;   // (Qwen3-4B shape, 320 tiles: 66.4 vs 68.9 ms per forward)
+        if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8f_min))) {
+            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K);
+            return hipGetLastError();
+        }
         if (dma_ok && (long long)(M / DBM) * (N / DBN) >= dma_min && kind != 3) {
             hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
             return hipGetLastError();
@@ -3782,6 +3808,10 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     half_t* c = (half_t*)C;
     if (epi == EPI_GATED_SILU || epi == EPI_GATED_GELU) {   // W = [gate rows (N / 2) | up rows (N / 2)], C is M x N / 2
         if (!gemm_gated(a, w, c, M, N / 2, K, epi == EPI_GATED_GELU, st, &er)) return -2;
+        return er == hipSuccess ? 0 : -1;
+    }
+    if (epi == EPI_RESIDUAL_F32) {   // R and C are fp32 [M][N] here (the decoder's residual stream), no bias
+        er = gemm<EPI_RESIDUAL_F32>(a, w, nullptr, r, c, M, N, K, st, kind);
         return er == hipSuccess ? 0 : -1;
     }
     if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st, kind);
