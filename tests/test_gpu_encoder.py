@@ -799,16 +799,19 @@ def test_ragged_batch_takes_the_packed_forward_and_matches_torch(vf, kind):
     ids = rng.integers(lo, 900, size=(b, t)).astype(np.int64)
     mask = (np.arange(t)[None, :] < lens[:, None]).astype(np.int64)
     ids[mask == 0] = pad_id
+    # BERT: segment ids too (second half of every sequence is segment 1, as a (query, passage) pair would be)
+    tt = ((np.arange(t)[None, :] >= (lens[:, None] // 2)) & (mask == 1)).astype(np.int64) if kind == "bert-embedder" else None
     with torch.no_grad():
         if kind == "bert-embedder":
-            ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state[:, 0]
+            ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                    token_type_ids=torch.from_numpy(tt)).last_hidden_state[:, 0]
             ref = torch.nn.functional.normalize(ref, dim=-1).numpy()
         else:
             ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits[:, 0].numpy()
     enc = vf.HipEncoder.from_hf(m)
     try:
         n0 = L.vf_debug_packed_forwards()
-        got = enc.forward(ids.astype(np.int32), mask.astype(np.int32))
+        got = enc.forward(ids.astype(np.int32), mask.astype(np.int32), None if tt is None else tt.astype(np.int32))
         assert L.vf_debug_packed_forwards() == n0 + 1, "the ragged batch did not take the packed path"
         tol = 8e-4 if kind == "bert-embedder" else 2.5e-3
         assert float(np.abs(got - ref).max()) < tol, float(np.abs(got - ref).max())
