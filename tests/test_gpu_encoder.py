@@ -925,3 +925,36 @@ def test_fp32_residual_gemm_matches_torch(vf, kind):
     ref = R + A.float() @ W.float().T
     err = (C - ref).abs().max().item()
     assert not torch.isnan(C).any() and err < 2e-3, err
+
+
+def test_long_ragged_batch_packs_through_the_streaming_attention(vf):
+    """bge-m3's regime: documents of very different lengths up to 1536 tokens in one batch.  Wider than 512 tokens the packed
+    forward runs the streaming attention kernel over the row offsets; the embeddings still match HF fp32."""
+    import ctypes
+    import torch
+    from transformers import XLMRobertaConfig, XLMRobertaModel
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_packed_forwards.restype = ctypes.c_longlong
+    torch.manual_seed(4)
+    cfg = XLMRobertaConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=900,
+                           max_position_embeddings=1600, type_vocab_size=1, pad_token_id=1)
+    m = XLMRobertaModel(cfg, add_pooling_layer=False).eval()
+    m = m.half().float()
+    rng = np.random.default_rng(8)
+    b, t = 5, 1536
+    lens = np.array([1536, 700, 33, 1200, 260])
+    ids = rng.integers(5, 900, size=(b, t)).astype(np.int64)
+    mask = (np.arange(t)[None, :] < lens[:, None]).astype(np.int64)
+    ids[mask == 0] = 1
+    with torch.no_grad():
+        ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state[:, 0]
+        ref = torch.nn.functional.normalize(ref, dim=-1).numpy()
+    enc = vf.HipEncoder.from_hf(m)
+    try:
+        n0 = L.vf_debug_packed_forwards()
+        got = enc.forward(ids.astype(np.int32), mask.astype(np.int32))
+        assert L.vf_debug_packed_forwards() == n0 + 1
+        assert float(np.abs(got - ref).max()) < 8e-4, float(np.abs(got - ref).max())
+    finally:
+        enc.close()

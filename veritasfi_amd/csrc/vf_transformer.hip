@@ -3221,7 +3221,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         if (att_stream || T > kEncResidentT) {
             hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
                                sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
-                               e->q_folded ? -1.f : 0.125f, e->ctx, H);
+                               e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
         } else if (e->q_folded) {
             launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         } else {
@@ -3314,12 +3314,12 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
         VFT_HIP(hipStreamSynchronize(gs));
         return VF_OK;
     }
-    // Ragged batch (right-padded, CLS pooling or a classification head, resident attention): the rows are PACKED -- every
+    // Ragged batch (right-padded, CLS pooling or a classification head): the rows are PACKED -- every
     // sequence keeps ceil32(length) rows -- so the GEMMs, LayerNorms and attention only see the tokens that exist.  A row's
     // output does not depend on its neighbours or its padding (masked keys weigh exactly 0), so this is the same forward
     // on fewer rows; FlagEmbedding sorts by length for the same reason (the reference's compute_score / encode).
     static const bool no_pack = getenv("VF_NO_PACKED") != nullptr;   // A/B switch
-    if (!no_pack && e->q_folded && t <= kEncResidentT && b >= 8 && (e->cfg.head == 1 || e->cfg.pooling == 0)) {
+    if (!no_pack && e->q_folded && b >= 2 && (e->cfg.head == 1 || e->cfg.pooling == 0)) {   // (any width: the streaming attention packs too)
         std::vector<int32_t>& pk = e->pk;
         pk.resize((size_t)b + 1);
         long long rows = 0;
