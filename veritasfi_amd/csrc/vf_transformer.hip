@@ -2201,6 +2201,7 @@ struct AttnStreamLds {
     half_t k[2][SKT][DH + 8];
     half_t vt[2][DH][SKT + 8];
     float mb[2][SKT];
+    int padded[2];   // the tile holds a masked key (or runs past the sequence's end)
 };
 
 template <int DH, bool CAUSAL>
@@ -2268,7 +2269,11 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
                 *(h8*)(&L.vt[buf][kc * 8 + e][tb * 8]) = rowv;
             }
         }
-        if (tid < SKT) L.mb[buf][tid] = rmb;
+        if (tid < SKT) {   // (wave 0 exactly)
+            L.mb[buf][tid] = rmb;
+            const bool any = __ballot(rmb != 0.f) != 0ull;
+            if (tid == 0) L.padded[buf] = any ? 1 : 0;
+        }
     };
     // Q fragments (B operand), pre-scaled
     h8 qf[KS];
@@ -2313,19 +2318,29 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
                 for (int ks = 1; ks < KS; ++ks)
                     s[half_t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), qf[ks], s[half_t_], 0, 0, 0);
             }
-            // masks: key padding (and tile tail) always; causal only on tiles that reach past the wave's first query
+            // masks, each behind a wave-uniform branch: key padding (and tile tail) only on tiles that hold a masked key
+            // (L.padded, set when the tile was stashed), causal only on tiles that reach past the wave's first query
             const bool diag = CAUSAL && (kt + SKT - 1 > q0);
+            if (L.padded[buf]) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) s[sx][reg] += L.mb[buf][sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+            }
+            if (diag) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int kl = sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        if (kt + kl > q0 + r31) s[sx][reg] = -30000.f;
+                    }
+            }
             float tmax = -1e30f;
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int kl = sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    float v = s[sx][reg] + L.mb[buf][kl];
-                    if (diag && kt + kl > q0 + r31) v = -30000.f;
-                    s[sx][reg] = v;
-                    tmax = fmaxf(tmax, v);
-                }
+                for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, s[sx][reg]);
             {
                 float lo, hi;
                 halves(tmax, lo, hi);
@@ -2351,12 +2366,12 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
             }
             l_run = l_run * alpha + psum;
             m_run = m_new;
-            if (__ballot(alpha != 1.0f) != 0ull) {
+            // unconditional: behind a "did any maximum move" branch the compiler copies all of O on the path that skips
+            // the multiply (86 v_mov per tile measured) -- more than the multiplies cost
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
-            }
+                for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
             // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h of 16-key group st <-> key 16 st + (j&3) + 8 (j>>2) + 4 h
 #pragma unroll
             for (int st = 0; st < 4; ++st)
