@@ -87,6 +87,52 @@ def test_embedding_encoder_matches_torch_fp32(vf, name, hidden, layers, heads, f
     assert herr.mean() < 3e-3 and herr.max() < 4e-2
 
 
+@pytest.mark.parametrize("hidden,layers,heads,ffn,b,t", [
+    (768, 12, 12, 3072, 1, 32),     # BERT-base shape, one query string (faissRetriever.py:33)
+    (768, 4, 12, 3072, 1, 40),      # padded to 64 tokens: four row tiles
+    (768, 4, 12, 3072, 2, 32),      # two short strings: one sequence per (head, sequence) workgroup
+    (1024, 6, 16, 4096, 1, 64),     # XLM-R-large / bge-m3 shape: the largest LDS image (64 rows x 1024)
+    (256, 3, 4, 1024, 1, 20),       # fewer column tiles than workgroups everywhere
+])
+def test_one_query_persistent_forward(vf, hidden, layers, heads, ffn, b, t):
+    """k_sq_forward (all layers of a <= 64-token forward in one persistent launch, grid barriers between phases; an
+    experiment, off by default) against torch fp32, against the launch-per-product path, and run phase by phase (no barrier)
+    -- the last two must agree bit for bit with each other, and with the launch-per-product path up to the summation order
+    of the K splits."""
+    import ctypes, torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_sq_mode.restype = ctypes.c_int
+    L.vf_debug_sq_mode.argtypes = [ctypes.c_int]
+    model = _hf_bert(hidden, layers, heads, ffn)
+    rng = np.random.default_rng(11)
+    ids, mask = _batch(rng, b, t, 1000)
+    mask[0, t - 3:] = 0                                  # some padding in every case
+    with torch.no_grad():
+        ref_h = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state.numpy()
+    ref = ref_h[:, 0] / np.linalg.norm(ref_h[:, 0], axis=1, keepdims=True)
+    enc = vf.HipEncoder.from_hf(model, pooling=0, normalize=True)
+    out, hid = {}, {}
+    try:
+        for mode in (0, 1, 2):
+            L.vf_debug_sq_mode(mode)
+            out[mode] = [enc.forward(ids, mask) for _ in range(3)]      # replays of the captured graph too
+            hid[mode] = enc.hidden_states(ids, mask)
+    finally:
+        L.vf_debug_sq_mode(0)
+        enc.close()
+    valid = mask.astype(bool)
+    for mode in (0, 1, 2):
+        for o in out[mode]:
+            assert np.array_equal(o, out[mode][0])                      # deterministic
+        err = np.abs(out[mode][0] - ref).max()
+        herr = np.abs(hid[mode] - ref_h)[valid]
+        print("mode", mode, "max|d emb|", err, "hidden mean/max", herr.mean(), herr.max())
+        assert err < 8e-4 and herr.mean() < 3e-3 and herr.max() < 4e-2
+    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(hid[1][valid], hid[2][valid])
+    assert np.abs(hid[1] - hid[0])[valid].max() < 2e-2
+
+
 def test_pooling_variants(vf):
     import torch
     from veritasfi_amd.retrieval import get_embeddings

@@ -132,7 +132,9 @@ __device__ __forceinline__ void ln_finish(float (&v)[4][8], float s, int l32, in
 
 __global__ __launch_bounds__(256) void k_embed_ln(const int* ids, const int* pos, const int* tts, const half_t* word,
                                                    const half_t* posw, const half_t* typew, const float* g,
-                                                   const float* bta, float eps, int M, int H, half_t* out) {
+                                                   const float* bta, float eps, int M, int H, half_t* out,
+                                                   unsigned* zero2 = nullptr) {
+    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;   // k_sq_forward's barrier words
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
     const h8* w = (const h8*)(word + (long long)ids[row] * H);
@@ -968,6 +970,563 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t*
             o[e] = (half_t)v;
         }
         *(h4*)(C + (long long)row * N + n0 + c0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sq_forward: EVERY layer of a one-query forward (B T <= 64 tokens) in ONE persistent launch.
+// With separate launches such a forward is ~90 dependent kernels of 5-8 us that each move a few hundred KB: the time is
+// kernel boundaries and dependent memory round trips, not work.  Here one workgroup per CU stays resident and a layer is
+// FOUR phases separated by a grid barrier (one agent-scope arrive counter, polled):
+//   P1  per (head, sequence): LayerNorm of the previous layer's FFN sum on load (rows -> LDS, fp16, k_layernorm's
+//       arithmetic), the head's 192 QKV columns (12 waves = 12 column tiles of 16, W streamed straight into MFMA B
+//       operands), then the head's attention out of LDS (S^T = K Q^T so that the probabilities come out in the A-operand
+//       layout of P V; keys of an operand are permuted the same way on both sides);   -> ctx
+//   P2  per 16 output columns: ctx Wo^T + b + residual   (waves split K; fp32 partials meet in LDS)   -> y
+//   P3  per 16 columns: LayerNorm(y) on load, W1, erf-GELU                                            -> hbuf
+//   P4  per 16 columns: hbuf W2^T + b + residual                                                      -> y
+// The residual of P2 / P4 is the LayerNorm OUTPUT of the rows P1 / P3 normalised: instead of publishing those rows, one
+// workgroup of P1 / P3 publishes the row statistics (mean, rstd) and the consumer recomputes its 16 columns from the
+// pre-LayerNorm sum -- the same arithmetic, hence the same fp16 values.  The final LayerNorm and the pooling stay
+// separate launches.
+// Hand-off between workgroups (the XCDs' L2s are not coherent with each other): every activation store is a 16- or 8-byte
+// sc1 (write-through) buffer store, every activation load an sc1 buffer load; a workgroup arrives (one lane, agent-scope
+// atomic add) after every wave's s_waitcnt vmcnt(0) and a workgroup barrier, and loads only behind the barrier that follows
+// the poll (MI355X_MICROARCH.md, hand-off table, first row).  A cache-wide release / acquire fence per wave and barrier
+// was measured at ~60 us per barrier.  Weights never change: a phase's first weight operands are fetched BEFORE its
+// barrier wait, so their latency hides behind the slowest workgroup of the previous phase.
+// Every wait is bounded: a barrier that does not complete within ~1 s raises bar[1] and lets the grid drain.
+// Requires H % 256 == 0, F % 256 == 0, head dim 64, T in {32, 64}; grid <= the number of CUs (all workgroups resident).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSqWaves = 12, kSqThreads = kSqWaves * 64, kSqHead = 1024, kSqRedSlots = 6;
+constexpr unsigned kSqSpinLimit = 1u << 20;
+
+struct SqParams {
+    const half_t* w16;            // first layer's fp16 blob  [Wqkv | Wo | W1 | W2]
+    const float* w32;             // first layer's fp32 blob  [bqkv | bo | g1 | b1n | b1 | b2 | g2 | b2n]
+    long long layer16, layer32;   // per-layer strides
+    int H, F, heads, layers, B, T;
+    float eps;
+    int q_folded;
+    const int* mask;
+    half_t *x, *y, *ctx, *hbuf;
+    float* stats;                 // [2][64][2]: (mean, rstd) of the rows P1 normalised, then of the rows P3 normalised
+    unsigned* bar;                // [0] barrier arrivals, [1] timeout (both zeroed by the launch before this one)
+    unsigned* timeout;            // host-mapped flag
+    int nsleep;                   // poll period of the barrier wait, in units of 512 cycles
+    unsigned long long* stamps;   // diagnostics (vf_debug_sq_stamps): [phase][workgroup][4] s_memrealtime clocks, or nullptr
+};
+__device__ __forceinline__ void sq_stamp(const SqParams& p, int ph, int which) {
+    if (p.stamps && threadIdx.x == 0) p.stamps[((long long)ph * gridDim.x + blockIdx.x) * 4 + which] = __builtin_amdgcn_s_memrealtime();
+}
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t sq_rsrc_t;
+__device__ __forceinline__ sq_rsrc_t sq_rsrc(const void* q) { return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, 0x7ffffff0, 0x00020000); }
+// sc1 (aux bit 16) accesses; byte offsets
+__device__ __forceinline__ h8 sq_ld8(sq_rsrc_t r, int off) { return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16)); }
+__device__ __forceinline__ h4 sq_ld4(sq_rsrc_t r, int off) { return __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16)); }
+__device__ __forceinline__ void sq_st8(sq_rsrc_t r, int off, h8 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), r, off, 0, 16); }
+__device__ __forceinline__ void sq_st4(sq_rsrc_t r, int off, h4 v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2v, v), r, off, 0, 16); }
+
+// workgroup barrier for LDS traffic only (no wait for outstanding global stores)
+__device__ __forceinline__ void sq_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ void sq_arrive(const SqParams& p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sq_wait(const SqParams& p, unsigned target) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            for (int i = 0; i < p.nsleep; ++i) __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0 && (spins > kSqSpinLimit || __hip_atomic_load(p.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(p.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// rows [r0, r0 + nrows) of src -> the LDS image xs (row stride ld halves); g != nullptr: LayerNorm on the way (half a
+// wave per row, exactly k_layernorm's arithmetic) and, with stats != nullptr, (mean, rstd) of row r to stats[2 (r0 + r)].
+// NR rounds of 24 rows; the loads of all rounds are issued before the first row is reduced (one memory round trip).
+template <int NR>
+__device__ __forceinline__ void sq_rows_to_lds(sq_rsrc_t src, int r0, int nrows, int H, const float* g, const float* bta,
+                                               float eps, half_t* xs, int ld, float* stats, int tid) {
+    const int hw = tid >> 5, l32 = tid & 31, nch = H >> 3;
+    h8 raw[NR][4];
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+        const int r = hw + rd * (kSqThreads / 32);
+        if (r < nrows) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (l32 + 32 * i < nch) raw[rd][i] = sq_ld8(src, ((r0 + r) * H + (l32 + 32 * i) * 8) * 2);
+        }
+    }
+    // statistics per row (the opaque copies keep the compiler from holding a second, fp32 copy of the rows: this code runs
+    // next to the registers of prefetched weights), then chunk by chunk: gamma / beta once, applied to every round's row
+    float mean[NR], rstd[NR];
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+        mean[rd] = 0.f; rstd[rd] = 1.f;
+        const int r = hw + rd * (kSqThreads / 32);
+        if (g && r < nrows) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (l32 + 32 * i < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum += (float)raw[rd][i][e];
+                }
+            mean[rd] = half_wave_sum(sum) / H;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                i4v bits = __builtin_bit_cast(i4v, raw[rd][i]);
+                asm volatile("" : "+v"(bits));
+                raw[rd][i] = __builtin_bit_cast(h8, bits);
+                if (l32 + 32 * i < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = (float)raw[rd][i][e] - mean[rd]; q += d * d; }
+                }
+            }
+            rstd[rd] = rsqrtf(half_wave_sum(q) / H + eps);
+            if (stats && l32 == 0) {
+                const float2 mr = {mean[rd], rstd[rd]};
+                __hip_atomic_store((unsigned long long*)(stats + 2 * (r0 + r)), __builtin_bit_cast(unsigned long long, mr),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l32 + 32 * i;
+        if (c < nch) {
+            float gg[8], bb[8];
+            if (g) {
+                const float4 g0 = *(const float4*)(g + c * 8), g1 = *(const float4*)(g + c * 8 + 4);
+                const float4 b0 = *(const float4*)(bta + c * 8), b1 = *(const float4*)(bta + c * 8 + 4);
+                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+                bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+            }
+#pragma unroll
+            for (int rd = 0; rd < NR; ++rd) {
+                const int r = hw + rd * (kSqThreads / 32);
+                if (r < nrows) {
+                    h8 o = raw[rd][i];
+                    if (g) {
+                        i4v bits = __builtin_bit_cast(i4v, raw[rd][i]);
+                        asm volatile("" : "+v"(bits));
+                        const h8 x = __builtin_bit_cast(h8, bits);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)x[e] - mean[rd]) * rstd[rd] * gg[e] + bb[e]);
+                    }
+                    *(h8*)(xs + r * ld + c * 8) = o;
+                }
+            }
+        }
+    }
+}
+
+// The residual of thread (row, columns c .. c + 3) of a P2 / P4 tile: the LayerNorm output the producing phase normalised,
+// recomputed from the pre-LayerNorm sum y and the published row statistics (or, in the first layer, the embedding rows x).
+struct SqRes { h4 y; float2 mr; float4 g, b; };
+__device__ __forceinline__ void sq_res_load(SqRes& r, bool ln, sq_rsrc_t src, int row, int H, int c, const float* stats,
+                                            const float* g, const float* bta) {
+    r.y = sq_ld4(src, (row * H + c) * 2);
+    r.mr = float2{0.f, 1.f};
+    r.g = float4{1.f, 1.f, 1.f, 1.f};
+    r.b = float4{0.f, 0.f, 0.f, 0.f};
+    if (ln) {
+        const unsigned long long v = __hip_atomic_load((const unsigned long long*)(stats + 2 * row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.mr = __builtin_bit_cast(float2, v);
+        r.g = *(const float4*)(g + c);
+        r.b = *(const float4*)(bta + c);
+    }
+}
+__device__ __forceinline__ void sq_res_value(const SqRes& r, bool ln, float (&out)[4]) {
+    const float gg[4] = {r.g.x, r.g.y, r.g.z, r.g.w}, bb[4] = {r.b.x, r.b.y, r.b.z, r.b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        out[e] = ln ? (float)(half_t)(((float)r.y[e] - r.mr.x) * r.mr.y * gg[e] + bb[e]) : (float)r.y[e];
+}
+
+// The weight operands of one 16-column tile for this wave: k-steps wid + 12 (c0 + u), u < CH (of 32 halves, < ksteps), of
+// rows n0 .. n0 + 15 of W starting at column k0.  Weights never change: these loads may be issued before the grid barrier.
+template <int CH>
+__device__ __forceinline__ void sq_tile_w(const half_t* W, int ldw, int k0, int ksteps, int n0, int c0, h8 (&bf)[CH], int tid) {
+    const int lane = tid & 63, wid = tid >> 6, r15 = lane & 15, kb = lane >> 4;
+    const half_t* wp = W + (long long)(n0 + r15) * ldw + k0 + kb * 8;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        const int s0 = wid + kSqWaves * (c0 + u);
+        const int s = s0 < ksteps ? s0 : (wid < ksteps ? wid : 0);   // clamped: always a valid address
+        bf[u] = *(const h8*)(wp + s * 32);
+    }
+}
+
+// One 16-column tile of C[16 MT][.] = A . W^T over k-steps [0, ksteps) of 32 starting at column k0 of both operands.  The
+// twelve waves take the k-steps round-robin, CH per wave and pass (bf: the first pass's weight operands, see sq_tile_w);
+// their fp32 tiles meet in `red` (six slots: waves 6..11 deposit, waves 0..5 add theirs on top), and thread t < 64 MT
+// returns the sums of row t >> 2, columns 4 (t & 3) .. + 3.  A comes from LDS (ALDS: xs, row stride lda) or through ra.
+template <int MT, int CH, bool ALDS>
+__device__ __forceinline__ void sq_tile(const half_t* A, sq_rsrc_t ra, int lda, const half_t* W, int ldw, int k0, int ksteps,
+                                        int n0, h8 (&bf)[CH], float (*red)[64][17], float (&sum)[4], int tid,
+                                        const SqParams& p, int ph) {
+    const int lane = tid & 63, wid = tid >> 6, r15 = lane & 15, kb = lane >> 4;
+    f4v acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    for (int c0 = 0; wid + kSqWaves * c0 < ksteps; c0 += CH) {
+        if (c0) sq_tile_w<CH>(W, ldw, k0, ksteps, n0, c0, bf, tid);
+        h8 af[CH][MT];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s0 = wid + kSqWaves * (c0 + u);
+            const int s = s0 < ksteps ? s0 : (wid < ksteps ? wid : 0);
+            const int off = r15 * lda + k0 + kb * 8 + s * 32;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                af[u][t] = ALDS ? *(const h8*)(A + off + t * 16 * lda) : sq_ld8(ra, (off + t * 16 * lda) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (wid + kSqWaves * (c0 + u) < ksteps) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][t], bf[u], acc[t], 0, 0, 0);
+            }
+    }
+    if (p.stamps && tid == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0])); sq_stamp(p, ph, 2); }   // diagnostics: this wave's MFMAs are done
+    if (wid >= kSqRedSlots) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) red[wid - kSqRedSlots][t * 16 + 4 * kb + reg][r15] = acc[t][reg];
+    }
+    sq_lds_sync();
+    if (wid < kSqRedSlots) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) red[wid][t * 16 + 4 * kb + reg][r15] += acc[t][reg];
+    }
+    sq_lds_sync();
+    const int row = tid >> 2, c0 = (tid & 3) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum[e] = 0.f;
+    if (row < MT * 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int w = 0; w < kSqRedSlots; ++w) sum[e] += red[w][row][c0 + e];
+    }
+    if (p.stamps && tid == 0) { asm volatile("s_nop 0" :: "v"(sum[0])); sq_stamp(p, ph, 3); }      // diagnostics: reduced
+}
+
+// P1's weight stream of one wave: eight k-steps of its 16 W rows starting at k-step s0
+__device__ __forceinline__ void sq_p1_w(const half_t* wrow, int s0, h8 (&w8)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w8[q] = *(const h8*)(wrow + (s0 + q) * 32);
+}
+template <int MTS>
+__device__ __forceinline__ void sq_p1_mma(const half_t* xs, int ld, int s0, const h8 (&w8)[8], f4v (&acc)[MTS], int tid) {
+    const int lane = tid & 63, r15 = lane & 15, kb = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int t = 0; t < MTS; ++t) {
+            const h8 af = *(const h8*)(xs + (16 * t + r15) * ld + kb * 8 + (s0 + q) * 32);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, w8[q], acc[t], 0, 0, 0);
+        }
+}
+
+// MTS: 16-row tiles of ONE sequence (T / 16), MTG: of the whole batch (B T / 16); NB: batches of eight k-steps of the QKV
+// weights a wave holds before P1's barrier wait (3: all of H = 768; later batches are fetched as registers free up)
+template <int MTS, int MTG, int NB>
+__global__ __launch_bounds__(kSqThreads) void k_sq_forward(SqParams p, int ph0, int ph1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const int H = p.H, F = p.F, T = MTS * 16, M = MTG * 16, ld = H + 8;
+    constexpr int CH4 = 16 / MTG;                                 // k-steps per wave and pass of the FFN-down product
+    float* mbias = (float*)smem;                                  // [64] key-padding bias of the sequence (0 / -inf)
+    half_t* xs = (half_t*)(smem + kSqHead);                       // [M][ld] normalised rows
+    float (*red)[64][17] = (float (*)[64][17])(smem + kSqHead + (size_t)M * ld * 2);
+    // P1's second life of the xs region
+    half_t* qs = xs;                      // [T][72]
+    half_t* ksm = qs + T * 72;            // [T][72]
+    half_t* vt = ksm + T * 72;            // [64][T + 8]
+    const sq_rsrc_t rx = sq_rsrc(p.x), ry = sq_rsrc(p.y), rctx = sq_rsrc(p.ctx), rhb = sq_rsrc(p.hbuf);
+    float* stats2 = p.stats;              // rows P1 normalised (the previous layer's second LayerNorm)
+    float* stats1 = p.stats + 128;        // rows P3 normalised (this layer's first LayerNorm)
+    unsigned done = 0;                    // barriers passed
+    // Every phase: arrive at the barrier that ends the previous one, THEN fetch this phase's first weights (they do not
+    // depend on it), then wait -- the weight stream's latency hides behind the slowest workgroup of the previous phase.
+    for (int l = ph0 >> 2; l <= (ph1 - 1) >> 2; ++l) {
+        // the lane coordinates are made opaque once per layer: otherwise every address of every phase is computed (LICM) before
+        // the loop and parked in scratch memory, to be fetched back on each phase's critical path
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), r15 = lane & 15, kb = lane >> 4;
+        const half_t* w = p.w16 + (long long)l * p.layer16;
+        const float* f = p.w32 + (long long)l * p.layer32;
+        const half_t *Wqkv = w, *Wo = Wqkv + (long long)3 * H * H, *W1 = Wo + (long long)H * H, *W2 = W1 + (long long)F * H;
+        const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F;
+        const float* gp = l ? f - p.layer32 + (3 * H + H + 2 * H + F + H) : nullptr;     // previous layer's g2 | b2n
+        if (4 * l >= ph0 && 4 * l < ph1) {
+            // ---- P1: LayerNorm on load, the head's Q K V, its attention
+            const int ph = 4 * l;
+            if (ph > ph0) ++done;
+            if (wg >= p.heads * p.B) {                 // nothing to do in this phase (its own branch: no half-defined registers)
+                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
+            } else {
+                h8 wq[NB][8];
+                const int part = wid >> 2, j = wid & 3, ks = H >> 5;       // ks: a multiple of 8
+                if (ph > ph0) sq_arrive(p);
+                {
+                    const half_t* wrow = Wqkv + (long long)(part * H + (wg % p.heads) * 64 + 16 * j + r15) * H + kb * 8;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) sq_p1_w(wrow, 8 * q < ks ? 8 * q : 0, wq[q]);
+                }
+                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
+                sq_stamp(p, ph, 0);
+                for (int u = wg; u < p.heads * p.B; u += nwg) {
+                    const int h = u % p.heads, b = u / p.heads;
+                    const int ncol = part * H + h * 64 + 16 * j + r15;
+                    const half_t* wrow = Wqkv + (long long)ncol * H + kb * 8;
+                    const float bias = bqkv[ncol];
+                    if (u != wg) {
+#pragma unroll
+                        for (int q = 0; q < NB; ++q) sq_p1_w(wrow, 8 * q < ks ? 8 * q : 0, wq[q]);
+                    }
+                    if (tid < T) mbias[tid] = p.mask[b * T + tid] ? 0.f : -INFINITY;
+                    sq_rows_to_lds<(MTS * 16 + 23) / 24>(l ? ry : rx, b * T, T, H, gp, gp ? gp + H : nullptr, p.eps, xs, ld,
+                                                         (l && h == 0) ? stats2 : nullptr, tid);
+                    sq_lds_sync();
+                    sq_stamp(p, ph, 2);
+                    f4v acc[MTS];
+#pragma unroll
+                    for (int t = 0; t < MTS; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+                    // batches 0 .. NB-1 are in registers; a register set is refilled with batch s + NB as soon as it has been used
+                    for (int s0 = 0; s0 < ks; s0 += 8 * NB) {
+#pragma unroll
+                        for (int q = 0; q < NB; ++q) {
+                            if (s0 + 8 * q < ks) sq_p1_mma<MTS>(xs, ld, s0 + 8 * q, wq[q], acc, tid);
+                            if (s0 + 8 * (q + NB) < ks) sq_p1_w(wrow, s0 + 8 * (q + NB), wq[q]);
+                        }
+                    }
+                    sq_lds_sync();                     // xs is dead: Q, K, V^T take its place
+                    sq_stamp(p, ph, 3);
+#pragma unroll
+                    for (int t = 0; t < MTS; ++t) {
+                        if (part == 2) {
+                            h4 o;
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) o[reg] = (half_t)(acc[t][reg] + bias);
+                            *(h4*)(vt + (16 * j + r15) * (T + 8) + 16 * t + 4 * kb) = o;
+                        } else {
+                            half_t* dst = part == 0 ? qs : ksm;
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) dst[(16 * t + 4 * kb + reg) * 72 + 16 * j + r15] = (half_t)(acc[t][reg] + bias);
+                        }
+                    }
+                    sq_lds_sync();
+                    if (wid < MTS) {
+                        const int i = wid;                 // query tile
+                        f4v st[MTS];
+#pragma unroll
+                        for (int jt = 0; jt < MTS; ++jt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) st[jt][e] = 0.f;
+#pragma unroll
+                            for (int k2 = 0; k2 < 2; ++k2) {
+                                const h8 a = *(const h8*)(ksm + (16 * jt + r15) * 72 + kb * 8 + 32 * k2);
+                                const h8 bq = *(const h8*)(qs + (16 * i + r15) * 72 + kb * 8 + 32 * k2);
+                                st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, st[jt], 0, 0, 0);
+                            }
+                        }
+                        // st[jt][reg]: key 16 jt + 4 kb + reg, query 16 i + r15
+                        const float sc = p.q_folded ? 1.f : 0.125f * 1.4426950408889634f;
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int jt = 0; jt < MTS; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                st[jt][reg] = st[jt][reg] * sc + mbias[16 * jt + 4 * kb + reg];
+                                mx = fmaxf(mx, st[jt][reg]);
+                            }
+                        mx = fmaxf(mx, __shfl_xor(mx, 16));
+                        mx = fmaxf(mx, __shfl_xor(mx, 32));
+                        if (mx == -INFINITY) mx = 0.f;     // no valid key: every weight is exp2(-inf) = 0
+                        float lsum = 0.f;
+                        h8 ph8[MTS / 2];
+#pragma unroll
+                        for (int jt = 0; jt < MTS; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                const half_t hp = (half_t)__builtin_amdgcn_exp2f(st[jt][reg] - mx);
+                                lsum += (float)hp;         // the sum of the weights the product really uses
+                                ph8[jt >> 1][(jt & 1) * 4 + reg] = hp;
+                            }
+                        lsum += __shfl_xor(lsum, 16);
+                        lsum += __shfl_xor(lsum, 32);
+                        f4v o[4];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[n][e] = 0.f;
+#pragma unroll
+                            for (int s2 = 0; s2 < MTS / 2; ++s2) {
+                                const h4 v0 = *(const h4*)(vt + (16 * n + r15) * (T + 8) + 32 * s2 + 4 * kb);
+                                const h4 v1 = *(const h4*)(vt + (16 * n + r15) * (T + 8) + 32 * s2 + 16 + 4 * kb);
+                                const h8 bv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph8[s2], bv, o[n], 0, 0, 0);
+                            }
+                        }
+                        // o[n][reg]: query 16 i + 4 kb + reg, column 16 n + r15; that query's sum lives in lane 4 kb + reg.
+                        // The tile goes through a wave-private 16 x 72 LDS image so that it leaves as 16-byte write-through stores.
+                        half_t* ot = (half_t*)red + i * (16 * 72);
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const float lq = __shfl(lsum, 4 * kb + reg);
+                            const float inv = lq > 0.f ? 1.f / lq : 0.f;
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) ot[(4 * kb + reg) * 72 + 16 * n + r15] = (half_t)(o[n][reg] * inv);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int rr = q * 8 + (lane >> 3), cc = (lane & 7) * 8;
+                            sq_st8(rctx, ((b * T + 16 * i + rr) * H + h * 64 + cc) * 2, *(const h8*)(ot + rr * 72 + cc));
+                        }
+                    }
+                    sq_lds_sync();                     // before the next unit rewrites the LDS image
+                }
+                sq_stamp(p, ph, 1);
+            }
+        }
+        if (4 * l + 1 >= ph0 && 4 * l + 1 < ph1) {
+            // ---- P2: attention output projection + bias + residual -> y
+            const int ph = 4 * l + 1;
+            if (ph > ph0) ++done;
+            if (wg >= H / 16) {
+                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
+            } else {
+                h8 bf[3];
+                if (ph > ph0) sq_arrive(p);
+                sq_tile_w<3>(Wo, H, 0, H >> 5, wg * 16, 0, bf, tid);
+                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
+                sq_stamp(p, ph, 0);
+                for (int tile = wg; tile < H / 16; tile += nwg) {
+                    const int n0 = tile * 16, row = tid >> 2, c0 = (tid & 3) * 4;
+                    const bool has_row = row < M;
+                    SqRes rs;
+                    float4 bpre = {0.f, 0.f, 0.f, 0.f};
+                    if (has_row) { sq_res_load(rs, l != 0, l ? ry : rx, row, H, n0 + c0, stats2, gp, gp ? gp + H : nullptr); bpre = *(const float4*)(bo + n0 + c0); }
+                    if (tile != wg) sq_tile_w<3>(Wo, H, 0, H >> 5, n0, 0, bf, tid);
+                    float sum[4];
+                    sq_tile<MTG, 3, false>(nullptr, rctx, H, Wo, H, 0, H >> 5, n0, bf, red, sum, tid, p, ph);
+                    if (has_row) {
+                        const float bb[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
+                        float res[4];
+                        sq_res_value(rs, l != 0, res);
+                        h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (half_t)(sum[e] + bb[e] + res[e]);
+                        sq_st4(ry, (row * H + n0 + c0) * 2, o);
+                    }
+                    sq_lds_sync();
+                }
+                sq_stamp(p, ph, 1);
+            }
+        }
+        if (4 * l + 2 >= ph0 && 4 * l + 2 < ph1) {
+            // ---- P3: LayerNorm(y) on load, FFN up + GELU -> hbuf; workgroup 0 publishes the row statistics (P4's residual)
+            const int ph = 4 * l + 2;
+            if (ph > ph0) ++done;
+            if (wg >= F / 16) {
+                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
+            } else {
+                h8 bf[3];
+                if (ph > ph0) sq_arrive(p);
+                sq_tile_w<3>(W1, H, 0, H >> 5, wg * 16, 0, bf, tid);
+                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
+                sq_stamp(p, ph, 0);
+                bool loaded = false;
+                for (int tile = wg; tile < F / 16; tile += nwg) {
+                    const int n0 = tile * 16, row = tid >> 2, c0 = (tid & 3) * 4;
+                    const bool has_row = row < M;
+                    float4 bpre = {0.f, 0.f, 0.f, 0.f};
+                    if (has_row) bpre = *(const float4*)(b1 + n0 + c0);
+                    if (tile != wg) sq_tile_w<3>(W1, H, 0, H >> 5, n0, 0, bf, tid);
+                    if (!loaded) {
+                        sq_rows_to_lds<(MTG * 16 + 23) / 24>(ry, 0, M, H, g1, b1n, p.eps, xs, ld, wg == 0 ? stats1 : nullptr, tid);
+                        sq_lds_sync();
+                        loaded = true;
+                    }
+                    float sum[4];
+                    sq_tile<MTG, 3, true>(xs, ry, ld, W1, H, 0, H >> 5, n0, bf, red, sum, tid, p, ph);
+                    if (has_row) {
+                        const float bb[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
+                        h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (half_t)gelu_erf(sum[e] + bb[e]);
+                        sq_st4(rhb, (row * F + n0 + c0) * 2, o);
+                    }
+                    sq_lds_sync();
+                }
+                sq_stamp(p, ph, 1);
+            }
+        }
+        if (4 * l + 3 >= ph0 && 4 * l + 3 < ph1) {
+            // ---- P4: FFN down + bias + residual -> y   (K = F: 16 / MTG k-steps per wave and pass)
+            const int ph = 4 * l + 3;
+            if (ph > ph0) ++done;
+            if (wg >= H / 16) {
+                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
+            } else {
+                h8 bf[CH4];
+                if (ph > ph0) sq_arrive(p);
+                sq_tile_w<CH4>(W2, F, 0, F >> 5, wg * 16, 0, bf, tid);
+                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
+                sq_stamp(p, ph, 0);
+                for (int tile = wg; tile < H / 16; tile += nwg) {
+                    const int n0 = tile * 16, row = tid >> 2, c0 = (tid & 3) * 4;
+                    const bool has_row = row < M;
+                    SqRes rs;
+                    float4 bpre = {0.f, 0.f, 0.f, 0.f};
+                    if (has_row) { sq_res_load(rs, true, ry, row, H, n0 + c0, stats1, g1, b1n); bpre = *(const float4*)(b2 + n0 + c0); }
+                    if (tile != wg) sq_tile_w<CH4>(W2, F, 0, F >> 5, n0, 0, bf, tid);
+                    float sum[4];
+                    sq_tile<MTG, CH4, false>(nullptr, rhb, F, W2, F, 0, F >> 5, n0, bf, red, sum, tid, p, ph);
+                    if (has_row) {
+                        const float bb[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
+                        float res[4];
+                        sq_res_value(rs, true, res);
+                        h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (half_t)(sum[e] + bb[e] + res[e]);
+                        sq_st4(ry, (row * H + n0 + c0) * 2, o);
+                    }
+                    sq_lds_sync();
+                }
+                sq_stamp(p, ph, 1);
+            }
+        }
     }
 }
 
@@ -2843,6 +3402,12 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<4, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2903,9 +3468,15 @@ struct vf_encoder {
     // split-K GEMM (forwards of <= kSplitMaxRows tokens): fp32 slabs [kSplitMax][kSplitMaxRows][max(3H, F)] + tile counters
     float* sk_part = nullptr;
     unsigned* sk_cnt = nullptr;
+    // persistent one-query forward (k_sq_forward): barrier words (+ the published row statistics, 256 bytes in) on the device,
+    // a host-mapped timeout flag
+    unsigned* sq_bar = nullptr;
+    unsigned *sq_flag_h = nullptr, *sq_flag_d = nullptr;
+    int sq_grid = 0;
+    bool sq_ok = false;
     // Small forwards (one query string: faissRetriever.py:33) are ~90 dependent launches of a few microseconds each and
     // run host-bound when launched one by one: they are captured once per shape into a hipGraph and replayed.
-    struct GraphKey { int B, T, Tv, tt, pooling, normalize; bool operator==(const GraphKey& o) const { return B == o.B && T == o.T && Tv == o.Tv && tt == o.tt && pooling == o.pooling && normalize == o.normalize; } };
+    struct GraphKey { int B, T, Tv, tt, pooling, normalize, sq; bool operator==(const GraphKey& o) const { return B == o.B && T == o.T && Tv == o.Tv && tt == o.tt && pooling == o.pooling && normalize == o.normalize && sq == o.sq; } };
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     hipStream_t gstream = nullptr;
@@ -2959,6 +3530,8 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     if (e->d_flag) (void)hipFree(e->d_flag);
     if (e->sk_part) (void)hipFree(e->sk_part);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
+    if (e->sq_bar) (void)hipFree(e->sq_bar);
+    if (e->sq_flag_h) (void)hipHostFree(e->sq_flag_h);
     delete e;
     return VF_OK;
 }
@@ -3002,10 +3575,26 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
         if (er == hipSuccess) er = hipMalloc((void**)&e->sk_cnt, 4096 * sizeof(unsigned));
         if (er == hipSuccess) er = hipMemset(e->sk_cnt, 0, 4096 * sizeof(unsigned));
     }
+    if (er == hipSuccess) er = hipMalloc((void**)&e->sq_bar, 4096);
+    if (er == hipSuccess) er = hipMemset(e->sq_bar, 0, 4096);
+    if (er == hipSuccess) er = hipHostMalloc((void**)&e->sq_flag_h, sizeof(unsigned), hipHostMallocMapped);
+    if (er == hipSuccess) { *e->sq_flag_h = 0u; er = hipHostGetDevicePointer((void**)&e->sq_flag_d, e->sq_flag_h, 0); }
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = configure_once();
     e->q_folded = getenv("VF_ATT_V1") == nullptr;   // A/B switch: the first-generation kernel scales Q itself
+    if (er == hipSuccess && c.hidden % 256 == 0 && c.ffn % 256 == 0) {
+        // persistent one-query forward: every workgroup must be resident (grid <= CUs, one workgroup per CU fits)
+        int cus = 0, nb = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 0;
+        const int grid = cus < 256 ? cus : 256;
+        const size_t lds = kSqHead + (size_t)64 * (c.hidden + 8) * 2 + sizeof(float) * kSqRedSlots * 64 * 17;
+        if (grid >= 1 && lds <= 160 * 1024 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_sq_forward<4, 4, 3>, kSqThreads, lds) == hipSuccess && nb >= 1) {
+            e->sq_ok = true; e->sq_grid = grid;
+        }
+        (void)hipGetLastError();
+    }
     if (er == hipSuccess && e->q_folded) {
         const float qs = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(64)
         for (int l = 0; l < c.layers; ++l) {
@@ -3198,6 +3787,17 @@ static hipError_t gemm_skinny(const half_t* A, const half_t* W, const float* bia
     return hipGetLastError();
 }
 
+// The persistent one-query forward is an EXPERIMENT, off by default: measured on MI355X it is slower than the launch-per-product
+// path (BERT-base shape, 32 tokens: 0.65-0.71 vs 0.59 ms) -- a hand-off between workgroups costs more
+// than the kernel boundary it replaces.  VF_SQ_FUSED=1 (persistent) / VF_SQ_PHASES=1 (its phases as separate launches) in
+// the environment, or vf_debug_sq_mode(mode) at run time (returns the previous mode).
+static std::atomic<int> g_sq_mode{getenv("VF_SQ_FUSED") ? 1 : getenv("VF_SQ_PHASES") ? 2 : 0};
+// Diagnostics: a device buffer of [4 layers][grid][2] 64-bit words that receives every workgroup's phase begin / end clocks
+// (s_memrealtime, 100 MHz); nullptr switches the stamps off.  Captured graphs keep the pointer they were captured with.
+static std::atomic<unsigned long long*> g_sq_stamps{nullptr};
+extern "C" void vf_debug_sq_stamps(void* buf) { g_sq_stamps.store((unsigned long long*)buf); }
+extern "C" int vf_debug_sq_mode(int mode) { return mode >= 0 && mode <= 2 ? g_sq_mode.exchange(mode) : g_sq_mode.load(); }
+
 // ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
 // seq_off != nullptr: PACKED rows (forward_impl's ragged-batch path) -- Mpk rows in all, sequence b in rows
 // [seq_off[b], seq_off[b + 1]), T = the longest; ids / mask / position ids are already packed on the device.
@@ -3210,10 +3810,43 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     const bool small = !no_splitk && Ms <= kSplitMaxRows && H % 64 == 0 && F % 64 == 0;
     static const bool no_skinny = getenv("VF_NO_SKINNY") != nullptr;  // A/B switch
     const bool skinny = !no_skinny && M <= 64 && H % 256 == 0 && F % 256 == 0;   // one short sequence: weight-streaming GEMMs
+    // one short query (or two): all layers in ONE persistent launch (k_sq_forward)
+    const int sq_mode = g_sq_mode.load(std::memory_order_relaxed);   // 0 off, 1 persistent, 2 one launch per phase (no grid barrier)
+    const bool sq_phases = sq_mode == 2;
+    const bool sq = skinny && sq_mode != 0 && e->sq_ok && !seq_off && (T == 32 || T == 64);
     if (!seq_off) hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
-                       c.ln_eps, M, H, e->x);
+                       c.ln_eps, M, H, e->x, sq ? e->sq_bar : nullptr);
+    if (sq) {
+        SqParams p{};
+        p.w16 = e->w16 + e->o_layers; p.w32 = e->w32 + e->f_layers;
+        p.layer16 = (long long)e->layer16; p.layer32 = (long long)e->layer32;
+        p.H = H; p.F = F; p.heads = c.heads; p.layers = c.layers; p.B = B; p.T = T;
+        p.eps = c.ln_eps; p.q_folded = e->q_folded ? 1 : 0;
+        p.mask = e->d_mask; p.x = e->x; p.y = e->y; p.ctx = e->ctx; p.hbuf = e->hbuf;
+        p.stats = (float*)(e->sq_bar + 64); p.bar = e->sq_bar; p.timeout = e->sq_flag_d;
+        p.stamps = g_sq_stamps.load(std::memory_order_relaxed);
+        static const int nsleep = getenv("VF_SQ_SLEEP") ? atoi(getenv("VF_SQ_SLEEP")) : 1;
+        p.nsleep = nsleep;
+        const size_t lds = kSqHead + (size_t)M * (H + 8) * 2 + sizeof(float) * kSqRedSlots * 64 * 17;
+        const int nph = 4 * c.layers;
+        for (int ph = 0; ph < nph; ph = sq_phases ? ph + 1 : nph) {
+            const int pe = sq_phases ? ph + 1 : nph;
+            const dim3 grid(e->sq_grid), block(kSqThreads);
+            if (H >= 768) {      // a wave holds 24 k-steps of its QKV weight rows across the barrier
+                if (T == 64) hipLaunchKernelGGL((k_sq_forward<4, 4, 3>), grid, block, lds, st, p, ph, pe);
+                else if (B == 2) hipLaunchKernelGGL((k_sq_forward<2, 4, 3>), grid, block, lds, st, p, ph, pe);
+                else hipLaunchKernelGGL((k_sq_forward<2, 2, 3>), grid, block, lds, st, p, ph, pe);
+            } else {
+                if (T == 64) hipLaunchKernelGGL((k_sq_forward<4, 4, 1>), grid, block, lds, st, p, ph, pe);
+                else if (B == 2) hipLaunchKernelGGL((k_sq_forward<2, 4, 1>), grid, block, lds, st, p, ph, pe);
+                else hipLaunchKernelGGL((k_sq_forward<2, 2, 1>), grid, block, lds, st, p, ph, pe);
+            }
+        }
+        const float* fl = e->w32 + e->f_layers + (size_t)(c.layers - 1) * e->layer32;
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, fl + 7 * H + F, fl + 8 * H + F, c.ln_eps, M, H, e->x);
+    }
     // V^T row stride: (T + pad) halves with (T + pad) / 2 == 2 (mod 64) -> conflict-free 8-byte reads
     // (rows must also be 16-byte aligned for the transposed staging writes -> multiple of 8 halves; a
     //  row stride of 4 (mod 64) dwords keeps the 8-byte reads of 32 lanes within a 2-way conflict)
@@ -3221,7 +3854,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     while ((((T + pad) / 2) & 63) != 4) pad += 8;
     const int vt_ld = T + pad;
     const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4 + 64;  // K, V^T, mask, tile states
-    for (int l = 0; l < c.layers; ++l) {
+    for (int l = 0; l < (sq ? 0 : c.layers); ++l) {
         const half_t* w = e->w16 + e->o_layers + (size_t)l * e->layer16;
         const float* f = e->w32 + e->f_layers + (size_t)l * e->layer32;
         const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
@@ -3274,6 +3907,16 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     return VF_OK;
 }
 
+// k_sq_forward's barrier gave up (a workgroup was not resident within its time limit): the output is not a forward's.
+// The persistent path is switched off for this handle; the caller gets an error and may simply call again.
+static int enc_check_sq(vf_encoder* e) {
+    if (!e->sq_flag_h || !*e->sq_flag_h) return VF_OK;
+    *e->sq_flag_h = 0u;
+    e->sq_ok = false;
+    enc_drop_graphs(e);
+    return fail(VF_EHIP, "k_sq_forward: grid barrier timed out; the persistent one-query path is now disabled for this handle");
+}
+
 static std::atomic<long long> g_packed_forwards{0};
 // Test hook: how many forwards took the packed (ragged-batch) path in this process.
 extern "C" long long vf_debug_packed_forwards() { return g_packed_forwards.load(std::memory_order_relaxed); }
@@ -3305,7 +3948,8 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     if (!no_graph && n <= 256 && e->cfg.pooling != 2) {   // (last-token pooling reads a flag back mid-forward: not capturable)
         if (!e->gstream) VFT_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
         hipStream_t gs = e->gstream;
-        const vf_encoder::GraphKey key{b, t, t_valid, type_ids != nullptr, e->cfg.pooling, e->cfg.normalize};
+        const vf_encoder::GraphKey key{b, t, t_valid, type_ids != nullptr, e->cfg.pooling, e->cfg.normalize,
+                                       e->sq_ok ? g_sq_mode.load(std::memory_order_relaxed) : 0};
         hipGraphExec_t exec = nullptr;
         for (auto& g : e->graphs) if (g.key == key) { exec = g.exec; break; }
         VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, gs));
@@ -3327,7 +3971,7 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
         VFT_HIP(hipGraphLaunch(exec, gs));
         VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, gs));
         VFT_HIP(hipStreamSynchronize(gs));
-        return VF_OK;
+        return enc_check_sq(e);
     }
     // Ragged batch (right-padded, CLS pooling or a classification head): the rows are PACKED -- every
     // sequence keeps ceil32(length) rows -- so the GEMMs, LayerNorms and attention only see the tokens that exist.  A row's
@@ -3387,7 +4031,7 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     if (rc != VF_OK) return rc;
     VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
     VFT_HIP(hipStreamSynchronize(nullptr));
-    return VF_OK;
+    return enc_check_sq(e);
 }
 
 extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
@@ -3433,7 +4077,7 @@ extern "C" int vf_encoder_forward_hidden(vf_encoder* e, const int32_t* ids, cons
     hipLaunchKernelGGL(k_to_f32, dim3(1024), dim3(256), 0, nullptr, e->x, tot, e->d_hidden);
     VFT_HIP(hipMemcpyAsync(out_hidden, e->d_hidden, (size_t)tot * 4, hipMemcpyDeviceToHost, nullptr));
     VFT_HIP(hipStreamSynchronize(nullptr));
-    return VF_OK;
+    return enc_check_sq(e);
 }
 
 extern "C" int vf_encoder_info(vf_encoder* e, vf_encoder_config* out) {
