@@ -335,6 +335,24 @@ def main():
         if rank == 0:
             print(f"verify ok: bucket of {E} batches through all-gather + merge", file=sys.stderr)
     index.set_option("profile", 0)
+    # The boundary the reference binds (FaissRetriever.invoke -> vf_index_search) takes HOST buffers: the same batches with the
+    # queries copied in and the results copied out over PCIe, one call at a time (no overlap between calls).  Reported beside
+    # `value`, never as it.
+    host_entry = None
+    if world == 1 and not devs and rank == 0:
+        try:
+            qh = [q.cpu().numpy() for q in qpool]
+            index.search(qh[0], args.k)
+            n_h = max(3, min(args.steps, 20))
+            th = time.perf_counter()
+            for i in range(n_h):
+                index.search(qh[i % len(qh)], args.k)
+            dt = (time.perf_counter() - th) / n_h
+            host_entry = {"ms_per_batch": round(dt * 1e3, 4), "queries_per_s": round(args.batch / dt, 1), "calls": n_h,
+                          "what": "vf_index_search: host fp32 queries in, host ids + scores out, calls back to back (PCIe copies "
+                                  "and a stream synchronise inside every call)"}
+        except Exception as e:  # noqa: BLE001
+            host_entry = {"error": f"{type(e).__name__}: {e}"}
     # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
     rr_ms, rr_info, emb_info, rr_large, lat_info = (None, None, None, None, None)
     if rank == 0 and not args.no_rerank:
@@ -427,6 +445,7 @@ def main():
             "rerank_large": rr_large,
             "embed": emb_info,
             "request_latency": lat_info,
+            "host_entry": host_entry,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
