@@ -87,7 +87,7 @@ struct Slot {
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
     DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
-    DevBuf dbg, wgbase, tilecnt;
+    DevBuf dbg, wgbase, tilecnt, sib;
     int64_t wgbase_n = -1; int wgbase_grid = -1;
     DevBuf dense_s, cn_tmp, parts_ids, parts_sc, run_ids, run_sc, qsel; // exact-path scratch
     int* h_flags = nullptr;      // pinned, [max batches * 64]
@@ -136,7 +136,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1;  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
+            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1;   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
@@ -478,6 +478,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
     else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
+    else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
     else return fail(VF_EINVAL, "vf_index_set_option: unknown option " + s);
@@ -646,6 +647,11 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     VF_HIP(launch_sel0(a, qtot, st));
     for (int o = 0; o < kSlots; ++o)
         if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
+    if (J > 1 && ix->wide_sync >= 0) {   // sibling progress words of the main pass (see k_scan_wide)
+        VF_TRY(s.sib.ensure((size_t)RG * 4 * sizeof(u32)));
+        VF_HIP(hipMemsetAsync(s.sib.p, 0, (size_t)RG * 4 * sizeof(u32), st));
+        a.sib = s.sib.as<u32>(); a.sib_slack = (int)ix->wide_sync;
+    }
     if (timed) VF_HIP(hipEventRecord(s.ev_t[0], st));
     VF_HIP(launch_scan_wide(a, kModeMain, f8, st));
     VF_HIP(hipEventRecord(s.ev_scan, st));

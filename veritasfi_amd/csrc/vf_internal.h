@@ -57,6 +57,8 @@ struct ScanArgs {
     int scan_grid;           // workgroups of the main scan (k_sel0 resets that many counters)
     // wide scan (k_scan_wide): queries in the global image, 256-query tiles per pass, row groups
     int qn_total, jtiles, rgroups;
+    u32* sib;                // [rgroups][4] super-tiles finished by each query-tile workgroup of a row group (zeroed per launch), or null
+    int sib_slack;           // a workgroup starts super-tile t + 1 once every sibling has finished t - sib_slack
     unsigned long long* dbg; // optional [grid][8 waves][4] wall-clock stamps (debug bit 7), else null
     int debug;               // bit 0: timing experiment -- seed tau so that nothing passes (results invalid)
 };

@@ -1406,6 +1406,7 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
         kc = kc + 1 == NCH ? 0 : kc + 1;                                      \
     } while (0)
     long long myrow[kWideM], nxrow[kWideM];
+    bool sib_on = J > 1;
     rows_of(0, myrow);
     wide_issue_a<F8>(A0, a.rows, a.row_bytes, myrow, 0, h);
     VF_ISSUE_B(0);
@@ -1461,6 +1462,27 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
                 for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
         }
         if (MODE == kModeMain) {
+            // The J workgroups that scan the same rows (one XCD, dispatch permitting) read them once from HBM only while they
+            // stay within an L2's reach of each other (8 row groups x 256 KB per super-tile against 4 MB): left alone they
+            // drift and the shard was read 1.33 times.  Each publishes the super-tiles it has finished and waits (bounded --
+            // this is a speed hint, never a correctness condition; a workgroup whose siblings are not resident stops waiting)
+            // until the slowest sibling is at most sib_slack behind.
+            if (a.sib && tid == 0 && sib_on) {
+                u32* pr = a.sib + rg * 4;
+                __hip_atomic_store(pr + jt, (u32)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 need = (u32)(st + 1) > (u32)a.sib_slack ? (u32)(st + 1) - (u32)a.sib_slack : 0u;
+                int spins = 0;
+                for (;;) {
+                    u32 m = 0xffffffffu;
+                    for (int j = 0; j < J; ++j) {
+                        const u32 v = __hip_atomic_load(pr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        m = v < m ? v : m;
+                    }
+                    if (m >= need) break;
+                    if (++spins > 512) { sib_on = false; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
             __syncthreads();
             if (*(const u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
         }
