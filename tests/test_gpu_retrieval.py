@@ -752,6 +752,10 @@ def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
     try:
         got_i, got_s = ix.search(q, k)
         st = ix.stats()
+        ix.set_option("wide_sync", 0)                       # sibling workgroups in lock-step (a speed hint): identical answer
+        sync_i, sync_s = ix.search(q, k)
+        assert np.array_equal(sync_i, got_i) and np.array_equal(_bits(sync_s), _bits(got_s))
+        ix.set_option("wide_sync", -1)
         ix.set_option("wide", 0)                            # the 64-query passes on the same handle: identical answer
         ref_i, ref_s = ix.search(q[:70], k)
     finally:

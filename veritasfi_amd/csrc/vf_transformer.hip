@@ -2964,6 +2964,193 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_attention_stream2<CAUSAL>: k_attention_stream at head dim 128 with the operand path of k_attention2 -- K and V tiles
+// go global -> LDS VERBATIM by LDS-DMA (no register staging, no 8 x 8 register transposes by the first two waves, 48
+// fewer live registers), 256-byte rows whose 16-byte chunks are XOR-swizzled through the SOURCE addresses of the DMA
+// lanes: K chunk c of row r sits at c ^ (r & 15) (a ds_read_b128 lane group = 16 rows at one logical chunk -> 16 distinct
+// slots), V chunk c at c ^ ((r & 3) << 2) (a transposing read's 32-lane half covers 4 keys x 64 B -> 4 distinct 64-byte
+// groups).  V^T fragments come from ds_read_b64_tr_b16 (a2_tr_read) in the key order the score tiles already have.
+// Everything else (tile loop, one barrier per 64-key tile, online softmax, causal / padding masks, packed rows) is
+// k_attention_stream's.
+// ------------------------------------------------------------------------------------------------
+struct AttnStream2Lds {
+    char k[2][SKT * 256];
+    char v[2][SKT * 256];
+    float mb[2][SKT];
+    int padded[2];
+};
+__device__ __forceinline__ int s2_koff(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
+__device__ __forceinline__ int s2_voff(int row, int ch) { return row * 256 + ((ch ^ ((row & 3) << 2)) << 4); }
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
+                                                            int ld, int heads, int kv_heads, float scale,
+                                                            half_t* __restrict__ ctx, int ctx_ld, const int* __restrict__ seq_off = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AttnStream2Lds& L = *reinterpret_cast<AttnStream2Lds*>(smem);
+    constexpr int DH = 128, KS = DH / 16, MT = DH / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int hk = hd / (heads / kv_heads);
+    const long long row0 = seq_off ? (long long)seq_off[b] : (long long)b * Targ;
+    const int T = seq_off ? seq_off[b + 1] - seq_off[b] : Targ;
+    if (qb * 128 >= T) return;
+    const int q_dim = heads * DH, kv_dim = kv_heads * DH;
+    const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
+    const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
+    const int q0 = qb * 128 + wid * 32;
+    const bool wave_active = q0 < T;
+    const int last_q = (qb * 128 + 127 < T - 1) ? qb * 128 + 127 : T - 1;
+    const int ntiles = CAUSAL ? (last_q / SKT + 1) : (T + SKT - 1) / SKT;
+    // ---- staging: a tile of K (and of V) is 1024 chunks of 16 B; DMA round j of thread t fills physical chunk t + 256 j
+    //      = row (t >> 4) + 16 j, slot t & 15, with the LOGICAL chunk that the swizzle puts there (tile-invariant: a tile is 64 rows)
+    const int srow = tid >> 4, slot = tid & 15;
+    const int klc = slot ^ (srow & 15), vlc = slot ^ ((srow & 3) << 2);      // (rows 16 j apart share row & 15 and row & 3)
+    float rmb = 0.f;
+    auto stage = [&](int tile, int buf) {
+        const int kt = tile * SKT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = kt + srow + 16 * j < T ? kt + srow + 16 * j : T - 1;
+            a2_dma16(Kg + (long long)key * ld + klc * 8, L.k[buf] + (64 * wid + 256 * j) * 16);
+            a2_dma16(Vg + (long long)key * ld + vlc * 8, L.v[buf] + (64 * wid + 256 * j) * 16);
+        }
+        if (tid < SKT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
+    };
+    auto stash_mask = [&](int buf) {
+        if (tid < SKT) {   // (wave 0 exactly)
+            L.mb[buf][tid] = rmb;
+            const bool any = __ballot(rmb != 0.f) != 0ull;
+            if (tid == 0) L.padded[buf] = any ? 1 : 0;
+        }
+    };
+    h8 qf[KS];
+    {
+        const int qrow = q0 + r31 < T ? q0 + r31 : T - 1;
+        const half_t* Qg = qkv + (row0 + qrow) * ld + hd * DH + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            h8 v = *(const h8*)(Qg + ks * 16);
+            if (scale > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
+            }
+            qf[ks] = v;
+        }
+    }
+    f16v o[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float LOG2E = scale > 0.f ? 1.4426950408889634f : 1.0f;
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;     // transposing-read coordinates (a2_read_v)
+    stage(0, 0);
+    stash_mask(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1, kt = tile * SKT;
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);     // every wave left buffer buf ^ 1 before the last barrier
+        const bool visit = wave_active && (!CAUSAL || kt <= q0 + 31);
+        if (visit) {
+            const char* Kb = L.k[buf];
+            const char* Vb = L.v[buf];
+            f16v s[2];
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                f16v z;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff(sx * 32 + r31, h)), qf[0], z, 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks)
+                    s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff(sx * 32 + r31, 2 * ks + h)), qf[ks], s[sx], 0, 0, 0);
+            }
+            const bool diag = CAUSAL && (kt + SKT - 1 > q0);
+            if (L.padded[buf]) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) s[sx][reg] += L.mb[buf][sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+            }
+            if (diag) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int kl = sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        if (kt + kl > q0 + r31) s[sx][reg] = -30000.f;
+                    }
+            }
+            float tmax = -1e30f;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, s[sx][reg]);
+            {
+                float lo, hi;
+                halves(tmax, lo, hi);
+                tmax = fmaxf(lo, hi);
+            }
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const float mneg = -m_new * LOG2E;
+            float psum = 0.f;
+            h8 pf[4];
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[sx][reg], LOG2E, mneg));
+                    psum += p;
+                    pf[sx * 2 + (reg >> 3)][reg & 7] = (half_t)p;
+                }
+            {
+                float lo, hi;
+                halves(psum, lo, hi);
+                psum = lo + hi;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+            // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h of 16-key group st <-> key 16 st + (j&3) + 8 (j>>2) + 4 h
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int key = 16 * st + 4 * h + vq, ch = 4 * mt + 2 * vg + (vp >> 1);
+                    h8 vf;
+                    a2_tr_read(vf, Vb + s2_voff(key, ch) + 8 * (vp & 1), Vb + s2_voff(key + 8, ch) + 8 * (vp & 1));
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
+                }
+        }
+        if (tile + 1 < ntiles) stash_mask(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of the next tile has landed
+        __syncthreads();
+    }
+    if (wave_active && q0 + r31 < T) {
+        const float inv = 1.0f / l_run;
+        half_t* dst = ctx + (row0 + q0 + r31) * ctx_ld + hd * DH;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
+                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooling / heads: one 256-thread block per sequence -> out[b, :]
 //   pooling 0 CLS (token 0), 1 unmasked mean over T (continuous_retrieval.py:148 quirk), 2 last
 //   token per last_token_pool (step3_mul.py:181-188: position T-1 if EVERY row's last mask bit is 1,
@@ -3422,6 +3609,7 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
     return er;
@@ -4288,8 +4476,13 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
             hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
                                t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else if (DH == 128) {
-            hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
-                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
+            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
+            if (stream_v1)
+                hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
+                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
+            else
+                hipLaunchKernelGGL((k_attention_stream2<true>), agrid, dim3(256), sizeof(AttnStream2Lds), st, d->qkv, d->d_mask,
+                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else {
             hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
                                t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
