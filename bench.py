@@ -165,6 +165,49 @@ def rerank_p50(args, shape=None):
                             "what": "same pairs count, right-padded ragged lengths: packed forward"}}
 
 
+def rerank_p50_sharded(args, device):
+    """N > 1: the same 100 pairs scored data-parallel -- every rank holds a replica and scores its contiguous block of the
+    pairs, ONE all-gather (RCCL) returns the 100 logits to every rank (veritasfi_amd.ShardedScorer).  Called by
+    ALL ranks; the time of an iteration is this rank's wall time from a barrier to the gathered result."""
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_rerank import random_encoder
+    from veritasfi_amd import ShardedScorer, shard_bounds
+    import torch
+    shape = args.rerank_shape
+    enc, cfg, err = None, None, None
+    try:
+        enc, cfg = random_encoder(shape, head=1, vocab=32000)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0 if enc is None else 1], dtype=torch.int32, device=device)   # a rank without a replica must not leave
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                                         # the others waiting in a collective
+    if int(ok.item()) == 0:
+        if enc is not None:
+            enc.close()
+        raise RuntimeError(err or "a rank could not create its re-ranker replica")
+    rng = np.random.default_rng(99)
+    ids = rng.integers(5, cfg["vocab"], size=(args.rerank_pairs, args.rerank_tokens)).astype(np.int32)
+    mask = np.ones_like(ids)
+    scorer = ShardedScorer(lambda lo, hi: enc.forward(ids[lo:hi], mask[lo:hi]).reshape(-1), device=device)
+    first = scorer(args.rerank_pairs)
+    ts = []
+    for _ in range(12):
+        dist.barrier(device_ids=[device.index])
+        t0 = time.perf_counter()
+        out = scorer(args.rerank_pairs)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    enc.close()
+    assert out.shape == (args.rerank_pairs,) and np.array_equal(out, first)
+    lo, hi = shard_bounds(args.rerank_pairs, dist.get_world_size(), dist.get_rank())
+    p50 = float(np.median(ts))
+    return p50, {"model_shape": shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens,
+                 "parallelism": f"dp{dist.get_world_size()}: a replica per GPU, pairs split in contiguous blocks, one all-gather of the logits",
+                 "pairs_on_rank0": hi - lo, "weights": "seeded random (no checkpoints offline)",
+                 "what": "median of 12 sharded calls on pre-tokenised ids, rank 0's wall time from a barrier to the gathered logits"}
+
+
 def embed_rate(args):
     """Chunk-embedding throughput of the embed loop (src/load_data.py:120-128,151: batches of 100 chunks) on a
     BERT-base-shaped embedder (bge-base: CLS + L2), 512-token chunks, seeded random weights: BASELINE configs[3]."""
@@ -355,7 +398,13 @@ def main():
             host_entry = {"error": f"{type(e).__name__}: {e}"}
     # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
     rr_ms, rr_info, emb_info, rr_large, lat_info = (None, None, None, None, None)
-    if rank == 0 and not args.no_rerank:
+    if world > 1 and not devs and not args.no_rerank:
+        # N > 1: the re-rank leg is the data-parallel form (all ranks take part); the single-GPU legs are reported by the N = 1 run
+        try:
+            rr_ms, rr_info = rerank_p50_sharded(args, device)
+        except Exception as e:  # noqa: BLE001
+            rr_info = {"error": f"{type(e).__name__}: {e}"}
+    elif rank == 0 and not args.no_rerank:
         try:
             rr_ms, rr_info = rerank_p50(args)
         except Exception as e:  # noqa: BLE001

@@ -631,6 +631,25 @@ for nq, k in ((7, 51), (64, 100)):          # nq * k odd: part strides are padde
     fi, fs = C.search(corpus, q, k)
     assert np.array_equal(ids.cpu().numpy(), fi), "ids differ from the unsharded oracle"
     assert np.array_equal(sc.cpu().numpy().view(np.uint32), fs.view(np.uint32)), "score bits differ"
+# data-parallel re-rank (ShardedScorer): each rank scores its block of the pairs with a real cross-encoder replica; the
+# gathered logits must be the unsharded forward's, bit for bit (a pair's logit does not depend on its batch)
+sys.path.insert(0, os.path.join(os.environ["VF_ROOT"], "tools"))
+from bench_rerank import random_encoder
+SH = dict(vocab=500, hidden=128, layers=2, heads=2, ffn=512, max_pos=130, type_vocab=1, roberta_pad_idx=1, pooling=0,
+          normalize=0, head=1, ln_eps=1e-5)
+from veritasfi_amd import _ffi
+import ctypes
+c = _ffi.EncoderConfig(**SH); n16 = _ffi.c_i64(0); n32 = _ffi.c_i64(0)
+_ffi.lib().vf_encoder_weight_sizes(ctypes.byref(c), ctypes.byref(n16), ctypes.byref(n32))
+wr = np.random.default_rng(3)
+enc = vf.HipEncoder(SH, (wr.standard_normal(n16.value, dtype=np.float32) * 0.05).astype(np.float16),
+                    wr.standard_normal(n32.value, dtype=np.float32) * 0.05 + 0.5)
+ids = np.random.default_rng(4).integers(5, 500, size=(11, 64)).astype(np.int32)
+mask = np.ones_like(ids); mask[3, 40:] = 0
+whole = enc.forward(ids, mask).reshape(-1)
+got = vf.ShardedScorer(lambda lo, hi: enc.forward(ids[lo:hi], mask[lo:hi]).reshape(-1))(11)
+enc.close()
+assert got.shape == (11,) and np.array_equal(got.view(np.uint32), whole.view(np.uint32)), (got, whole)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

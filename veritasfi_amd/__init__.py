@@ -15,13 +15,14 @@ Drop-in names (same signatures as the reference):
                                             ``reranker.compute_score`` (``src/utils/vllmManager.py:451``)
 * ``EnsembleRetriever``                  -- ``src/utils/ensembleRetriever.py:19-232`` (candidate gathering around the search)
 * ``ShardedRetriever``                   -- row-sharded multi-GPU search
+* ``ShardedScorer``                      -- data-parallel re-rank / embed: a replica per rank + one all-gather of the scores
 """
 from .index import (DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device,  # noqa: F401
                     merge_topk_packed_device, packed_part_bytes, packed_result_buffer)
 from .faiss_retriever import FaissRetriever  # noqa: F401
 from .retrieval import get_embeddings, last_token_pool, select_top_chunks, select_top_chunks_batch  # noqa: F401
 from .similarity import compute_similarity, compute_similarity_mtx, fuse_and_rank, time_scores  # noqa: F401
-from .sharded import ShardedRetriever, shard_bounds  # noqa: F401
+from .sharded import ShardedRetriever, ShardedScorer, shard_bounds  # noqa: F401
 from .encoder import (HipDecoder, HipDecoderEmbeddings, HipDecoderModel, HipEmbeddings, HipEncoder, HipLLMReranker, HipModel,  # noqa: F401
                       HipReranker, build_llm_reranker_inputs, pack_hf_decoder_weights, pack_hf_weights)
 from .rank import rank_chunk  # noqa: F401

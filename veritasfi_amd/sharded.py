@@ -86,3 +86,42 @@ class ShardedRetriever:
         self.dist.all_gather_into_tensor(all_ids, ids.contiguous(), group=self.group)
         self.dist.all_gather_into_tensor(all_sc, scores.contiguous(), group=self.group)
         return self.merge_fn(all_ids.view(self.world, nq, k), all_sc.view(self.world, nq, k), k)
+
+
+class ShardedScorer:
+    """Data-parallel re-ranking / embedding over the ranks of one node ("replicas only ... split the 100 pairs
+    across GPUs and all-gather 100 floats").  Every rank holds a replica of the model; rank r scores the contiguous block
+    ``shard_bounds(n, world, r)`` of the items and ONE all-gather returns all ``n x width`` values to every rank, in item
+    order.  ``score_fn(lo, hi) -> array [hi - lo] or [hi - lo, width]`` is the local model call (e.g.
+    ``lambda lo, hi: encoder.forward(ids[lo:hi], mask[lo:hi])``); it is not called for an empty block.
+
+    The reference scores its candidates on one device behind a lock (``src/utils/vllmManager.py:450-452``); this is the
+    multi-GPU form of that call, nothing else."""
+
+    def __init__(self, score_fn, group=None, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.score_fn = score_fn
+        self.device = device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def __call__(self, n: int, width: int = 1) -> np.ndarray:
+        import torch
+        lo, hi = shard_bounds(n, self.world, self.rank)
+        local = np.zeros((0, width), dtype=np.float32)
+        if hi > lo:
+            local = np.asarray(self.score_fn(lo, hi), dtype=np.float32).reshape(hi - lo, width)
+        if self.world == 1:
+            return local[:, 0] if width == 1 else local
+        per = -(-n // self.world)                        # every rank sends `per` rows (the last blocks are padded)
+        send = torch.zeros((per, width), dtype=torch.float32)
+        send[:hi - lo] = torch.from_numpy(local)
+        on_dev = self.device is not None and self.dist.get_backend(self.group) == "nccl"
+        if on_dev:
+            send = send.to(self.device)
+        out = torch.empty((self.world * per, width), dtype=torch.float32, device=send.device)
+        self.dist.all_gather_into_tensor(out, send, group=self.group)
+        res = out[:n].cpu().numpy()                      # block r starts at r * per: rank order is item order
+        return res[:, 0] if width == 1 else res
