@@ -398,7 +398,7 @@ def main():
             host_entry = {"error": f"{type(e).__name__}: {e}"}
     # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
     rr_ms, rr_info, emb_info, rr_large, lat_info = (None, None, None, None, None)
-    if world > 1 and not devs and not args.no_rerank:
+    if (world > 1 or (exchange and dist.is_initialized())) and not devs and not args.no_rerank:   # (the one-rank rehearsal takes it too)
         # N > 1: the re-rank leg is the data-parallel form (all ranks take part); the single-GPU legs are reported by the N = 1 run
         try:
             rr_ms, rr_info = rerank_p50_sharded(args, device)
