@@ -133,6 +133,51 @@ def test_one_query_persistent_forward(vf, hidden, layers, heads, ffn, b, t):
     assert np.abs(hid[1] - hid[0])[valid].max() < 2e-2
 
 
+def test_layernorm_in_the_tail_of_the_residual_products(vf):
+    """From 384 tiles up the o-proj / FFN-down products CAN carry their LayerNorm (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>: extra
+    workgroups of the same launch normalise finished row tiles, hand-off by write-through stores + an agent-scope counter;
+    an experiment, off by default -- it measured no faster).  Same arithmetic as the separate LayerNorm launch: the
+    embeddings and every hidden state must be bit-identical with the tail switched off, and match torch fp32; a second
+    shape (ragged, packed rows) restarts the counters."""
+    import ctypes, torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_ln_tail.restype = ctypes.c_longlong
+    L.vf_debug_ln_tail.argtypes = [ctypes.c_int]
+    model = _hf_bert(768, 2, 12, 3072)
+    rng = np.random.default_rng(21)
+    b, t = 64, 512                                           # 32768 rows: 128 x 3 = 384 tiles
+    ids, mask = _batch(rng, b, t, 1000, ragged=False)
+    enc = vf.HipEncoder.from_hf(model, pooling=0, normalize=True)
+    try:
+        L.vf_debug_ln_tail(1)
+        n0 = L.vf_debug_ln_tail(-1)
+        got = [enc.forward(ids, mask) for _ in range(3)]     # generations 1..12 of the counters
+        hid = enc.hidden_states(ids[:, :], mask)
+        fused_calls = L.vf_debug_ln_tail(-1) - n0
+        L.vf_debug_ln_tail(0)
+        ref = enc.forward(ids, mask)
+        ref_h = enc.hidden_states(ids, mask)
+        L.vf_debug_ln_tail(1)
+        # a different row count on the same handle (the counters restart), ragged: packed rows
+        ids2, mask2 = _batch(np.random.default_rng(22), 160, 512, 1000)
+        mask2[:, 400:] = 0
+        a = enc.forward(ids2, mask2)
+        L.vf_debug_ln_tail(0)
+        a_ref = enc.forward(ids2, mask2)
+    finally:
+        L.vf_debug_ln_tail(0)
+        enc.close()
+    assert fused_calls == 4 * 2 * 2, fused_calls             # 4 forwards x 2 layers x 2 products
+    for g in got:
+        assert np.array_equal(g, ref)
+    assert np.array_equal(hid, ref_h)
+    assert np.array_equal(a, a_ref)
+    with torch.no_grad():
+        want = model(input_ids=torch.from_numpy(ids[:4]), attention_mask=torch.from_numpy(mask[:4])).last_hidden_state.numpy()
+    assert np.abs(hid[:4] - want).max() < 4e-2
+
+
 def test_pooling_variants(vf):
     import torch
     from veritasfi_amd.retrieval import get_embeddings

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float*
 // reference runs those models in the checkpoint's wider dtype: experiments/retriever/step3_mul.py:62-64), only the
 // GEMM operands are fp16.
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 = 3,
-       EPI_GATED_SILU = 4, EPI_GATED_GELU = 5 };   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
+       EPI_GATED_SILU = 4, EPI_GATED_GELU = 5,
+       EPI_BIAS_RESIDUAL_LN = 6 };   // k_gemm8p_tn only: EPI_BIAS_RESIDUAL + the LayerNorm of finished row tiles in the same launch (LnTail)   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
 
 // exact-GELU x Phi(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2), with the complementary error function as
 // exp2 of a polynomial:  -log2 erfc(a / sqrt 2) = a (c1 + a (c2 + a (c3 + a (c4 + a c5)))), fitted on [0, 6] with the
@@ -1530,6 +1531,116 @@ __global__ __launch_bounds__(kSqThreads) void k_sq_forward(SqParams p, int ph0, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm in the tail of the residual product (EPI_BIAS_RESIDUAL_LN).  600 tiles on 256 CUs are 2.34 rounds of work in
+// 3: while the last round's 88 tiles run, 168 CUs idle -- and then a LayerNorm launch reads the sums back and writes the
+// rows again (2 x 29 us per layer).  Here the launch carries up to 256 EXTRA workgroups behind its tiles; the dispatcher
+// hands them to the CUs the partial round leaves free, and they normalise the row tiles whose N-tiles have all been stored:
+//   * a tile's workgroup stores its sums write-through (sc1), drains (s_waitcnt vmcnt(0), barrier) and counts itself in
+//     mdone[row tile] (agent-scope add; monotone over calls: generation gen of a row tile is complete at gen * Nt);
+//   * a worker claims units of 64 rows in the order the row tiles' last tiles are dispatched (`order`, built on the
+//     host from the tile map), polls mdone, reads the rows with sc1 loads (MI355X_MICROARCH.md hand-off table, first row),
+//     applies k_layernorm's arithmetic and marks the unit done (= gen);
+//   * every wait is bounded and nothing depends on dispatch order: a worker that times out simply leaves, and the clean-up
+//     launch k_layernorm_rest normalises whatever units are not marked (normally none: it costs one flag read per 8 rows).
+// The residual operand and the LayerNorm output are the SAME buffer (x): a row tile's x rows are rewritten only after all
+// tiles that read them as residual have finished.
+// ------------------------------------------------------------------------------------------------
+struct LnTail {
+    half_t* x;               // LayerNorm output [M][N]
+    const float* g;
+    const float* b;
+    float eps;
+    unsigned* mdone;         // [M / 256]
+    unsigned* next;          // [64] claim counters: slot gen % 64; this launch resets slot (gen + 1) % 64
+    unsigned* done;          // [M / 64]
+    const int* order;        // [M / 256]
+    unsigned gen;
+    int ntiles;              // workgroups of the product itself; blockIdx >= ntiles: workers
+    int nowait;              // timing experiment (results invalid): workers do not wait for their row tile
+};
+constexpr int kLnUnitRows = 64, kLnSpinLimit = 4096;
+
+// thread 0: claim the next unit and wait (bounded) for its row tile; returns the unit, or 0xffffffff when there is no more
+// work or the wait timed out (k_layernorm_rest then does what is left)
+__device__ __forceinline__ unsigned ln_tail_claim(const LnTail& lt, int nunits, int upt, unsigned target) {
+    const unsigned u = __hip_atomic_fetch_add(lt.next + (lt.gen & 63u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (u >= (unsigned)nunits) return 0xffffffffu;
+    const int mt = lt.order[u / upt];
+    int spins = 0;
+    while ((int)(__hip_atomic_load(lt.mdone + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > kLnSpinLimit) return 0xffffffffu;
+    }
+    return u;
+}
+
+__device__ __forceinline__ void ln_tail_worker(const LnTail& lt, const half_t* Y, int M, int N, char* smem) {
+    const int tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31, nch = N >> 3;
+    const int Nt = N / 256, upt = 256 / kLnUnitRows, nunits = (M / 256) * upt;
+    unsigned* s_unit = (unsigned*)smem;       // [2]: the unit being normalised / the next one (claimed while the rows load)
+    const sq_rsrc_t ry = sq_rsrc(Y);
+    const unsigned target = lt.nowait ? 0u : lt.gen * (unsigned)Nt;
+    if (tid == 0) s_unit[0] = ln_tail_claim(lt, nunits, upt, target);
+    __syncthreads();
+    for (int it = 0;; ++it) {
+        const unsigned u = s_unit[it & 1];
+        if (u == 0xffffffffu) return;
+        const long long row0 = (long long)lt.order[u / upt] * 256 + (u % upt) * kLnUnitRows;
+        // 16 half-waves x 4 rows, all 16 loads of a lane in flight; the next claim (an atomic and a poll) rides on their latency
+        h8 raw[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (l32 + 32 * i < nch) raw[r][i] = sq_ld8(ry, (int)(((row0 + 4 * hw + r) * N + (l32 + 32 * i) * 8) * 2));
+        if (tid == 0) s_unit[(it + 1) & 1] = ln_tail_claim(lt, nunits, upt, target);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[4][8];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (l32 + 32 * i < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[i][e] = (float)raw[r][i][e]; sum += v[i][e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+                }
+            }
+            ln_finish(v, sum, l32, nch, N, lt.g, lt.b, lt.eps, lt.x + (row0 + 4 * hw + r) * N);
+        }
+        if (tid == 0) lt.done[u] = lt.gen;                     // (read by the next launch: plain store)
+        __syncthreads();
+    }
+}
+
+// LayerNorm of the 64-row units the tail workers did not mark (done[unit] != gen); y -> x.  One workgroup per unit.
+__global__ __launch_bounds__(256) void k_layernorm_rest(const half_t* y, const float* g, const float* bta, float eps, int M,
+                                                         int H, half_t* x, const unsigned* done, unsigned gen) {
+    if (done[blockIdx.x] == gen) return;
+    const int l32 = threadIdx.x & 31, nch = H >> 3;
+    for (int row = blockIdx.x * kLnUnitRows + (threadIdx.x >> 5); row < (int)(blockIdx.x + 1) * kLnUnitRows && row < M; row += 8) {
+        const h8* src = (const h8*)(y + (long long)row * H);
+        float v[4][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = l32 + 32 * i;
+            if (c < nch) {
+                const h8 a = src[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e]; s += v[i][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+            }
+        }
+        ln_finish(v, s, l32, nch, H, g, bta, eps, x + (long long)row * H);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_gemm8p_tn: 256 x 256 x 64 tiles, 8 waves (2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles,
 // 128 accumulator VGPRs), ONE workgroup per CU, LDS-DMA staging with a counted vmcnt and raw barriers --
 // the "8-phase" schedule of the CDNA GEMM playbook, derived here for this operand layout:
@@ -1560,9 +1671,14 @@ constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLD
 template <int EPI>
 __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                           const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K) {
+                                                          half_t* __restrict__ C, int M, int N, int K, LnTail lt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: [2 K-tiles][4 half-tiles][16 KB] + dump
     const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) {
+        if ((int)blockIdx.x >= lt.ntiles) { ln_tail_worker(lt, C, M, N, smem); return; }
+        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(lt.next + ((lt.gen + 1u) & 63u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    constexpr bool RES16 = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
     int mt_idx, nt_idx;
@@ -1586,7 +1702,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
         const int bn0 = (i >> 5) * 64 + (i & 31), bn1 = bn0 + 32;
         src[0][j] = A + (m0 + am0) * K + lc * 8;
-        if (EPI >= EPI_GATED_SILU) {
+        if ((EPI == EPI_GATED_SILU || EPI == EPI_GATED_GELU)) {
             // gated product: the tile's 256 columns are 128 gate columns and the SAME 128 up columns, laid out so that a wave's
             // first 32 columns (half-tile B_n0) are gate rows and its second 32 (B_n1) the matching up rows of W
             const long long gr = (long long)nt_idx * 128 + (i >> 5) * 32 + (i & 31);
@@ -1713,7 +1829,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
             }
         return;
     }
-    if (EPI >= EPI_GATED_SILU) {
+    if ((EPI == EPI_GATED_SILU || EPI == EPI_GATED_GELU)) {
         // gated epilogue: out[row][32 wc + 16 ni + r15] = act(gate) * up with gate = acc[.][ni], up = acc[.][ni + 2] (ni = 0, 1),
         // fp32 throughout (the unfused path rounds both products to fp16 first); a [256][128] fp16 image, then 16-byte chunks
         half_t* Eg = (half_t*)smem;
@@ -1764,12 +1880,18 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
         h8 o = *(const h8*)(Es + row * PBN + cc * 8);
         const long long off = (m0 + row) * N + n0 + cc * 8;
-        if (EPI == EPI_BIAS_RESIDUAL) {
+        if (RES16) {
             const h8 r = *(const h8*)(R + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
         }
-        *(h8*)(C + off) = o;
+        if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) sq_st8(sq_rsrc(C), (int)(off * 2), o);   // write-through: the tail workers read it
+        else *(h8*)(C + off) = o;
+    }
+    if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's stores have reached memory ...
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(lt.mdone + mt_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the tile counts
     }
 }
 
@@ -3599,6 +3721,7 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
@@ -3673,6 +3796,12 @@ struct vf_encoder {
     // split-K GEMM (forwards of <= kSplitMaxRows tokens): fp32 slabs [kSplitMax][kSplitMaxRows][max(3H, F)] + tile counters
     float* sk_part = nullptr;
     unsigned* sk_cnt = nullptr;
+    // LayerNorm in the tail of the residual products (EPI_BIAS_RESIDUAL_LN): per-row-tile completion counters, claim counters,
+    // per-unit done marks, the row tiles in dispatch-completion order; generation counter (host)
+    unsigned *ln_mdone = nullptr, *ln_next = nullptr, *ln_done = nullptr;
+    int* ln_order = nullptr;
+    int ln_cap_mt = 0, ln_mt = 0, ln_nt = 0;
+    unsigned ln_gen = 0;
     // persistent one-query forward (k_sq_forward): barrier words (+ the published row statistics, 256 bytes in) on the device,
     // a host-mapped timeout flag
     unsigned* sq_bar = nullptr;
@@ -3735,6 +3864,10 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     if (e->d_flag) (void)hipFree(e->d_flag);
     if (e->sk_part) (void)hipFree(e->sk_part);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
+    if (e->ln_mdone) (void)hipFree(e->ln_mdone);
+    if (e->ln_next) (void)hipFree(e->ln_next);
+    if (e->ln_done) (void)hipFree(e->ln_done);
+    if (e->ln_order) (void)hipFree(e->ln_order);
     if (e->sq_bar) (void)hipFree(e->sq_bar);
     if (e->sq_flag_h) (void)hipHostFree(e->sq_flag_h);
     delete e;
@@ -3894,7 +4027,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: 8-phase, the 128 x 256 DMA kernel or the 128 x 128 one
         static const long long p8f_min = getenv("VF_GEMM_8P_F32_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_F32_MIN_WGS")) : 256;   // (Qwen3-4B shape, 320 tiles: 66.4 vs 68.9 ms per forward)
         if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8f_min))) {
-            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K);
+            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{});
             return hipGetLastError();
         }
         if (dma_ok && (long long)(M / DBM) * (N / DBN) >= dma_min && kind != 3) {
@@ -3925,7 +4058,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K);
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{});
         return hipGetLastError();
     }
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
@@ -3966,9 +4099,9 @@ static bool gemm_gated(const half_t* A, const half_t* Wgu, half_t* C, int M, int
     *er = hipSuccess;
     if (off || M % PBM || N % PBN || F % 128 || K % PBK || K < 2 * PBK || (long long)(M / PBM) * (N / PBN) < 384) return false;
     if (act_kind == 1)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K);
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{});
     else
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K);
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{});
     *er = hipGetLastError();
     return true;
 }
@@ -3990,6 +4123,84 @@ static hipError_t gemm_skinny(const half_t* A, const half_t* W, const float* bia
     default: hipLaunchKernelGGL((k_gemm_skinny<EPI, 4>), grid, block, 0, st, A, W, bias, R, C, Mvalid, N, K, S, part, counters); break;
     }
     return hipGetLastError();
+}
+
+// OFF by default: measured on the 100-pair re-rank forward it returns nothing (12.21 vs 12.33 ms, 11.96 vs 11.97 on another
+// box): the LayerNorm pass is a full-bandwidth sweep of 157 MB, the K = 768 product it would hide under is itself limited
+// by the memory system (+19 us for the product, -29 for the launch it replaces), and the third of the row tiles that
+// complete in the last round have nothing left to hide under.  VF_LN_TAIL=1 switches it on.
+static std::atomic<int> g_ln_tail{getenv("VF_LN_TAIL") ? 1 : 0};
+static std::atomic<long long> g_ln_tail_calls{0};
+// Test hook: switch the LayerNorm tail on / off at run time (returns the previous setting); -1 returns the number of fused
+// launches so far instead.
+extern "C" long long vf_debug_ln_tail(int on) {
+    if (on < 0) return g_ln_tail_calls.load();
+    return g_ln_tail.exchange(on ? 1 : 0);
+}
+
+// Residual product + LayerNorm in one launch (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, see LnTail) followed by the clean-up launch.
+// Returns false when the shape does not take the 8-phase kernel (the caller then runs the product and k_layernorm).
+static bool gemm_residual_ln(vf_encoder* e, const half_t* A, const half_t* W, const float* bias, half_t* x, half_t* y,
+                             const float* g, const float* b, int Mp, int N, int K, hipStream_t st, hipError_t* er) {
+    const bool off = g_ln_tail.load(std::memory_order_relaxed) == 0;   // A/B switch: VF_LN_TAIL=1 or vf_debug_ln_tail(1)
+    static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
+    static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
+    *er = hipSuccess;
+    const int Mt = Mp / PBM, Nt = N / PBN;
+    if (off || env_kind != 0 || Mp % PBM || N % PBN || N > 1024 || K % PBK || K < 2 * PBK || (long long)Mt * Nt < p8_min ||
+        (long long)Mp * N * 2 >= (1ll << 31))
+        return false;
+    if (Mt > e->ln_cap_mt) {
+        if (e->ln_mdone) { (void)hipFree(e->ln_mdone); (void)hipFree(e->ln_done); (void)hipFree(e->ln_order); }
+        e->ln_mdone = nullptr; e->ln_done = nullptr; e->ln_order = nullptr; e->ln_cap_mt = 0;
+        hipError_t a = hipMalloc((void**)&e->ln_mdone, (size_t)Mt * sizeof(unsigned));
+        if (a == hipSuccess) a = hipMalloc((void**)&e->ln_done, (size_t)Mt * (PBM / kLnUnitRows) * sizeof(unsigned));
+        if (a == hipSuccess) a = hipMalloc((void**)&e->ln_order, (size_t)Mt * sizeof(int));
+        if (a == hipSuccess && !e->ln_next) a = hipMalloc((void**)&e->ln_next, 64 * sizeof(unsigned));
+        if (a != hipSuccess) { *er = a; return true; }
+        e->ln_cap_mt = Mt; e->ln_mt = 0;
+    }
+    if (Mt != e->ln_mt || Nt != e->ln_nt) {
+        // a new shape: counters restart (generation 0 = nothing done), and the order in which the row tiles complete --
+        // the dispatch index of a tile is 8 (position within its XCD's contiguous range) + XCD; a row tile is complete when
+        // its last-dispatched tile is
+        const int nwg = Mt * Nt, q8 = nwg >> 3, r8 = nwg & 7;
+        std::vector<long long> key(Mt, -1);
+        for (int xcd = 0; xcd < 8; ++xcd) {
+            const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, cnt = xcd < r8 ? q8 + 1 : q8;
+            for (int i = 0; i < cnt; ++i) {
+                const int p = start + i, GM = 4;
+                const int gq = p / (GM * Nt), r = p - gq * (GM * Nt);
+                const int gm = (Mt - gq * GM) < GM ? (Mt - gq * GM) : GM;
+                const int nt = r / gm, mt = gq * GM + (r - nt * gm);
+                const long long orig = (long long)i * 8 + xcd;
+                if (orig > key[mt]) key[mt] = orig;
+            }
+        }
+        std::vector<int> order(Mt);
+        for (int i = 0; i < Mt; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return key[a2] < key[b2]; });
+        hipError_t a = hipMemcpyAsync(e->ln_order, order.data(), (size_t)Mt * sizeof(int), hipMemcpyHostToDevice, st);
+        if (a == hipSuccess) a = hipMemsetAsync(e->ln_mdone, 0, (size_t)Mt * sizeof(unsigned), st);
+        if (a == hipSuccess) a = hipMemsetAsync(e->ln_done, 0, (size_t)Mt * (PBM / kLnUnitRows) * sizeof(unsigned), st);
+        if (a == hipSuccess) a = hipMemsetAsync(e->ln_next, 0, 64 * sizeof(unsigned), st);
+        if (a == hipSuccess) a = hipStreamSynchronize(st);     // (the host vector goes out of scope)
+        if (a != hipSuccess) { *er = a; return true; }
+        e->ln_mt = Mt; e->ln_nt = Nt; e->ln_gen = 0;
+    }
+    LnTail lt{};
+    lt.x = x; lt.g = g; lt.b = b; lt.eps = e->cfg.ln_eps;
+    lt.mdone = e->ln_mdone; lt.next = e->ln_next; lt.done = e->ln_done; lt.order = e->ln_order;
+    lt.gen = ++e->ln_gen; lt.ntiles = Mt * Nt;
+    static const bool nowait = getenv("VF_LN_TAIL_NOWAIT") != nullptr;
+    lt.nowait = nowait ? 1 : 0;
+    static const int env_workers = getenv("VF_LN_TAIL_WORKERS") ? atoi(getenv("VF_LN_TAIL_WORKERS")) : -1;   // experiments
+    const int workers = env_workers >= 0 ? env_workers : std::min(device_cus(), Mt * (PBM / kLnUnitRows));
+    hipLaunchKernelGGL(k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, dim3(lt.ntiles + workers), dim3(PTHREADS), PLDS, st, A, W, bias, x, y, Mp, N, K, lt);
+    hipLaunchKernelGGL(k_layernorm_rest, dim3(Mp / kLnUnitRows), dim3(256), 0, st, y, g, b, e->cfg.ln_eps, Mp, N, x, e->ln_done, lt.gen);
+    *er = hipGetLastError();
+    g_ln_tail_calls.fetch_add(1, std::memory_order_relaxed);
+    return true;
 }
 
 // The persistent one-query forward is an EXPERIMENT, off by default: measured on MI355X it is slower than the launch-per-product
@@ -4081,11 +4292,15 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
                                0.125f, 1.4426950408889634f, e->ctx);
         }
+        bool fused_ln = false;          // the residual product carried its LayerNorm (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>)
+        hipError_t ler = hipSuccess;
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
+        else if ((fused_ln = gemm_residual_ln(e, e->ctx, Wo, bo, e->x, e->y, g1, b1n, Mp, H, H, st, &ler))) VFT_HIP(ler);
         else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
+        if (!fused_ln) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, M, F, H, st));
         else VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
+        fused_ln = false;
         if (skinny) {
             VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, M, H, F, st, e->sk_part, e->sk_cnt));
         } else if (small && F >= 2048) {
@@ -4093,10 +4308,12 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             // forward); the K = hidden products are not (the split's extra dependent memory round trips cost more than
             // 12 short K-steps), nor anything from 256 tokens up (measured slower)
             VFT_HIP(gemm_splitk<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Ms, H, F, e->sk_part, e->sk_cnt, st));
+        } else if ((fused_ln = gemm_residual_ln(e, e->hbuf, W2, b2, e->x, e->y, g2, b2n, Mp, H, F, st, &ler))) {
+            VFT_HIP(ler);
         } else {
             VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st));
         }
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
+        if (!fused_ln) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
     }
     int all_last = 0;
     if (c.pooling == 2) {
