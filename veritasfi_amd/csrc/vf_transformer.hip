@@ -3330,9 +3330,19 @@ __global__ __launch_bounds__(256) void k_pool(const half_t* x, const int* mask, 
         // one-row-per-wave variants were measured 2-4x SLOWER here (dependent L2 round trips per row); the head is
         // 0.4 % of a 100-pair forward, so the simple form stays.
         for (int o = tid; o < H; o += 256) {
-            float s = bd[o];
-            for (int j = 0; j < H; ++j) s += (float)Wd[(long long)o * H + j] * v[j];
-            y[o] = tanhf(s);
+            // 16-byte loads of the weight row, four independent partial sums (H % 32 == 0: hidden is a multiple of 128)
+            const h8* wr8 = (const h8*)(Wd + (long long)o * H);
+            float s4[4] = {bd[o], 0.f, 0.f, 0.f};
+            for (int j8 = 0; j8 < (H >> 3); j8 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const h8 w8 = wr8[j8 + q];
+                    const float* vv = v + (j8 + q) * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s4[q] += (float)w8[e] * vv[e];
+                }
+            }
+            y[o] = tanhf((s4[0] + s4[1]) + (s4[2] + s4[3]));
         }
         __syncthreads();
         float part = 0.f;
