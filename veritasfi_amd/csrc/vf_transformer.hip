@@ -3107,22 +3107,27 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
 // Everything else (tile loop, one barrier per 64-key tile, online softmax, causal / padding masks, packed rows) is
 // k_attention_stream's.
 // ------------------------------------------------------------------------------------------------
+// Head dim 128: 64-key tiles; head dim 256 (gemma): 32-key tiles, the wave's Q fragments in registers (64 of them) instead
+// of a 66 KB LDS tile, so that two workgroups share a CU (the register-staged kernel it replaces: one workgroup, one wave
+// per SIMD, two LDS reads per QK^T MFMA -- 0.13 PFLOP/s).  A tile is 16 KB of K and 16 KB of V either way.
+template <int DH>
 struct AttnStream2Lds {
-    char k[2][SKT * 256];
-    char v[2][SKT * 256];
-    float mb[2][SKT];
+    static constexpr int KT = DH == 256 ? 32 : 64;
+    char k[2][KT * DH * 2];
+    char v[2][KT * DH * 2];
+    float mb[2][KT];
     int padded[2];
 };
-__device__ __forceinline__ int s2_koff(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
-__device__ __forceinline__ int s2_voff(int row, int ch) { return row * 256 + ((ch ^ ((row & 3) << 2)) << 4); }
+template <int DH> __device__ __forceinline__ int s2_koff(int row, int ch) { return row * (DH * 2) + ((ch ^ (row & 15)) << 4); }
+template <int DH> __device__ __forceinline__ int s2_voff(int row, int ch) { return row * (DH * 2) + ((ch ^ ((row & 3) << 2)) << 4); }
 
-template <bool CAUSAL>
+template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
                                                             int ld, int heads, int kv_heads, float scale,
                                                             half_t* __restrict__ ctx, int ctx_ld, const int* __restrict__ seq_off = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    AttnStream2Lds& L = *reinterpret_cast<AttnStream2Lds*>(smem);
-    constexpr int DH = 128, KS = DH / 16, MT = DH / 32;
+    AttnStream2Lds<DH>& L = *reinterpret_cast<AttnStream2Lds<DH>*>(smem);
+    constexpr int KS = DH / 16, MT = DH / 32, KT = AttnStream2Lds<DH>::KT, NS = KT / 32, CPR = DH / 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r31 = lane & 31, h = lane >> 5;
@@ -3137,26 +3142,28 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
     const int q0 = qb * 128 + wid * 32;
     const bool wave_active = q0 < T;
     const int last_q = (qb * 128 + 127 < T - 1) ? qb * 128 + 127 : T - 1;
-    const int ntiles = CAUSAL ? (last_q / SKT + 1) : (T + SKT - 1) / SKT;
+    const int ntiles = CAUSAL ? (last_q / KT + 1) : (T + KT - 1) / KT;
     // ---- staging: a tile of K (and of V) is 1024 chunks of 16 B; DMA round j of thread t fills physical chunk t + 256 j
-    //      = row (t >> 4) + 16 j, slot t & 15, with the LOGICAL chunk that the swizzle puts there (tile-invariant: a tile is 64 rows)
-    const int srow = tid >> 4, slot = tid & 15;
-    const int klc = slot ^ (srow & 15), vlc = slot ^ ((srow & 3) << 2);      // (rows 16 j apart share row & 15 and row & 3)
+    //      = row t / CPR + (256 / CPR) j, slot t % CPR, with the LOGICAL chunk that the swizzle puts there
+    const int srow = tid / CPR, slot = tid % CPR;
+    constexpr int RSTEP = 256 / CPR;      // rows between a thread's DMA rounds: 16 (head dim 128) or 8 (256)
     float rmb = 0.f;
     auto stage = [&](int tile, int buf) {
-        const int kt = tile * SKT;
+        const int kt = tile * KT;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int key = kt + srow + 16 * j < T ? kt + srow + 16 * j : T - 1;
+            const int row = srow + RSTEP * j;
+            const int key = kt + row < T ? kt + row : T - 1;
+            const int klc = slot ^ (row & 15), vlc = slot ^ ((row & 3) << 2);
             a2_dma16(Kg + (long long)key * ld + klc * 8, L.k[buf] + (64 * wid + 256 * j) * 16);
             a2_dma16(Vg + (long long)key * ld + vlc * 8, L.v[buf] + (64 * wid + 256 * j) * 16);
         }
-        if (tid < SKT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
+        if (tid < KT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
     };
     auto stash_mask = [&](int buf) {
-        if (tid < SKT) {   // (wave 0 exactly)
-            L.mb[buf][tid] = rmb;
-            const bool any = __ballot(rmb != 0.f) != 0ull;
+        if (tid < 64) {   // (wave 0 exactly; lanes >= KT carry 0)
+            if (tid < KT) L.mb[buf][tid] = rmb;
+            const bool any = __ballot(tid < KT && rmb != 0.f) != 0ull;
             if (tid == 0) L.padded[buf] = any ? 1 : 0;
         }
     };
@@ -3187,33 +3194,33 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1, kt = tile * SKT;
+        const int buf = tile & 1, kt = tile * KT;
         if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);     // every wave left buffer buf ^ 1 before the last barrier
         const bool visit = wave_active && (!CAUSAL || kt <= q0 + 31);
         if (visit) {
             const char* Kb = L.k[buf];
             const char* Vb = L.v[buf];
-            f16v s[2];
+            f16v s[NS];
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
+            for (int sx = 0; sx < NS; ++sx) {
                 f16v z;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff(sx * 32 + r31, h)), qf[0], z, 0, 0, 0);
+                s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff<DH>(sx * 32 + r31, h)), qf[0], z, 0, 0, 0);
 #pragma unroll
                 for (int ks = 1; ks < KS; ++ks)
-                    s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff(sx * 32 + r31, 2 * ks + h)), qf[ks], s[sx], 0, 0, 0);
+                    s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff<DH>(sx * 32 + r31, 2 * ks + h)), qf[ks], s[sx], 0, 0, 0);
             }
-            const bool diag = CAUSAL && (kt + SKT - 1 > q0);
+            const bool diag = CAUSAL && (kt + KT - 1 > q0);
             if (L.padded[buf]) {
 #pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
+                for (int sx = 0; sx < NS; ++sx)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) s[sx][reg] += L.mb[buf][sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
             }
             if (diag) {
 #pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
+                for (int sx = 0; sx < NS; ++sx)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int kl = sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -3222,7 +3229,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
             }
             float tmax = -1e30f;
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
+            for (int sx = 0; sx < NS; ++sx)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, s[sx][reg]);
             {
@@ -3234,9 +3241,9 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
             const float mneg = -m_new * LOG2E;
             float psum = 0.f;
-            h8 pf[4];
+            h8 pf[2 * NS];
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
+            for (int sx = 0; sx < NS; ++sx)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(s[sx][reg], LOG2E, mneg));
@@ -3256,12 +3263,12 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
                 for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
             // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h of 16-key group st <-> key 16 st + (j&3) + 8 (j>>2) + 4 h
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 2 * NS; ++st)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int key = 16 * st + 4 * h + vq, ch = 4 * mt + 2 * vg + (vp >> 1);
                     h8 vf;
-                    a2_tr_read(vf, Vb + s2_voff(key, ch) + 8 * (vp & 1), Vb + s2_voff(key + 8, ch) + 8 * (vp & 1));
+                    a2_tr_read(vf, Vb + s2_voff<DH>(key, ch) + 8 * (vp & 1), Vb + s2_voff<DH>(key + 8, ch) + 8 * (vp & 1));
                     o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
                 }
         }
@@ -3764,7 +3771,8 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<128>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<256>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
     return er;
@@ -4729,11 +4737,16 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
                 hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
             else
-                hipLaunchKernelGGL((k_attention_stream2<true>), agrid, dim3(256), sizeof(AttnStream2Lds), st, d->qkv, d->d_mask,
+                hipLaunchKernelGGL((k_attention_stream2<128, true>), agrid, dim3(256), sizeof(AttnStream2Lds<128>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else {
-            hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
-                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
+            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: the Q-in-LDS, register-staged kernel
+            if (stream_v1)
+                hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
+                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
+            else
+                hipLaunchKernelGGL((k_attention_stream2<256, true>), agrid, dim3(256), sizeof(AttnStream2Lds<256>), st, d->qkv, d->d_mask,
+                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         }
         VFT_HIP(gemm<EPI_RESIDUAL_F32>(d->ctx, Wo, nullptr, (const half_t*)px, (half_t*)py, Mp, H, QD, st));
         std::swap(px, py);
