@@ -794,7 +794,7 @@ def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, 
     ref = reference(qkv, mask, b, t, heads, rows=rows)
     valid = mask.reshape(b, t)[:rows].reshape(-1).bool()
     vmax = float(qkv[:, 2 * heads * 64:].float().abs().max())
-    for kind in (2, 1, 3):
+    for kind in (2, 1, 3, 4):                                # k_attention2, first generation, streaming (register-staged, LDS-DMA)
         ctx = torch.full((b * t, heads * 64), float("nan"), dtype=torch.float16, device=dev)
         run(L, kind, qkv, mask, b, t, heads, ctx)
         torch.cuda.synchronize()

@@ -3109,17 +3109,21 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __res
 // ------------------------------------------------------------------------------------------------
 // Head dim 128: 64-key tiles; head dim 256 (gemma): 32-key tiles, the wave's Q fragments in registers (64 of them) instead
 // of a 66 KB LDS tile, so that two workgroups share a CU (the register-staged kernel it replaces: one workgroup, one wave
-// per SIMD, two LDS reads per QK^T MFMA -- 0.13 PFLOP/s).  A tile is 16 KB of K and 16 KB of V either way.
+// per SIMD, two LDS reads per QK^T MFMA -- 0.13 PFLOP/s); head dim 64 (the encoder beyond 512 tokens: bge-m3 documents):
+// 128-key tiles of 128-byte rows with k_attention2's swizzles.  A tile is 16 KB of K and 16 KB of V in every case.
 template <int DH>
 struct AttnStream2Lds {
-    static constexpr int KT = DH == 256 ? 32 : 64;
+    static constexpr int KT = DH == 256 ? 32 : DH == 128 ? 64 : 128;
     char k[2][KT * DH * 2];
     char v[2][KT * DH * 2];
     float mb[2][KT];
-    int padded[2];
+    int padded[2][2];    // per buffer and staging wave: the wave's keys hold a masked one (or run past the sequence's end)
 };
-template <int DH> __device__ __forceinline__ int s2_koff(int row, int ch) { return row * (DH * 2) + ((ch ^ (row & 15)) << 4); }
-template <int DH> __device__ __forceinline__ int s2_voff(int row, int ch) { return row * (DH * 2) + ((ch ^ ((row & 3) << 2)) << 4); }
+// chunk swizzles (16-byte chunks of a row): rows of 256 / 512 bytes sit on the same banks, rows of 128 bytes alternate
+template <int DH> __device__ __forceinline__ int s2_kswz(int row) { return DH == 64 ? (row >> 1) & 7 : row & 15; }
+template <int DH> __device__ __forceinline__ int s2_vswz(int row) { return DH == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; }
+template <int DH> __device__ __forceinline__ int s2_koff(int row, int ch) { return row * (DH * 2) + ((ch ^ s2_kswz<DH>(row)) << 4); }
+template <int DH> __device__ __forceinline__ int s2_voff(int row, int ch) { return row * (DH * 2) + ((ch ^ s2_vswz<DH>(row)) << 4); }
 
 template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
@@ -3154,17 +3158,17 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
         for (int j = 0; j < 4; ++j) {
             const int row = srow + RSTEP * j;
             const int key = kt + row < T ? kt + row : T - 1;
-            const int klc = slot ^ (row & 15), vlc = slot ^ ((row & 3) << 2);
+            const int klc = slot ^ s2_kswz<DH>(row), vlc = slot ^ s2_vswz<DH>(row);
             a2_dma16(Kg + (long long)key * ld + klc * 8, L.k[buf] + (64 * wid + 256 * j) * 16);
             a2_dma16(Vg + (long long)key * ld + vlc * 8, L.v[buf] + (64 * wid + 256 * j) * 16);
         }
         if (tid < KT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
     };
     auto stash_mask = [&](int buf) {
-        if (tid < 64) {   // (wave 0 exactly; lanes >= KT carry 0)
+        if (tid < 128) {   // (waves 0 and 1 exactly; lanes >= KT carry 0)
             if (tid < KT) L.mb[buf][tid] = rmb;
             const bool any = __ballot(tid < KT && rmb != 0.f) != 0ull;
-            if (tid == 0) L.padded[buf] = any ? 1 : 0;
+            if (lane == 0) L.padded[buf][wid] = any ? 1 : 0;
         }
     };
     h8 qf[KS];
@@ -3212,7 +3216,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
                     s[sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(Kb + s2_koff<DH>(sx * 32 + r31, 2 * ks + h)), qf[ks], s[sx], 0, 0, 0);
             }
             const bool diag = CAUSAL && (kt + KT - 1 > q0);
-            if (L.padded[buf]) {
+            if (L.padded[buf][0] | L.padded[buf][1]) {
 #pragma unroll
                 for (int sx = 0; sx < NS; ++sx)
 #pragma unroll
@@ -3771,6 +3775,8 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<64>));
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<256>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
@@ -4313,9 +4319,15 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         // src/utils/ragManager.py:50) cannot keep K and V^T of a head resident in LDS: they take the streaming kernel
         // (64-key tiles through LDS, online softmax), which has no length limit.
         if (att_stream || T > kEncResidentT) {
-            hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
-                               sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
-                               e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
+            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
+            if (stream_v1)
+                hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
+                                   sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
+                                   e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
+            else
+                hipLaunchKernelGGL((k_attention_stream2<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
+                                   sizeof(AttnStream2Lds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
+                                   e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
         } else if (e->q_folded) {
             launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         } else {
@@ -4729,8 +4741,13 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         hipLaunchKernelGGL(k_qknorm_rope, dim3((M + 256 / (DH / 16) - 1) / (256 / (DH / 16)), 3), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
                            qn, kn, c.rms_eps, c.qk_norm, d->rope, pos);
         if (DH == 64) {
-            hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
-                               t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
+            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;
+            if (stream_v1)
+                hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
+                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
+            else
+                hipLaunchKernelGGL((k_attention_stream2<64, true>), agrid, dim3(256), sizeof(AttnStream2Lds<64>), st, d->qkv, d->d_mask,
+                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else if (DH == 128) {
             static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
             if (stream_v1)
@@ -4947,7 +4964,7 @@ extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T
     hipError_t er = configure_once();
     if (er != hipSuccess) return -1;
     if (B <= 0 || heads <= 0 || T <= 0 || T % 32) return -2;
-    if (kind != 3 && T > kEncResidentT) return -2;
+    if (kind != 3 && kind != 4 && T > kEncResidentT) return -2;
     hipStream_t st = (hipStream_t)stream;
     const int H = heads * ADH;
     if (kind == 1) {
@@ -4963,6 +4980,9 @@ extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T
         launch_attention2<6>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
     } else if (kind == 3) {
         hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStreamLds<64>), st,
+                           (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
+    } else if (kind == 4) {
+        hipLaunchKernelGGL((k_attention_stream2<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStream2Lds<64>), st,
                            (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
     } else {
         return -2;
