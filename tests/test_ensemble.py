@@ -130,28 +130,34 @@ def test_invoke_matches_literal_restatement(expand, prefetch):
 def test_constructor_defaults_and_empty_cases():
     from veritasfi_amd.ensemble import EnsembleRetriever
     chroma, ts, emb, bm, queries, metas, titles = _world(1, n=40, n_titles=4)
-    er = EnsembleRetriever("dir", chroma, ts, 3, emb, retriever_cls=CosineRetriever)   # ragManager.py:112 call shape
-    assert (er.faiss_k, er.faiss_ts_k, er.bm25_k, er.enable_expand) == (3, 3, 0, False)  # no BM25 object -> branch off
+    # ragManager.py:112 call shape.  The BM25 branch is on by default (bm25_k = k): without the host application's
+    # BM25Retriever on the import path the constructor must fail, never drop a third of the recall silently
+    with pytest.raises(ImportError, match="bm25_k"):
+        EnsembleRetriever("dir", chroma, ts, 3, emb, retriever_cls=CosineRetriever)
+    # ... and with it importable (ensembleRetriever.py:13,37) the unchanged call builds BM25Retriever(bm25_dir) itself
+    import sys
+    import types
+    seen = []
+    host = types.ModuleType("bm25Retriever")
+    host.BM25Retriever = lambda d: (seen.append(d), bm)[1]
+    sys.modules["bm25Retriever"] = host
+    try:
+        er = EnsembleRetriever("some/bm25_dir", chroma, ts, 3, emb, retriever_cls=CosineRetriever)
+    finally:
+        del sys.modules["bm25Retriever"]
+    assert seen == ["some/bm25_dir"] and er.bm25_retriever is bm
+    assert (er.faiss_k, er.faiss_ts_k, er.bm25_k, er.enable_expand) == (3, 3, 3, False)
+    assert {c["retriever"] for q, h in queries for c in er.invoke(q, h)} == {"FAISS", "Title Summary", "BM25"}
+    er = EnsembleRetriever("dir", chroma, ts, 3, emb, bm25_k=0, retriever_cls=CosineRetriever)   # explicitly off
+    assert (er.faiss_k, er.faiss_ts_k, er.bm25_k) == (3, 3, 0) and er.bm25_retriever is None
     got = er.invoke(queries[0][0], [])
     assert got and all(c["retriever"] in ("FAISS", "Title Summary") for c in got)
-    er0 = EnsembleRetriever("dir", chroma, ts, 0, emb, retriever_cls=CosineRetriever)
+    er0 = EnsembleRetriever("dir", chroma, ts, 0, emb, retriever_cls=CosineRetriever)   # k = 0: every branch off
     assert er0.invoke(queries[0][0], []) == []
     # corpus smaller than the 2048-deep search: padded ids (-1) are skipped, nothing is emitted twice
     rows = [c["metadata"]["doc_id"] for c in got]
     assert len(rows) == len(set(rows))
 
 
-@pytest.mark.gpu
-def test_gpu_end_to_end_matches_injected():
-    """Same world through the real GPU FaissRetriever: identical output to the injected exact-cosine retriever
-    (scores compared to 1e-6, everything else exactly)."""
-    from veritasfi_amd.ensemble import EnsembleRetriever
-    chroma, ts, emb, bm, queries, metas, titles = _world(2)
-    gpu = EnsembleRetriever("d", chroma, ts, 6, emb, faiss_ts_k=2, bm25_k=4, enable_expand=True, bm25_retriever=bm)
-    cpu = EnsembleRetriever("d", chroma, ts, 6, emb, faiss_ts_k=2, bm25_k=4, enable_expand=True, bm25_retriever=bm,
-                            retriever_cls=CosineRetriever)
-    for q, hyde in queries:
-        a, b = gpu.invoke(q, hyde), cpu.invoke(q, hyde)
-        assert [(c["retriever"], c["page_content"], c["bundle_id"]) for c in a] == \
-               [(c["retriever"], c["page_content"], c["bundle_id"]) for c in b]
-        assert max(abs(x["score"] - y["score"]) for x, y in zip(a, b)) < 1e-5
+# The GPU end-to-end case compares with the REAL reference's output: tests/test_control_flow_golden.py
+# (test_g5_gpu_ensemble_matches_reference_invoke).

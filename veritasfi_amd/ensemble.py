@@ -9,18 +9,38 @@ through this package's ``FaissRetriever`` (GPU).  Output schema, ordering, the `
 neighbour expansion (score > 0.72, neighbours > 0.66 in the 2048-deep score map, at most 4 rows, ``:85-107``) and
 the running ``bundle_id`` counter are the reference's.
 
-BM25 is outside this path: pass any object with ``invoke(query, k) -> (ids, scores)`` (the reference's
-``BM25Retriever.invoke`` surface, ``src/utils/bm25Retriever.py:50-87``) or leave ``bm25_retriever=None`` with
-``bm25_k=0``.  The stores are anything with Chroma's ``get(include=[...])`` / ``get(ids=[...], include=[...])``.
+BM25 itself is outside this path (CPU, sparse): the constructor does what the reference's does (``:37``) -- it builds the
+host application's own ``BM25Retriever(bm25_dir)`` -- unless an object with ``invoke(query, k) -> (ids, scores)``
+(``src/utils/bm25Retriever.py:50-87``) is handed in as ``bm25_retriever``.  When the BM25 branch is on (``bm25_k`` resolves
+to > 0) and neither works, construction FAILS; the branch is never dropped silently.  The stores are anything with
+Chroma's ``get(include=[...])`` / ``get(ids=[...], include=[...])``.
 """
 from __future__ import annotations
 
+import importlib
 from typing import Dict, List
 
 from .faiss_retriever import FaissRetriever
 from .similarity import compute_similarity, compute_similarity_mtx
 
 EXPAND_SCORE, NEIGHBOUR_SCORE, MAX_EXPANDED, SEARCH_DEPTH = 0.72, 0.66, 4, 2048
+# where the host application's BM25Retriever lives, as seen from its entry points (src/ on sys.path, or the repo root)
+BM25_MODULES = ("utils.bm25Retriever", "src.utils.bm25Retriever", "bm25Retriever")
+
+
+def _host_bm25(bm25_dir):
+    """``BM25Retriever(bm25_dir)`` of the application this class is dropped into (ensembleRetriever.py:13,37)."""
+    tried = []
+    for name in BM25_MODULES:
+        try:
+            mod = importlib.import_module(name)
+        except ImportError as e:
+            tried.append(f"{name}: {e}")
+            continue
+        return mod.BM25Retriever(bm25_dir)
+    raise ImportError("EnsembleRetriever: the BM25 branch is on (bm25_k > 0) but no BM25Retriever is importable ("
+                      + "; ".join(tried) + ") -- pass bm25_retriever=<object with invoke(query, k)>, or bm25_k=0 to "
+                      "switch the branch off explicitly")
 
 
 class EnsembleRetriever:
@@ -28,7 +48,8 @@ class EnsembleRetriever:
                  faiss_ts_k: int = None, enable_expand: bool = False, bm25_retriever=None, retriever_cls=FaissRetriever,
                  prefetch_documents: bool = False):
         """Positional arguments as upstream (``ragManager.py:112`` passes bm25_dir, chroma, ts_chroma, k, embeddings).
-        ``bm25_dir`` is kept for signature compatibility; hand the BM25 object itself in ``bm25_retriever``.
+        ``bm25_dir`` goes to the host application's ``BM25Retriever`` exactly as upstream (``:37``) unless
+        ``bm25_retriever`` is given.
         ``prefetch_documents=True`` loads every chunk's text once and serves bundles from memory in the requested
         row order instead of one ``chroma.get(ids=...)`` per bundle (Chroma returns rows in ITS order, so leave this
         off when byte-identical ordering inside a bundle matters)."""
@@ -40,8 +61,8 @@ class EnsembleRetriever:
         self.chroma = chroma
         self.bm25_dir = bm25_dir
         self.bm25_retriever = bm25_retriever
-        if self.bm25_retriever is None:
-            self.bm25_k = 0
+        if self.bm25_retriever is None and self.bm25_k > 0:
+            self.bm25_retriever = _host_bm25(bm25_dir)
 
         include = ["metadatas", "embeddings"] + (["documents"] if prefetch_documents else [])
         docs = chroma.get(include=include)
