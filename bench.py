@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of exact cosine top-100 over a 10M x 768 fp16 corpus (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N --steps 200 --warmup 20      (N > 1: this process starts its own N ranks, see launch_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W           (a launcher's ranks are used as they are)
 
 A "step" is one pass of the hot path over one batch of 64 synthetic queries: the whole corpus
 (row-sharded over the N ranks; total rows FIXED, so scaling is strong) is scanned once, per-shard
@@ -19,6 +19,8 @@ bounded sample on this box's host cores, scaled to the full corpus -- reported, 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,12 +42,22 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--opt", action="append", default=[], help="index option name=value (tuning)")
-    ap.add_argument("--no-rerank", action="store_true")
+    ap.add_argument("--no-rerank", action="store_true", help="skip every transformer leg (re-rank, embed, latency, llm, c4)")
+    ap.add_argument("--no-llm", action="store_true", help="skip the gemma-2b-shape LLM re-ranker leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] end-to-end chain")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed run push one bucket through the exchange path and compare the merged result "
-                         "with per-batch searches (exact on one rank; sortedness + id ranges on several)")
+                         "with per-batch searches (one rank) / with the CPU oracle run per shard (several ranks: on by default)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the oracle check of the merged result")
+    ap.add_argument("--verify-queries", type=int, default=4, help="N > 1: queries of the bucket the per-shard oracle checks")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal without a GPU: the ranks meet over gloo, agree on the sharding and rank 0 "
+                         "prints a JSON line; nothing is measured (tests/test_bench_launch.py)")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="--dry-launch: that rank exits non-zero (rc relay test)")
+    ap.add_argument("--cpu-full", choices=["auto", "on", "off"], default="auto",
+                    help="cpu_baseline: time the oracle over ALL rows (in 1M-row blocks copied from the GPU corpus) and check "
+                         "the GPU result against it; auto = when the pass is estimated under ~25 s")
     ap.add_argument("--exchange-every", type=int, default=0,
                     help="multi-GPU: batches per all-gather + merge (results are bucketed, nothing is skipped); 0 = auto (4)")
     ap.add_argument("--corpus-dtype", choices=["f16", "fp8"], default="f16",
@@ -59,6 +71,65 @@ def parse():
     ap.add_argument("--rerank-pairs", type=int, default=100)
     ap.add_argument("--rerank-tokens", type=int, default=512)
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks OURSELVES, as the reference's
+    multi-GPU entry spawns its own workers (experiments/retriever/step3_mul.py:405-452), relay rank 0's JSON line and
+    fail if any rank failed.  This parent never touches the GPU (torch.cuda.device_count() does not initialise it on this
+    image) and never exec()s: the ranks are children of `python -m torch.distributed.run`."""
+    import torch
+    if not args.dry_launch:
+        seen = torch.cuda.device_count()
+        if seen < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for, {seen} GPU(s) visible -- refusing to run a smaller job under "
+                  f"that name", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:             # ranks' stderr passes through; stdout is relayed and the JSON line remembered
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.lstrip().startswith("{"):
+            line = out
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {args.gpus}-rank job failed (torch.distributed.run exit code {rc})", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_launch(args):
+    """--dry-launch: what the ranks of a real run do before and after the GPU work, on the CPU over gloo."""
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    if rank == args.dry_fail_rank:
+        print(f"rank {rank}: failing on request", file=sys.stderr)
+        os._exit(3)
+    per = (args.rows + world - 1) // world
+    lo, hi = min(args.rows, rank * per), min(args.rows, (rank + 1) * per)
+    got = [None] * world
+    dist.all_gather_object(got, {"rank": rank, "pid": os.getpid(), "rows": [lo, hi], "local_rank": int(os.environ["LOCAL_RANK"])})
+    dist.barrier()
+    if rank == 0:
+        assert [g["rank"] for g in got] == list(range(world)) and got[0]["rows"][0] == 0 and got[-1]["rows"][1] == args.rows
+        assert all(a["rows"][1] == b["rows"][0] for a, b in zip(got, got[1:])), "shards are not contiguous"
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": dist.get_backend(), "ranks": got,
+                          "rows_per_gpu": [g["rows"][1] - g["rows"][0] for g in got]}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def make_shard(torch, lo, hi, d, device, dtype="f16"):
@@ -79,49 +150,123 @@ def make_shard(torch, lo, hi, d, device, dtype="f16"):
     return out
 
 
-def cpu_baseline(args):
+def host_rows(torch, corpus, lo, hi):
+    """Rows [lo, hi) of the GPU-resident corpus as the fp16 ndarray the oracle reads (fp8-e4m3 rows: decoded values,
+    every e4m3 value is an fp16 value)."""
     import numpy as np
-    from oracle import canonical as oracle  # the checker / baseline leg: allowed to use the oracle
-    n = min(args.cpu_sample_rows, args.rows)
-    rng = np.random.default_rng(1234)
-    corpus = np.empty((n, args.dim), dtype=np.float16)
-    for i in range(0, n, 100_000):
-        m = min(100_000, n - i)
-        corpus[i:i + m] = rng.standard_normal((m, args.dim), dtype=np.float32).astype(np.float16)
-    q = np.random.default_rng(4321).standard_normal((args.batch, args.dim)).astype(np.float32)
-    oracle.search(corpus[:20_000], q, args.k)  # warm the thread pool
-    best = 1e30
-    t_all = time.time()
-    reps = 0
-    while reps < 3 or (time.time() - t_all < 10.0 and reps < 8):
-        t0 = time.time()
-        oracle.search(corpus, q, args.k)
-        best = min(best, time.time() - t0)
-        reps += 1
-    t_full = best * (args.rows / n)
-    out = {
-        "value": round(args.batch / t_full, 3), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-        "extrapolated_from_rows": n, "extrapolation_factor": round(args.rows / n, 3), "reps": reps,
-        "sample": f"oracle/vf_oracle.c exact cosine top-{args.k}, {args.batch} queries x {n} of the {args.rows} "
-                  f"rows (fp16, d={args.dim}), best of {reps} runs = {best:.3f}s, scaled x{args.rows / n:.1f} to the full corpus",
-    }
-    # (A) of BASELINE.md 3: the reference's literal experiment path (step3_mul.py:275-283: sklearn-style
-    # normalise-both-every-call + fp32 matmul + full argsort per row), NumPy restatement, on a smaller slice
+    blk = corpus[lo:hi]
+    if blk.dtype == torch.float16:
+        return blk.cpu().numpy()
     from oracle import ref_numpy
-    na = min(n, 100_000)
-    ca = corpus[:na].astype(np.float32)
-    ta = 1e30
-    for _ in range(3):
+    return ref_numpy.decode_e4m3(blk.view(torch.uint8).cpu().numpy()).astype(np.float16)
+
+
+def cpu_baseline(args, torch, vf, corpus, queries, gpu_ids, gpu_scores):
+    """The CPU oracle on the SAME rows and queries the GPU leg used (identical synthetic inputs): the rows
+    are copied out of the GPU-resident corpus.  (1) configs[1] shape MEASURED: the first 1M rows, both CPU forms, and the
+    GPU's result over those rows compared bit for bit with the oracle's; (2) the whole corpus in 1M-row blocks (one timed
+    oracle pass per block + one merge): the metric's own workload measured rather than extrapolated, and the GPU's
+    full-corpus result compared with it.  One definition of `cores` for every figure: the threads both forms ran on."""
+    import numpy as np
+    from oracle import canonical as oracle, ref_numpy  # the checker / baseline leg: allowed to use the oracle
+    cores = oracle.num_threads()
+    q = queries.cpu().numpy()
+    k, B = args.k, q.shape[0]
+    n1 = min(1_000_000, args.rows)
+    host1 = host_rows(torch, corpus, 0, n1)
+    oracle.search(host1[:20_000], q, k)  # warm the thread pool
+    t1, reps = 1e30, 0
+    t_all = time.time()
+    while reps < 2 or (time.time() - t_all < 4.0 and reps < 5):
         t0 = time.time()
-        ref_numpy.select_top_chunks_batch(q, ca, args.k)
-        ta = min(ta, time.time() - t0)
+        ids1, sc1 = oracle.search(host1, q, k)
+        t1 = min(t1, time.time() - t0)
+        reps += 1
+    with vf.DenseIndex(corpus[:n1]) as ix1:            # zero-copy view of the same rows
+        g1_ids, g1_sc = ix1.search_device(queries, k)
+        g1_ids, g1_sc = g1_ids.cpu().numpy(), g1_sc.cpu().numpy()
+    ok1 = bool(np.array_equal(g1_ids, ids1) and np.array_equal(g1_sc.view(np.uint32), sc1.view(np.uint32)))
+    out = {"unit": "queries/s", "cores": cores, "kind": "port",
+           "c2_measured": {"rows": n1, "value": round(B / t1, 3), "seconds_per_batch": round(t1, 4), "reps": reps,
+                           "gpu_equals_oracle": ok1,
+                           "what": f"oracle/vf_oracle.c exact cosine top-{k}, {B} queries x the first {n1} rows of the GPU's "
+                                   f"corpus (configs[1] shape), best of {reps}; GPU ids and score bits over the same rows compared"}}
+    # (A) of BASELINE.md 3: the reference's literal experiment path (step3_mul.py:275-283: normalise both matrices every
+    # call + fp32 matmul + full argsort per row), NumPy restatement, on the same 1M rows, BLAS limited to `cores` threads
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=cores)
+    except Exception:  # noqa: BLE001
+        limit = None
+    na = n1 if cores >= 32 else min(n1, 200_000)   # ~18 s per 1M rows on 8 cores: keep the default run short there
+    ca = host1[:na].astype(np.float32)
+    t0 = time.time()
+    ref_numpy.select_top_chunks_batch(q, ca, k)
+    ta = time.time() - t0
+    del ca
+    if limit is not None:
+        limit.restore_original_limits()
     out["reference_faithful"] = {
-        "value": round(args.batch / (ta * args.rows / na), 3), "unit": "queries/s", "kind": "port",
-        "cores": os.cpu_count(), "extrapolated_from_rows": na, "extrapolation_factor": round(args.rows / na, 3), "reps": 3,
-        "sample": f"oracle/ref_numpy.py select_top_chunks_batch (normalise every call + full argsort), {args.batch} queries "
-                  f"x {na} rows, best of 3 runs = {ta:.3f}s, scaled x{args.rows / na:.1f}; BLAS threads = NumPy default",
+        "value": round(B / (ta * args.rows / na), 3), "unit": "queries/s", "kind": "port", "cores": cores,
+        "measured_rows": na, "seconds_per_batch": round(ta, 3), "extrapolation_factor": round(args.rows / na, 3),
+        "value_at_measured_rows": round(B / ta, 3),
+        "sample": f"oracle/ref_numpy.py select_top_chunks_batch (normalise every call + full argsort, step3_mul.py:275-283), "
+                  f"{B} queries x the first {na} rows, one run = {ta:.2f}s; `value` scales it x{args.rows / na:.1f} to {args.rows} rows",
     }
+    full = args.cpu_full == "on" or (args.cpu_full == "auto" and args.rows > n1 and t1 * args.rows / n1 <= 25.0)
+    if args.rows <= n1:
+        out.update(value=round(B / t1, 3), extrapolated=False, verified=ok1,
+                   sample=f"all {n1} rows measured (see c2_measured)")
+    elif full:
+        parts_i, parts_s, tf = [ids1], [sc1], t1
+        for lo in range(n1, args.rows, n1):
+            hi = min(args.rows, lo + n1)
+            blk = host_rows(torch, corpus, lo, hi)      # the copy out of HBM is not CPU-baseline time
+            t0 = time.time()
+            bi, bs = oracle.search(blk, q, k, id_offset=lo)
+            tf += time.time() - t0
+            parts_i.append(bi); parts_s.append(bs)
+            del blk
+        t0 = time.time()
+        fi, fs = oracle.merge_topk(np.stack(parts_i), np.stack(parts_s), k)
+        tf += time.time() - t0
+        okf = bool(np.array_equal(gpu_ids.cpu().numpy(), fi) and
+                   np.array_equal(gpu_scores.cpu().numpy().view(np.uint32), fs.view(np.uint32)))
+        out.update(value=round(B / tf, 3), extrapolated=False, verified=bool(ok1 and okf), gpu_equals_oracle_full=okf,
+                   seconds_per_batch=round(tf, 3),
+                   sample=f"oracle/vf_oracle.c exact cosine top-{k}, {B} queries x ALL {args.rows} rows of the GPU's corpus in "
+                          f"{len(parts_i)} blocks of {n1} (one timed pass per block + one merge = {tf:.2f}s of CPU time; block "
+                          f"copies out of HBM not counted); the GPU's ids and score bits for these queries equal the merged "
+                          f"result: {okf}")
+    else:
+        out.update(value=round(B / (t1 * args.rows / n1), 3), extrapolated=True, extrapolation_factor=round(args.rows / n1, 3),
+                   verified=ok1, sample=f"c2_measured scaled x{args.rows / n1:.1f} to {args.rows} rows (full pass skipped: "
+                                        f"--cpu-full {args.cpu_full}, estimated {t1 * args.rows / n1:.0f}s)")
     return out
+
+
+def verify_sharded(args, torch, dist, vf, corpus, lo, queries, merged_ids, merged_scores):
+    """N ranks: every rank runs the CPU oracle over ITS shard (rows copied out of HBM) for the first few queries of the
+    bucket, the per-shard lists meet on rank 0 (all_gather_object), are merged by the oracle and must equal the ids and
+    score bits the GPUs' all-gather + merge produced."""
+    import numpy as np
+    from oracle import canonical as oracle
+    world, rank = dist.get_world_size(), dist.get_rank()
+    nv = max(1, min(args.verify_queries, args.batch))
+    oracle.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    host = host_rows(torch, corpus, 0, corpus.shape[0])
+    q = queries[:nv].cpu().numpy()
+    ids, sc = oracle.search(host, q, args.k, id_offset=lo)
+    del host
+    parts = [None] * world
+    dist.all_gather_object(parts, (ids, sc))
+    if rank != 0:
+        return None
+    fi, fs = oracle.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), args.k)
+    gi, gs = merged_ids[:nv].cpu().numpy(), merged_scores[:nv].cpu().numpy()
+    ok = bool(np.array_equal(gi, fi) and np.array_equal(gs.view(np.uint32), fs.view(np.uint32)))
+    return {"verified": ok, "queries": nv, "what": "merged result of one bucket vs the CPU oracle run per shard and merged "
+                                                   "(ids and score bits)"}
 
 
 def rerank_p50(args, shape=None):
@@ -163,6 +308,98 @@ def rerank_p50(args, shape=None):
                  "ragged": {"lengths": f"uniform {max(1, args.rerank_tokens // 4)}..{args.rerank_tokens}",
                             "valid_tokens": int(lens.sum()), "p50_ms": round(float(np.median(tr)), 3),
                             "what": "same pairs count, right-padded ragged lengths: packed forward"}}
+
+
+def rerank_llm(args):
+    """The CONFIGURED re-ranker (config/example.yaml:9: bge-reranker-v2-gemma, a gemma-2b decoder scoring the "Yes" logit):
+    100 (query, passage) pairs built by build_llm_reranker_inputs at max_length=1024 (stress_test.py:97-146), left-padded,
+    through HipLLMReranker.compute_score -- the call vllmManager.py:450-452 makes.  Random weights of the gemma-2b shape."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _synth import LLMHashTokenizer, sentence
+    from bench_decoder import decoder_flops, random_decoder
+    import veritasfi_amd as vf
+    vocab = 32000
+    tok = LLMHashTokenizer(vocab)
+    dec, cfg = random_decoder("gemma-2b", score_token=9, vocab=vocab)
+    rr = vf.HipLLMReranker(tok, dec, max_length=1024)
+    rng = np.random.default_rng(97)
+    query = sentence(rng, 24)
+    pairs = [[query, sentence(rng, int(n))] for n in rng.integers(400, 1400, size=args.rerank_pairs)]
+    rows = vf.build_llm_reranker_inputs(pairs, tok, max_length=1024)
+    lens = np.array([len(r) for r in rows])
+    rr.compute_score(pairs[:8], batch_size=8)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        scores = rr.compute_score(pairs, batch_size=8)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    dec.close()
+    p50 = float(np.median(ts))
+    fl = sum(decoder_flops("gemma-2b", 1, int(n)) for n in lens)      # the tokens that exist (the forward runs packed)
+    tf = fl / p50 / 1e9
+    return {"model_shape": "gemma-2b (bge-reranker-v2-gemma's architecture: 18 layers, hidden 2048, MQA head dim 256, GeGLU 16384)",
+            "pairs": len(pairs), "max_length": 1024, "tokens_per_pair": {"min": int(lens.min()), "mean": round(float(lens.mean()), 1), "max": int(lens.max())},
+            "p50_ms": round(p50, 2), "tflops": round(tf, 1), "bound": "mfma", "peak_tflops": 2500.0, "frac": round(tf / 2500.0, 4),
+            "finite": bool(np.isfinite(scores).all()), "weights": "seeded random (no checkpoints offline)",
+            "what": "median of 4 HipLLMReranker.compute_score(pairs, batch_size=8) calls: host-side input construction "
+                    "(tokenizer stand-in, truncations, prompt), left padding, packed decoder forward, D2H of the logits"}
+
+
+def c4_chain(args, torch, vf, corpus):
+    """BASELINE configs[3], text leg, end to end for ONE query: embed_query (bge-base shape) -> exact top-100 over a
+    5M x 768 corpus -> 100 (query, passage) pairs x 512 tokens through the cross-encoder (bge-reranker-base shape) ->
+    rank_chunk (time score + fusion + chunk similarity matrix + greedy bundle selection) -> the 20 best.  Stage and
+    whole-chain p50 over 8 requests.  The table / figure encoders the config names do not exist in the reference
+     and are not built."""
+    import numpy as np
+    from datetime import datetime
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _synth import HashTokenizer, sentence
+    from bench_rerank import random_encoder
+    n = min(5_000_000, int(corpus.shape[0]))
+    e_enc, e_cfg = random_encoder("bert-base", head=0)
+    r_enc, r_cfg = random_encoder("xlmr-base", head=1, vocab=32000)
+    emb = vf.HipEmbeddings(HashTokenizer(e_cfg["vocab"]), e_enc, max_length=512, batch_size=100)
+    rr = vf.HipReranker(HashTokenizer(r_cfg["vocab"]), r_enc, max_length=512)
+    rng = np.random.default_rng(5)
+    passages = [sentence(rng, 470) for _ in range(256)]       # chunk texts by id (mod 256): ~512 tokens per pair
+    stages = {k: [] for k in ("embed_query", "search_top100", "rerank_100x512", "similarity_mtx", "fuse_select", "chain")}
+    clock = time.perf_counter
+    with vf.DenseIndex(corpus[:n]) as ix:
+        for it in range(10):
+            question = sentence(rng, 16)
+            t0 = clock()
+            qv = np.asarray(emb.embed_query(question), np.float32)[None, :]
+            t1 = clock()
+            ids, _ = ix.search(qv, 100)
+            t2 = clock()
+            chunks = [{"page_content": passages[int(i) % 256] + f" #{int(i)}", "bundle_id": j // 2,
+                       "metadata": {"date_published": f"2024-{1 + j % 12:02d}-{1 + j % 28:02d}"}} for j, i in enumerate(ids[0])]
+            scores = rr.compute_score([[question, c["page_content"]] for c in chunks], batch_size=8)
+            t3 = clock()
+            mtx = vf.compute_similarity_mtx(emb, [c["page_content"] for c in chunks], as_torch=False)
+            t4 = clock()
+
+            class _Cached:      # rank_chunk calls compute_score itself; the stage split above already paid for it once
+                def compute_score(self, pairs, batch_size=8):
+                    return scores
+            picked = vf.rank_chunk(chunks, question, datetime(2024, 6, 15), _Cached(), emb, 20)
+            t5 = clock()
+            tc = clock()
+            picked2 = vf.rank_chunk(chunks, question, datetime(2024, 6, 15), rr, emb, 20)
+            chain = (t2 - t0) + (clock() - tc)
+            assert picked2 == picked and len(picked) <= 20 and mtx.shape == (100, 100)
+            if it >= 2:
+                for key, v in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, (t5 - t4) - (t4 - t3), chain)):
+                    stages[key].append(v * 1e3)
+    e_enc.close(); r_enc.close()
+    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20,
+            "p50_ms": {k: round(float(np.median(v)), 3) for k, v in stages.items()},
+            "what": "configs[3] text leg: embed_query (bert-base shape, ~20 tokens) -> vf_index_search top-100 (host entry) -> "
+                    "HipReranker.compute_score over 100 pairs of ~512 tokens (xlmr-base shape) -> rank_chunk (re-embeds the 100 "
+                    "chunks in ONE batched call for the similarity matrix, vf_fuse_rank, greedy selection); chain = embed + "
+                    "search + rank_chunk with the real scorer; random weights, hash tokenizer stand-in (no checkpoints offline)"}
 
 
 def rerank_p50_sharded(args, device):
@@ -262,11 +499,20 @@ def request_latency(args):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and not args.single_process and \
+            (args.gpus > 1 or args.dry_launch or os.environ.get("VF_BENCH_LAUNCH") == "1"):
+        # no launcher around us: be the launcher (VF_BENCH_LAUNCH=1 rehearses that with one rank on a one-GPU box)
+        sys.exit(launch_ranks(args))
+    if args.dry_launch:
+        sys.exit(dry_launch(args))
     import torch
     import torch.distributed as dist
     import veritasfi_amd as vf
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.single_process:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -292,6 +538,7 @@ def main():
         torch.cuda.set_device(devs[0])
         device = torch.device("cuda", devs[0])
         index = vf.DenseIndex.group(parts)
+        corpus = None
     else:
         lo, hi = vf.shard_bounds(args.rows, world, rank)
         corpus = make_shard(torch, lo, hi, args.dim, device, args.corpus_dtype)
@@ -363,7 +610,8 @@ def main():
         elapsed = float(t.item())
     prof = index.profile()
     stats = index.stats()
-    if args.verify and exchange:
+    verify_info = None
+    if exchange and (args.verify or (world > 1 and not args.no_verify)):
         run(E)                      # exactly one full bucket: batches 0 .. E-1 of the query pool
         fence()
         mi, ms = merged[0]
@@ -375,8 +623,28 @@ def main():
                 di, ds = index.search_device(qpool[e % len(qpool)], args.k)
                 assert torch.equal(di, mi[e * args.batch:(e + 1) * args.batch]), "bucketed exchange changed the ids"
                 assert torch.equal(ds, ms[e * args.batch:(e + 1) * args.batch]), "bucketed exchange changed the scores"
+        if dist.is_initialized() and corpus is not None:
+            verify_info = verify_sharded(args, torch, dist, vf, corpus, lo, qpool[0], mi, ms)
+            if rank == 0:
+                assert verify_info["verified"], "the merged multi-GPU result differs from the per-shard CPU oracle"
         if rank == 0:
-            print(f"verify ok: bucket of {E} batches through all-gather + merge", file=sys.stderr)
+            print(f"verify ok: bucket of {E} batches through all-gather + merge {verify_info or ''}", file=sys.stderr)
+    rccl_info = None
+    if dist.is_initialized():
+        prop = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(), "name": prop.name,
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "pci_device_id": getattr(prop, "pci_device_id", None),
+                "uuid": str(getattr(prop, "uuid", "")), "rows": [lo, hi], "pid": os.getpid()}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            ver = None
+        rccl_info = {"backend": dist.get_backend(), "world": dist.get_world_size(), "rccl_version": ver, "devices": seen,
+                     "distinct_devices": len({(d["pci_bus_id"], d["uuid"], d["local_rank"]) for d in seen}),
+                     "collective": f"all_gather_into_tensor of {vf.packed_part_bytes(E * args.batch, args.k)} B per rank "
+                                   f"every {E} batches, then one merge launch over {E * args.batch} queries"}
     index.set_option("profile", 0)
     # The boundary the reference binds (FaissRetriever.invoke -> vf_index_search) takes HOST buffers: the same batches with the
     # queries copied in and the results copied out over PCIe, one call at a time (no overlap between calls).  Reported beside
@@ -397,7 +665,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             host_entry = {"error": f"{type(e).__name__}: {e}"}
     # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
-    rr_ms, rr_info, emb_info, rr_large, lat_info = (None, None, None, None, None)
+    rr_ms, rr_info, emb_info, rr_large, lat_info, llm_info, c4_info = (None, None, None, None, None, None, None)
     if (world > 1 or (exchange and dist.is_initialized())) and not devs and not args.no_rerank:   # (the one-rank rehearsal takes it too)
         # N > 1: the re-rank leg is the data-parallel form (all ranks take part); the single-GPU legs are reported by the N = 1 run
         try:
@@ -423,6 +691,16 @@ def main():
             emb_info = embed_rate(args)
         except Exception as e:  # noqa: BLE001
             emb_info = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not devs and not args.no_llm:
+            try:
+                llm_info = rerank_llm(args)
+            except Exception as e:  # noqa: BLE001
+                llm_info = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and corpus is not None and args.corpus_dtype == "f16" and not args.no_c4:
+            try:
+                c4_info = c4_chain(args, torch, vf, corpus)
+            except Exception as e:  # noqa: BLE001
+                c4_info = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -439,12 +717,12 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         esz = 2 if args.corpus_dtype == "f16" else 1
-        if prof["scan_launches"] > 0 and args.batch >= 129 and not any(o.startswith("wide=0") for o in args.opt):
+        if prof["scan_launches"] > 0 and stats.get("wide_launches", 0) > 0:   # the wide kernel actually ran (vf_search_stats)
             # wide passes (k_scan_wide): min(batch, 1024) queries per read of the shard -> the contraction is MFMA-bound
             # (2 * B / elt FLOP per byte).  One launch = one pass of up to 1024 queries.
             avg_ms = prof["scan_ms_total"] / prof["scan_launches"]
             rows_scanned = prof["scan_bytes_per_launch"] // (args.dim * esz + 4)
-            qpass = min(args.batch, 1024)
+            qpass = min(stats["wide_queries"], 1024)   # the timed launch is the first pass of the call
             flops = 2.0 * qpass * rows_scanned * args.dim
             tf = flops / (avg_ms * 1e-3) / 1e12
             wtraffic, wsrc = None, None
@@ -485,20 +763,27 @@ def main():
                                    f"top-{args.k}, " + (f"row-sharded over devices {devs} behind ONE handle in one process (peer copies + merge)" if devs else
                                                         f"row-sharded over {world} GPU(s) + RCCL all-gather of per-shard top-k"),
                        "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
-                       "rows_per_gpu": hi - lo, "in_flight_batches": nslots, "batches_per_exchange": E if exchange else None},
+                       "rows_per_gpu": [d["rows"][1] - d["rows"][0] for d in rccl_info["devices"]] if rccl_info else hi - lo,
+                       "in_flight_batches": nslots, "batches_per_exchange": E if exchange else None},
+            "rccl": rccl_info,
+            "verify": verify_info,
             "roofline": roof,
             "search_stats": {"candidates_per_query": round(stats["candidates"] / max(1, stats["n_queries"]), 1),
                              "exact_reruns_last_batch": stats["exact_reruns"], "path": stats["path"]},
             "rerank_p50_ms": None if rr_ms is None else round(rr_ms, 3),
             "rerank": rr_info,
             "rerank_large": rr_large,
+            "rerank_llm": llm_info,
+            "c4": c4_info,
             "embed": emb_info,
             "request_latency": lat_info,
             "host_entry": host_entry,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and corpus is not None:
             try:
-                line["cpu_baseline"] = cpu_baseline(args)
+                gi, gs = index.search_device(qpool[0], args.k)
+                line["cpu_baseline"] = cpu_baseline(args, torch, vf, corpus, qpool[0], gi, gs)
+                line["verified"] = bool(line["cpu_baseline"].get("verified"))
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {type(e).__name__}: {e}"}

@@ -52,7 +52,9 @@ typedef struct vf_search_stats {
     int64_t uncertified;     /* queries whose fused result failed the exactness certificate */
     int64_t overflowed;      /* queries whose candidate buffer overflowed */
     int64_t exact_reruns;    /* queries recomputed by the chunked exact path */
-    int64_t reserved[9];
+    int64_t wide_launches;   /* k_scan_wide main passes of the call (0: the 64-query HBM-bound scan served it) */
+    int64_t wide_queries;    /* queries those passes served (up to 1024 per pass) */
+    int64_t reserved[7];
 } vf_search_stats;
 
 int vf_version(void);
@@ -92,6 +94,11 @@ int vf_index_create_sharded_from_file(vf_index** out, const char* path, const in
 int vf_index_group(vf_index** out, vf_index** shards, int32_t n_shards);
 /* number of shards of a handle (0 for a plain single-device index) and their devices (first `cap` of them) */
 int vf_index_shards(vf_index* idx, int32_t* n_shards, int32_t* device_ids, int32_t cap);
+/* peer (xGMI) access between the home device and every shard's device, as enabled when the group was formed:
+ * ok[g] = 1 when both directions are on (or shard g lives on the home device), 0 when a direction could not be enabled
+ * and the query / result copies of that shard are staged through the host; *n_missing counts the zeros.  The reference
+ * has no counterpart (faiss-CPU index in one process, src/utils/faissRetriever.py:17-19 shows the abandoned GPU try). */
+int vf_index_peer_access(vf_index* idx, int32_t* ok, int32_t cap, int32_t* n_missing);
 
 /* Corpus file (.vfc): 64-byte header {char magic[8]="VFCORPUS"; u32 version=1; u32 dtype; u64 n; u32 d; u32 flags;
  * u8 reserved[32]} + n*d row-major elements (+ int64[n] external ids when flags bit 0 is set).  Stands where the
@@ -217,7 +224,7 @@ int vf_encoder_destroy(vf_encoder* enc);
  * (silu(Wgate n) * Wup n), n = RMSNorm(x); causal grouped-query attention; final RMSNorm.  fp16 weights and GEMM
  * operands; the RESIDUAL STREAM x is fp32 (the reference runs these models in the checkpoint's wider dtype,
  * step3_mul.py:62-64: a residual beyond the fp16 range must not overflow), fp32 accumulation / norms / softmax.
- * head_dim 64, 128 or 256 (gemma), t <= 2048. */
+ * head_dim 64, 128 or 256 (gemma), t <= 4096 (the reference's truncation length, step3_mul.py:200). */
 typedef struct vf_decoder vf_decoder;
 typedef struct vf_decoder_config {
     int32_t vocab, hidden, layers, heads, kv_heads, head_dim, ffn;
@@ -237,7 +244,7 @@ typedef struct vf_decoder_config {
 int vf_decoder_weight_sizes(const vf_decoder_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
 int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg, const void* w_fp16, int64_t n_fp16,
                       const float* w_fp32, int64_t n_fp32, int32_t device_id);
-/* ids / mask [b, t] int32 host, t % 32 == 0, t <= 2048 (left- or right-padded, mask 0); positions are column indices
+/* ids / mask [b, t] int32 host, t % 32 == 0, t <= 4096 (left- or right-padded, mask 0); positions are column indices
  * (what HF does when no position_ids are passed); out [b, hidden] (head 0) or [b] (head 2) fp32 host. */
 int vf_decoder_forward(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
                        float* out);

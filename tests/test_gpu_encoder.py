@@ -10,6 +10,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ROOT = ROOT
+# Decoder-family tolerances (fp16 operands, fp32 residual stream, against HF fp32 on the CPU): ~3x the largest value
+# measured over the decoder tests (profiles/r03_decoder_errors.jsonl).  PROVISIONAL until the first GPU run of round 3.
+DEC_COS_TOL, DEC_REL_TOL, DEC_LOGIT_TOL = 5e-4, 2e-2, 2e-2
 
 
 @pytest.fixture(scope="module")
@@ -437,11 +441,33 @@ def _hf_qwen3(hidden, layers, heads, kv_heads, head_dim, ffn, vocab=800, seed=3,
     return m
 
 
+def _measured(test, **vals):
+    """Every decoder test prints what it measured and appends it to gpurun_out/decoder_errors.jsonl; the asserted
+    bounds are ~3x the values recorded in profiles/r03_decoder_errors.jsonl."""
+    import json
+    rec = {"test": test, **{k: (float(v) if np.ndim(v) == 0 else np.asarray(v).tolist()) for k, v in vals.items()}}
+    print("measured", json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(_ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(_ROOT, "gpurun_out", "decoder_errors.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+def _embedding_errors(got, want):
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    return float(1.0 - cos.min()), float(rel)
+
+
 @pytest.mark.parametrize("name,hidden,layers,heads,kv_heads,head_dim,ffn,b,t,left_pad", [
     ("gqa-dh64", 256, 2, 4, 2, 64, 512, 3, 48, False),
     ("gqa-dh128-leftpad", 512, 3, 4, 1, 128, 1024, 4, 100, True),
     ("mha-dh128-long", 256, 2, 2, 2, 128, 768, 2, 300, False),
     ("gqa-dh128-2000", 256, 2, 4, 2, 128, 512, 1, 2000, False),   # beyond 512 tokens: RoPE table, 32 key tiles
+    ("gqa-dh128-4096", 256, 2, 4, 2, 128, 512, 2, 4096, True),    # the reference's truncation length (step3_mul.py:200)
+    ("gqa-dh64-3000", 256, 2, 4, 2, 64, 512, 1, 3000, False),     # a 3000-token chunk in the reference's own call shape
 ])
 def test_decoder_embedder_matches_hf_fp32(vf, name, hidden, layers, heads, kv_heads, head_dim, ffn, b, t, left_pad):
     """last_token_pool embeddings of a random Qwen3-architecture model against HF fp32 on the CPU (same weights,
@@ -466,9 +492,9 @@ def test_decoder_embedder_matches_hf_fp32(vf, name, hidden, layers, heads, kv_he
     got = dec.forward(ids, mask)
     dec.close()
     assert got.shape == (b, hidden)
-    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
-    rel = np.abs(got - want).max() / np.abs(want).max()
-    assert cos.min() > 0.9995 and rel < 2e-2, (name, cos, rel)
+    one_minus_cos, rel = _embedding_errors(got, want)
+    _measured(f"decoder_embedder[{name}]", one_minus_cos=one_minus_cos, rel=rel)
+    assert one_minus_cos < DEC_COS_TOL and rel < DEC_REL_TOL, (name, one_minus_cos, rel)
 
 
 def test_decoder_token_logit_scorer_matches_hf_fp32(vf):
@@ -486,7 +512,9 @@ def test_decoder_token_logit_scorer_matches_hf_fp32(vf):
     dec = vf.HipDecoder.from_hf(model, score_token=yes)
     got = dec.forward(ids, mask)
     dec.close()
-    assert got.shape == (5,) and np.abs(got - want).max() < 2e-2 * max(1.0, np.abs(want).max()), (got, want)
+    err = float(np.abs(got - want).max())
+    _measured("decoder_token_logit", abs_err=err, logit_scale=np.abs(want).max())
+    assert got.shape == (5,) and err < DEC_LOGIT_TOL, (got, want)
 
 
 class _StubLLMTokenizer:
@@ -548,9 +576,11 @@ def test_llm_reranker_compute_score(vf):
     rr.fuse_batches = False
     s4 = rr.compute_score(pairs, batch_size=4)                         # literal micro-batching: same scores
     assert len(s8) == len(pairs) and all(isinstance(v, float) for v in s8)
-    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
-    assert np.abs(np.asarray(s8) - want).max() < tol and np.abs(np.asarray(s4) - want).max() < tol
-    assert np.abs(np.asarray(s8) - np.asarray(s4)).max() < 5e-3
+    e8, e4 = float(np.abs(np.asarray(s8) - want).max()), float(np.abs(np.asarray(s4) - want).max())
+    _measured("llm_reranker_compute_score", abs_err_fused=e8, abs_err_micro=e4, fused_vs_micro=np.abs(np.asarray(s8) - np.asarray(s4)).max(),
+              logit_scale=np.abs(want).max())
+    assert e8 < DEC_LOGIT_TOL and e4 < DEC_LOGIT_TOL
+    assert np.abs(np.asarray(s8) - np.asarray(s4)).max() < DEC_LOGIT_TOL
     rr.decoder.close()
 
 
@@ -570,7 +600,7 @@ def _hf_gemma(hidden, layers, heads, kv_heads, head_dim, ffn, vocab=800, seed=5,
     return m
 
 
-@pytest.mark.parametrize("b,t,left_pad", [(3, 100, True), (2, 300, False), (2, 1100, True)])
+@pytest.mark.parametrize("b,t,left_pad", [(3, 100, True), (2, 300, False), (2, 1100, True), (1, 4096, False)])
 def test_gemma_style_decoder_matches_hf_fp32(vf, b, t, left_pad):
     """The configured re-ranker's architecture (config/example.yaml:9, bge-reranker-v2-gemma = gemma): head dim 256
     (Q tile in LDS, 32-key tiles), multi-query attention, (1 + w) RMSNorm, embeddings x sqrt(hidden), tanh-GELU gate;
@@ -596,13 +626,15 @@ def test_gemma_style_decoder_matches_hf_fp32(vf, b, t, left_pad):
     assert emb.cfg["head_dim"] == 256 and emb.cfg["act"] == 1 and emb.cfg["norm_plus_one"] == 1 and emb.cfg["qk_norm"] == 0
     got_h = emb.forward(ids, mask)
     emb.close()
-    cos = (got_h * want_h).sum(1) / (np.linalg.norm(got_h, axis=1) * np.linalg.norm(want_h, axis=1))
-    rel = np.abs(got_h - want_h).max() / np.abs(want_h).max()
-    assert cos.min() > 0.9995 and rel < 2e-2, (cos, rel)
+    one_minus_cos, rel = _embedding_errors(got_h, want_h)
     sc = vf.HipDecoder.from_hf(model, score_token=77)
     got_logit = sc.forward(ids, mask)
     sc.close()
-    assert np.abs(got_logit - want_logit).max() < 2e-2 * max(1.0, float(np.abs(want_logit).max())), (got_logit, want_logit)
+    lerr = float(np.abs(got_logit - want_logit).max())
+    _measured(f"gemma_decoder[{b}x{t},left={left_pad}]", one_minus_cos=one_minus_cos, rel=rel, logit_abs_err=lerr,
+              logit_scale=np.abs(want_logit).max())
+    assert one_minus_cos < DEC_COS_TOL and rel < DEC_REL_TOL, (one_minus_cos, rel)
+    assert lerr < DEC_LOGIT_TOL, (got_logit, want_logit)
 
 
 def test_decoder_embedder_drop_in(vf):
@@ -922,7 +954,8 @@ def test_ragged_batch_takes_the_packed_forward_and_matches_torch(vf, kind):
 @pytest.mark.parametrize("name,hidden,layers,heads,kv_heads,head_dim,ffn,b,t,left_pad", [
     ("qwen-dh64-right", 256, 2, 4, 2, 64, 512, 12, 160, False),
     ("qwen-dh128-left", 256, 2, 4, 1, 128, 512, 10, 224, True),
-])
+    ("qwen-dh128-left-unaligned", 256, 2, 4, 1, 128, 512, 10, 200, True),   # width % 32 != 0: HipDecoder.forward adds alignment
+])                                                                            # columns on the RIGHT of a left-padded batch
 def test_decoder_ragged_batch_takes_the_packed_forward(vf, name, hidden, layers, heads, kv_heads, head_dim, ffn, b, t, left_pad):
     """A ragged batch padded on one side runs PACKED through the decoder (rows = sum of ceil32(length), each token keeping
     its original column as RoPE position) and gives last_token_pool's embeddings of HF fp32; the token-logit head likewise."""
@@ -953,15 +986,16 @@ def test_decoder_ragged_batch_takes_the_packed_forward(vf, name, hidden, layers,
     got = dec.forward(ids, mask)
     assert L.vf_debug_packed_forwards() == n0 + 1, "the ragged batch did not take the packed path"
     dec.close()
-    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
-    rel = np.abs(got - want).max() / np.abs(want).max()
-    assert cos.min() > 0.9995 and rel < 2e-2, (name, cos, rel)
+    one_minus_cos, rel = _embedding_errors(got, want)
     scorer = vf.HipDecoder.from_hf(model, score_token=7)
     n1 = L.vf_debug_packed_forwards()
     got_logit = scorer.forward(ids, mask)
     assert L.vf_debug_packed_forwards() == n1 + 1
     scorer.close()
-    assert np.abs(got_logit - want_logit).max() < 2e-2 * max(1.0, np.abs(want_logit).max()), (got_logit, want_logit)
+    lerr = float(np.abs(got_logit - want_logit).max())
+    _measured(f"decoder_ragged_packed[{name}]", one_minus_cos=one_minus_cos, rel=rel, logit_abs_err=lerr, logit_scale=np.abs(want_logit).max())
+    assert one_minus_cos < DEC_COS_TOL and rel < DEC_REL_TOL, (name, one_minus_cos, rel)
+    assert lerr < DEC_LOGIT_TOL, (got_logit, want_logit)
 
 
 @pytest.mark.parametrize("act", ["silu", "gelu_tanh"])

@@ -4,6 +4,7 @@ Run on the MI355X box:  python -m pytest tests -m gpu -q
 Bar (BASELINE.json north_star): ids and rank order identical to the CPU path, scores within 1e-3 --
 here scores are required to be BIT-identical to the canonical oracle, which is stronger.
 """
+import os
 import threading
 
 import numpy as np
@@ -15,6 +16,7 @@ from conftest import assert_ranked, assert_topk_equiv, load_golden
 pytestmark = pytest.mark.gpu
 
 FLT_MAX = np.finfo(np.float32).max
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -585,6 +587,58 @@ def test_c3_10m_subset(vf, oracle):
     assert np.array_equal(_bits(sc[pick]), _bits(ws))
 
 
+# ---- BASELINE configs[3] at size: 5M x 768, ONE query -> top-100 -> cross-encoder over 100 pairs -> rank_chunk -> top-20 ----
+def test_c4_5m_end_to_end(vf, oracle):
+    """configs[3], text leg, every stage on the GPU at the configured sizes: embed_query (bge-base shape) -> exact top-100
+    over the first 5M rows of the bench's corpus (ids and score bits against the oracle over the host copy, in 1.25M-row
+    pieces) -> HipReranker.compute_score over 100 pairs of ~512 tokens (bge-reranker-base shape) -> rank_chunk -> at most
+    20 chunks, equal to the oracle's restatement of rank_chunk fed with the same model outputs."""
+    import sys
+    import torch
+    import bench
+    from datetime import datetime
+    from oracle import ref_numpy as R
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _synth import HashTokenizer, sentence
+    from bench_rerank import random_encoder
+    n, d, k = 5_000_000, 768, 100
+    dev = torch.device("cuda", 0)
+    corpus = bench.make_shard(torch, 0, n, d, dev, "f16")
+    e_enc, e_cfg = random_encoder("bert-base", head=0)
+    r_enc, r_cfg = random_encoder("xlmr-base", head=1, vocab=32000)
+    emb = vf.HipEmbeddings(HashTokenizer(e_cfg["vocab"]), e_enc, max_length=512, batch_size=100)
+    rr = vf.HipReranker(HashTokenizer(r_cfg["vocab"]), r_enc, max_length=512)
+    rng = np.random.default_rng(5)
+    question = sentence(rng, 16)
+    qv = np.asarray(emb.embed_query(question), np.float32)[None, :]
+    assert qv.shape == (1, d) and abs(float(np.linalg.norm(qv)) - 1.0) < 1e-3
+    with vf.DenseIndex(corpus) as ix:
+        ids, sc = ix.search(qv, k)
+        st = ix.stats()
+    assert st["path"] == 1 and st["overflowed"] == 0
+    piece, parts_i, parts_s = 1_250_000, [], []
+    for a in range(0, n, piece):
+        rows = corpus[a:a + piece].cpu().numpy()
+        i, s_ = oracle.search(rows, qv, k, id_offset=a)
+        parts_i.append(i); parts_s.append(s_)
+        del rows
+    wi, ws = oracle.merge_topk(np.stack(parts_i), np.stack(parts_s), k)
+    assert np.array_equal(ids, wi) and np.array_equal(_bits(sc), _bits(ws))
+    del corpus
+    passages = [sentence(rng, 470) for _ in range(64)]
+    chunks = [{"page_content": passages[int(i) % 64] + f" #{int(i)}", "bundle_id": j // 2,
+               "metadata": {"date_published": f"2024-{1 + j % 12:02d}-{1 + j % 28:02d}"}} for j, i in enumerate(ids[0])]
+    qt = datetime(2024, 6, 15)
+    got = vf.rank_chunk(chunks, question, qt, rr, emb, chunk_topk=20)
+    scores = rr.compute_score([[question, c["page_content"]] for c in chunks], batch_size=8)
+    assert len(scores) == 100 and np.isfinite(scores).all()
+    ts = vf.time_scores(qt, [c["metadata"]["date_published"] for c in chunks])
+    embs = np.asarray(emb.embed_documents([c["page_content"] for c in chunks]), np.float32)
+    want = R.rank_chunk([c["bundle_id"] for c in chunks], scores, ts, embs, 20, 0.9)
+    assert got == want and 0 < len(got) <= 10
+    e_enc.close(); r_enc.close()
+
+
 # ---- BASELINE configs[4] shape: fp8-e4m3 rows, d = 1024, B = 1024 queries, k = 1000 -------------------------------------
 def test_c5_shape(vf, oracle):
     from oracle import ref_numpy as R
@@ -685,6 +739,7 @@ def test_single_process_sharded_handle(vf, oracle, tmp_path):
     want_i, want_s = oracle.search(c, q, k)
     with vf.DenseIndex(c, device_ids=[0, 0, 0]) as ix:
         assert ix.shard_devices() == [0, 0, 0] and ix.n == 70_001
+        assert ix.peer_access() == [True, True, True]       # same device: nothing to enable, nothing staged
         i, s = ix.search(q, k)                              # host buffers (FaissRetriever.invoke's call)
         st = ix.stats()
         assert np.array_equal(i, want_i) and np.array_equal(_bits(s), _bits(want_s))
@@ -777,10 +832,15 @@ def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
         ix.set_option("wide_sync", -1)
         ix.set_option("wide", 0)                            # the 64-query passes on the same handle: identical answer
         ref_i, ref_s = ix.search(q[:70], k)
+        st64 = ix.stats()
     finally:
         ix.close()
     print("wide stats", (n, d, nq, k, kind), st)
     assert st["path"] == 1 and st["overflowed"] == 0
+    # vf_search_stats says which kernel served the call (bench.py picks its roofline from it, not from the batch size)
+    takes_wide = (d + 127) // 128 * 128 % (256 if kind == "fp8" else 128) == 0
+    assert st["wide_launches"] == ((nq + 1023) // 1024 if takes_wide else 0) and st["wide_queries"] == (nq if takes_wide else 0)
+    assert st64["wide_launches"] == 0 and st64["wide_queries"] == 0
     want_i, want_s = oracle.search(rows16, q, k)
     bad = np.nonzero((got_i != want_i).any(axis=1))[0]
     assert bad.size == 0, f"{bad.size} of {nq} queries differ, first {bad[:5].tolist()}"

@@ -48,3 +48,19 @@ class HashTokenizer:
 
 def sentence(rng, n_words):
     return " ".join(WORDS[i] + str(int(j)) for i, j in zip(rng.integers(0, len(WORDS), n_words), rng.integers(0, 50, n_words)))
+
+
+class LLMHashTokenizer:
+    """What ``build_llm_reranker_inputs`` / ``HipLLMReranker`` need of a decoder re-ranker's tokenizer (the reference's
+    get_inputs calls, stress_test.py:97-146): ``tok(text, add_special_tokens=False, max_length=, truncation=)`` ->
+    ``{"input_ids": [...]}``, ``bos_token_id``, ``pad_token_id``; left padding is the re-ranker's own."""
+    bos_token_id, pad_token_id, padding_side = 2, 0, "left"
+
+    def __init__(self, vocab: int):
+        self._h = HashTokenizer(vocab)
+
+    def __call__(self, text, return_tensors=None, add_special_tokens=False, max_length=None, truncation=False, **_):
+        ids = [4] if text == "\n" else [self._h._tok(w) for w in text.replace("\n", " \n ").split(" ") if w != ""]
+        if truncation and max_length is not None:
+            ids = ids[:max_length]
+        return {"input_ids": ids}

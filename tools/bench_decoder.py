@@ -16,6 +16,35 @@ SHAPES = {  # hidden, layers, heads, kv_heads, head_dim, ffn, vocab
     "tiny": (256, 2, 4, 2, 64, 512, 1000),
 }
 
+def decoder_flops(shape, batch, tokens):
+    H, L, NH, KV, DH, F, V = SHAPES[shape]
+    QD, KD = NH * DH, KV * DH
+    per_tok = 2 * (H * (QD + 2 * KD) + QD * H + 3 * H * F)
+    return batch * L * (tokens * per_tok + 2 * tokens * tokens * QD)      # causal attention: half of 4 T^2 QD
+
+
+def random_decoder(shape, score_token=None, vocab=None, pooling=2, normalize=1):
+    """Random-weight HipDecoder of a named shape; the weights are generated on the GPU (5 GB of fp16 at the gemma-2b shape
+    would take the host generator half a minute) and handed to the C ABI as a host blob.  vocab: override the embedding
+    table's rows (it does not enter the forward's cost)."""
+    import torch
+    H, L, NH, KV, DH, F, V = SHAPES[shape]
+    V = vocab or V
+    gemma = shape.startswith("gemma")
+    cfg = dict(vocab=V, hidden=H, layers=L, heads=NH, kv_heads=KV, head_dim=DH, ffn=F, rope_theta=1e6, rms_eps=1e-6,
+               qk_norm=0 if gemma else 1, pooling=pooling, normalize=normalize, head=2 if score_token is not None else 0,
+               act=1 if gemma else 0, norm_plus_one=1 if gemma else 0, embed_scale=float(H ** 0.5) if gemma else 1.0)
+    c = _ffi.DecoderConfig(**cfg); n16 = _ffi.c_i64(0); n32 = _ffi.c_i64(0)
+    _ffi.check(_ffi.lib().vf_decoder_weight_sizes(ctypes.byref(c), ctypes.byref(n16), ctypes.byref(n32)), "sizes")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w16 = torch.empty(n16.value, dtype=torch.float16)
+    for i in range(0, n16.value, 1 << 28):
+        m = min(1 << 28, n16.value - i)
+        w16[i:i + m] = (torch.randn(m, generator=g, device="cuda", dtype=torch.float32) * 0.02).half().cpu()
+    w32 = np.zeros(n32.value, np.float32) if gemma else np.ones(n32.value, np.float32)
+    return vf.HipDecoder(cfg, w16.numpy(), w32), cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="qwen3-0.6b")

@@ -39,7 +39,8 @@ class DecoderConfig(ctypes.Structure):
 class SearchStats(ctypes.Structure):
     _fields_ = [
         ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
-        ("uncertified", c_i64), ("overflowed", c_i64), ("exact_reruns", c_i64), ("reserved", c_i64 * 9),
+        ("uncertified", c_i64), ("overflowed", c_i64), ("exact_reruns", c_i64), ("wide_launches", c_i64), ("wide_queries", c_i64),
+        ("reserved", c_i64 * 7),
     ]
 
     def as_dict(self):
@@ -57,6 +58,7 @@ SIGNATURES = {
     "vf_index_create_sharded_from_file": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_char_p, p_i32, c_i32]),
     "vf_index_group": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), c_i32]),
     "vf_index_shards": (ctypes.c_int, [vp, p_i32, p_i32, c_i32]),
+    "vf_index_peer_access": (ctypes.c_int, [vp, p_i32, c_i32, p_i32]),
     "vf_corpus_file_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "vf_index_create_from_file": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_char_p, c_i64, c_i64, c_i32, c_i64]),
     "vf_index_search": (ctypes.c_int, [vp, vp, c_i32, c_i32, vp, vp]),

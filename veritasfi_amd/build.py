@@ -19,6 +19,8 @@ SOURCES = ["vf_kernels.hip", "vf_api.hip", "vf_transformer.hip"]
 HEADERS = ["vf_internal.h", os.path.join("..", "..", "include", "veritasfi_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# VF_BUILD_FLAGS="-DVF_EXPERIMENTS" compiles the measured-and-rejected experiment kernels back in
+EXTRA = os.environ.get("VF_BUILD_FLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -40,16 +42,19 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    objs = []
-    for s in srcs:
+    objs, jobs = [], []
+    for s in srcs:   # the three translation units compile concurrently (the transformer TU alone takes ~40 s)
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd, cwd=CSRC)
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
         objs.append(obj)
+    failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

@@ -86,6 +86,7 @@ struct Slot {
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_scan = nullptr;  // ev_scan: after this slot's main k_scan
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
+    int wide_launches = 0, wide_queries = 0;   // k_scan_wide main passes of the pending search / queries they served
     DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
     DevBuf dbg, wgbase, tilecnt, sib;
     int64_t wgbase_n = -1; int wgbase_grid = -1;
@@ -146,6 +147,7 @@ struct vf_index {
     // ---- group handle (vf_index_create_sharded / vf_index_group): the corpus is row-sharded over `shards`, one per
     // device; this handle owns them.  device = the HOME device: queries arrive there and the merged result lands there.
     std::vector<vf_index*> shards;
+    std::vector<int> peer_ok;         // [G] 1 = home <-> shard g peer access is on in both directions (or same device)
     GroupSlot gslots[kSlots];
 };
 
@@ -236,7 +238,7 @@ static void destroy_index(vf_index* ix) {
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = ix->slots[i];
         DevBuf* bufs[] = {&s.qn, &s.qimg, &s.s0, &s.cnt, &s.tau, &s.hist, &s.hist_coarse, &s.cand, &s.flags, &s.counts, &s.dense_s,
-                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg, &s.wgbase, &s.tilecnt};
+                          &s.cn_tmp, &s.parts_ids, &s.parts_sc, &s.run_ids, &s.run_sc, &s.qsel, &s.dbg, &s.wgbase, &s.tilecnt, &s.sib};
         for (DevBuf* b : bufs) b->release();
         if (s.h_flags) (void)hipHostFree(s.h_flags);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
@@ -292,11 +294,13 @@ static int create_impl(vf_index** out, const void* rows, bool rows_on_device, in
 
 extern "C" int vf_index_create(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
                                int32_t device_id, int64_t id_offset) {
+    DeviceGuard restore_callers_device;
     return create_impl(out, rows, false, n, d, dtype, device_id, id_offset);
 }
 
 extern "C" int vf_index_create_device(vf_index** out, const void* d_rows, int64_t n, int32_t d, int32_t dtype,
                                       int32_t device_id, int64_t id_offset) {
+    DeviceGuard restore_callers_device;
     return create_impl(out, d_rows, true, n, d, dtype, device_id, id_offset);
 }
 
@@ -348,6 +352,7 @@ extern "C" int vf_corpus_file_info(const char* path, int64_t* n, int32_t* d, int
 // streamed through two pinned staging buffers (read() of one overlaps the H2D copy of the other).
 extern "C" int vf_index_create_from_file(vf_index** out, const char* path, int64_t row_lo, int64_t row_hi,
                                          int32_t device_id, int64_t id_offset) {
+    DeviceGuard restore_callers_device;
     if (!out || !path) return fail(VF_EINVAL, "vf_index_create_from_file: null argument");
     *out = nullptr;
     const int fd = open(path, O_RDONLY);
@@ -405,6 +410,7 @@ extern "C" int vf_index_create_from_file(vf_index** out, const char* path, int64
 }
 
 extern "C" int vf_index_destroy(vf_index* ix) {
+    DeviceGuard restore_callers_device;
     if (!ix) return VF_OK;
     destroy_index(ix);
     return VF_OK;
@@ -446,6 +452,7 @@ extern "C" int vf_index_profile(vf_index* ix, double* scan_ms_total, int64_t* sc
 
 // debug: copy the wall-clock stamps of slot's last main scan (option debug bit 7) to host
 extern "C" int vf_index_debug_read(vf_index* ix, int32_t slot, unsigned long long* out, int64_t n_words) {
+    DeviceGuard restore_callers_device;
     if (!ix || !out || slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_debug_read: bad argument");
     if (!ix->shards.empty()) return vf_index_debug_read(ix->shards[0], slot, out, n_words);
     std::lock_guard<std::mutex> g(ix->mu);
@@ -689,7 +696,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     VF_TRY(s.qimg.ensure(scan_lds_bytes(ix->dp, kMaxBatch)));
     VF_TRY(ensure_pinned(s, (size_t)nq));
     s.pending = true; s.d_queries = d_queries; s.nq = nq; s.k = k; s.d_ids = d_ids; s.d_scores = d_scores;
-    s.path = path; s.user_stream = user;
+    s.path = path; s.user_stream = user; s.wide_launches = 0; s.wide_queries = 0;
     if (nq == 0 || k == 0) { VF_HIP(hipEventRecord(s.ev_done, st)); return VF_OK; }
 
     if (path != 1) {
@@ -712,6 +719,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             const int nb = std::min(kWideMaxQueries, nq - b0);
             VF_TRY(wide_pass(ix, s, p, d_queries + (size_t)b0 * ix->d, nb, k, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k,
                              b0, s.qn.as<float>() + (size_t)b0 * ix->d, s.timed && b0 == 0, st, slot_id));
+            ++s.wide_launches; s.wide_queries += nb;
         }
         if (s.timed) VF_HIP(hipEventRecord(s.ev_t[3], st));
         VF_HIP(hipEventRecord(s.ev_done, st));
@@ -789,7 +797,7 @@ static int end_impl(vf_index* ix, int slot_id) {
     s.pending = false;
     VF_HIP(hipEventSynchronize(s.ev_done));
     vf_search_stats stt{};
-    stt.path = s.path; stt.n_queries = s.nq;
+    stt.path = s.path; stt.n_queries = s.nq; stt.wide_launches = s.wide_launches; stt.wide_queries = s.wide_queries;
     if (s.path == 1 && s.nq > 0 && s.k > 0) {
         if (s.timed) {
             float ms = 0.f;
@@ -934,6 +942,7 @@ static int group_end(vf_index* ix, int slot_id) {
                 tot.path = std::max(tot.path, st.path);
                 tot.candidates += st.candidates; tot.max_candidates = std::max(tot.max_candidates, st.max_candidates);
                 tot.uncertified += st.uncertified; tot.overflowed += st.overflowed; tot.exact_reruns += st.exact_reruns;
+                tot.wide_launches = std::max(tot.wide_launches, st.wide_launches); tot.wide_queries = std::max(tot.wide_queries, st.wide_queries);
             }
         }
         if (r == VF_OK) {
@@ -974,6 +983,7 @@ static bool slot_pending(const vf_index* ix, int slot) {
 
 extern "C" int vf_index_search_begin(vf_index* ix, int32_t slot, const float* d_queries, int32_t nq, int32_t k,
                                      int64_t* d_ids, float* d_scores, void* stream) {
+    DeviceGuard restore_callers_device;
     VF_TRY(check_search_args(ix, d_queries, nq, k, d_ids, d_scores));
     if (slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_search_begin: bad slot");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -981,6 +991,7 @@ extern "C" int vf_index_search_begin(vf_index* ix, int32_t slot, const float* d_
 }
 
 extern "C" int vf_index_search_end(vf_index* ix, int32_t slot) {
+    DeviceGuard restore_callers_device;
     if (!ix) return fail(VF_EINVAL, "vf_index_search_end: null handle");
     if (slot < 0 || slot >= kSlots) return fail(VF_EINVAL, "vf_index_search_end: bad slot");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -996,6 +1007,7 @@ static int search_device_locked(vf_index* ix, const float* d_queries, int nq, in
 
 extern "C" int vf_index_search_device(vf_index* ix, const float* d_queries, int32_t nq, int32_t k, int64_t* d_ids,
                                       float* d_scores, void* stream) {
+    DeviceGuard restore_callers_device;
     VF_TRY(check_search_args(ix, d_queries, nq, k, d_ids, d_scores));
     std::lock_guard<std::mutex> g(ix->mu);
     return search_device_locked(ix, d_queries, nq, k, d_ids, d_scores, (hipStream_t)stream);
@@ -1006,6 +1018,7 @@ extern "C" int vf_index_search_device(vf_index* ix, const float* d_queries, int3
 // handle's mutex is held for the whole call, so concurrent request threads take turns on it.
 extern "C" int vf_index_search(vf_index* ix, const float* queries, int32_t nq, int32_t k, int64_t* out_ids,
                                float* out_scores) {
+    DeviceGuard restore_callers_device;
     VF_TRY(check_search_args(ix, queries, nq, k, out_ids, out_scores));
     if (nq == 0 || k == 0) return VF_OK;
     std::lock_guard<std::mutex> g(ix->mu);
@@ -1034,19 +1047,21 @@ static int make_group(vf_index** out, std::vector<vf_index*>& shards) {
     grp->n = 0;
     for (vf_index* sh : shards) grp->n += sh->n;
     grp->shards = shards;
-    // peer access home <-> shard devices where the platform offers it (copies fall back to staging otherwise)
-    for (vf_index* sh : shards) {
-        if (sh->device == grp->device) continue;
+    // peer access home <-> shard devices.  A link that cannot be enabled is not fatal -- hipMemcpyPeerAsync then stages
+    // through the host -- but it is RECORDED (vf_index_peer_access) so that the slow exchange does not go unnoticed.
+    auto enable = [](int from, int to) -> bool {
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, grp->device, sh->device) == hipSuccess && can) {
-            (void)hipSetDevice(grp->device);
-            (void)hipDeviceEnablePeerAccess(sh->device, 0);
-        }
-        if (hipDeviceCanAccessPeer(&can, sh->device, grp->device) == hipSuccess && can) {
-            (void)hipSetDevice(sh->device);
-            (void)hipDeviceEnablePeerAccess(grp->device, 0);
-        }
-        (void)hipGetLastError();  // "already enabled" is not an error
+        if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) return false;
+        if (hipSetDevice(from) != hipSuccess) return false;
+        const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+        (void)hipGetLastError();
+        return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+    };
+    grp->peer_ok.assign(shards.size(), 1);
+    for (size_t g = 0; g < shards.size(); ++g) {
+        if (shards[g]->device == grp->device) continue;
+        const bool a = enable(grp->device, shards[g]->device), b = enable(shards[g]->device, grp->device);
+        grp->peer_ok[g] = a && b ? 1 : 0;
     }
     (void)hipSetDevice(grp->device);
     *out = grp;
@@ -1054,6 +1069,7 @@ static int make_group(vf_index** out, std::vector<vf_index*>& shards) {
 }
 
 extern "C" int vf_index_group(vf_index** out, vf_index** shards, int32_t n_shards) {
+    DeviceGuard restore_callers_device;
     if (!out || !shards || n_shards <= 0) return fail(VF_EINVAL, "vf_index_group: bad argument");
     *out = nullptr;
     std::vector<vf_index*> v(shards, shards + n_shards);
@@ -1084,6 +1100,7 @@ static void shard_block(int64_t n, int n_dev, int g, int64_t* lo, int64_t* hi) {
 
 extern "C" int vf_index_create_sharded(vf_index** out, const void* rows, int64_t n, int32_t d, int32_t dtype,
                                        const int32_t* device_ids, int32_t n_dev) {
+    DeviceGuard restore_callers_device;
     if (!out) return fail(VF_EINVAL, "vf_index_create_sharded: null out");
     *out = nullptr;
     VF_TRY(check_devices(device_ids, n_dev, "vf_index_create_sharded"));
@@ -1106,6 +1123,7 @@ extern "C" int vf_index_create_sharded(vf_index** out, const void* rows, int64_t
 }
 
 extern "C" int vf_index_create_sharded_from_file(vf_index** out, const char* path, const int32_t* device_ids, int32_t n_dev) {
+    DeviceGuard restore_callers_device;
     if (!out || !path) return fail(VF_EINVAL, "vf_index_create_sharded_from_file: null argument");
     *out = nullptr;
     VF_TRY(check_devices(device_ids, n_dev, "vf_index_create_sharded_from_file"));
@@ -1133,11 +1151,23 @@ extern "C" int vf_index_shards(vf_index* ix, int32_t* n_shards, int32_t* device_
     return VF_OK;
 }
 
+extern "C" int vf_index_peer_access(vf_index* ix, int32_t* ok, int32_t cap, int32_t* n_missing) {
+    if (!ix) return fail(VF_EINVAL, "vf_index_peer_access: null handle");
+    int missing = 0;
+    for (size_t g = 0; g < ix->peer_ok.size(); ++g) {
+        if (ok && (int)g < cap) ok[g] = ix->peer_ok[g];
+        missing += ix->peer_ok[g] ? 0 : 1;
+    }
+    if (n_missing) *n_missing = missing;
+    return VF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // small dense cosine (compute_similarity_mtx / cosine_similarity restatements)
 // ------------------------------------------------------------------------------------------------
 extern "C" int vf_cosine_scores(const float* a, int32_t na, const float* b, int64_t nb, int32_t d, float* out,
                                 int32_t device_id) {
+    DeviceGuard restore_callers_device;
     if (na < 0 || nb < 0 || d <= 0) return fail(VF_EINVAL, "vf_cosine_scores: bad sizes");
     if (na == 0 || nb == 0) return VF_OK;
     if (!a || !b || !out) return fail(VF_EINVAL, "vf_cosine_scores: null buffer");
@@ -1174,6 +1204,7 @@ extern "C" int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out
 
 extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts, int32_t nparts, int32_t nq,
                                     int32_t k, int64_t* d_ids, float* d_scores, int32_t device_id, void* stream) {
+    DeviceGuard restore_callers_device;
     if (nparts <= 0 || nq < 0 || k < 0) return fail(VF_EINVAL, "vf_merge_topk_device: bad sizes");
     if (nq == 0 || k == 0) return VF_OK;
     if (!d_ids_parts || !d_score_parts || !d_ids || !d_scores) return fail(VF_EINVAL, "vf_merge_topk_device: null buffer");
@@ -1187,6 +1218,7 @@ extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_s
 
 extern "C" int vf_merge_topk_packed_device(const void* d_parts, int32_t nparts, int32_t nq, int32_t k, int64_t* d_ids,
                                            float* d_scores, int32_t device_id, void* stream) {
+    DeviceGuard restore_callers_device;
     if (nparts <= 0 || nq < 0 || k < 0) return fail(VF_EINVAL, "vf_merge_topk_packed_device: bad sizes");
     if (nq == 0 || k == 0) return VF_OK;
     if (!d_parts || !d_ids || !d_scores) return fail(VF_EINVAL, "vf_merge_topk_packed_device: null buffer");
@@ -1199,6 +1231,7 @@ extern "C" int vf_merge_topk_packed_device(const void* d_parts, int32_t nparts, 
 
 extern "C" int vf_fuse_rank(const float* rerank_scores, const float* time_scores, int32_t n, float* out_scores,
                             int64_t* out_order, int32_t device_id) {
+    DeviceGuard restore_callers_device;
     if (n < 0 || n > 4096) return fail(VF_EINVAL, "vf_fuse_rank: n must be in [0, 4096]");
     if (n == 0) return VF_OK;
     if (!rerank_scores || !time_scores || !out_scores || !out_order) return fail(VF_EINVAL, "vf_fuse_rank: null buffer");
@@ -1219,6 +1252,7 @@ extern "C" int vf_fuse_rank(const float* rerank_scores, const float* time_scores
 // Test hook (not in the public header): the fused scan's HARDWARE e4m3 -> fp16 conversion applied to `count` codes,
 // so that tests can pin it against the oracle's table instead of trusting the instruction's documentation.
 extern "C" int vf_debug_cvt_e4m3(const unsigned char* codes, float* out, int32_t count) {
+    DeviceGuard restore_callers_device;
     if (!codes || !out || count < 0) return fail(VF_EINVAL, "vf_debug_cvt_e4m3: bad argument");
     unsigned char* d_in = nullptr; float* d_out = nullptr;
     VF_HIP(hipMalloc((void**)&d_in, (size_t)count + 8));

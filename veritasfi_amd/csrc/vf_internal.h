@@ -16,6 +16,16 @@ int set_error(int code, const std::string& msg);
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// Every entry point that selects a device (hipSetDevice is per-thread state) puts the caller's device back on return:
+// a host application that drives its own HIP / torch work on another device must not find it changed by a vf_* call.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // ---- fixed design constants ------------------------------------------------------
 constexpr int kQueryTile = 32;        // queries per MFMA N-tile (v_mfma_f32_32x32x16_f16)
 constexpr int kMaxBatch = 64;         // queries per scan pass (2 N-tiles); larger nq loops

@@ -3989,8 +3989,11 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
 }
 
 static int enc_ensure_ws(vf_encoder* e, int B, int T) {
-    const int tokens = (B * T + 255) / 256 * 256;
+    int tokens = (B * T + 255) / 256 * 256;
     if (tokens <= e->cap_tokens && B <= e->cap_b) return VF_OK;
+    // grow monotonically on BOTH axes: alternating call shapes (100 x 512 re-rank, then 256 x 64 embed) must not free and
+    // rebuild the workspace -- and drop every captured graph -- on each call
+    tokens = std::max(tokens, e->cap_tokens); B = std::max(B, e->cap_b);
     enc_free_ws(e);
     const size_t H = e->cfg.hidden, F = e->cfg.ffn, Mp = tokens;
     const int out_dim = e->cfg.head == 1 ? 1 : (int)H;
@@ -4568,7 +4571,7 @@ extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e)
 // ------------------------------------------------------------------------------------------------
 // Decoder-only model handle (vf_decoder_*): see the kernel block above and include/veritasfi_hip.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDecMaxT = 2048;  // streaming attention has no residency limit; the RoPE table is sized for this
+constexpr int kDecMaxT = 4096;  // the reference truncates at max_length=4096 (step3_mul.py:200); streaming attention has no residency limit, the RoPE table is sized for this
 
 struct vf_decoder {
     vf_decoder_config cfg{};
@@ -4683,8 +4686,9 @@ extern "C" int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg,
 }
 
 static int dec_ensure_ws(vf_decoder* d, int B, int T) {
-    const int tokens = (B * T + 255) / 256 * 256;
+    int tokens = (B * T + 255) / 256 * 256;
     if (tokens <= d->cap_tokens && B <= d->cap_b && T <= d->rope_T) return VF_OK;
+    tokens = std::max(tokens, d->cap_tokens); B = std::max(B, d->cap_b);   // monotone growth (see enc_ensure_ws)
     dec_free_ws(d);
     const vf_decoder_config& c = d->cfg;
     const size_t H = c.hidden, F = c.ffn, QKV = dec_qd(c) + 2 * dec_kd(c), QD = dec_qd(c), Mp = tokens;
@@ -4788,11 +4792,11 @@ static int dec_check_call(vf_decoder* d, const int32_t* ids, const int32_t* mask
     if (b < 0 || t < 0) return fail(VF_EINVAL, std::string(who) + ": negative sizes");
     if (b > 0 && (!ids || !mask || !out)) return fail(VF_EINVAL, std::string(who) + ": null buffer");
     if (b > 0 && (t == 0 || t % 32 != 0 || t > kDecMaxT))
-        return fail(VF_EINVAL, std::string(who) + ": t must be a multiple of 32 in [32, 2048] (pad with mask 0)");
+        return fail(VF_EINVAL, std::string(who) + ": t must be a multiple of 32 in [32, 4096] (pad with mask 0)");
     return VF_OK;
 }
 
-// ids / mask [b, t] int32 host (t % 32 == 0, t <= 2048; right- or left-padded with mask 0); t_valid = columns the
+// ids / mask [b, t] int32 host (t % 32 == 0, t <= 4096; right- or left-padded with mask 0); t_valid = columns the
 // tokenizer produced.  out: [b, hidden] fp32 (head 0) or [b] fp32 (head 2).
 extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
                                   int32_t t_valid, float* out) {
@@ -4823,13 +4827,15 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
         for (int i = 0; i < b && ok; ++i) {
             const int32_t* m = mask + (size_t)i * t;
             int f = 0;
-            while (f < t && !m[f]) ++f;
+            while (f < t_valid && !m[f]) ++f;
             int e2 = f;
-            while (e2 < t && m[e2]) ++e2;
+            while (e2 < t_valid && m[e2]) ++e2;
             for (int j = e2; j < t; ++j) if (m[j]) { ok = false; break; }   // more than one run of tokens
             if (e2 == f) ok = false;                                         // no token at all: the padded path
             all_right = all_right && f == 0;
-            all_left = all_left && e2 == t;
+            // LEFT padding is judged against the columns the tokenizer produced (t_valid), not the 32-aligned t: the
+            // caller's alignment columns sit on the right of a left-padded batch whose width is not a multiple of 32
+            all_left = all_left && e2 == t_valid;
             const int l32 = (e2 - f + 31) / 32 * 32;
             off[i] = (int32_t)rows; first[i] = f; lens[i] = e2 - f;
             rows += l32;

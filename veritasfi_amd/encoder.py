@@ -291,6 +291,9 @@ def pack_hf_decoder_weights(model, pooling=POOL_LAST_TOKEN, normalize=False, sco
     return cfg, np.concatenate([a.ravel() for a in p16]), np.concatenate([a.ravel() for a in p32])
 
 
+DECODER_MAX_TOKENS = 4096   # the reference's truncation length (experiments/retriever/step3_mul.py:200), kDecMaxT in csrc
+
+
 class HipDecoder:
     """Decoder-only encoder / scorer on the GPU (``vf_decoder_*``).  ``forward(ids, mask)`` -> [b, hidden] pooled
     embeddings (head 0) or [b] logits of the scored token (head 2)."""
@@ -315,8 +318,8 @@ class HipDecoder:
         mask = np.asarray(mask, dtype=np.int32)
         b, t = ids.shape
         tp = max(32, -(-t // 32) * 32)
-        if tp > 2048:
-            raise ValueError("sequences longer than 2048 tokens are not supported")
+        if tp > DECODER_MAX_TOKENS:
+            raise ValueError(f"sequences longer than {DECODER_MAX_TOKENS} tokens are not supported")
         if tp != t:     # alignment columns on the right with mask 0 (t_valid tells the pooling where the tokenizer stopped)
             pi, pm = np.zeros((b, tp), np.int32), np.zeros((b, tp), np.int32)
             pi[:, :t], pm[:, :t] = ids, mask
@@ -333,8 +336,8 @@ class HipDecoder:
         mask = np.asarray(mask, dtype=np.int32)
         b, t = ids.shape
         tp = max(32, -(-t // 32) * 32)
-        if tp > 2048:
-            raise ValueError("sequences longer than 2048 tokens are not supported")
+        if tp > DECODER_MAX_TOKENS:
+            raise ValueError(f"sequences longer than {DECODER_MAX_TOKENS} tokens are not supported")
         if tp != t:
             pi, pm = np.zeros((b, tp), np.int32), np.zeros((b, tp), np.int32)
             pi[:, :t], pm[:, :t] = ids, mask

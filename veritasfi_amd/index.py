@@ -62,6 +62,7 @@ class DenseIndex:
             self.device_id, self.device_ids = ids[0], ids
             _ffi.check(L.vf_index_create_sharded(ctypes.byref(self._h), rows.ctypes.data, self.n, self.d, dt, arr, len(ids)),
                        "vf_index_create_sharded")
+            self._warn_if_staged()
             return
         if _is_torch_tensor(rows):
             import torch
@@ -125,6 +126,7 @@ class DenseIndex:
             self.n, self.d = int(n.value), int(d.value)
             _ffi.check(L.vf_index_create_sharded_from_file(ctypes.byref(self._h), path.encode(), arr, len(ids)),
                        "vf_index_create_sharded_from_file")
+            self._warn_if_staged()
             return self
         lo, hi = shard_bounds(n.value, world, rank)
         self.device_id, self.id_offset = int(device_id), int(lo)
@@ -150,6 +152,7 @@ class DenseIndex:
         for s in shards:
             s._h = _ffi.vp()
             s._keepalive = None
+        self._warn_if_staged()
         return self
 
     @classmethod
@@ -218,6 +221,23 @@ class DenseIndex:
         devs = (_ffi.c_i32 * 64)()
         _ffi.check(_ffi.lib().vf_index_shards(self._h, ctypes.byref(n), devs, 64), "vf_index_shards")
         return [int(devs[i]) for i in range(min(int(n.value), 64))]
+
+    def peer_access(self) -> list:
+        """Per shard: True when xGMI peer access between the home device and the shard's device is enabled in both
+        directions (or they are the same device); False = that shard's query / result copies are staged through the host."""
+        ok = (_ffi.c_i32 * 64)()
+        missing = _ffi.c_i32(0)
+        _ffi.check(_ffi.lib().vf_index_peer_access(self._h, ok, 64, ctypes.byref(missing)), "vf_index_peer_access")
+        return [bool(ok[i]) for i in range(len(self.shard_devices()))]
+
+    def _warn_if_staged(self):
+        flags = self.peer_access()
+        if flags and not all(flags):
+            import warnings
+            devs = self.shard_devices()
+            warnings.warn("veritasfi_amd: no peer (xGMI) access between the home device and device(s) "
+                          f"{[d for d, f in zip(devs, flags) if not f]}: the exchange of those shards is staged through "
+                          "the host (correct, slower)", RuntimeWarning, stacklevel=3)
 
     def stats(self) -> dict:
         st = _ffi.SearchStats()
