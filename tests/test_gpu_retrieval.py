@@ -587,6 +587,27 @@ def test_c3_10m_subset(vf, oracle):
     assert np.array_equal(_bits(sc[pick]), _bits(ws))
 
 
+@pytest.mark.parametrize("nq", [1, 3, 20])
+def test_few_queries_over_a_large_corpus_stay_on_the_fused_path(vf, oracle, nq):
+    """The serve path's call shape at scale (one question + up to three hyde chunks, ensembleRetriever.py:64-66) over a
+    2M-row shard: the thresholds must keep rising although a workgroup stages only a few dozen candidates per query
+    (round 3: publication blocks scale with the query count) -- no candidate list overflows, nothing is re-run exactly,
+    and the result is the oracle's bit for bit."""
+    import torch
+    import bench
+    n, d, k = 2_000_000, 768, 100
+    corpus = bench.make_shard(torch, 0, n, d, torch.device("cuda", 0), "f16")
+    q = np.random.default_rng(77).standard_normal((nq, d)).astype(np.float32)
+    with vf.DenseIndex(corpus) as ix:
+        ids, sc = ix.search(q, k)
+        st = ix.stats()
+    print("few-queries stats", nq, st)
+    assert st["path"] == 1 and st["overflowed"] == 0 and st["exact_reruns"] == 0 and st["uncertified"] == 0
+    assert st["max_candidates"] < 4096
+    wi, ws = oracle.search(corpus.cpu().numpy(), q, k)
+    assert np.array_equal(ids, wi) and np.array_equal(_bits(sc), _bits(ws))
+
+
 # ---- BASELINE configs[3] at size: 5M x 768, ONE query -> top-100 -> cross-encoder over 100 pairs -> rank_chunk -> top-20 ----
 def test_c4_5m_end_to_end(vf, oracle):
     """configs[3], text leg, every stage on the GPU at the configured sizes: embed_query (bge-base shape) -> exact top-100
@@ -615,7 +636,7 @@ def test_c4_5m_end_to_end(vf, oracle):
     with vf.DenseIndex(corpus) as ix:
         ids, sc = ix.search(qv, k)
         st = ix.stats()
-    assert st["path"] == 1 and st["overflowed"] == 0
+    assert st["path"] == 1 and st["overflowed"] == 0 and st["exact_reruns"] == 0, st
     piece, parts_i, parts_s = 1_250_000, [], []
     for a in range(0, n, piece):
         rows = corpus[a:a + piece].cpu().numpy()

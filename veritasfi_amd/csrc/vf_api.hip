@@ -755,7 +755,13 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         a.tile_cnt = ix->steal_opt ? s.tilecnt.as<u32>() : nullptr; a.scan_grid = p.grid;
         a.dbg = nullptr;
         if (ix->debug & 128) { VF_TRY(s.dbg.ensure((size_t)p.total_waves * 4 * sizeof(u64))); a.dbg = s.dbg.as<u64>(); }
-        a.refresh_every = (int)std::min<int64_t>(256, std::max<int64_t>(1, ix->refresh_every)); a.nq = nb; a.debug = (int)ix->debug;
+        // A workgroup publishes its staged candidates (and refreshes one threshold) per BLOCK of refresh_every staged entries,
+        // whatever query they belong to: the option is stated for a full 64-query batch and scales with the batch's query
+        // count, so that a query sees the same publication granularity at nq = 1 as at nq = 64.  (Unscaled, a single
+        // query over 5M rows staged ~76 entries per workgroup, never completed a 128-entry block, never raised its
+        // threshold above the sample's and overflowed its candidate list: exact re-run, 38 ms instead of 1.5.)
+        a.refresh_every = (int)std::min<int64_t>(256, std::max<int64_t>(4, std::max<int64_t>(1, ix->refresh_every) * nb / kMaxBatch));
+        a.nq = nb; a.debug = (int)ix->debug;
         // sample slots no wave writes (a wave range shorter than samp) must read as empty: 0xFF bytes
         // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
         if (ix->n / p.total_waves < p.samp)
