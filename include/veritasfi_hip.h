@@ -54,7 +54,10 @@ typedef struct vf_search_stats {
     int64_t exact_reruns;    /* queries recomputed by the chunked exact path */
     int64_t wide_launches;   /* k_scan_wide main passes of the call (0: the 64-query HBM-bound scan served it) */
     int64_t wide_queries;    /* queries those passes served (up to 1024 per pass) */
-    int64_t reserved[7];
+    int64_t aux_cus;         /* CUs the main scan left to the small kernels of the other slots (0 = no CU split) */
+    int64_t scans_overlap;   /* 1 = main scans of consecutive slots were not ordered against each other */
+    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide */
+    int64_t reserved[4];
 } vf_search_stats;
 
 int vf_version(void);
@@ -141,6 +144,10 @@ int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
  * k_scan launch reads (rows scanned x (d*2 + 4)). */
 int vf_index_profile(vf_index* idx, double* scan_ms_total, int64_t* scan_launches, double* pipeline_ms_total,
                      int64_t* scan_bytes_per_launch);
+/* Makespan of the timed main scans since "profile" was set: the first launch's begin to the last launch's end (HIP events
+ * on the streams the scans run on) and the number of launches.  Small shards run their scans OVERLAPPED (option
+ * overlap_scans, vf_search_stats.scans_overlap): span / launches is then the launch interval the roofline is computed from. */
+int vf_index_profile_span(vf_index* idx, double* span_ms, int64_t* launches);
 /* Debug aid (not part of the reference surface): wall-clock stamps of the last main scan of `slot`
  * when option "debug" has bit 7 set; returns the number of 64-bit words copied (>= 0) or VF_E*. */
 int vf_index_debug_read(vf_index* idx, int32_t slot, unsigned long long* out, int64_t n_words);

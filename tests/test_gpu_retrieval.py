@@ -587,6 +587,38 @@ def test_c3_10m_subset(vf, oracle):
     assert np.array_equal(_bits(sc[pick]), _bits(ws))
 
 
+@pytest.mark.parametrize("n,d,nq,k,want_kernel", [
+    (60_000, 768, 64, 100, 2),      # the headline shape: image 96 KB + four 12-KB rings
+    (60_000, 768, 9, 10, 2),        # one N-tile
+    (50_011, 100, 64, 50, 2),       # dp = 128: two segments per row (shorter than the ring is deep), ragged last tile
+    (40_000, 384, 40, 100, 2),      # six segments
+    (40_000, 1024, 64, 100, 1),     # 128 KB image: the rings do not fit beside it -> k_scan
+    (40_000, 1024, 20, 100, 2),     # ... but they do beside a 32-query image
+    (30_000, 1536, 64, 10, 2),      # too wide for a 64-query image at all: 32-query passes, whose 96 KB image leaves room for the rings
+    (20_000, 2400, 8, 10, 1),       # dp = 2432: a 152 KB image, register kernel only
+])
+def test_scan_kernels_agree_and_match_oracle(vf, oracle, n, d, nq, k, want_kernel):
+    """k_scan2 (whole-line LDS-DMA corpus loads, one wave per SIMD) where image + rings + candidate stage fit the LDS, k_scan
+    (register loads) elsewhere and on request: both bit-identical to the oracle; vf_search_stats names the kernel that ran;
+    with and without the CU split / overlapping scans (speed options only)."""
+    c, q = _data(90 + d % 7, n, d, nq, np.float16)
+    want_i, want_s = oracle.search(c, q, k)
+    with vf.DenseIndex(c) as ix:
+        ix.set_option("force_path", 1)
+        for impl, aux, ov in ((2, -1, -1), (1, -1, -1), (2, 0, 0), (2, 32, 0)):
+            ix.set_option("scan_impl", impl)
+            ix.set_option("overlap_scans", ov)
+            i, s_ = ix.search(q, k)
+            st = ix.stats()
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), (impl, aux, ov)
+            assert st["path"] == 1 and st["exact_reruns"] == 0 and st["scan_kernel"] == (want_kernel if impl == 2 else 1), st
+    with vf.DenseIndex(c) as ix:                        # the split is fixed when a slot's streams are created
+        ix.set_option("force_path", 1)
+        ix.set_option("aux_cus", 0)
+        i, s_ = ix.search(q, k)
+        assert ix.stats()["aux_cus"] == 0 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+
+
 @pytest.mark.parametrize("nq", [1, 3, 20])
 def test_few_queries_over_a_large_corpus_stay_on_the_fused_path(vf, oracle, nq):
     """The serve path's call shape at scale (one question + up to three hyde chunks, ensembleRetriever.py:64-66) over a

@@ -33,6 +33,11 @@ static int run(const char* name, hipStream_t st, unsigned* d_out, int grid) {
     }
     printf("%-28s distinct CUs %3zu  per XCC:", name, cus.size());
     for (int x = 0; x < 8; ++x) printf(" %2zu", per[x].size());
+    // CUs per shader engine of XCC 0 (a dispatch that hands every SE the same number of workgroups needs them equal)
+    int per_se[8] = {0};
+    for (unsigned key : per[0]) ++per_se[(key >> 8) & 7];
+    printf("   XCC0 per SE:");
+    for (int e = 0; e < 8; ++e) if (per_se[e]) printf(" se%d=%d", e, per_se[e]);
     printf("\n");
     (void)per_xcc;
     return (int)cus.size();
@@ -61,5 +66,8 @@ int main() {
     masked("bits [0, 8)", 0, 8);
     masked("bits [0, 32)", 0, 32);
     masked("bits [0, ncu/2)", 0, ncu / 2);
+    masked("bits [0, ncu-16)", 0, ncu - 16);
+    masked("bits [0, ncu-32)", 0, ncu - 32);
+    masked("bits [ncu-32, ncu)", ncu - 32, ncu);
     return 0;
 }

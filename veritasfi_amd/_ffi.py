@@ -40,7 +40,7 @@ class SearchStats(ctypes.Structure):
     _fields_ = [
         ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
         ("uncertified", c_i64), ("overflowed", c_i64), ("exact_reruns", c_i64), ("wide_launches", c_i64), ("wide_queries", c_i64),
-        ("reserved", c_i64 * 7),
+        ("aux_cus", c_i64), ("scans_overlap", c_i64), ("scan_kernel", c_i64), ("reserved", c_i64 * 4),
     ]
 
     def as_dict(self):
@@ -70,6 +70,7 @@ SIGNATURES = {
     "vf_index_stats": (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
     "vf_index_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, c_i64]),
     "vf_index_profile": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), p_i64, ctypes.POINTER(ctypes.c_double), p_i64]),
+    "vf_index_profile_span": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), p_i64]),
     "vf_index_debug_read": (ctypes.c_int, [vp, c_i32, vp, c_i64]),
     "vf_index_destroy": (ctypes.c_int, [vp]),
     "vf_cosine_matrix": (ctypes.c_int, [vp, c_i32, c_i32, vp, c_i32]),

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libveritasfi_hip.so")
+LIB = os.path.join(LIBDIR, os.environ.get("VF_BUILD_LIB", "libveritasfi_hip.so"))   # VF_BUILD_LIB: name of an A/B variant
 SOURCES = ["vf_kernels.hip", "vf_api.hip", "vf_transformer.hip"]
 HEADERS = ["vf_internal.h", os.path.join("..", "..", "include", "veritasfi_hip.h")]
 ARCH = "gfx950"
@@ -45,7 +45,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     objs, jobs = [], []
     for s in srcs:   # the three translation units compile concurrently (the transformer TU alone takes ~40 s)
         src = os.path.join(CSRC, s)
-        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, s.replace(".hip", os.environ.get("VF_BUILD_TAG", "") + ".o"))
         if force or _stale(obj, [src] + hdrs):
             cmd = [hipcc] + FLAGS + EXTRA + ["-c", src, "-o", obj]
             if verbose:

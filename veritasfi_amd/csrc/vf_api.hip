@@ -82,11 +82,14 @@ struct DevBuf {
 };
 
 struct Slot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // everything but the main scan (any CU)
+    hipStream_t scan_stream = nullptr;   // the main k_scan launches: CU-masked to the scan partition when the split is on, else == stream
+    hipEvent_t ev_pro = nullptr;         // this slot's prologue (queries, sample pass, threshold seed) is done
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_scan = nullptr;  // ev_scan: after this slot's main k_scan
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // profile: scan begin/end, pipeline begin/end
     bool timed = false;
     int wide_launches = 0, wide_queries = 0;   // k_scan_wide main passes of the pending search / queries they served
+    int scan_kernel = 0;                       // main-scan kernel of the pending search: 1 k_scan, 2 k_scan2, 3 k_scan_wide
     DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
     DevBuf dbg, wgbase, tilecnt, sib;
     int64_t wgbase_n = -1; int wgbase_grid = -1;
@@ -137,11 +140,15 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1;   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
+            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1,
+            aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
     int64_t prof_launches = 0, prof_bytes = 0;
+    hipEvent_t ev_span = nullptr;     // profile: the first timed main scan since the option was set began here (scan stream)
+    bool span_started = false;
+    bool span_slot[4] = {false, false, false, false};   // slots whose ev_t[1] (end of their latest timed scan) belongs to this span
     // host-buffer entry (vf_index_search): per-handle device staging, grown on demand, reused across calls
     DevBuf st_q, st_ids, st_sc;
     // ---- group handle (vf_index_create_sharded / vf_index_group): the corpus is row-sharded over `shards`, one per
@@ -202,12 +209,41 @@ static int build_common(vf_index* ix) {
 
 // A slot's stream and events are created on its first use: a one-shot index (the reference builds one per
 // select_top_chunks call, step3_mul.py:233-253) only ever touches slot 0.
-static int ensure_slot(Slot& s) {
+// CU split and scan overlap, resolved.  Auto (-1): shards of up to 4M rows run their main scans on all but 32 CUs (one
+// per shader engine: a mask that takes CUs from only some SEs leaves those SEs with more workgroups than CUs -- the
+// dispatcher hands every SE the same number -- and a scan then takes two rounds; tools/ubench/cu_mask_probe.hip) and let
+// consecutive scans overlap; larger shards keep the whole chip and ordered scans (measured, round 3: 1.25M rows 0.384 ->
+// 0.362 ms per batch, 2.5M 0.717 -> 0.682, 5M 1.280 -> 1.269, 10M no change; profiles/r03_scan2_sweep.log).
+constexpr int64_t kSplitMaxRows = 4'000'000;
+static int64_t resolved_aux(const vf_index* ix) {
+    int64_t a = ix->aux_cus >= 0 ? ix->aux_cus : (ix->n <= kSplitMaxRows ? 32 : 0);
+    if (a <= 0 || ix->n_cu < 64 || a * 2 > ix->n_cu) return 0;
+    return a;
+}
+static bool resolved_overlap(const vf_index* ix) {
+    return ix->overlap_scans >= 0 ? ix->overlap_scans != 0 : resolved_aux(ix) > 0;
+}
+
+static int ensure_slot(vf_index* ix, Slot& s) {
     if (s.stream) return VF_OK;
     VF_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    // CU partition ("small shards"): a main-scan workgroup owns its CU (234 VGPRs x 8 waves, 128 KB LDS), so the
+    // prologue and k_final of the OTHER slots used to queue behind it.  The main scans run on a stream whose CU mask
+    // leaves `aux_cus` CUs alone (mask bits interleave over the 8 XCDs: bits [0, n_cu - aux) = all but the last aux / 8 CUs
+    // of every XCD; tools/ubench/cu_mask_probe.hip); everything else runs on an unmasked stream and finds those CUs free.
+    s.scan_stream = s.stream;
+    if (const int64_t aux = resolved_aux(ix)) {
+        const int words = (ix->n_cu + 31) / 32;
+        std::vector<uint32_t> mask(words, 0u);
+        for (int b = 0; b < ix->n_cu - (int)aux; ++b) mask[b / 32] |= 1u << (b % 32);
+        hipStream_t ms = nullptr;
+        if (hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, mask.data()) == hipSuccess && ms) s.scan_stream = ms;
+        else (void)hipGetLastError();   // no CU masking on this stack: one stream, as before
+    }
     VF_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
     VF_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     VF_HIP(hipEventCreateWithFlags(&s.ev_scan, hipEventDisableTiming));
+    VF_HIP(hipEventCreateWithFlags(&s.ev_pro, hipEventDisableTiming));
     for (int e = 0; e < 4; ++e) VF_HIP(hipEventCreate(&s.ev_t[e]));
     return VF_OK;
 }
@@ -242,7 +278,9 @@ static void destroy_index(vf_index* ix) {
         for (DevBuf* b : bufs) b->release();
         if (s.h_flags) (void)hipHostFree(s.h_flags);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
+        if (s.scan_stream && s.scan_stream != s.stream) (void)hipStreamDestroy(s.scan_stream);
         if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.ev_pro) (void)hipEventDestroy(s.ev_pro);
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         if (s.ev_scan) (void)hipEventDestroy(s.ev_scan);
@@ -253,6 +291,7 @@ static void destroy_index(vf_index* ix) {
     if (ix->norm) (void)hipFree(ix->norm);
     if (ix->inv_scan) (void)hipFree(ix->inv_scan);
     if (ix->cn_cache) (void)hipFree(ix->cn_cache);
+    if (ix->ev_span) (void)hipEventDestroy(ix->ev_span);
     delete ix;
 }
 
@@ -450,6 +489,26 @@ extern "C" int vf_index_profile(vf_index* ix, double* scan_ms_total, int64_t* sc
     return VF_OK;
 }
 
+// Makespan of the timed main scans: first launch's begin -> last launch's end, on the streams the scans run on.  With
+// ordered scans it is the sum of the brackets plus the gaps between launches; with overlapping scans (small shards) it is
+// the only well-defined "time per launch": span / launches.  Call after the searches have ended.
+extern "C" int vf_index_profile_span(vf_index* ix, double* span_ms, int64_t* launches) {
+    if (!ix || !span_ms || !launches) return fail(VF_EINVAL, "vf_index_profile_span: null argument");
+    DeviceGuard restore_callers_device;
+    vf_index* t = ix->shards.empty() ? ix : ix->shards[0];   // a group: its first shard (equal blocks run in step)
+    std::lock_guard<std::mutex> g(t->mu);
+    *span_ms = 0.0; *launches = t->prof_launches;
+    if (!t->span_started || !t->ev_span) return VF_OK;
+    VF_HIP(hipSetDevice(t->device));
+    for (int i = 0; i < kSlots; ++i) {
+        if (!t->span_slot[i] || !t->slots[i].ev_t[1] || t->slots[i].pending) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t->ev_span, t->slots[i].ev_t[1]) == hipSuccess && ms > *span_ms) *span_ms = ms;
+        else (void)hipGetLastError();
+    }
+    return VF_OK;
+}
+
 // debug: copy the wall-clock stamps of slot's last main scan (option debug bit 7) to host
 extern "C" int vf_index_debug_read(vf_index* ix, int32_t slot, unsigned long long* out, int64_t n_words) {
     DeviceGuard restore_callers_device;
@@ -486,8 +545,19 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
     else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
+    else if (s == "aux_cus") {   // takes effect for slots created afterwards (set it before the first search)
+        if (!in_range(-1, 128)) return fail(VF_EINVAL, "aux_cus must be -1 (auto) or in [0, 128]");
+        ix->aux_cus = value;
+    }
+    else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
+    else if (s == "scan_impl") { if (!in_range(1, 2)) return fail(VF_EINVAL, "scan_impl must be 1 or 2"); ix->scan_impl = value; }
+    else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
-    else if (s == "profile") { ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0; }
+    else if (s == "profile") {
+        ix->profile = value != 0; ix->prof_scan_ms = ix->prof_pipe_ms = 0.0; ix->prof_launches = 0;
+        ix->span_started = false;
+        for (bool& b : ix->span_slot) b = false;
+    }
     else return fail(VF_EINVAL, "vf_index_set_option: unknown option " + s);
     return VF_OK;
 }
@@ -576,7 +646,8 @@ static FusedPlan make_plan(const vf_index* ix, int k) {
     if (ix->cap_opt > 0) { cap = 1; while (cap < ix->cap_opt) cap <<= 1; cap = std::min(cap, 16384); }
     while (cap < 2 * p.kprime) cap <<= 1;
     p.cap = cap;
-    int64_t wgs = std::min<int64_t>(ix->n_cu, std::max<int64_t>(1, ix->n / 512));
+    const int64_t scan_cus = ix->n_cu - resolved_aux(ix);
+    int64_t wgs = std::min<int64_t>(scan_cus, std::max<int64_t>(1, ix->n / 512));
     if (ix->waves_opt > 0) wgs = std::max<int64_t>(1, ix->waves_opt / (kScanThreads / 64));
     p.grid = (int)wgs;
     p.total_waves = p.grid * (kScanThreads / 64);
@@ -687,7 +758,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     if (path < 0) return fail(VF_EUNSUPPORTED, "forced fused path is not possible for this n / k / d");
     if (path != 1 && ix->n > kSmallN && k > 8192)  // checked before anything is enqueued (k_merge_topk's LDS sort)
         return fail(VF_EUNSUPPORTED, "exact chunked search supports k <= 8192 when n > 16384");
-    VF_TRY(ensure_slot(s));
+    VF_TRY(ensure_slot(ix, s));
     VF_HIP(hipEventRecord(s.ev_in, user));
     VF_HIP(hipStreamWaitEvent(s.stream, s.ev_in, 0));
     hipStream_t st = s.stream;
@@ -696,7 +767,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
     VF_TRY(s.qimg.ensure(scan_lds_bytes(ix->dp, kMaxBatch)));
     VF_TRY(ensure_pinned(s, (size_t)nq));
     s.pending = true; s.d_queries = d_queries; s.nq = nq; s.k = k; s.d_ids = d_ids; s.d_scores = d_scores;
-    s.path = path; s.user_stream = user; s.wide_launches = 0; s.wide_queries = 0;
+    s.path = path; s.user_stream = user; s.wide_launches = 0; s.wide_queries = 0; s.scan_kernel = 0;
     if (nq == 0 || k == 0) { VF_HIP(hipEventRecord(s.ev_done, st)); return VF_OK; }
 
     if (path != 1) {
@@ -719,7 +790,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             const int nb = std::min(kWideMaxQueries, nq - b0);
             VF_TRY(wide_pass(ix, s, p, d_queries + (size_t)b0 * ix->d, nb, k, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k,
                              b0, s.qn.as<float>() + (size_t)b0 * ix->d, s.timed && b0 == 0, st, slot_id));
-            ++s.wide_launches; s.wide_queries += nb;
+            ++s.wide_launches; s.wide_queries += nb; s.scan_kernel = 3;
         }
         if (s.timed) VF_HIP(hipEventRecord(s.ev_t[3], st));
         VF_HIP(hipEventRecord(s.ev_done, st));
@@ -766,22 +837,50 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
         if (ix->n / p.total_waves < p.samp)
             VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qt * p.total_waves * p.samp * sizeof(float), st));
-        VF_HIP(launch_scan(a, kModeSample, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, st));
+        // sample pass: a FEW workgroups walk the sample parts of all ranges (each stages the query image once)
+        // (auto: 4 workgroups per spare CU when the CU split is on, one per range otherwise)
+        const int64_t sg_opt = ix->sample_grid >= 0 ? ix->sample_grid : (s.scan_stream != s.stream ? 4 * resolved_aux(ix) : 0);
+        const int sgrid = sg_opt > 0 ? (int)std::min<int64_t>(sg_opt, p.grid) : p.grid;
+        VF_HIP(launch_scan(a, kModeSample, qt, sgrid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, st));
         VF_HIP(launch_sel0(a, qt, st));
-        // Main scans of different slots cannot share a CU (one 96 KB+ LDS workgroup each), so they run
-        // back to back anyway; ordering them explicitly keeps queueing time out of the timed bracket
-        // while this slot's prep / sample / seed kernels still overlap the other slot's scan.
-        for (int o = 0; o < kSlots; ++o)
-            if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
-        if (s.timed && b0 == 0) VF_HIP(hipEventRecord(s.ev_t[0], st));
-        VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, st));
-        VF_HIP(hipEventRecord(s.ev_scan, st));
+        hipStream_t sst = s.scan_stream;
+        if (sst != st) {   // the main scan runs on the CU-masked stream, behind this slot's prologue
+            VF_HIP(hipEventRecord(s.ev_pro, st));
+            VF_HIP(hipStreamWaitEvent(sst, s.ev_pro, 0));
+        }
+        // Main scans of different slots run one after the other (a scan workgroup owns its CU); ordering them explicitly
+        // keeps queueing time out of the timed bracket.  With overlap_scans they are left to the dispatcher: the next
+        // scan's workgroups start on the CUs the previous one has finished with (no idle tail), at the price of that bracket.
+        if (!resolved_overlap(ix))
+            for (int o = 0; o < kSlots; ++o)
+                if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(sst, ix->slots[o].ev_scan, 0));
         if (s.timed && b0 == 0) {
-            VF_HIP(hipEventRecord(s.ev_t[1], st));
+            if (!ix->span_started) {   // makespan of the timed launches: from here to the last launch's end (vf_index_profile_span)
+                if (!ix->ev_span) VF_HIP(hipEventCreate(&ix->ev_span));
+                VF_HIP(hipEventRecord(ix->ev_span, sst));
+                ix->span_started = true;
+            }
+            ix->span_slot[slot_id] = true;
+            VF_HIP(hipEventRecord(s.ev_t[0], sst));
+        }
+        const int cap2 = (ix->scan_impl == 2 && ix->dtype != VF_DTYPE_FP8_E4M3 && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt) : 0;
+        if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
+            ScanArgs a2 = a;
+            a2.stage_cap = cap2;
+            VF_HIP(launch_scan2(a2, qt, p.grid, sst));
+            s.scan_kernel = 2;
+        } else {
+            VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, sst));
+            s.scan_kernel = 1;
+        }
+        VF_HIP(hipEventRecord(s.ev_scan, sst));
+        if (s.timed && b0 == 0) {
+            VF_HIP(hipEventRecord(s.ev_t[1], sst));
             const int64_t per_wave = ix->n / p.total_waves;
             const int64_t sampled = std::min<int64_t>(ix->n, (int64_t)p.total_waves * std::min<int64_t>(p.samp, per_wave));
             ix->prof_bytes = (ix->n - sampled) * ((int64_t)ix->d * (ix->dtype == VF_DTYPE_FP8_E4M3 ? 1 : 2) + 4);
         }
+        if (sst != st) VF_HIP(hipStreamWaitEvent(st, s.ev_scan, 0));
         FinalArgs f{};
         f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.tau_bin = a.tau_bin; f.rows_orig = ix->rows_orig;
         f.orig_dtype = ix->dtype; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
@@ -804,6 +903,9 @@ static int end_impl(vf_index* ix, int slot_id) {
     VF_HIP(hipEventSynchronize(s.ev_done));
     vf_search_stats stt{};
     stt.path = s.path; stt.n_queries = s.nq; stt.wide_launches = s.wide_launches; stt.wide_queries = s.wide_queries;
+    stt.aux_cus = (s.path == 1 && s.scan_stream && s.scan_stream != s.stream) ? resolved_aux(ix) : 0;
+    stt.scans_overlap = (s.path == 1 && resolved_overlap(ix)) ? 1 : 0;
+    stt.scan_kernel = s.scan_kernel;
     if (s.path == 1 && s.nq > 0 && s.k > 0) {
         if (s.timed) {
             float ms = 0.f;
@@ -949,6 +1051,8 @@ static int group_end(vf_index* ix, int slot_id) {
                 tot.candidates += st.candidates; tot.max_candidates = std::max(tot.max_candidates, st.max_candidates);
                 tot.uncertified += st.uncertified; tot.overflowed += st.overflowed; tot.exact_reruns += st.exact_reruns;
                 tot.wide_launches = std::max(tot.wide_launches, st.wide_launches); tot.wide_queries = std::max(tot.wide_queries, st.wide_queries);
+                tot.aux_cus = std::max(tot.aux_cus, st.aux_cus); tot.scans_overlap = std::max(tot.scans_overlap, st.scans_overlap);
+                tot.scan_kernel = std::max(tot.scan_kernel, st.scan_kernel);
             }
         }
         if (r == VF_OK) {

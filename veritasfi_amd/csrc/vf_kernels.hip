@@ -16,6 +16,7 @@
 #include "vf_internal.h"
 
 #include <float.h>
+#include <algorithm>
 #include <type_traits>
 
 #include <mutex>
@@ -532,6 +533,23 @@ hipError_t launch_fuse_rank(const float* a, const float* b, int n, float* out, l
 // Accumulator layout (v_mfma_f32_32x32x16_f16 C/D): lane holds query (lane & 31) of N-tile nt and
 // corpus rows (reg & 3) + 8 * (reg >> 2) + 4 * h, reg = 0..15.
 // ------------------------------------------------------------------------------------------------
+// Corpus rows are read once per batch, which invites the non-temporal hint (global_load_dwordx4 ... nt).  MEASURED
+// (round 3, tools/gpu_r03_nt.sh, same box, same process tree): with nt the main scan runs at 0.41 of peak instead of 0.77
+// at 10M rows (4.73 vs 2.48 ms) and 0.37 instead of 0.66 at 1M -- a lane pair shares every 128-B line and four
+// instructions walk it; without L1 allocation each of them goes out again.  Plain loads stay; -DVF_SCAN_NT=1 rebuilds the
+// experiment.
+#ifndef VF_SCAN_NT
+#define VF_SCAN_NT 0
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if VF_SCAN_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <int G>
 __device__ __forceinline__ void issue_loads(h8 (&buf)[4 * G], const char* rows, long long row_bytes, long long myrow,
                                             int ss /* superstep within the tile */, int h) {
@@ -539,7 +557,7 @@ __device__ __forceinline__ void issue_loads(h8 (&buf)[4 * G], const char* rows, 
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buf[g * 4 + i] = *(const h8*)(p + g * 128 + i * 16);
+        for (int i = 0; i < 4; ++i) buf[g * 4 + i] = stream_load((const h8*)(p + g * 128 + i * 16));
 }
 
 template <int NT, int G>
@@ -582,7 +600,11 @@ __device__ __forceinline__ void issue_loads_f8(uint4 (&buf)[2 * G], const char* 
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) buf[g * 2 + i] = *(const uint4*)(p + g * 64 + i * 16);
+        for (int i = 0; i < 2; ++i) {
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v w = stream_load((const u4v*)(p + g * 64 + i * 16));
+            buf[g * 2 + i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
 }
 
 template <int NT, int G>
@@ -835,7 +857,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
-    const long long grid = gridDim.x;
+    // The corpus is cut into `grid` row ranges (one per MAIN-scan workgroup).  Main mode: gridDim.x == grid, a workgroup
+    // owns its range.  Sample mode: gridDim.x may be SMALLER (a.scan_grid ranges, walked v = blockIdx.x, + gridDim.x, ...):
+    // a few workgroups then stage the query image once and score the sample part of many ranges, so that the sample pass
+    // of batch i + 1 fits the handful of CUs the main scan of batch i leaves free (vf_api.hip: CU-partitioned streams).
+    const long long grid = (MODE == kModeSample && a.scan_grid > 0) ? a.scan_grid : gridDim.x;
     const long long swg = (long long)a.samp * WAVES;
     // row range of workgroup v's part in this mode: the sample part is the first swg rows of its range, the main part the rest
     long long lo, hi;
@@ -848,6 +874,22 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     };
     part_of(blockIdx.x, lo, hi);
     ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);  // per workgroup: < 2^31 / 32 rows
+    // sample mode: tile T of this workgroup = tile (T % tps) of the sample part of range blockIdx.x + (T / tps) * gridDim.x
+    const int tps = (int)((swg + kRowTile - 1) / kRowTile);
+    if (MODE == kModeSample) {
+        const long long mine = ((long long)grid - blockIdx.x + gridDim.x - 1) / gridDim.x;   // ranges this workgroup walks
+        ntiles = (int)(mine > 0 ? mine : 0) * tps;
+    }
+    // (first row, end of the part, sample-slot base) of a sample tile
+    auto sample_tile = [&](int tile, long long& t0, long long& thi, long long& sbase) {
+        const int m = tile / tps, j = tile - m * tps;
+        const long long v = blockIdx.x + (long long)m * gridDim.x;
+        long long plo, phi;
+        part_of(v < grid ? v : grid - 1, plo, phi);
+        t0 = plo + (long long)j * kRowTile;
+        thi = phi;
+        sbase = v * swg + (long long)j * kRowTile;
+    };
     // Main mode with a.tile_cnt: the LAST kPoolDiv-th of every range is a POOL that any workgroup may take tiles from
     // (global counters, set to 0 by k_sel0); the first part is the owner's alone (LDS counter: a global atomic per
     // tile on every tile measured 10 % slower -- its latency sits in the in-order memory queue ahead of the prefetch).
@@ -884,6 +926,12 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     // row index of this lane in `tile`, clamped into the part (32-bit: a shard has < 2^32 rows)
     u32 lo32 = (u32)lo + (u32)r31, hi32m1 = (u32)(hi - 1);
     auto rowof = [&](int tile) {
+        if (MODE == kModeSample) {
+            long long t0s, this_, sb;
+            sample_tile(tile < ntiles ? tile : (ntiles > 0 ? ntiles - 1 : 0), t0s, this_, sb);
+            const long long r = t0s + r31;
+            return r < this_ - 1 ? r : this_ - 1;
+        }
         const u32 r = lo32 + (u32)tile * kRowTile;
         return (long long)(r < hi32m1 ? r : hi32m1);
     };
@@ -919,7 +967,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
         // SS is even (launch_scan picks G so): a tile is SS/2 pairs (A0 then A1) and always starts in A0.
         const int pairs = SS >> 1;
         while (true) {
-            const long long t0 = lo + (long long)cur_tile * kRowTile;
+            long long t0 = lo + (long long)cur_tile * kRowTile, t_hi = hi, t_s0 = s0_base + (t0 - lo);
+            if (MODE == kModeSample) sample_tile(cur_tile, t0, t_hi, t_s0);
             {   // one claim per wave (LDS atomic, or an L2 atomic in main mode); the result is consumed at the tile's end
                 int v_ = 0;
                 if (lane == 0) v_ = (int)atomicAdd(seg_cnt, 1u);
@@ -943,7 +992,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
             VF_ISSUE(A0, a.rows, a.row_bytes, rowof(more ? claimed : cur_tile), 0, h);
             __builtin_amdgcn_sched_barrier(0);
             VF_COMPUTE(acc, A1, lds_lane, SS - 1);
-            tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, s0_base + (t0 - lo), lane, ctl);
+            tile_epilogue<NT, MODE>(a, acc, epi, t0, t_hi, t_s0, lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1026,6 +1075,234 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
         }
         if (dbg) dbg[3] = wall_clock64();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan2: the main scan with WHOLE-LINE corpus loads (round 3).  fp16 rows, main mode.
+//
+// What round 3 measured (tools/ubench/stream_read.hip, profiles/r03_stream_read.log): k_scan's A-operand loads -- lane
+// (r, h) reads 16 B of ITS row, so one instruction touches 32 cache lines and takes 32 B of each, and four instructions
+// walk every line -- stream at 5.4-5.8 TB/s on 256 CUs, 5.1-5.5 on 224 and 4.5-5.0 on 192, and DEEPER prefetch makes it
+// worse: the pattern is bound per CU (every line stays allocated in the 32 KB L1 until its fourth instruction has come
+// by).  The same bytes read as whole lines (8 lanes x 16 B per line, 8 lines per instruction) stream at 6.2-6.4 TB/s
+// on ANY of those CU counts.  An MFMA A operand cannot be loaded that way into registers (a row lives in two lanes, a
+// line would land in eight), so the rows go global -> LDS by LDS-DMA (global_load_lds_dwordx4: the lanes of a DMA
+// instruction fetch whole lines, and WHICH piece a lane fetches is free, so the bank swizzle is applied through the
+// source addresses) and the A fragments are read back with ds_read_b128, like the B fragments (queries).
+//
+// Geometry: 256 threads = one wave per SIMD; a wave owns 32-row tiles (claimed from the LDS counter as in k_scan) and
+// a private ring of kRing 4-KB segment buffers (32 rows x 128 B): no barrier anywhere in the loop.  A segment is four
+// DMA instructions; two segments (8 KB) stay in flight while the third is consumed.  LDS: query image (96 KB at d = 768)
+// + ring 4 x 12 KB + per-wave scratch + control block + candidate stage (what is left: ~15 KB).
+//   slot(row r, piece p) of a segment buffer = r * 8 + (p ^ ((r >> 1) & 7))   [16-byte slots]: a ds_read_b128 phase (16
+//   lanes = rows 16 g .. 16 g + 15, one piece) then hits 16 distinct bank groups.
+//   DMA instruction m (0..3) fills slots 64 m .. 64 m + 63: lane l -> row 8 m + (l >> 3), piece (l & 7) ^ ((row >> 1) & 7).
+// The per-tile epilogue operands (1 / norm of the 32 rows, and the global thresholds when this wave's turn to sync them
+// comes) travel by the same DMA queue into the wave's scratch at the START of the tile, so the loop contains no vector
+// memory instruction the compiler knows about and none of its s_waitcnt vmcnt(0) (it cannot count hand-issued DMAs).
+// MFMA layout, k-slot map, accumulators, threshold filter, candidate stage, refresh and flush are k_scan's.
+// ------------------------------------------------------------------------------------------------
+constexpr int kScan2Threads = 256, kScan2Waves = 4, kRing = 3, kSegBytes = 4096, kScratchBytes = 1024;   // scratch: two 512-B halves (tile parity)
+
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+size_t scan2_lds_bytes(int dp, int qn_tile, int stage_cap) {
+    const size_t img = (size_t)dp * qn_tile * 2;
+    return img + (size_t)kScan2Waves * (kRing * kSegBytes + kScratchBytes) + kCtlBytes + (size_t)stage_cap * 16;
+}
+int scan2_stage_cap(int dp, int qn_tile) {   // candidate-stage entries that fit beside image + rings; < 256 = "does not fit"
+    const size_t fixed = scan2_lds_bytes(dp, qn_tile, 0);
+    if (fixed + 256 * 16 > 160 * 1024) return 0;
+    const size_t area = std::min<size_t>(160 * 1024 - fixed, 32 * 1024);
+    return (int)(area / 16);
+}
+
+template <int NT>
+__global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int QN = NT * kQueryTile;
+    constexpr int MODE = kModeMain;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const long long grid = gridDim.x;
+    const long long swg = (long long)a.samp * (kScanThreads / 64);   // the sample part is defined by the sample pass's geometry
+    const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
+    const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
+    const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
+    const int S = a.dp >> 6;                                          // 128-byte segments per row
+    // LDS carve-up (offsets are multiples of 16; the rings of 1024)
+    char* ring = smem + (size_t)wid * (kRing * kSegBytes);
+    char* img = smem + kScan2Waves * kRing * kSegBytes;
+    char* scratch = img + (size_t)a.dp * QN * 2 + (size_t)wid * kScratchBytes;   // per tile parity: [0,256) tau_bin[64] | [256,512) 1/norm of the tile's 32 rows (twice)
+    char* ctl = img + (size_t)a.dp * QN * 2 + kScan2Waves * kScratchBytes;
+    u32* next_tile = (u32*)(ctl + 4);
+    // wave-uniform LDS bases of the DMAs (M0 is a scalar register: make the uniformity explicit)
+    const unsigned ring_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(ring)), scratch_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(scratch));
+
+    // this lane's part in the four DMA instructions of a segment: row 8 m + (lane >> 3), piece (lane & 7) ^ swizzle(row)
+    const int drow = lane >> 3;
+    auto src_of = [&](int tile, int m) -> const char* {
+        const int row = 8 * m + drow;
+        long long r = lo + (long long)tile * kRowTile + row;
+        r = r < hi - 1 ? r : hi - 1;                                  // rows past the part's end re-read its last row (masked in the epilogue)
+        return a.rows + r * a.row_bytes + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
+    };
+    auto issue_seg = [&](const char* const (&src)[4], int seg, int buf) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dma16(src[m] + (long long)seg * 128, ring_l + buf * kSegBytes + m * 1024);
+    };
+    // 1 / norm of a tile's rows (+ the global thresholds) into the scratch half of that tile's parity: a tile's operands are
+    // issued while the PREVIOUS tile is still being consumed and may land before that tile's epilogue has read its own
+    auto issue_epi = [&](long long t0, bool sync_tau, int par) {
+        dma4(a.inv_scan + t0 + r31, scratch_l + par * 512 + 256);     // 64 words: lanes 32..63 repeat the 32 rows
+        if (sync_tau) dma4(a.tau_bin + (lane < QN ? lane : QN - 1), scratch_l + par * 512);
+    };
+
+    int cur_tile = wid;
+    bool active = cur_tile < ntiles;
+    const char* src_cur[4];
+    const char* src_nxt[4];
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
+        issue_epi(lo + (long long)cur_tile * kRowTile, true, 0);
+        issue_seg(src_cur, 0, 0);
+        issue_seg(src_cur, 1 < S ? 1 : 0, 1);
+    }
+    {   // query image -> LDS verbatim; control block + candidate stage zeroed
+        const uint4* srcq = (const uint4*)a.qimg;
+        uint4* dst = (uint4*)img;
+        const int nvec = (a.dp >> 3) * QN;
+#pragma unroll 4
+        for (int i = tid; i < nvec; i += kScan2Threads) dst[i] = srcq[i];
+        uint4* z = (uint4*)ctl;
+        const int nz = kCtlBytes / 16 + a.stage_cap;
+        for (int i = tid; i < nz; i += kScan2Threads) z[i] = make_uint4(0u, (i == 0) ? (u32)kScan2Waves : 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (tid < QN) ((int*)(ctl + 16))[tid] = a.tau_bin[tid];
+    __syncthreads();
+
+    const char* lds_lane = img + ((4 * h) * QN + r31) * 16;
+    const int asw = (r31 >> 1) & 7;
+    const char* a_lane = ring + r31 * 128;                             // + buf * 4096 + ((4 h + i) ^ asw) * 16
+    unsigned long long* dbg = ((a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * 4 : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
+    if (active) {
+        f16v acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+        int buf = 0;                                                   // ring buffer of the segment about to be consumed
+        int tiles_done = 0;
+        while (true) {
+            const long long t0 = lo + (long long)cur_tile * kRowTile;
+            int claimed;
+            {
+                int v_ = 0;
+                if (lane == 0) v_ = (int)atomicAdd(next_tile, 1u);
+                claimed = __builtin_amdgcn_readfirstlane(v_);
+            }
+            const bool more = claimed < ntiles;
+            const int nxt = more ? claimed : cur_tile;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
+            const bool sync_now = (tiles_done & (kScan2Waves - 1)) == wid;
+            const bool sync_next = ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
+            for (int sg = 0; sg < S; ++sg) {
+                // segment sg + 2 goes into the buffer consumed one step ago (its fragments are in registers: the MFMAs
+                // that used them have issued); past the tile's end it is the next tile's segment 0 / 1, preceded by that
+                // tile's epilogue operands
+                int b2 = buf + 2; b2 = b2 >= kRing ? b2 - kRing : b2;
+                const int s2 = sg + 2;
+                if (s2 < S) issue_seg(src_cur, s2, b2);
+                else {
+                    if (s2 == S) issue_epi(lo + (long long)nxt * kRowTile, sync_next, (tiles_done + 1) & 1);
+                    issue_seg(src_nxt, s2 - S < S ? s2 - S : 0, b2);
+                }
+                // everything issued before the two newest segments (and the <= 2 epilogue words between them) has landed
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                const char* ab = a_lane + buf * kSegBytes;
+                const char* bb = lds_lane + (long long)sg * (8 * QN * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const h8 af = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const h8 bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
+                    }
+                }
+                buf = buf + 1 == kRing ? 0 : buf + 1;
+            }
+            // epilogue operands of THIS tile landed long ago (issued before its first segment, into its parity's half)
+            const char* sc = scratch + (tiles_done & 1) * 512;
+            EpiRegs<NT> epi;
+            epi.inv_lane = *(const float*)(sc + 256 + r31 * 4);
+            epi.sync_tau = sync_now;
+            if (sync_now) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) epi.tau_g[nt] = *(const int*)(sc + (nt * kQueryTile + r31) * 4);
+            }
+            tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, 0, lane, ctl);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+            ++tiles_done;
+            if (!more) break;
+            cur_tile = claimed;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) prefetches have landed before LDS is reused
+    if (dbg) dbg[1] = wall_clock64();
+    // ---- flush the staged candidates (k_scan's, on this block size)
+    __syncthreads();
+    if (dbg) dbg[2] = wall_clock64();
+    {
+        const u32 staged = *(const u32*)ctl;
+        const u32 nst = staged < (u32)a.stage_cap ? staged : (u32)a.stage_cap;
+        uint4* ent = (uint4*)(ctl + kCtlBytes);
+        u32* qcnt = (u32*)img;          // the query image is dead now
+        u32* qbase = qcnt + QN;
+        if (tid < QN) qcnt[tid] = 0u;
+        __syncthreads();
+        for (u32 i = tid; i < nst; i += kScan2Threads) {
+            const uint4 e = ent[i];
+            const u32 q = e.z & 0xFFu;
+            if (e.w != 1u || q >= (u32)QN) continue;
+            ent[i].w = 2u + atomicAdd(qcnt + q, 1u);
+        }
+        __syncthreads();
+        if (tid < QN) {
+            const u32 c = qcnt[tid];
+            qbase[tid] = c ? atomicAdd(a.cnt + tid * kCntStride, c) : 0u;
+        }
+        __syncthreads();
+        for (u32 i = tid; i < nst; i += kScan2Threads) {
+            const uint4 e = ent[i];
+            if (e.w < 2u) continue;
+            const u32 q = e.z & 0xFFu;
+            const u32 gs = qbase[q] + (e.w - 2u);
+            if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)e.y << 32) | (u64)e.x;
+        }
+    }
+    if (dbg) dbg[3] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1560,6 +1837,13 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
+    const size_t lds = scan2_lds_bytes(a.dp, qn_tile, a.stage_cap);
+    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2<1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+    else hipLaunchKernelGGL((k_scan2<2>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int NT, int G, int MODE>
 static hipError_t configure_one() {
     hipError_t e = hipFuncSetAttribute((const void*)k_scan<NT, G, MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1996,6 +2280,8 @@ hipError_t scan_configure() {
     VF_CFG(1, 1) VF_CFG(1, 2) VF_CFG(1, 3) VF_CFG(1, 4)
     VF_CFG(2, 1) VF_CFG(2, 2) VF_CFG(2, 3) VF_CFG(2, 4)
 #undef VF_CFG
+    if ((e = hipFuncSetAttribute((const void*)k_scan2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

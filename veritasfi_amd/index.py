@@ -249,8 +249,10 @@ class DenseIndex:
         ms, n, pipe, nbytes = ctypes.c_double(0), _ffi.c_i64(0), ctypes.c_double(0), _ffi.c_i64(0)
         _ffi.check(_ffi.lib().vf_index_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(pipe),
                                                ctypes.byref(nbytes)), "vf_index_profile")
+        span, nl = ctypes.c_double(0), _ffi.c_i64(0)
+        _ffi.check(_ffi.lib().vf_index_profile_span(self._h, ctypes.byref(span), ctypes.byref(nl)), "vf_index_profile_span")
         return {"scan_ms_total": ms.value, "scan_launches": int(n.value), "pipeline_ms_total": pipe.value,
-                "scan_bytes_per_launch": int(nbytes.value)}
+                "scan_bytes_per_launch": int(nbytes.value), "span_ms": span.value}
 
     def set_option(self, name: str, value: int) -> None:
         _ffi.check(_ffi.lib().vf_index_set_option(self._h, name.encode(), int(value)), "vf_index_set_option")
