@@ -590,7 +590,8 @@ def test_c3_10m_subset(vf, oracle):
 @pytest.mark.parametrize("n,d,nq,k,want_kernel", [
     (60_000, 768, 64, 100, 2),      # the headline shape: image 96 KB + four 12-KB rings
     (60_000, 768, 9, 10, 2),        # one N-tile
-    (50_011, 100, 64, 50, 2),       # dp = 128: two segments per row (shorter than the ring is deep), ragged last tile
+    (50_011, 100, 64, 50, 1),       # dp = 128: two segments per row, fewer than the ring is deep -> k_scan; ragged last tile
+    (50_011, 200, 64, 50, 2),       # dp = 256: four segments, ragged last tile
     (40_000, 384, 40, 100, 2),      # six segments
     (40_000, 1024, 64, 100, 1),     # 128 KB image: the rings do not fit beside it -> k_scan
     (40_000, 1024, 20, 100, 2),     # ... but they do beside a 32-query image

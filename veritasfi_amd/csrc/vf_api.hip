@@ -209,12 +209,12 @@ static int build_common(vf_index* ix) {
 
 // A slot's stream and events are created on its first use: a one-shot index (the reference builds one per
 // select_top_chunks call, step3_mul.py:233-253) only ever touches slot 0.
-// CU split and scan overlap, resolved.  Auto (-1): shards of up to 4M rows run their main scans on all but 32 CUs (one
+// CU split and scan overlap, resolved.  Auto (-1): shards of up to 6M rows run their main scans on all but 32 CUs (one
 // per shader engine: a mask that takes CUs from only some SEs leaves those SEs with more workgroups than CUs -- the
 // dispatcher hands every SE the same number -- and a scan then takes two rounds; tools/ubench/cu_mask_probe.hip) and let
 // consecutive scans overlap; larger shards keep the whole chip and ordered scans (measured, round 3: 1.25M rows 0.384 ->
 // 0.362 ms per batch, 2.5M 0.717 -> 0.682, 5M 1.280 -> 1.269, 10M no change; profiles/r03_scan2_sweep.log).
-constexpr int64_t kSplitMaxRows = 4'000'000;
+constexpr int64_t kSplitMaxRows = 6'000'000;
 static int64_t resolved_aux(const vf_index* ix) {
     int64_t a = ix->aux_cus >= 0 ? ix->aux_cus : (ix->n <= kSplitMaxRows ? 32 : 0);
     if (a <= 0 || ix->n_cu < 64 || a * 2 > ix->n_cu) return 0;

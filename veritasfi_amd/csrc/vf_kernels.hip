@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 //
 // Geometry: 256 threads = one wave per SIMD; a wave owns 32-row tiles (claimed from the LDS counter as in k_scan) and
 // a private ring of kRing 4-KB segment buffers (32 rows x 128 B): no barrier anywhere in the loop.  A segment is four
-// DMA instructions; two segments (8 KB) stay in flight while the third is consumed.  LDS: query image (96 KB at d = 768)
+// DMA instructions; two segments (8 KB) stay in flight while the third is consumed, all three during a tile's epilogue.  LDS: query image (96 KB at d = 768)
 // + ring 4 x 12 KB + per-wave scratch + control block + candidate stage (what is left: ~15 KB).
 //   slot(row r, piece p) of a segment buffer = r * 8 + (p ^ ((r >> 1) & 7))   [16-byte slots]: a ds_read_b128 phase (16
 //   lanes = rows 16 g .. 16 g + 15, one piece) then hits 16 distinct bank groups.
@@ -1124,6 +1124,7 @@ size_t scan2_lds_bytes(int dp, int qn_tile, int stage_cap) {
 }
 int scan2_stage_cap(int dp, int qn_tile) {   // candidate-stage entries that fit beside image + rings; < 256 = "does not fit"
     const size_t fixed = scan2_lds_bytes(dp, qn_tile, 0);
+    if ((dp >> 6) < kRing) return 0;                       // the ring holds three segments of ONE row set at start-up
     if (fixed + 256 * 16 > 160 * 1024) return 0;
     const size_t area = std::min<size_t>(160 * 1024 - fixed, 32 * 1024);
     return (int)(area / 16);
@@ -1178,8 +1179,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
         issue_epi(lo + (long long)cur_tile * kRowTile, true, 0);
-        issue_seg(src_cur, 0, 0);
-        issue_seg(src_cur, 1 < S ? 1 : 0, 1);
+        for (int sg = 0; sg < kRing; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S >= kRing: scan2_stage_cap)
     }
     {   // query image -> LDS verbatim; control block + candidate stage zeroed
         const uint4* srcq = (const uint4*)a.qimg;
@@ -1223,17 +1223,8 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
             const bool sync_now = (tiles_done & (kScan2Waves - 1)) == wid;
             const bool sync_next = ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
             for (int sg = 0; sg < S; ++sg) {
-                // segment sg + 2 goes into the buffer consumed one step ago (its fragments are in registers: the MFMAs
-                // that used them have issued); past the tile's end it is the next tile's segment 0 / 1, preceded by that
-                // tile's epilogue operands
-                int b2 = buf + 2; b2 = b2 >= kRing ? b2 - kRing : b2;
-                const int s2 = sg + 2;
-                if (s2 < S) issue_seg(src_cur, s2, b2);
-                else {
-                    if (s2 == S) issue_epi(lo + (long long)nxt * kRowTile, sync_next, (tiles_done + 1) & 1);
-                    issue_seg(src_nxt, s2 - S < S ? s2 - S : 0, b2);
-                }
-                // everything issued before the two newest segments (and the <= 2 epilogue words between them) has landed
+                // segments sg + 1 and sg + 2 (8 DMA instructions, and the <= 2 epilogue words issued among them) may still be in
+                // flight; everything older has landed
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 const char* ab = a_lane + buf * kSegBytes;
                 const char* bb = lds_lane + (long long)sg * (8 * QN * 16);
@@ -1245,6 +1236,17 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                         const h8 bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
                     }
+                }
+                // the buffer just consumed (its fragments are in registers: the MFMAs that used them have issued) takes
+                // segment sg + 3 -- past the tile's end the next tile's segment 0 / 1 / 2, preceded by that tile's epilogue
+                // operands -- so that all THREE ring buffers are in flight while the epilogue below runs (with the issue in
+                // front of the compute, as first written, a tile whose epilogue takes the candidate path left the queue dry:
+                // a wave has no partner on its SIMD to cover for it)
+                const int s3 = sg + kRing;
+                if (s3 < S) issue_seg(src_cur, s3, buf);
+                else {
+                    if (s3 == S) issue_epi(lo + (long long)nxt * kRowTile, sync_next, (tiles_done + 1) & 1);
+                    issue_seg(src_nxt, s3 - S, buf);
                 }
                 buf = buf + 1 == kRing ? 0 : buf + 1;
             }
