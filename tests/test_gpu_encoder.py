@@ -246,6 +246,66 @@ def test_reranker_matches_torch_fp32(vf, hidden, layers, heads, ffn, b, t):
     assert np.array_equal(np.argsort(-ref), np.argsort(-got)) or np.abs(ref - got).max() < np.min(np.diff(np.sort(ref)))
 
 
+@pytest.mark.parametrize("kind,hidden,layers,heads,ffn,b,t,ragged", [
+    ("embedder", 256, 4, 4, 1024, 16, 128, True),
+    ("embedder-768", 768, 3, 12, 3072, 8, 256, True),       # three column tiles of row sums per row
+    ("reranker", 256, 3, 4, 1024, 24, 96, True),            # 2304 rows: packed forward (ragged, CLS head) on the folded path
+    ("reranker-full", 512, 2, 8, 2048, 8, 256, False),
+])
+def test_layernorm_folded_into_the_products(vf, kind, hidden, layers, heads, ffn, b, t, ragged):
+    """LayerNorm without a launch (LnFold): with every product of a layer on the 8-phase kernel, the residual products leave
+    raw sums + row sums, the next product reads them through gamma-folded weights and the next residual product normalises
+    its residual element by element (an option: measured slower than the launches it removes).  Against HF
+    fp32 at the tolerances of the unfolded path, and against the unfolded path itself; vf_debug_ln_fold_forwards proves the folded path ran (the tile threshold is lowered for the small model)."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_gemm_8p_min_wgs.restype = ctypes.c_longlong
+    L.vf_debug_gemm_8p_min_wgs.argtypes = [ctypes.c_longlong]
+    L.vf_debug_ln_fold_forwards.restype = ctypes.c_longlong
+    was_on = L.vf_debug_ln_fold(1)                         # measured slower than the two launches it replaces: off by default
+    rng = np.random.default_rng(21)
+    head = kind.startswith("reranker")
+    model = _hf_xlmr_cls(hidden, layers, heads, ffn) if head else _hf_bert(hidden, layers, heads, ffn)
+    with torch.no_grad():                                  # LayerNorm gains / shifts away from (1, 0): the fold must carry them
+        for name, p_ in model.named_parameters():
+            if "LayerNorm" in name:
+                p_.add_(0.2 * torch.randn_like(p_))
+                p_.copy_(p_.half().float())
+    ids, mask = _batch(rng, b, t, 1200 if head else 1000, pad_id=1 if head else 0, ragged=ragged)
+    tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    with torch.no_grad():
+        if head:
+            ref = model(input_ids=tid, attention_mask=tm).logits.view(-1).numpy()
+        else:
+            ref_h = model(input_ids=tid, attention_mask=tm).last_hidden_state.numpy()
+            ref = ref_h[:, 0] / np.linalg.norm(ref_h[:, 0], axis=1, keepdims=True)
+    enc = vf.HipEncoder.from_hf(model) if head else vf.HipEncoder.from_hf(model, pooling=0, normalize=True)
+    prev = L.vf_debug_gemm_8p_min_wgs(1)
+    try:
+        n0 = L.vf_debug_ln_fold_forwards()
+        got = enc.forward(ids, mask)
+        hs = None if head else enc.hidden_states(ids, mask)
+        assert L.vf_debug_ln_fold_forwards() >= n0 + 1, "the forward did not take the folded-LayerNorm path"
+        L.vf_debug_gemm_8p_min_wgs(1 << 40)                # the same forward on the launch-per-LayerNorm path
+        n1 = L.vf_debug_ln_fold_forwards()
+        plain = enc.forward(ids, mask)
+        assert L.vf_debug_ln_fold_forwards() == n1
+    finally:
+        L.vf_debug_gemm_8p_min_wgs(prev)
+        L.vf_debug_ln_fold(was_on)
+        enc.close()
+    err, dplain = float(np.abs(got - ref).max()), float(np.abs(got - plain).max())
+    print("ln-fold", kind, "max|d| vs HF fp32", err, "vs the unfolded path", dplain, "unfolded vs HF", float(np.abs(plain - ref).max()))
+    if head:
+        assert err < 2.5e-3 * max(1.0, np.abs(ref).max()) and dplain < 2.5e-3 * max(1.0, np.abs(ref).max())
+    else:
+        herr = np.abs(hs - ref_h)[mask.astype(bool)]
+        print("   hidden mean / max err", herr.mean(), herr.max())
+        assert err < 8e-4 and dplain < 8e-4 and herr.mean() < 3e-3 and herr.max() < 4e-2
+
+
 def test_drop_in_embedder_and_reranker_objects(vf):
     """HipEmbeddings / HipReranker carry the reference's method names and feed FaissRetriever / rank fusion."""
     import torch

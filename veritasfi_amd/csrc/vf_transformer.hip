@@ -195,7 +195,12 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float*
 // GEMM operands are fp16.
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 = 3,
        EPI_GATED_SILU = 4, EPI_GATED_GELU = 5,
-       EPI_BIAS_RESIDUAL_LN = 6 };   // k_gemm8p_tn only: EPI_BIAS_RESIDUAL + the LayerNorm of finished row tiles in the same launch (LnTail)   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
+       EPI_BIAS_RESIDUAL_LN = 6,
+       // LayerNorm folded into the products around it (k_gemm8p_tn only; LnFold, DESIGN.md 7 "LayerNorm without a launch"):
+       EPI_LNA = 7,            // C = rstd_m (A.W'^T - mean_m colsum(W')_n) + c_n : A is the RAW pre-LayerNorm sum, W' = W diag(gamma)
+       EPI_LNA_GELU = 8,       // ... + GELU
+       EPI_RES_STATS = 9,      // C = A.W^T + b + R (R already normalised), and the row sums (sum, sum of squares) of C
+       EPI_LNRES_STATS = 10 }; // C = A.W^T + b + LayerNorm(R) from the raw R and its row sums, and the row sums of C   // k_gemm8p_tn only: EPI_BIAS_RESIDUAL + the LayerNorm of finished row tiles in the same launch (LnTail)   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
 
 // exact-GELU x Phi(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2), with the complementary error function as
 // exp2 of a polynomial:  -log2 erfc(a / sqrt 2) = a (c1 + a (c2 + a (c3 + a (c4 + a c5)))), fitted on [0, 6] with the
@@ -1559,6 +1564,21 @@ __global__ __launch_bounds__(kSqThreads) void k_sq_forward(SqParams p, int ph0, 
 // The residual operand and the LayerNorm output are the SAME buffer (x): a row tile's x rows are rewritten only after all
 // tiles that read them as residual have finished.
 // ------------------------------------------------------------------------------------------------
+// LayerNorm folded into the neighbouring products: a residual product (EPI_RES_STATS / EPI_LNRES_STATS) leaves, per 256-column
+// tile, the sums (sum y, sum y^2) of every row of its fp16 output y; the consumers read the raw y and the n_parts partial
+// sums: the next product as its A operand (EPI_LNA*: the LayerNorm's gamma is folded into the weights, its mean / beta
+// terms enter through colsum(W') and c), the next residual product as its residual (normalised element by element).
+struct LnFold {
+    const float* stats_in;   // [n_parts][Mp][2] partial row sums of the raw operand (A for EPI_LNA*, R for EPI_LNRES_STATS)
+    float* stats_out;        // [N / 256][Mp][2] (EPI_*_STATS)
+    const float* colsum;     // [N] column sums of the folded weights (EPI_LNA*)
+    const float* gR;         // [N] gamma / beta of the LayerNorm applied to R (EPI_LNRES_STATS)
+    const float* bR;
+    int n_parts;             // hidden / 256
+    int Mp;                  // rows of the stats arrays
+    float inv_h, eps;        // 1 / hidden
+};
+
 struct LnTail {
     half_t* x;               // LayerNorm output [M][N]
     const float* g;
@@ -1685,14 +1705,15 @@ constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLD
 template <int EPI>
 __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                           const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K, LnTail lt) {
+                                                          half_t* __restrict__ C, int M, int N, int K, LnTail lt, LnFold lf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: [2 K-tiles][4 half-tiles][16 KB] + dump
     const int tid = threadIdx.x, lane = tid & 63;
     if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) {
         if ((int)blockIdx.x >= lt.ntiles) { ln_tail_worker(lt, C, M, N, smem); return; }
         if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(lt.next + ((lt.gen + 1u) & 63u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    constexpr bool RES16 = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN;
+    constexpr bool RES16 = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN || EPI == EPI_RES_STATS || EPI == EPI_LNRES_STATS;
+    constexpr bool LNA = EPI == EPI_LNA || EPI == EPI_LNA_GELU, STATS = EPI == EPI_RES_STATS || EPI == EPI_LNRES_STATS;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
     int mt_idx, nt_idx;
@@ -1872,22 +1893,51 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     // epilogue through LDS: fp16(acc + bias [+GELU]) into a [256][256] fp16 image (the two K-tile buffers), then
     // 16-byte row chunks out (residual added in fp32 on the vector side)
     half_t* Es = (half_t*)smem;
+    float2* rowst = (float2*)(smem + 8 * PSLOT);   // the dump slot: (mean, rstd) of the tile's 256 rows (LnFold)
+    if constexpr (LNA || EPI == EPI_LNRES_STATS) {
+        if (tid < PBM) {
+            float sm = 0.f, sq = 0.f;
+            for (int pz = 0; pz < lf.n_parts; ++pz) {
+                const float2 v = *(const float2*)(lf.stats_in + ((long long)pz * lf.Mp + m0 + tid) * 2);
+                sm += v.x; sq += v.y;
+            }
+            const float mean = sm * lf.inv_h;
+            const float var = fmaxf(sq * lf.inv_h - mean * mean, 0.f);
+            rowst[tid] = make_float2(mean, rsqrtf(var + lf.eps));
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int col = wc * 64 + ni * 16 + r15;
         const float bv = bias ? bias[n0 + col] : 0.f;
+        float csv = 0.f;
+        if constexpr (LNA) csv = lf.colsum[n0 + col];
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
             for (int reg = 0; reg < 4; reg += 2) {
                 const int row = wr * 128 + mi * 16 + 4 * kb + reg;
-                f2v v = {acc[mi][ni][reg] + bv, acc[mi][ni][reg + 1] + bv};
-                if (EPI == EPI_BIAS_GELU) v = gelu_erf2(v);
+                f2v v;
+                if constexpr (LNA) {   // rstd (acc - mean colsum) + c   (c arrives as `bias`)
+                    const float2 s0 = rowst[row], s1 = rowst[row + 1];
+                    v[0] = s0.y * (acc[mi][ni][reg] - s0.x * csv) + bv;
+                    v[1] = s1.y * (acc[mi][ni][reg + 1] - s1.x * csv) + bv;
+                } else {
+                    v[0] = acc[mi][ni][reg] + bv; v[1] = acc[mi][ni][reg + 1] + bv;
+                }
+                if (EPI == EPI_BIAS_GELU || EPI == EPI_LNA_GELU) v = gelu_erf2(v);
                 Es[row * PBN + col] = (half_t)v[0];
                 Es[(row + 1) * PBN + col] = (half_t)v[1];
             }
     }
     __syncthreads();
+    float gr[8], br[8];
+    if constexpr (EPI == EPI_LNRES_STATS) {   // a thread's 16 chunks all sit in the same 8 columns
+        const int cc0 = tid & 31;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gr[e] = lf.gR[n0 + cc0 * 8 + e]; br[e] = lf.bR[n0 + cc0 * 8 + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
@@ -1895,8 +1945,22 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         const long long off = (m0 + row) * N + n0 + cc * 8;
         if (RES16) {
             const h8 r = *(const h8*)(R + off);
+            if constexpr (EPI == EPI_LNRES_STATS) {
+                const float2 st = rowst[row];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (((float)r[e] - st.x) * st.y * gr[e] + br[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+            }
+        }
+        if constexpr (STATS) {   // row sums of the ROUNDED output: the 32 lanes of a half-wave hold one row's 32 chunks
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float y = (float)o[e]; sm += y; sq += y * y; }
+#pragma unroll
+            for (int d_ = 16; d_; d_ >>= 1) { sm += __shfl_xor(sm, d_, 32); sq += __shfl_xor(sq, d_, 32); }
+            if (cc == 0) *(float2*)(lf.stats_out + ((long long)nt_idx * lf.Mp + m0 + row) * 2) = make_float2(sm, sq);
         }
         if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) sq_st8(sq_rsrc(C), (int)(off * 2), o);   // write-through: the tail workers read it
         else *(h8*)(C + off) = o;
@@ -3755,6 +3819,10 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNRES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
@@ -3838,6 +3906,12 @@ struct vf_encoder {
     int* ln_order = nullptr;
     int ln_cap_mt = 0, ln_mt = 0, ln_nt = 0;
     unsigned ln_gen = 0;
+    // LayerNorm folded into the products (LnFold): gamma-folded copies of Wqkv (layers >= 1) and W1 (fp16, per layer
+    // [3H][H] + [F][H]), their column sums and the folded bias vectors (fp32, per layer 3H + 3H + F + F); built on first use.
+    // Row-sum partials of the two raw residual sums [H / 256][cap_tokens][2] live with the workspace.
+    half_t* fold16 = nullptr;
+    float* fold32 = nullptr;
+    float *stats_a = nullptr, *stats_b = nullptr;
     // persistent one-query forward (k_sq_forward): barrier words (+ the published row statistics, 256 bytes in) on the device,
     // a host-mapped timeout flag
     unsigned* sq_bar = nullptr;
@@ -3881,9 +3955,10 @@ static void enc_drop_graphs(vf_encoder* e) {
 
 static void enc_free_ws(vf_encoder* e) {
     enc_drop_graphs(e);   // captured launches hold the workspace pointers
-    void* p[] = {e->x, e->y, e->qkv, e->ctx, e->hbuf, e->d_ids, e->d_mask, e->d_tt, e->d_pos, e->d_out, e->d_hidden, e->d_seq};
+    void* p[] = {e->x, e->y, e->qkv, e->ctx, e->hbuf, e->d_ids, e->d_mask, e->d_tt, e->d_pos, e->d_out, e->d_hidden, e->d_seq, e->stats_a, e->stats_b};
     for (void* q : p) if (q) (void)hipFree(q);
     e->x = e->y = e->qkv = e->ctx = e->hbuf = nullptr;
+    e->stats_a = e->stats_b = nullptr;
     e->d_ids = e->d_mask = e->d_tt = e->d_pos = e->d_seq = nullptr;
     e->d_out = nullptr; e->d_hidden = nullptr;
     e->cap_tokens = 0; e->cap_b = 0;
@@ -3901,6 +3976,8 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     if (e->sk_part) (void)hipFree(e->sk_part);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
     if (e->ln_mdone) (void)hipFree(e->ln_mdone);
+    if (e->fold16) (void)hipFree(e->fold16);
+    if (e->fold32) (void)hipFree(e->fold32);
     if (e->ln_next) (void)hipFree(e->ln_next);
     if (e->ln_done) (void)hipFree(e->ln_done);
     if (e->ln_order) (void)hipFree(e->ln_order);
@@ -4009,6 +4086,12 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
     VFT_HIP(hipMalloc((void**)&e->d_seq, ((size_t)B + 1) * 4));
     VFT_HIP(hipMalloc((void**)&e->d_out, (size_t)B * out_dim * 4));
     VFT_HIP(hipMalloc((void**)&e->d_hidden, Mp * H * 4));
+    if (H % 256 == 0) {
+        VFT_HIP(hipMalloc((void**)&e->stats_a, (H / 256) * Mp * 2 * sizeof(float)));
+        VFT_HIP(hipMalloc((void**)&e->stats_b, (H / 256) * Mp * 2 * sizeof(float)));
+        VFT_HIP(hipMemset(e->stats_a, 0, (H / 256) * Mp * 2 * sizeof(float)));
+        VFT_HIP(hipMemset(e->stats_b, 0, (H / 256) * Mp * 2 * sizeof(float)));
+    }
     // padded rows are read by the GEMMs: keep them finite
     VFT_HIP(hipMemset(e->x, 0, Mp * H * 2));
     VFT_HIP(hipMemset(e->y, 0, Mp * H * 2));
@@ -4048,6 +4131,8 @@ static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bia
     return hipGetLastError();
 }
 
+static long long p8_min_wgs();   // tiles from which the 8-phase kernel is the default (defined with the LnFold helpers)
+
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
                        int K, hipStream_t st, int force_kind = 0) {
@@ -4066,7 +4151,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: 8-phase, the 128 x 256 DMA kernel or the 128 x 128 one
         static const long long p8f_min = getenv("VF_GEMM_8P_F32_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_F32_MIN_WGS")) : 256;   // (Qwen3-4B shape, 320 tiles: 66.4 vs 68.9 ms per forward)
         if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8f_min))) {
-            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{});
+            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, LnFold{});
             return hipGetLastError();
         }
         if (dma_ok && (long long)(M / DBM) * (N / DBN) >= dma_min && kind != 3) {
@@ -4081,7 +4166,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // 256 x 256 8-phase tiles (one workgroup per CU) once they fill the chip 1.5 times over; measured against the
     // 128 x 256 DMA kernel at M = 51200: 225 / 79 / 265 / 246 us vs 278 / 79 / 296 / 295 us (QKV / out / FFN-up / FFN-down
     // shapes of a 768-wide encoder; the vendor library: 210 / 66 / 234 / 217)
-    static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
+    const long long p8_min = p8_min_wgs();
     // The PERSISTENT 8-phase form (k_gemm8q_tn, VF_GEMM_KIND=8) is an experiment, not the default.  Back to back on the same
     // operands it wins everywhere (209 / 71 / 247 / 237 us on the four shapes, 1.02 - 1.11 x the vendor library; GELU / residual
     // epilogues 331 / 79 + 247 vs 366 / 86 + 254 us: profiles/r02b_gemm_persistent.log), but INSIDE the forward, where the
@@ -4097,7 +4182,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{});
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, LnFold{});
         return hipGetLastError();
     }
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
@@ -4138,9 +4223,9 @@ static bool gemm_gated(const half_t* A, const half_t* Wgu, half_t* C, int M, int
     *er = hipSuccess;
     if (off || M % PBM || N % PBN || F % 128 || K % PBK || K < 2 * PBK || (long long)(M / PBM) * (N / PBN) < 384) return false;
     if (act_kind == 1)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{});
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, LnFold{});
     else
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{});
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, LnFold{});
     *er = hipGetLastError();
     return true;
 }
@@ -4182,7 +4267,7 @@ extern "C" long long vf_debug_ln_tail(int on) {
 static bool gemm_residual_ln(vf_encoder* e, const half_t* A, const half_t* W, const float* bias, half_t* x, half_t* y,
                              const float* g, const float* b, int Mp, int N, int K, hipStream_t st, hipError_t* er) {
     const bool off = g_ln_tail.load(std::memory_order_relaxed) == 0;   // A/B switch: VF_LN_TAIL=1 or vf_debug_ln_tail(1)
-    static const long long p8_min = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
+    const long long p8_min = p8_min_wgs();
     static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
     *er = hipSuccess;
     const int Mt = Mp / PBM, Nt = N / PBN;
@@ -4235,7 +4320,7 @@ static bool gemm_residual_ln(vf_encoder* e, const half_t* A, const half_t* W, co
     lt.nowait = nowait ? 1 : 0;
     static const int env_workers = getenv("VF_LN_TAIL_WORKERS") ? atoi(getenv("VF_LN_TAIL_WORKERS")) : -1;   // experiments
     const int workers = env_workers >= 0 ? env_workers : std::min(device_cus(), Mt * (PBM / kLnUnitRows));
-    hipLaunchKernelGGL(k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, dim3(lt.ntiles + workers), dim3(PTHREADS), PLDS, st, A, W, bias, x, y, Mp, N, K, lt);
+    hipLaunchKernelGGL(k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, dim3(lt.ntiles + workers), dim3(PTHREADS), PLDS, st, A, W, bias, x, y, Mp, N, K, lt, LnFold{});
     hipLaunchKernelGGL(k_layernorm_rest, dim3(Mp / kLnUnitRows), dim3(256), 0, st, y, g, b, e->cfg.ln_eps, Mp, N, x, e->ln_done, lt.gen);
     *er = hipGetLastError();
     g_ln_tail_calls.fetch_add(1, std::memory_order_relaxed);
@@ -4252,6 +4337,90 @@ static std::atomic<int> g_sq_mode{getenv("VF_SQ_FUSED") ? 1 : getenv("VF_SQ_PHAS
 static std::atomic<unsigned long long*> g_sq_stamps{nullptr};
 extern "C" void vf_debug_sq_stamps(void* buf) { g_sq_stamps.store((unsigned long long*)buf); }
 extern "C" int vf_debug_sq_mode(int mode) { return mode >= 0 && mode <= 2 ? g_sq_mode.exchange(mode) : g_sq_mode.load(); }
+
+// ---- LayerNorm folded into the products (LnFold) ---------------------------------------------------------------------
+// W'[n][k] = fp16(W[n][k] * gamma[k]);  colsum[n] = sum_k W'[n][k] (of the ROUNDED values: what the MFMA multiplies);
+// c[n] = sum_k W[n][k] * beta[k] + b[n].  One wave per output row.
+__global__ __launch_bounds__(256) void k_fold_ln(const half_t* __restrict__ W, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ b, int N, int K,
+                                                 half_t* __restrict__ Wf, float* __restrict__ colsum, float* __restrict__ cvec) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float cs = 0.f, cv = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(long long)n * K + k];
+        const half_t wf = (half_t)(w * gamma[k]);
+        Wf[(long long)n * K + k] = wf;
+        cs += (float)wf;
+        cv += w * beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { cs += __shfl_xor(cs, o); cv += __shfl_xor(cv, o); }
+    if (lane == 0) { colsum[n] = cs; cvec[n] = cv + b[n]; }
+}
+
+static std::atomic<long long> g_p8_min_override{-1};
+static std::atomic<long long> g_ln_fold_forwards{0};
+// MEASURED SLOWER, so off unless asked for (VF_LN_FOLD=1 / vf_debug_ln_fold(1)): the two k_layernorm launches of a layer cost
+// 2 x 29.5 us; the folded form removes them and adds their arithmetic to four epilogues that run on the MFMA waves with
+// nothing beside them on the CU -- re-rank p50 12.14 vs 11.94 ms (XLM-R-base shape), 37.2 vs 35.7 (large), same box
+// (tools/gpu_r03_fold.sh).  It is exact to the same tolerances (errors vs HF fp32 slightly smaller: x is never rounded to fp16).
+static std::atomic<int> g_ln_fold{getenv("VF_LN_FOLD") ? 1 : 0};
+extern "C" int vf_debug_ln_fold(int on) { return on >= 0 ? g_ln_fold.exchange(on ? 1 : 0) : g_ln_fold.load(); }
+// Test hooks: lower the tile count from which the 8-phase kernel (and with it the folded LayerNorm) is used, so that a small
+// model exercises that path; forwards that took the folded path so far.
+extern "C" long long vf_debug_gemm_8p_min_wgs(long long v) { return g_p8_min_override.exchange(v); }
+extern "C" long long vf_debug_ln_fold_forwards() { return g_ln_fold_forwards.load(std::memory_order_relaxed); }
+static long long p8_min_wgs() {
+    static const long long env = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
+    const long long o = g_p8_min_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : env;
+}
+
+static size_t fold16_layer(const vf_encoder_config& c) { return (size_t)3 * c.hidden * c.hidden + (size_t)c.ffn * c.hidden; }
+static size_t fold32_layer(const vf_encoder_config& c) { return (size_t)6 * c.hidden + 2 * (size_t)c.ffn; }
+
+// the folded path serves a forward whose four products per layer all take the 8-phase kernel
+static bool enc_fold_ok(const vf_encoder* e, int Mp) {
+    const bool off = g_ln_fold.load(std::memory_order_relaxed) == 0;
+    static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
+    const vf_encoder_config& c = e->cfg;
+    if (off || env_kind != 0 || g_ln_tail.load(std::memory_order_relaxed)) return false;
+    if (Mp % PBM || c.hidden % PBN || c.ffn % PBN || c.hidden < 2 * PBK || !e->stats_a) return false;
+    return (long long)(Mp / PBM) * (c.hidden / PBN) >= p8_min_wgs();
+}
+
+static int enc_ensure_fold(vf_encoder* e, hipStream_t st) {
+    if (e->fold16) return VF_OK;
+    const vf_encoder_config& c = e->cfg;
+    const int H = c.hidden, F = c.ffn;
+    VFT_HIP(hipMalloc((void**)&e->fold16, (size_t)c.layers * fold16_layer(c) * sizeof(half_t)));
+    VFT_HIP(hipMalloc((void**)&e->fold32, (size_t)c.layers * fold32_layer(c) * sizeof(float)));
+    for (int l = 0; l < c.layers; ++l) {
+        const half_t* w = e->w16 + e->o_layers + (size_t)l * e->layer16;
+        const float* f = e->w32 + e->f_layers + (size_t)l * e->layer32;
+        const half_t *Wqkv = w, *W1 = Wqkv + (size_t)4 * H * H;
+        const float *bqkv = f, *g1 = f + 4 * H, *b1n = g1 + H, *b1 = b1n + H;
+        half_t* d16 = e->fold16 + (size_t)l * fold16_layer(c);
+        float* d32 = e->fold32 + (size_t)l * fold32_layer(c);
+        if (l > 0) {   // the LayerNorm in front of this layer's QKV projection is the previous layer's second one
+            const float* fp = e->w32 + e->f_layers + (size_t)(l - 1) * e->layer32;
+            const float *g2p = fp + 7 * H + F, *b2np = g2p + H;
+            hipLaunchKernelGGL(k_fold_ln, dim3((3 * H + 3) / 4), dim3(256), 0, st, Wqkv, g2p, b2np, bqkv, 3 * H, H, d16, d32, d32 + 3 * H);
+        }
+        hipLaunchKernelGGL(k_fold_ln, dim3((F + 3) / 4), dim3(256), 0, st, W1, g1, b1n, b1, F, H, d16 + (size_t)3 * H * H,
+                           d32 + 6 * H, d32 + 6 * H + F);
+    }
+    VFT_HIP(hipGetLastError());
+    return VF_OK;
+}
+
+template <int EPI>
+static hipError_t gemm8p_fold(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                              const LnFold& lf, hipStream_t st) {
+    hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf);
+    return hipGetLastError();
+}
 
 // ids / mask / type ids already in e->d_ids / d_mask / d_tt; result lands in e->d_out
 // seq_off != nullptr: PACKED rows (forward_impl's ragged-batch path) -- Mpk rows in all, sequence b in rows
@@ -4309,13 +4478,29 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     while ((((T + pad) / 2) & 63) != 4) pad += 8;
     const int vt_ld = T + pad;
     const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4 + 64;  // K, V^T, mask, tile states
+    // LayerNorm without a launch (LnFold): when every product of a layer takes the 8-phase kernel, the two LayerNorm sweeps of
+    // the layer (2 x 29.5 us of 970 at 100 x 512 tokens) disappear into the products around them -- the residual products
+    // write the RAW sums and their row sums, the next product reads the raw sum as its A operand through gamma-folded
+    // weights, the next residual product normalises its residual element by element.  e->y holds y1 (attention sum),
+    // e->x holds y2 (FFN sum) of the previous layer; the last layer writes y2 over y1 and one k_layernorm produces e->x.
+    const bool fold = !sq && !skinny && !small && enc_fold_ok(e, Mp);
+    if (fold) { VFT_TRY(enc_ensure_fold(e, st)); g_ln_fold_forwards.fetch_add(1, std::memory_order_relaxed); }
+    LnFold lf0{};
+    lf0.n_parts = H / 256; lf0.Mp = e->cap_tokens; lf0.inv_h = 1.0f / (float)H; lf0.eps = c.ln_eps;
     for (int l = 0; l < (sq ? 0 : c.layers); ++l) {
         const half_t* w = e->w16 + e->o_layers + (size_t)l * e->layer16;
         const float* f = e->w32 + e->f_layers + (size_t)l * e->layer32;
         const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
         const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F, *g2 = b2 + H,
                     *b2n = g2 + H;
+        const half_t* f16 = fold ? e->fold16 + (size_t)l * fold16_layer(c) : nullptr;
+        const float* f32 = fold ? e->fold32 + (size_t)l * fold32_layer(c) : nullptr;
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, M, 3 * H, H, st));
+        else if (fold && l > 0) {   // A = the previous layer's raw FFN sum; its LayerNorm sits in the folded weights + epilogue
+            LnFold lf = lf0;
+            lf.stats_in = e->stats_b; lf.colsum = f32;
+            VFT_HIP(gemm8p_fold<EPI_LNA>(e->x, f16, f32 + 3 * H, nullptr, e->qkv, Mp, 3 * H, H, lf, st));
+        }
         else VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
         static const bool att_stream = getenv("VF_ATT_STREAM") != nullptr;  // A/B switch: streaming kernel on the BERT path
         // Sequences longer than 512 tokens (bge-m3 = XLM-R-large with an 8194-entry position table: config/example.yaml:3,
@@ -4339,6 +4524,25 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         }
         bool fused_ln = false;          // the residual product carried its LayerNorm (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>)
         hipError_t ler = hipSuccess;
+        if (fold) {
+            LnFold lf = lf0;
+            lf.stats_out = e->stats_a;
+            if (l == 0) VFT_HIP(gemm8p_fold<EPI_RES_STATS>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, lf, st));   // residual = the embedding LayerNorm's output
+            else {
+                const float* fp = e->w32 + e->f_layers + (size_t)(l - 1) * e->layer32;
+                lf.stats_in = e->stats_b; lf.gR = fp + 7 * H + F; lf.bR = fp + 8 * H + F;                    // previous layer's g2 / b2n
+                VFT_HIP(gemm8p_fold<EPI_LNRES_STATS>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, lf, st));
+            }
+            LnFold lu = lf0;
+            lu.stats_in = e->stats_a; lu.colsum = f32 + 6 * H;
+            VFT_HIP(gemm8p_fold<EPI_LNA_GELU>(e->y, f16 + (size_t)3 * H * H, f32 + 6 * H + F, nullptr, e->hbuf, Mp, F, H, lu, st));
+            LnFold ld = lf0;
+            ld.stats_in = e->stats_a; ld.gR = g1; ld.bR = b1n; ld.stats_out = e->stats_b;
+            half_t* dst = l + 1 < c.layers ? e->x : e->y;      // the last layer's sum goes over y1 (same chunk read and written by a thread)
+            VFT_HIP(gemm8p_fold<EPI_LNRES_STATS>(e->hbuf, W2, b2, e->y, dst, Mp, H, F, ld, st));
+            if (l + 1 == c.layers) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
+            continue;
+        }
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
         else if ((fused_ln = gemm_residual_ln(e, e->ctx, Wo, bo, e->x, e->y, g1, b1n, Mp, H, H, st, &ler))) VFT_HIP(ler);
         else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
