@@ -25,6 +25,17 @@ def vf():
     return m
 
 
+def _experiments_built():
+    """The shipped library holds one kernel per operation; the measured-and-rejected ones (persistent one-query forward,
+    LayerNorm in the products' tail, first-generation attention, the other GEMM tilings) are compiled in only with
+    VF_BUILD_FLAGS=-DVF_EXPERIMENTS."""
+    import ctypes
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_experiments.restype = ctypes.c_int
+    return L.vf_debug_experiments() == 1
+
+
 def _hf_bert(hidden, layers, heads, ffn, vocab=1000, seed=0):
     import torch
     from transformers import BertConfig, BertModel
@@ -106,6 +117,8 @@ def test_one_query_persistent_forward(vf, hidden, layers, heads, ffn, b, t):
     of the K splits."""
     import ctypes, torch
     from veritasfi_amd import _ffi
+    if not _experiments_built():
+        pytest.skip("k_sq_forward is an experiment kernel: build with VF_BUILD_FLAGS=-DVF_EXPERIMENTS")
     L = _ffi.lib()
     L.vf_debug_sq_mode.restype = ctypes.c_int
     L.vf_debug_sq_mode.argtypes = [ctypes.c_int]
@@ -146,6 +159,8 @@ def test_layernorm_in_the_tail_of_the_residual_products(vf):
     shape (ragged, packed rows) restarts the counters."""
     import ctypes, torch
     from veritasfi_amd import _ffi
+    if not _experiments_built():
+        pytest.skip("the LayerNorm-in-the-tail epilogue is an experiment kernel: build with VF_BUILD_FLAGS=-DVF_EXPERIMENTS")
     L = _ffi.lib()
     L.vf_debug_ln_tail.restype = ctypes.c_longlong
     L.vf_debug_ln_tail.argtypes = [ctypes.c_int]
@@ -425,6 +440,8 @@ def test_gemm_kernels_match_torch(vf, kind, epi):
     import ctypes
     import torch
     from veritasfi_amd import _ffi
+    if kind in (1, 2, 6, 8) and not _experiments_built():
+        pytest.skip("GEMM kinds 1, 2, 6, 8 are experiment kernels: build with VF_BUILD_FLAGS=-DVF_EXPERIMENTS")
     L = _ffi.lib()
     L.vf_debug_gemm.restype = ctypes.c_int
     L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
@@ -887,7 +904,8 @@ def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, 
     ref = reference(qkv, mask, b, t, heads, rows=rows)
     valid = mask.reshape(b, t)[:rows].reshape(-1).bool()
     vmax = float(qkv[:, 2 * heads * 64:].float().abs().max())
-    for kind in (2, 1, 3, 4):                                # k_attention2, first generation, streaming (register-staged, LDS-DMA)
+    kinds = (2, 1, 3, 4) if _experiments_built() else (2, 4)   # k_attention2, [first generation, register-staged streaming,] LDS-DMA streaming
+    for kind in kinds:
         ctx = torch.full((b * t, heads * 64), float("nan"), dtype=torch.float16, device=dev)
         run(L, kind, qkv, mask, b, t, heads, ctx)
         torch.cuda.synchronize()
@@ -896,11 +914,11 @@ def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, 
         err = float((got - ref[valid]).abs().max())
         # measured <= 2.5e-4 * max|v| on these cases (fp16 probabilities and outputs); 3x that
         assert err <= 7.5e-4 * vmax, (kind, err, vmax)
-    # the last pairs too (the persistent kernel's later rounds), kind 2 against kind 3
+    # the last pairs too (the persistent kernel's later rounds), kind 2 against the streaming kernel
     c2 = torch.zeros(b * t, heads * 64, dtype=torch.float16, device=dev)
     c3 = torch.zeros_like(c2)
     run(L, 2, qkv, mask, b, t, heads, c2)
-    run(L, 3, qkv, mask, b, t, heads, c3)
+    run(L, 3 if _experiments_built() else 4, qkv, mask, b, t, heads, c3)
     torch.cuda.synchronize()
     allv = mask.bool()
     assert float((c2.float()[allv] - c3.float()[allv]).abs().max()) <= 1.5e-3 * vmax

@@ -1650,6 +1650,7 @@ __device__ __forceinline__ void ln_tail_worker(const LnTail& lt, const half_t* Y
 }
 
 // LayerNorm of the 64-row units the tail workers did not mark (done[unit] != gen); y -> x.  One workgroup per unit.
+#ifdef VF_EXPERIMENTS
 __global__ __launch_bounds__(256) void k_layernorm_rest(const half_t* y, const float* g, const float* bta, float eps, int M,
                                                          int H, half_t* x, const unsigned* done, unsigned gen) {
     if (done[blockIdx.x] == gen) return;
@@ -1673,6 +1674,7 @@ __global__ __launch_bounds__(256) void k_layernorm_rest(const half_t* y, const f
         ln_finish(v, s, l32, nch, H, g, bta, eps, x + (long long)row * H);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_gemm8p_tn: 256 x 256 x 64 tiles, 8 waves (2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles,
@@ -2002,7 +2004,7 @@ __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, const c
                  : "memory");
 }
 
-constexpr int QLDS = PLDS + 1024;   // + one tile's bias (256 floats)
+[[maybe_unused]] constexpr int QLDS = PLDS + 1024;   // + one tile's bias (256 floats)
 
 // tile of a dispatch index: XCD-contiguous, n-major groups of 4 m-tiles (as k_gemm8p_tn)
 __device__ __forceinline__ void q_tile_of(int orig, int Mt, int Nt, int& mt, int& nt) {
@@ -2232,7 +2234,8 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict
 // matched by reading V^T as two 8-byte groups).  Online softmax over 32-key tiles.
 // dh = 64, T % 32 == 0, T <= 512.
 // ------------------------------------------------------------------------------------------------
-constexpr int ADH = 64, AKLD = ADH + 8, ATHREADS = 512;
+constexpr int ADH = 64;
+[[maybe_unused]] constexpr int AKLD = ADH + 8, ATHREADS = 512;
 
 // Both 32-lane halves of v in every lane, without an LDS round trip: gfx950's v_permlane32_swap exchanges lanes
 // [32, 64) of its first operand with lanes [0, 32) of its second, so two copies of v become (lower half everywhere,
@@ -2319,6 +2322,7 @@ __device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], fl
             o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pf[st], o[mt], 0, 0, 0);
 }
 
+#ifdef VF_EXPERIMENTS
 __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask,
                                                          int T, int H, int vt_ld, float qs, float ex, half_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2431,6 +2435,7 @@ __global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict
             }
     }
 }
+#endif
 
 // weight preparation: the attention kernels take scores in log2 units, so log2(e) / sqrt(dh) is folded into the query
 // projection (rows [0, H) of Wqkv and of its bias) once, when the weights are loaded
@@ -3797,39 +3802,57 @@ __global__ __launch_bounds__(64) void k_token_logit(const half_t* x, const int* 
 using namespace vft;
 
 // Opt every kernel into its dynamic LDS size (idempotent; cheap).
+// VF_EXPERIMENTS (VF_BUILD_FLAGS="-DVF_EXPERIMENTS" python -m veritasfi_amd.build --force) compiles the measured-and-rejected
+// kernels back in: k_gemm256_tn, k_gemm_dma_tn (32x32x16 MFMAs), the 128-wide DMA instance, the persistent k_gemm8q_tn, the
+// all-layers k_sq_forward, LayerNorm in the tail of the residual products, first-generation attention (k_attention, the
+// register-staged k_attention_stream / _stream256).  The shipped library holds ONE kernel per operation and shape class; the
+// VF_* switches and vf_debug_* hooks of the experiments answer "not built" without the flag.
 static hipError_t configure_once() {
     hipError_t er = hipSuccess;
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNRES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<4, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -3837,18 +3860,23 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<256>));
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
+#endif
     return er;
 }
 
@@ -4033,6 +4061,7 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = configure_once();
+#ifdef VF_EXPERIMENTS
     e->q_folded = getenv("VF_ATT_V1") == nullptr;   // A/B switch: the first-generation kernel scales Q itself
     if (er == hipSuccess && c.hidden % 256 == 0 && c.ffn % 256 == 0) {
         // persistent one-query forward: every workgroup must be resident (grid <= CUs, one workgroup per CU fits)
@@ -4046,6 +4075,7 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
         }
         (void)hipGetLastError();
     }
+#endif
     if (er == hipSuccess && e->q_folded) {
         const float qs = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(64)
         for (int l = 0; l < c.layers; ++l) {
@@ -4174,11 +4204,13 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // already runs at 328 / 161 / 187 us per layer and the persistent one at 328 / 162 / 184 (XLM-R-large shape: 498 / 258 / 289
     // vs 508 / 270 / 291): what it hides -- load latency at the tile seams -- is not what the forward waits for, and its
     // static tile schedule gives up the dispatcher's balancing.  The epilogue still runs on the waves that own the MFMAs.
+#ifdef VF_EXPERIMENTS
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && kind == 8) {
         const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
         hipLaunchKernelGGL(k_gemm8q_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), QLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
     }
+#endif
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
@@ -4189,6 +4221,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
     }
+#ifdef VF_EXPERIMENTS
     // The same kernel with 128-wide N tiles (48 KB LDS, three workgroups per CU).  Measured on the mid-size problems it
     // was meant for (decoder residual products, 8..32-pair micro-batches): equal or up to 6 % SLOWER than the
     // register-staged 128 x 128 kernel below, so it is off unless asked for (kind 6 / VF_GEMM_DMA128_MIN_WGS).
@@ -4208,6 +4241,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
                            N, K);
         return hipGetLastError();
     }
+#endif
     const dim3 grid((N / GBN) * (M / GBM));
     const size_t lds = (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t);
     hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
@@ -4266,6 +4300,10 @@ extern "C" long long vf_debug_ln_tail(int on) {
 // Returns false when the shape does not take the 8-phase kernel (the caller then runs the product and k_layernorm).
 static bool gemm_residual_ln(vf_encoder* e, const half_t* A, const half_t* W, const float* bias, half_t* x, half_t* y,
                              const float* g, const float* b, int Mp, int N, int K, hipStream_t st, hipError_t* er) {
+#ifndef VF_EXPERIMENTS
+    (void)e; (void)A; (void)W; (void)bias; (void)x; (void)y; (void)g; (void)b; (void)Mp; (void)N; (void)K; (void)st; (void)er;
+    return false;   // LayerNorm in the tail of the residual products: an experiment (VF_EXPERIMENTS)
+#else
     const bool off = g_ln_tail.load(std::memory_order_relaxed) == 0;   // A/B switch: VF_LN_TAIL=1 or vf_debug_ln_tail(1)
     const long long p8_min = p8_min_wgs();
     static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
@@ -4325,6 +4363,7 @@ static bool gemm_residual_ln(vf_encoder* e, const half_t* A, const half_t* W, co
     *er = hipGetLastError();
     g_ln_tail_calls.fetch_add(1, std::memory_order_relaxed);
     return true;
+#endif
 }
 
 // The persistent one-query forward is an EXPERIMENT, off by default: measured on MI355X it is slower than the launch-per-product
@@ -4336,7 +4375,13 @@ static std::atomic<int> g_sq_mode{getenv("VF_SQ_FUSED") ? 1 : getenv("VF_SQ_PHAS
 // (s_memrealtime, 100 MHz); nullptr switches the stamps off.  Captured graphs keep the pointer they were captured with.
 static std::atomic<unsigned long long*> g_sq_stamps{nullptr};
 extern "C" void vf_debug_sq_stamps(void* buf) { g_sq_stamps.store((unsigned long long*)buf); }
+#ifdef VF_EXPERIMENTS
 extern "C" int vf_debug_sq_mode(int mode) { return mode >= 0 && mode <= 2 ? g_sq_mode.exchange(mode) : g_sq_mode.load(); }
+extern "C" int vf_debug_experiments(void) { return 1; }
+#else
+extern "C" int vf_debug_sq_mode(int) { return -1; }      // the persistent one-query forward is not built
+extern "C" int vf_debug_experiments(void) { return 0; }
+#endif
 
 // ---- LayerNorm folded into the products (LnFold) ---------------------------------------------------------------------
 // W'[n][k] = fp16(W[n][k] * gamma[k]);  colsum[n] = sum_k W'[n][k] (of the ROUNDED values: what the MFMA multiplies);
@@ -4436,12 +4481,13 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     const bool skinny = !no_skinny && M <= 64 && H % 256 == 0 && F % 256 == 0;   // one short sequence: weight-streaming GEMMs
     // one short query (or two): all layers in ONE persistent launch (k_sq_forward)
     const int sq_mode = g_sq_mode.load(std::memory_order_relaxed);   // 0 off, 1 persistent, 2 one launch per phase (no grid barrier)
-    const bool sq_phases = sq_mode == 2;
+    [[maybe_unused]] const bool sq_phases = sq_mode == 2;
     const bool sq = skinny && sq_mode != 0 && e->sq_ok && !seq_off && (T == 32 || T == 64);
     if (!seq_off) hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
                        c.ln_eps, M, H, e->x, sq ? e->sq_bar : nullptr);
+#ifdef VF_EXPERIMENTS
     if (sq) {
         SqParams p{};
         p.w16 = e->w16 + e->o_layers; p.w32 = e->w32 + e->f_layers;
@@ -4471,6 +4517,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         const float* fl = e->w32 + e->f_layers + (size_t)(c.layers - 1) * e->layer32;
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, fl + 7 * H + F, fl + 8 * H + F, c.ln_eps, M, H, e->x);
     }
+#endif
     // V^T row stride: (T + pad) halves with (T + pad) / 2 == 2 (mod 64) -> conflict-free 8-byte reads
     // (rows must also be 16-byte aligned for the transposed staging writes -> multiple of 8 halves; a
     //  row stride of 4 (mod 64) dwords keeps the 8-byte reads of 32 lanes within a 2-way conflict)
@@ -4507,20 +4554,27 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         // src/utils/ragManager.py:50) cannot keep K and V^T of a head resident in LDS: they take the streaming kernel
         // (64-key tiles through LDS, online softmax), which has no length limit.
         if (att_stream || T > kEncResidentT) {
+#ifdef VF_EXPERIMENTS
             static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
             if (stream_v1)
                 hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
                                    sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
                                    e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
             else
+#endif
                 hipLaunchKernelGGL((k_attention_stream2<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
                                    sizeof(AttnStream2Lds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
                                    e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
         } else if (e->q_folded) {
             launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         } else {
+#ifdef VF_EXPERIMENTS
             hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
                                0.125f, 1.4426950408889634f, e->ctx);
+#else
+            (void)att_lds;
+            return fail(VF_EUNSUPPORTED, "first-generation attention is not built (VF_EXPERIMENTS)");
+#endif
         }
         bool fused_ln = false;          // the residual product carried its LayerNorm (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>)
         hipError_t ler = hipSuccess;
@@ -4949,27 +5003,33 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         hipLaunchKernelGGL(k_qknorm_rope, dim3((M + 256 / (DH / 16) - 1) / (256 / (DH / 16)), 3), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
                            qn, kn, c.rms_eps, c.qk_norm, d->rope, pos);
         if (DH == 64) {
+#ifdef VF_EXPERIMENTS
             static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;
             if (stream_v1)
                 hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
             else
+#endif
                 hipLaunchKernelGGL((k_attention_stream2<64, true>), agrid, dim3(256), sizeof(AttnStream2Lds<64>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else if (DH == 128) {
+#ifdef VF_EXPERIMENTS
             static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
             if (stream_v1)
                 hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
             else
+#endif
                 hipLaunchKernelGGL((k_attention_stream2<128, true>), agrid, dim3(256), sizeof(AttnStream2Lds<128>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else {
+#ifdef VF_EXPERIMENTS
             static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: the Q-in-LDS, register-staged kernel
             if (stream_v1)
                 hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
             else
+#endif
                 hipLaunchKernelGGL((k_attention_stream2<256, true>), agrid, dim3(256), sizeof(AttnStream2Lds<256>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         }
@@ -5177,6 +5237,7 @@ extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T
     if (kind != 3 && kind != 4 && T > kEncResidentT) return -2;
     hipStream_t st = (hipStream_t)stream;
     const int H = heads * ADH;
+#ifdef VF_EXPERIMENTS
     if (kind == 1) {
         int pad = 8;
         while ((((T + pad) / 2) & 63) != 4) pad += 8;
@@ -5184,13 +5245,19 @@ extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T
         const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4 + 64;
         hipLaunchKernelGGL(k_attention, dim3(heads, B), dim3(ATHREADS), att_lds, st, (const half_t*)qkv, mask, T, H, vt_ld, 1.0f, 1.0f,
                            (half_t*)ctx);
+#else
+    if (kind == 1 || kind == 3) {
+        return -3;   // first-generation kernels: not built (VF_EXPERIMENTS)
+#endif
     } else if (kind == 2) {
         launch_attention2<0>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
     } else if (kind == 26) {
         launch_attention2<6>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
+#ifdef VF_EXPERIMENTS
     } else if (kind == 3) {
         hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStreamLds<64>), st,
                            (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
+#endif
     } else if (kind == 4) {
         hipLaunchKernelGGL((k_attention_stream2<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStream2Lds<64>), st,
                            (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
