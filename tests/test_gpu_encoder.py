@@ -431,6 +431,62 @@ def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):
     assert got == want and 0 < len(got) <= 10 and len(set(got)) == len(got)
 
 
+@pytest.mark.parametrize("M,N,K,epi,want_S", [
+    (25600, 768, 768, 0, 4),       # 300 tiles: 44 in the partial round, cut in 4 (12 K-tiles -> 3 each)
+    (51200, 768, 3072, 2, 2),      # the FFN-down product of 100 x 512 tokens: 88 tail tiles, cut in 2
+    (51200, 2304, 768, 0, 4),      # the QKV product: 8 tail tiles
+    (25600, 768, 320, 1, 2),       # 5 K-tiles: slices of 2 and 3 K-tiles, GELU epilogue
+])
+def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, want_S):
+    """The tiles of the 8-phase kernel's partial last round are cut along K (one workgroup per slice, fp32 partials handed
+    over through write-through stores, the last arrival adds them in slice order): against torch fp32, against the same
+    product without the split, and twice -- the result must not depend on which slice arrives last."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_gemm.restype = ctypes.c_int
+    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    L.vf_debug_splitk_tail.restype = ctypes.c_int
+    L.vf_debug_splitk_tail.argtypes = [ctypes.c_int]
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = (M // 256) * (N // 256)
+    ntail = tiles % cus
+    assert tiles > cus and ntail > 0 and min(cus // ntail, (K // 64) // 2, 4) == want_S
+    g = torch.Generator(device=dev).manual_seed(7 * epi + K)
+    A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()
+    bias = torch.randn(N, device=dev, generator=g) * 0.1
+    R = (torch.randn(M, N, device=dev, generator=g)).half()
+
+    def run():
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), R.data_ptr(), C.data_ptr(), M, N, K, epi,
+                             torch.cuda.current_stream().cuda_stream, 7)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return C
+    was = L.vf_debug_splitk_tail(2)                         # the general form (the default cuts long-K products only)
+    try:
+        c1, c2 = run(), run()
+        L.vf_debug_splitk_tail(0)
+        c0 = run()
+    finally:
+        L.vf_debug_splitk_tail(was)
+    assert torch.equal(c1, c2), "the split-K tail is not deterministic"
+    ref = A[-2048:].float() @ W.float().T + bias          # the tail tiles are the LAST dispatch indices: their rows are checked ...
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + R[-2048:].float()
+    assert not torch.isnan(c1).any()
+    err = float((c1[-2048:].float() - ref).abs().max())
+    d01 = float((c1.float() - c0.float()).abs().max())     # ... and the whole output against the unsplit launch
+    print("split-K tail", (M, N, K, epi), "max err vs torch", err, "vs the unsplit launch", d01)
+    assert err < 2e-2 and d01 < 1.6e-2      # fp16 output of O(10) values: one ulp is 7.8e-3
+
+
 @pytest.mark.parametrize("kind", [1, 2, 3, 5, 6, 7, 8])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_kernels_match_torch(vf, kind, epi):

@@ -1577,6 +1577,14 @@ struct LnFold {
     int n_parts;             // hidden / 256
     int Mp;                  // rows of the stats arrays
     float inv_h, eps;        // 1 / hidden
+    // Split-K TAIL (independent of the fold; rides in this struct so that every launch site passes one extra argument): the
+    // tiles of the partial last round -- dispatch indices >= sk_nfull -- are cut into sk_S slices along K, one workgroup each
+    // (600 tiles on 256 CUs are 2.34 rounds of work in 3; with the 88 tail tiles cut in two the third round is 176 half-length
+    // workgroups).  A slice leaves its fp32 accumulators in sk_ws (write-through) and counts itself in sk_cnt[tile]; the last
+    // arrival adds the others' IN SLICE ORDER (deterministic), runs the epilogue and resets the counter.
+    float* sk_ws;            // [tail tiles][sk_S][256 x 256] fp32
+    unsigned* sk_cnt;        // [tail tiles], zero between launches
+    int sk_nfull, sk_S;      // sk_S == 0: no split
 };
 
 struct LnTail {
@@ -1719,9 +1727,16 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
     int mt_idx, nt_idx;
+    int sk_tile = -1, sk_slice = 0;
     {   // XCD-contiguous, n-major groups of 4 m-tiles
         const int Mt = M / PBM, Nt = N / PBN, nwg = Mt * Nt;
-        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        int orig = blockIdx.x;
+        if (lf.sk_S > 1 && orig >= lf.sk_nfull) {   // a slice of a tail tile
+            const int j = orig - lf.sk_nfull;
+            sk_tile = j / lf.sk_S; sk_slice = j - sk_tile * lf.sk_S;
+            orig = lf.sk_nfull + sk_tile;
+        }
+        const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
         const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
         constexpr int GM = 4;
         const int g = p / (GM * Nt), r = p - g * (GM * Nt);
@@ -1751,7 +1766,10 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         }
         src[3][j] = A + (m0 + am1) * K + lc * 8;
     }
-    const int nk = K / PBK, G = 4 * nk;   // K-tiles, half-tiles
+    // K range of this workgroup: all of K, or slice sk_slice of sk_S (whole K-tiles, >= 2 each: the host checks)
+    const int nk_all = K / PBK;
+    const int kt_lo = sk_tile >= 0 ? nk_all * sk_slice / lf.sk_S : 0;
+    const int nk = (sk_tile >= 0 ? nk_all * (sk_slice + 1) / lf.sk_S : nk_all) - kt_lo, G = 4 * nk;   // K-tiles, half-tiles
     auto stage = [&](int g) {             // g: half-tile counted over the whole K loop (wave-uniform)
         const int s = g & 3;
         const int kt = g < G ? (g >> 2) : nk - 1;                                // past the end: re-read the last K-tile ...
@@ -1759,9 +1777,9 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         char* dst = smem + slot * PSLOT + (16 * wid) * 128;
         const half_t* s0 = s == 0 ? src[0][0] : s == 1 ? src[1][0] : s == 2 ? src[2][0] : src[3][0];
         const half_t* s1 = s == 0 ? src[0][1] : s == 1 ? src[1][1] : s == 2 ? src[2][1] : src[3][1];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (long long)kt * PBK),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (long long)(kt_lo + kt) * PBK),
                                          (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + (long long)kt * PBK),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + (long long)(kt_lo + kt) * PBK),
                                          (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
     };
     f4v acc[8][4];
@@ -1848,6 +1866,42 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
     __syncthreads();
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
+        if (sk_tile >= 0) {   // split-K tail: leave the partial, count, and only the last arrival goes on to the epilogue
+            const sq_rsrc_t rw = sq_rsrc(lf.sk_ws);
+            const int S = lf.sk_S;
+            const int my = ((sk_tile * S + sk_slice) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have reached memory ...
+            __syncthreads();
+            unsigned* flag = (unsigned*)(smem + 8 * PSLOT);
+            if (tid == 0) *flag = __hip_atomic_fetch_add(lf.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+            __syncthreads();
+            if (*flag != (unsigned)(S - 1)) return;
+            if (tid == 0) __hip_atomic_store(lf.sk_cnt + sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch
+            // slice order, whoever arrived last (its own partial is read back like the others): the sum does not depend on timing
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4v{0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < S; ++sl) {
+                const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[mi][ni][e] += v[e];
+                    }
+            }
+            __syncthreads();
+        }
+    }
     if (EPI == EPI_RESIDUAL_F32) {
         // fp32 residual stream (decoder): the MFMA operands were swapped (W fragment first), so a lane holds 4 consecutive
         // COLUMNS of one row -- out = R + acc as one 16-byte read-modify-write per tile, straight from the registers
@@ -2058,6 +2112,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict
         voff[2][j] = (unsigned)((bn1 * K + lc * 8) * 2);
         voff[3][j] = (unsigned)((am1 * K + lc * 8) * 2);
     }
+    // K range of this workgroup: all of K, or slice sk_slice of sk_S (whole K-tiles, >= 2 each: the host checks)
     const int nk = K / PBK, G = 4 * nk;   // K-tiles, half-tiles of one tile
     int mt_c, nt_c, mt_n = 0, nt_n = 0;
     int orig = blockIdx.x;
@@ -4162,6 +4217,36 @@ static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bia
 }
 
 static long long p8_min_wgs();   // tiles from which the 8-phase kernel is the default (defined with the LnFold helpers)
+static int device_cus();
+
+// split-K tail of the 8-phase products: one fp32 workspace + counters per device, grown on demand (forwards of one device
+// are serialised by their handles' streams; two handles on one device share it only if they run on the same stream order --
+// they do: every forward runs on the NULL stream or a captured graph replayed on it)
+static float* g_sk_tail_ws = nullptr;
+static unsigned* g_sk_tail_cnt = nullptr;
+static size_t g_sk_tail_bytes = 0;
+static int g_sk_tail_ntail = 0, g_sk_tail_dev = -1;
+static std::atomic<int> g_splitk_tail{getenv("VF_NO_SPLITK_TAIL") ? 0 : 1};
+extern "C" int vf_debug_splitk_tail(int on) { return on >= 0 ? g_splitk_tail.exchange(on > 2 ? 2 : on) : g_splitk_tail.load(); }   // 0 off, 1 long-K products only (default), 2 every product with a partial last round
+static bool splitk_tail_on() { return g_splitk_tail.load(std::memory_order_relaxed) != 0; }
+static hipError_t sk_tail_ensure(size_t bytes, int ntail) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev == g_sk_tail_dev && bytes <= g_sk_tail_bytes && ntail <= g_sk_tail_ntail) return hipSuccess;
+    e = hipDeviceSynchronize();   // nobody is using the old buffers
+    if (e != hipSuccess) return e;
+    if (g_sk_tail_ws) (void)hipFree(g_sk_tail_ws);
+    if (g_sk_tail_cnt) (void)hipFree(g_sk_tail_cnt);
+    g_sk_tail_ws = nullptr; g_sk_tail_cnt = nullptr; g_sk_tail_bytes = 0; g_sk_tail_ntail = 0; g_sk_tail_dev = -1;
+    const size_t nb = std::max(bytes, g_sk_tail_bytes);
+    const int nt = std::max(ntail, 256);
+    if ((e = hipMalloc((void**)&g_sk_tail_ws, nb)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&g_sk_tail_cnt, (size_t)nt * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemset(g_sk_tail_cnt, 0, (size_t)nt * sizeof(unsigned))) != hipSuccess) return e;
+    g_sk_tail_bytes = nb; g_sk_tail_ntail = nt; g_sk_tail_dev = dev;
+    return hipSuccess;
+}
 
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
@@ -4214,7 +4299,26 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, LnFold{});
+        // Round 3: the tiles of the partial last round are cut along K instead (LnFold::sk_*): S slices per tail tile so that
+        // the slices still fit one round, each at least two K-tiles long.
+        const int tiles = (N / PBN) * (M / PBM);
+        LnFold lf{};
+        int grid = tiles;
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
+            const int cus = device_cus(), ntail = cus > 0 ? tiles % cus : 0, nk = K / PBK;
+            // Measured (tools/gpu_r03_splitk.sh): a slice pays ~5 us to leave its 256 KB of partials and the last arrival ~9 us per
+            // 256 KB it reads back (one CU pulls 50-60 GB/s), so the cut only pays where half a tile's main loop is worth more:
+            // long-K products (K >= 2048: FFN-down), two slices.  Cutting the K = 768 products (S = 2..4) made the forward SLOWER
+            // (12.53 vs 12.26 ms); the general form stays reachable through vf_debug_splitk_tail(2).
+            const int mode = g_splitk_tail.load(std::memory_order_relaxed);
+            int S = ntail > 0 ? std::min(std::min(cus / ntail, nk / 2), 4) : 0;
+            if (mode == 1) S = (nk >= 32 && S >= 2) ? 2 : 0;
+            if (S >= 2 && tiles > cus && splitk_tail_on() && sk_tail_ensure((size_t)ntail * S * PBM * PBN * sizeof(float), ntail) == hipSuccess) {
+                lf.sk_ws = g_sk_tail_ws; lf.sk_cnt = g_sk_tail_cnt; lf.sk_nfull = tiles - ntail; lf.sk_S = S;
+                grid = tiles - ntail + ntail * S;
+            }
+        }
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3(grid), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf);
         return hipGetLastError();
     }
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
