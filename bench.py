@@ -732,7 +732,7 @@ def main():
         # inside the bench): reported only when the committed measurement is for exactly this workload
         traffic = None
         try:
-            traffic_file = os.path.join("profiles", "pmc_traffic_scan_10Mx768.json")
+            traffic_file = os.path.join("profiles", "pmc_traffic_scan2_10Mx768.json" if stats.get("scan_kernel") == 2 else "pmc_traffic_scan_10Mx768.json")
             rec = json.load(open(os.path.join(ROOT, traffic_file)))
             w = rec["workload"]
             if args.corpus_dtype == "f16" and not devs and (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (args.rows, args.dim, args.batch, args.k, world):
