@@ -620,6 +620,35 @@ def test_scan_kernels_agree_and_match_oracle(vf, oracle, n, d, nq, k, want_kerne
         assert ix.stats()["aux_cus"] == 0 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
 
 
+@pytest.mark.parametrize("n,d,nq,k,want_kernel", [
+    (60_000, 768, 64, 100, 2),      # six 128-code segments per row beside a 96 KB fp16 query image
+    (50_000, 1024, 24, 10, 2),      # one N-tile: 64 KB image
+    (50_000, 1024, 64, 100, 1),     # 128 KB image: register kernel
+    (40_003, 640, 64, 50, 2),       # five segments, ragged last tile
+    (40_000, 256, 64, 50, 1),       # two segments: fewer than the ring is deep
+])
+def test_scan_kernels_agree_on_fp8_rows(vf, oracle, n, d, nq, k, want_kernel):
+    """e4m3-resident rows through k_scan2 (option scan_impl = 3: the bytes go global -> LDS as whole lines; a lane reads two
+    16-byte pieces per 64-element chunk and converts them in registers) and through k_scan (the default for e4m3 rows: it
+    measured faster): both bit-identical to the oracle on the decoded rows."""
+    from oracle import ref_numpy as R
+    codes = _e4m3_codes(n, d, 70 + d % 11)
+    rows16 = R.decode_e4m3(codes).astype(np.float16)
+    q = np.random.default_rng(71).standard_normal((nq, d)).astype(np.float32)
+    want_i, want_s = oracle.search(rows16, q, k)
+    ix = vf.DenseIndex.from_e4m3(codes)
+    try:
+        ix.set_option("force_path", 1)
+        for impl in (3, 2, 1):                              # 3 = k_scan2 also for e4m3 rows (measured slower there: not the default)
+            ix.set_option("scan_impl", impl)
+            i, s_ = ix.search(q, k)
+            st = ix.stats()
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), impl
+            assert st["path"] == 1 and st["exact_reruns"] == 0 and st["scan_kernel"] == (want_kernel if impl == 3 else 1), st
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("nq", [1, 3, 20])
 def test_few_queries_over_a_large_corpus_stay_on_the_fused_path(vf, oracle, nq):
     """The serve path's call shape at scale (one question + up to three hyde chunks, ensembleRetriever.py:64-66) over a

@@ -550,7 +550,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
         ix->aux_cus = value;
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
-    else if (s == "scan_impl") { if (!in_range(1, 2)) return fail(VF_EINVAL, "scan_impl must be 1 or 2"); ix->scan_impl = value; }
+    else if (s == "scan_impl") { if (!in_range(1, 3)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (k_scan2 for fp16 rows) or 3 (k_scan2 wherever it fits)"); ix->scan_impl = value; }
     else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") {
@@ -863,11 +863,15 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             ix->span_slot[slot_id] = true;
             VF_HIP(hipEventRecord(s.ev_t[0], sst));
         }
-        const int cap2 = (ix->scan_impl == 2 && ix->dtype != VF_DTYPE_FP8_E4M3 && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt) : 0;
+        const int f8 = ix->dtype == VF_DTYPE_FP8_E4M3 ? 1 : 0;
+        // k_scan2 serves fp16 rows by default; e4m3 rows only on request (scan_impl = 3): per byte they carry twice the MFMA and
+        // LDS work plus the conversions, and with ONE wave per SIMD nothing hides it -- measured 0.53 against k_scan's 0.66 of
+        // peak at 10M x 768 fp8 (profiles/r03_f8_sweep.log)
+        const int cap2 = ((ix->scan_impl == 3 || (ix->scan_impl == 2 && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
         if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
             ScanArgs a2 = a;
             a2.stage_cap = cap2;
-            VF_HIP(launch_scan2(a2, qt, p.grid, sst));
+            VF_HIP(launch_scan2(a2, qt, p.grid, f8, sst));
             s.scan_kernel = 2;
         } else {
             VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, sst));

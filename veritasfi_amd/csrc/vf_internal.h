@@ -106,10 +106,10 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
                        int rows_are_fp8, hipStream_t s);
 // test hook: the scan's hardware e4m3 -> fp16 conversion over `count` codes (device pointers)
 hipError_t launch_debug_cvt_e4m3(const unsigned char* in, float* out, int count, hipStream_t s);
-// k_scan2: the main scan with whole-line LDS-DMA corpus loads (fp16 rows); a.stage_cap = scan2_stage_cap(dp, qn_tile) > 0
-hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, hipStream_t s);
+// k_scan2: the main scan with whole-line LDS-DMA corpus loads (fp16 or e4m3 rows); a.stage_cap = scan2_stage_cap(...) >= 256
+hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_fp8, hipStream_t s);
 size_t scan2_lds_bytes(int dp, int qn_tile, int stage_cap);
-int scan2_stage_cap(int dp, int qn_tile);
+int scan2_stage_cap(int dp, int qn_tile, int rows_are_fp8);
 hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s);
 size_t scan_wide_lds_bytes(int stage_cap);
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);

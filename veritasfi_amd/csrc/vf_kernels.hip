@@ -1122,15 +1122,15 @@ size_t scan2_lds_bytes(int dp, int qn_tile, int stage_cap) {
     const size_t img = (size_t)dp * qn_tile * 2;
     return img + (size_t)kScan2Waves * (kRing * kSegBytes + kScratchBytes) + kCtlBytes + (size_t)stage_cap * 16;
 }
-int scan2_stage_cap(int dp, int qn_tile) {   // candidate-stage entries that fit beside image + rings; < 256 = "does not fit"
+int scan2_stage_cap(int dp, int qn_tile, int rows_are_fp8) {   // candidate-stage entries that fit beside image + rings; < 256 = "does not fit"
     const size_t fixed = scan2_lds_bytes(dp, qn_tile, 0);
-    if ((dp >> 6) < kRing) return 0;                       // the ring holds three segments of ONE row set at start-up
+    if ((dp >> (rows_are_fp8 ? 7 : 6)) < kRing) return 0;  // the ring holds three 128-byte segments of ONE row set at start-up
     if (fixed + 256 * 16 > 160 * 1024) return 0;
     const size_t area = std::min<size_t>(160 * 1024 - fixed, 32 * 1024);
     return (int)(area / 16);
 }
 
-template <int NT>
+template <int NT, int F8>
 __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int QN = NT * kQueryTile;
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
     const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
     const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
-    const int S = a.dp >> 6;                                          // 128-byte segments per row
+    const int S = a.dp >> (F8 ? 7 : 6);                               // 128-byte segments per row (64 halves, or 128 e4m3 codes)
     // LDS carve-up (offsets are multiples of 16; the rings of 1024)
     char* ring = smem + (size_t)wid * (kRing * kSegBytes);
     char* img = smem + kScan2Waves * kRing * kSegBytes;
@@ -1227,14 +1227,37 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                 // flight; everything older has landed
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 const char* ab = a_lane + buf * kSegBytes;
-                const char* bb = lds_lane + (long long)sg * (8 * QN * 16);
+                if constexpr (F8 == 0) {
+                    const char* bb = lds_lane + (long long)sg * (8 * QN * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const h8 af = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
+                    for (int i = 0; i < 4; ++i) {
+                        const h8 af = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const h8 bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const h8 bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    // e4m3 rows: a 128-byte segment is 128 elements = two 64-element chunks; in chunk c lane (r, h) owns the
+                    // element blocks 8 c + 4 h + i (k_scan's map: the query image is shared), i.e. the two 16-byte pieces
+                    // 4 c + 2 h, + 1 of its row: two conflict-free ds_read_b128, converted in registers (exactly: every e4m3
+                    // value is an fp16 value)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const uint4 w0 = *(const uint4*)(ab + (((4 * c + 2 * h) ^ asw) << 4));
+                        const uint4 w1 = *(const uint4*)(ab + (((4 * c + 2 * h + 1) ^ asw) << 4));
+                        const char* bb = lds_lane + (long long)(sg * 16 + c * 8) * (QN * 16);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint4 w = i < 2 ? w0 : w1;
+                            const h8 af = (i & 1) ? cvt8_e4m3(w.z, w.w) : cvt8_e4m3(w.x, w.y);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const h8 bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
+                            }
+                        }
                     }
                 }
                 // the buffer just consumed (its fragments are in registers: the MFMAs that used them have issued) takes
@@ -1839,10 +1862,15 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
+hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_fp8, hipStream_t s) {
     const size_t lds = scan2_lds_bytes(a.dp, qn_tile, a.stage_cap);
-    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2<1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
-    else hipLaunchKernelGGL((k_scan2<2>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+    if (qn_tile == kQueryTile) {
+        if (rows_are_fp8) hipLaunchKernelGGL((k_scan2<1, 1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+        else hipLaunchKernelGGL((k_scan2<1, 0>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+    } else {
+        if (rows_are_fp8) hipLaunchKernelGGL((k_scan2<2, 1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+        else hipLaunchKernelGGL((k_scan2<2, 0>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -2282,8 +2310,10 @@ hipError_t scan_configure() {
     VF_CFG(1, 1) VF_CFG(1, 2) VF_CFG(1, 3) VF_CFG(1, 4)
     VF_CFG(2, 1) VF_CFG(2, 2) VF_CFG(2, 3) VF_CFG(2, 4)
 #undef VF_CFG
-    if ((e = hipFuncSetAttribute((const void*)k_scan2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
