@@ -11,10 +11,16 @@ top-k lists are all-gathered over RCCL and merged.  Corpus, queries and outputs 
 when the timed region starts.  Two batches are kept in flight (vf_index_search_begin / _end), as a
 serving loop would.  Rank 0 prints ONE JSON line.
 
-roofline: live HIP-event timing of the dominant kernel (k_scan main launch) inside the library,
-on the stream it runs on (vf_index_profile); algorithmic bytes = rows scanned x (d*2 + 4).
-cpu_baseline: the CPU oracle (oracle/vf_oracle.c, a port of the reference's CPU path) timed on a
-bounded sample on this box's host cores, scaled to the full corpus -- reported, not a target.
+roofline: live HIP-event timing of the dominant kernel (the main scan: k_scan2 -- whole-line LDS-DMA corpus loads -- for fp16
+rows, k_scan for fp8 rows, k_scan_wide above 128 queries; vf_search_stats.scan_kernel names it) inside the library, on the
+stream it runs on (vf_index_profile); algorithmic bytes = rows scanned x (d*2 + 4).  Shards of up to 6M rows run their scans
+OVERLAPPED on a CU partition: the launch time is then the launch interval (vf_index_profile_span) and the isolated kernel is
+reported beside it (roofline.isolated_launch).
+cpu_baseline: the CPU oracle (oracle/vf_oracle.c, a port of the reference's CPU path) on the SAME rows and queries, copied out
+of the GPU-resident corpus: configs[1] (1M rows) measured, then the whole corpus in 1M-row blocks (measured, ~10 s on 128
+cores), and the GPU's ids / score bits checked against both ("verified") -- reported, not a target.
+Other legs (N = 1): re-rank p50 (XLM-R base / large shapes), the configured LLM re-ranker (gemma-2b shape), the configs[3]
+chain for one query, the embed loop, per-request latencies, the host-buffer entry.
 """
 import argparse
 import json
