@@ -825,7 +825,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         a.hist_coarse = s.hist_coarse.as<u32>(); a.stage_cap = scan_stage_cap(ix->dp, qt);
         a.tile_cnt = ix->steal_opt ? s.tilecnt.as<u32>() : nullptr; a.scan_grid = p.grid;
         a.dbg = nullptr;
-        if (ix->debug & 128) { VF_TRY(s.dbg.ensure((size_t)p.total_waves * 4 * sizeof(u64))); a.dbg = s.dbg.as<u64>(); }
+        if (ix->debug & 128) { VF_TRY(s.dbg.ensure((size_t)p.total_waves * ((ix->debug & 512) ? 72 : 4) * sizeof(u64))); a.dbg = s.dbg.as<u64>(); if (ix->debug & 512) VF_HIP(hipMemsetAsync(s.dbg.p, 0, s.dbg.bytes, st)); }
         // A workgroup publishes its staged candidates (and refreshes one threshold) per BLOCK of refresh_every staged entries,
         // whatever query they belong to: the option is stated for a full 64-query batch and scales with the batch's query
         // count, so that a query sees the same publication granularity at nq = 1 as at nq = 64.  (Unscaled, a single

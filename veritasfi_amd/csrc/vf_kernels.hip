@@ -700,6 +700,26 @@ struct EpiRegs {
     bool sync_tau;
 };
 
+// Wave-wide OR / sum of a 32-bit value, result uniform (an SGPR): four DPP row rotations leave every lane with its row's
+// (16 lanes') result, four readlanes combine the rows.  ~12 instructions, no LDS crossbar.
+#define VF_DPP_ROR(v, n) (u32) __builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (n), 0xF, 0xF, false)
+__device__ __forceinline__ u32 wave_or_u32(u32 v) {
+    v |= VF_DPP_ROR(v, 1);
+    v |= VF_DPP_ROR(v, 2);
+    v |= VF_DPP_ROR(v, 4);
+    v |= VF_DPP_ROR(v, 8);
+    return (u32)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
+                 __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+    v += VF_DPP_ROR(v, 1);
+    v += VF_DPP_ROR(v, 2);
+    v += VF_DPP_ROR(v, 4);
+    v += VF_DPP_ROR(v, 8);
+    return (u32)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) +
+                 __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+}
+
 template <int NT, int MODE>
 __device__ __forceinline__ void epi_prefetch(EpiRegs<NT>& e, const ScanArgs& a, long long t0, int lane, bool sync_tau) {
     e.inv_lane = a.inv_scan[t0 + (lane & 31)];  // inv_scan is padded by 64 entries past n
@@ -712,7 +732,10 @@ __device__ __forceinline__ void epi_prefetch(EpiRegs<NT>& e, const ScanArgs& a, 
     }
 }
 
-template <int NT, int MODE>
+// PUBLISH = false (k_scan2): the wave only STAGES its candidates; publishing completed blocks to the global histograms and
+// refreshing thresholds is the service wave's job (k_scan2_service), so that no global atomic or dependent load of this
+// path ever sits in a streaming wave's in-order memory queue.
+template <int NT, int MODE, bool PUBLISH = true>
 __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&acc)[NT], const EpiRegs<NT>& e,
                                               long long t0, long long hi, long long s0_slot, int lane, char* ctl) {
     const int r31 = lane & 31, h = lane >> 5;
@@ -759,7 +782,12 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
         }
         __builtin_amdgcn_sched_barrier(0);  // one N-tile at a time: keeps the live set small
     }
-    if (__ballot(mask != 0u) == 0ull) return;
+    // wave-uniform OR of the masks: which (query tile, row register) pairs have a passing lane ANYWHERE in the wave.  The
+    // rare path below is unrolled over the 16 NT pairs; testing each pair on this scalar costs a scalar compare-and-branch
+    // instead of a vector test + exec-mask branch per pair (round 3: on a 1.25M-row shard nearly every tile has a candidate
+    // or two, and the 32 vector tests were a third of the path's ~0.45 us per tile)
+    const u32 umask = wave_or_u32(mask);
+    if (umask == 0u) return;
 
     // ---- rare path: stage candidates in LDS; once per block of `refresh_every` staged entries ONE
     // wave refreshes one tau and publishes that block to the global histograms.
@@ -769,46 +797,51 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
     if (a.debug & 4) return;  // timing experiment: filter only
     u32* stage_cnt = (u32*)ctl;
     uint4* stage_ent = (uint4*)(ctl + kCtlBytes);
-    const u32 c = (u32)__popc(mask);
     const u32 R = (u32)a.refresh_every;  // 1..256
-    u32 slot = 0;
-    bool need = false;
-    if (c > 0) {
-        slot = atomicAdd(stage_cnt, c);  // LDS atomic (wave-aggregated by the compiler)
-        need = (slot / R) != ((slot + c) / R);
-    }
-    const u32 slot_end = slot + c;
+    // one LDS atomic per wave claims the slots of all its candidates; lanes take theirs pair by pair (ballot prefix)
+    const u32 total = wave_sum_u32((u32)__popc(mask));
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(stage_cnt, total);
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    const bool need = (base / R) != ((base + total) / R);   // this wave completed a block
     if (a.debug & 8) return;  // timing experiment: claim slots, write nothing (flush skips w != 1)
+    u32 run = base;
+    const u32 edge = (base + total) / R * R - 1u;   // the slot that completed the block (meaningful when `need`)
+    int qq = 0;               // the query whose tau is refreshed: that of the pair holding the completing slot (its first lane)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int q = nt * kQueryTile + r31;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            if (mask & (1u << (nt * 16 + reg))) {
-                const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const float sc = acc[nt][reg] * inv_of(reg);
-                const u32 bin = (u32)bin_of_x(bin_x(sc));
-                const u32 key = orderkey(sc), row = (u32)(t0 + rr);
-                if (slot < (u32)a.stage_cap) {
-                    stage_ent[slot] = make_uint4(row, key, (u32)q | (bin << 8), 1u);  // w = 1: entry written
-                } else {  // stage full (hostile data): append straight to the global list
-                    const u32 gs = atomicAdd(a.cnt + q * kCntStride, 1u);
-                    if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)key << 32) | (u64)row;
-                    atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
-                    atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
+            const u32 bit = 1u << (nt * 16 + reg);
+            if (umask & bit) {                                   // scalar
+                const unsigned long long bal = __ballot((mask & bit) != 0u);
+                if (mask & bit) {
+                    const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const float sc = acc[nt][reg] * inv_of(reg);
+                    const u32 bin = (u32)bin_of_x(bin_x(sc));
+                    const u32 key = orderkey(sc), row = (u32)(t0 + rr);
+                    if (slot < (u32)a.stage_cap) {
+                        stage_ent[slot] = make_uint4(row, key, (u32)q | (bin << 8), 1u);  // w = 1: entry written
+                    } else {  // stage full (hostile data): append straight to the global list
+                        const u32 gs = atomicAdd(a.cnt + q * kCntStride, 1u);
+                        if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)key << 32) | (u64)row;
+                        atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
+                        atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
+                    }
                 }
-                ++slot;
+                const u32 nxt = run + (u32)__popcll(bal);
+                if (run <= edge && edge < nxt) qq = nt * kQueryTile + ((__ffsll((long long)bal) - 1) & 31);
+                run = nxt;
             }
         }
     }
     if (a.debug & 2) return;  // timing experiment: never publish / refresh
-    const unsigned long long m = __ballot(need);
-    if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        const u32 blk = (u32)__shfl((int)slot_end, leader) / R - 1u;  // the block this wave completed
+    if constexpr (!PUBLISH) return;
+    if (need) {
+        const u32 blk = (base + total) / R - 1u;  // the block this wave completed
         // (1) refresh one tau from what is published so far (two dependent L2 reads)
-        const u32 lm = (u32)__shfl((int)mask, leader);
-        const int qq = ((lm & 0xFFFFu) ? 0 : kQueryTile) + (leader & 31);
         const int nb = wave_tau_two_level(a.hist_coarse + qq * 64, a.hist + (long long)qq * kHistBins, a.kprime, lane);
         if (lane == 0 && nb > 0) {
             atomicMax(a.tau_bin + qq, nb);
@@ -1102,7 +1135,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 // memory instruction the compiler knows about and none of its s_waitcnt vmcnt(0) (it cannot count hand-issued DMAs).
 // MFMA layout, k-slot map, accumulators, threshold filter, candidate stage, refresh and flush are k_scan's.
 // ------------------------------------------------------------------------------------------------
-constexpr int kScan2Threads = 256, kScan2Waves = 4, kRing = 3, kSegBytes = 4096, kScratchBytes = 1024;   // scratch: two 512-B halves (tile parity)
+#ifndef VF_SCAN2_SERVICE
+#define VF_SCAN2_SERVICE 0   // 1: a fifth wave publishes the staged blocks (measured 8 % SLOWER, round 3: DESIGN.md, k_scan2) -- A/B builds only
+#endif
+constexpr bool kScan2Service = VF_SCAN2_SERVICE != 0;
+constexpr int kScan2Waves = 4, kScan2Threads = (kScan2Waves + (kScan2Service ? 1 : 0)) * 64, kRing = 3, kSegBytes = 4096, kScratchBytes = 1024;   // four streaming waves + the service wave; scratch: two 512-B halves (tile parity)
 
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_base) {
     unsigned keep;
@@ -1130,8 +1167,67 @@ int scan2_stage_cap(int dp, int qn_tile, int rows_are_fp8) {   // candidate-stag
     return (int)(area / 16);
 }
 
+// The SERVICE wave of k_scan2 (wave 4; it shares SIMD 0 with streaming wave 0).  Round 3 measured where a small shard's launch
+// loses its time (tools/stamps_tiles.py, profiles/r03_stamps_tiles.log): the first tiles after the sample-seeded threshold take
+// 10-13 us instead of 8 -- eight candidates per tile, and every completed block of staged candidates made ITS wave publish
+// 2 R histogram atomics and refresh a threshold with two dependent loads, all of it in that wave's in-order vmcnt queue ahead of
+// its prefetched segments: 37 us of a 330-us launch at 1.25M rows (11 %; with staging switched off the tiles run at 7.7 us
+// from the fourth on).  k_scan's second wave per SIMD covered for that; here one wave per SIMD streams and nothing did.
+// Now the streaming waves only stage (LDS), and this wave watches the stage counter: it publishes every completed block,
+// refreshes the threshold of that block's last query, and folds the global thresholds into the workgroup's copy -- the
+// sync_tau DMA of the streaming waves is gone with it.  It leaves when all four streaming waves have counted themselves out.
+template <int NT>
+__device__ __forceinline__ void k_scan2_service(const ScanArgs& a, char* ctl, int lane) {
+    constexpr int QN = NT * kQueryTile;
+    volatile u32* stage_cnt = (volatile u32*)ctl;
+    volatile u32* waves_done = (volatile u32*)(ctl + 8);
+    int* tau_lds = (int*)(ctl + 16);
+    const uint4* stage_ent = (const uint4*)(ctl + kCtlBytes);
+    const u32 R = (u32)a.refresh_every;
+    u32 done_blk = 0;
+    for (;;) {
+        const u32 fin = *waves_done;
+        const u32 staged = *stage_cnt;
+        const u32 avail = staged < (u32)a.stage_cap ? staged : (u32)a.stage_cap;
+        // a block is published once the NEXT one has started filling (its last entries have surely been written by then), or
+        // at the end
+        const u32 ready = fin == (u32)kScan2Waves ? avail / R : (avail >= R / 2 ? (avail - R / 2) / R : 0u);
+        if (done_blk < ready) {
+            const u32 blk = done_blk++;
+            int qq = -1;
+            for (u32 j = (u32)lane; j < R; j += 64u) {
+                const uint4 en = stage_ent[blk * R + j];
+                if (en.w == 1u) {
+                    const u32 q = en.z & 0xFFu, bin = en.z >> 8;
+                    if (q < (u32)QN && bin < (u32)kHistBins) {
+                        atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
+                        atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
+                        if (j == R - 1) qq = (int)q;
+                    }
+                }
+            }
+            // the block's last entry names the query whose threshold is refreshed (any lane may hold it)
+#pragma unroll
+            for (int o = 32; o; o >>= 1) qq = max(qq, __shfl_xor(qq, o));
+            if (qq >= 0 && !(a.debug & 2)) {
+                const int nb = wave_tau_two_level(a.hist_coarse + qq * 64, a.hist + (long long)qq * kHistBins, a.kprime, lane);
+                if (lane == 0 && nb > 0) { atomicMax(a.tau_bin + qq, nb); atomicMax(tau_lds + qq, nb); }
+            }
+            continue;
+        }
+        if (fin == (u32)kScan2Waves) break;
+        // nothing to publish: fold the other workgroups' thresholds in, then doze
+        if (lane < QN) {
+            const int tg = __hip_atomic_load(a.tau_bin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(tau_lds + lane, tg);
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+}
+
 template <int NT, int F8>
 __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
+    const unsigned long long t_entry = (a.debug & 512) ? wall_clock64() : 0ull;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int QN = NT * kQueryTile;
     constexpr int MODE = kModeMain;
@@ -1172,13 +1268,14 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     };
 
     int cur_tile = wid;
-    bool active = cur_tile < ntiles;
+    const bool service = kScan2Service && wid == kScan2Waves;          // wave 4: publishes blocks, refreshes and syncs thresholds (k_scan2_service)
+    bool active = !service && cur_tile < ntiles;
     const char* src_cur[4];
     const char* src_nxt[4];
     if (active) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
-        issue_epi(lo + (long long)cur_tile * kRowTile, true, 0);
+        issue_epi(lo + (long long)cur_tile * kRowTile, !kScan2Service, 0);
         for (int sg = 0; sg < kRing; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S >= kRing: scan2_stage_cap)
     }
     {   // query image -> LDS verbatim; control block + candidate stage zeroed
@@ -1198,8 +1295,11 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     const char* lds_lane = img + ((4 * h) * QN + r31) * 16;
     const int asw = (r31 >> 1) & 7;
     const char* a_lane = ring + r31 * 128;                             // + buf * 4096 + ((4 h + i) ^ asw) * 16
-    unsigned long long* dbg = ((a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * 4 : nullptr;
+    const int dbg_rec = (a.debug & 512) ? 72 : 4;   // bit 9: + the start time of the wave's first 64 tiles, [68] kernel entry, [69] tiles taken
+    unsigned long long* dbg = ((a.debug & 128) && a.dbg && lane == 0 && !service) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * dbg_rec : nullptr;
     if (dbg) dbg[0] = wall_clock64();
+    if (dbg && dbg_rec > 4) dbg[68] = t_entry;
+    if (service) k_scan2_service<NT>(a, ctl, lane);
     if (active) {
         f16v acc[NT];
 #pragma unroll
@@ -1220,8 +1320,10 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
             const int nxt = more ? claimed : cur_tile;
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
-            const bool sync_now = (tiles_done & (kScan2Waves - 1)) == wid;
-            const bool sync_next = ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
+            // the service wave folds the global thresholds into tau_lds; without it the waves take turns
+            const bool sync_now = !kScan2Service && (tiles_done & (kScan2Waves - 1)) == wid;
+            const bool sync_next = !kScan2Service && ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
+            if (dbg && dbg_rec > 4 && tiles_done < 64) dbg[4 + tiles_done] = wall_clock64();
             for (int sg = 0; sg < S; ++sg) {
                 // segments sg + 1 and sg + 2 (8 DMA instructions, and the <= 2 epilogue words issued among them) may still be in
                 // flight; everything older has landed
@@ -1282,7 +1384,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) epi.tau_g[nt] = *(const int*)(sc + (nt * kQueryTile + r31) * 4);
             }
-            tile_epilogue<NT, MODE>(a, acc, epi, t0, hi, 0, lane, ctl);
+            tile_epilogue<NT, MODE, !kScan2Service>(a, acc, epi, t0, hi, 0, lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1293,8 +1395,10 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
         }
+        if (dbg && dbg_rec > 4) dbg[69] = (unsigned long long)tiles_done;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) prefetches have landed before LDS is reused
+    if (!service && lane == 0) atomicAdd((u32*)(ctl + 8), 1u);   // this streaming wave is done: the service wave leaves after the fourth
     if (dbg) dbg[1] = wall_clock64();
     // ---- flush the staged candidates (k_scan's, on this block size)
     __syncthreads();
