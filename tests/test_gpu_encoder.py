@@ -436,6 +436,8 @@ def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):
     (51200, 768, 3072, 2, 2),      # the FFN-down product of 100 x 512 tokens: 88 tail tiles, cut in 2
     (51200, 2304, 768, 0, 4),      # the QKV product: 8 tail tiles
     (25600, 768, 320, 1, 2),       # 5 K-tiles: slices of 2 and 3 K-tiles, GELU epilogue
+    (6656, 768, 3072, 2, 3),       # less than one round (13 x 512 tokens, 78 tiles): EVERY tile is cut, in 3; the sliced grid is padded to 80 tiles
+    (3328, 1024, 1024, 0, 4),      # 52 tiles (padded to 56), cut in 4
 ])
 def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, want_S):
     """The tiles of the 8-phase kernel's partial last round are cut along K (one workgroup per slice, fp32 partials handed
@@ -452,8 +454,8 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
     dev = torch.device("cuda:0")
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = (M // 256) * (N // 256)
-    ntail = tiles % cus
-    assert tiles > cus and ntail > 0 and min(cus // ntail, (K // 64) // 2, 4) == want_S
+    ntail = tiles % cus if tiles > cus else tiles
+    assert ntail > 0 and min(cus // ((ntail + 7) // 8 * 8), (K // 64) // 2, 4) == want_S
     g = torch.Generator(device=dev).manual_seed(7 * epi + K)
     A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
     W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()

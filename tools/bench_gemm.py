@@ -22,6 +22,21 @@ def main():
     L = _ffi.lib()
     L.vf_debug_gemm.restype = ctypes.c_int
     L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    sk_mode = None
+    if os.environ.get("VF_SK_MODE") is not None:   # split-K of the 8-phase kernel: 0 off, 1 default policy, 2 every partial round
+        L.vf_debug_splitk_tail.restype = ctypes.c_int
+        L.vf_debug_splitk_tail.argtypes = [ctypes.c_int]
+        sk_mode = int(os.environ["VF_SK_MODE"])
+        L.vf_debug_splitk_tail(sk_mode)
+    def sk_stats():
+        if sk_mode is None:
+            return None
+        out = (ctypes.c_uint * 2)()
+        L.vf_debug_splitk_stats.restype = ctypes.c_int
+        L.vf_debug_splitk_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.vf_debug_splitk_stats(out, int(os.environ.get("VF_SK_DBG", "0")))
+        return [int(out[0]), int(out[1])]
+    sk_stats()
     dev = torch.device("cuda:0")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for sh in a.shapes.split(","):
@@ -65,7 +80,7 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             print(json.dumps({"shape": sh, "kind": kind, "epi": a.epi, "us": round(us, 1), "vendor_lib_us": lib_us,
                               "tflops": round(2 * M * N * K / us / 1e6, 1), "vs_vendor": None if lib_us is None else round(us / lib_us, 3),
-                              "max_err": err}), flush=True)
+                              "max_err": err, "sk_mode": sk_mode, "sk_readbacks_l2_mem": sk_stats()}), flush=True)
 
 
 if __name__ == "__main__":

@@ -1582,9 +1582,16 @@ struct LnFold {
     // (600 tiles on 256 CUs are 2.34 rounds of work in 3; with the 88 tail tiles cut in two the third round is 176 half-length
     // workgroups).  A slice leaves its fp32 accumulators in sk_ws (write-through) and counts itself in sk_cnt[tile]; the last
     // arrival adds the others' IN SLICE ORDER (deterministic), runs the epilogue and resets the counter.
+    // The slices of one tile sit at dispatch indices that are congruent modulo 8 -- one XCD under the round-robin placement
+    // -- and every slice notes the XCD it really ran on (HW_REG_XCC_ID): when they all match the reader's, the partials are
+    // still in THAT L2 (the write-through stores went through it) and the read-back uses L1-bypassing loads that hit it;
+    // otherwise it falls back to memory-side (sc1) loads.  Placement decides the speed, never the result.
     float* sk_ws;            // [tail tiles][sk_S][256 x 256] fp32
-    unsigned* sk_cnt;        // [tail tiles], zero between launches
+    unsigned* sk_cnt;        // [tail tiles][2]: arrivals, XCD mask; zero between launches
     int sk_nfull, sk_S;      // sk_S == 0: no split
+    int sk_ntail;            // tail tiles (the sliced part of the grid is padded to 8 tiles x sk_S: the excess workgroups leave)
+    unsigned* sk_stat;       // [4] read-backs through L2 / from memory, (timing experiments: bit 0 of sk_dbg skips the partial stores, bit 1 the read-back)
+    int sk_dbg;
 };
 
 struct LnTail {
@@ -1731,9 +1738,10 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     {   // XCD-contiguous, n-major groups of 4 m-tiles
         const int Mt = M / PBM, Nt = N / PBN, nwg = Mt * Nt;
         int orig = blockIdx.x;
-        if (lf.sk_S > 1 && orig >= lf.sk_nfull) {   // a slice of a tail tile
-            const int j = orig - lf.sk_nfull;
-            sk_tile = j / lf.sk_S; sk_slice = j - sk_tile * lf.sk_S;
+        if (lf.sk_S > 1 && orig >= lf.sk_nfull) {   // a slice of a tail tile: indices congruent mod 8 (one XCD) share a tile
+            const int j = orig - lf.sk_nfull, i = j >> 3;
+            sk_tile = (i / lf.sk_S) * 8 + (j & 7); sk_slice = i % lf.sk_S;
+            if (sk_tile >= lf.sk_ntail) return;     // padding of the sliced part (before any barrier)
             orig = lf.sk_nfull + sk_tile;
         }
         const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -1871,33 +1879,58 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
             const sq_rsrc_t rw = sq_rsrc(lf.sk_ws);
             const int S = lf.sk_S;
             const int my = ((sk_tile * S + sk_slice) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
+            if (!(lf.sk_dbg & 1)) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have reached memory ...
             __syncthreads();
             unsigned* flag = (unsigned*)(smem + 8 * PSLOT);
-            if (tid == 0) *flag = __hip_atomic_fetch_add(lf.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+            if (tid == 0) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                xcc &= 15u;
+                const unsigned seen = __hip_atomic_fetch_or(lf.sk_cnt + 2 * sk_tile + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flag[1] = (seen | (1u << xcc)) == (1u << xcc) ? 1u : 0u;   // (the returned value orders the two atomics)
+                flag[0] = __hip_atomic_fetch_add(lf.sk_cnt + 2 * sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+            }
             __syncthreads();
-            if (*flag != (unsigned)(S - 1)) return;
-            if (tid == 0) __hip_atomic_store(lf.sk_cnt + sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch
+            if (flag[0] != (unsigned)(S - 1)) return;
+            const bool same_xcd = flag[1] != 0u;   // the last arrival saw every slice's XCD: all its own
+            if (tid == 0) {                        // ready for the next launch
+                __hip_atomic_store(lf.sk_cnt + 2 * sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(lf.sk_cnt + 2 * sk_tile + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(lf.sk_stat + (same_xcd ? 0 : 1), 1u);
+            }
             // slice order, whoever arrived last (its own partial is read back like the others): the sum does not depend on timing
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4v{0.f, 0.f, 0.f, 0.f};
-            for (int sl = 0; sl < S; ++sl) {
+            for (int sl = 0; sl < ((lf.sk_dbg & 2) ? 0 : S); ++sl) {
                 const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
+                if (same_xcd) {   // sc0: past this CU's L1, into the L2 the slices' stores went through
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
+                    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 1));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[mi][ni][e] += v[e];
-                    }
+                            for (int e = 0; e < 4; ++e) acc[mi][ni][e] += v[e];
+                        }
+                } else {          // sc1: memory side
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[mi][ni][e] += v[e];
+                        }
+                }
             }
             __syncthreads();
         }
@@ -4226,8 +4259,18 @@ static float* g_sk_tail_ws = nullptr;
 static unsigned* g_sk_tail_cnt = nullptr;
 static size_t g_sk_tail_bytes = 0;
 static int g_sk_tail_ntail = 0, g_sk_tail_dev = -1;
-static std::atomic<int> g_splitk_tail{getenv("VF_NO_SPLITK_TAIL") ? 0 : 1};
+static std::atomic<int> g_splitk_tail{getenv("VF_NO_SPLITK_TAIL") ? 0 : getenv("VF_SPLITK_TAIL") ? std::min(2, std::max(0, atoi(getenv("VF_SPLITK_TAIL")))) : 1};
 extern "C" int vf_debug_splitk_tail(int on) { return on >= 0 ? g_splitk_tail.exchange(on > 2 ? 2 : on) : g_splitk_tail.load(); }   // 0 off, 1 long-K products only (default), 2 every product with a partial last round
+static std::atomic<int> g_sk_dbg{0};
+// read-backs served by the slices' own L2 / from memory since the last call (and the timing-experiment switches of LnFold::sk_dbg)
+extern "C" int vf_debug_splitk_stats(unsigned* out2, int dbg) {
+    if (dbg >= 0) g_sk_dbg.store(dbg);
+    if (!g_sk_tail_cnt || !out2) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned* p = g_sk_tail_cnt + 2 * (size_t)g_sk_tail_ntail;
+    if (hipMemcpy(out2, p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return hipMemset(p, 0, 4 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
+}
 static bool splitk_tail_on() { return g_splitk_tail.load(std::memory_order_relaxed) != 0; }
 static hipError_t sk_tail_ensure(size_t bytes, int ntail) {
     int dev = 0;
@@ -4242,8 +4285,8 @@ static hipError_t sk_tail_ensure(size_t bytes, int ntail) {
     const size_t nb = std::max(bytes, g_sk_tail_bytes);
     const int nt = std::max(ntail, 256);
     if ((e = hipMalloc((void**)&g_sk_tail_ws, nb)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&g_sk_tail_cnt, (size_t)nt * sizeof(unsigned))) != hipSuccess) return e;
-    if ((e = hipMemset(g_sk_tail_cnt, 0, (size_t)nt * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&g_sk_tail_cnt, ((size_t)nt * 2 + 4) * sizeof(unsigned))) != hipSuccess) return e;   // arrivals + XCD mask per tile, then 4 statistics words
+    if ((e = hipMemset(g_sk_tail_cnt, 0, ((size_t)nt * 2 + 4) * sizeof(unsigned))) != hipSuccess) return e;
     g_sk_tail_bytes = nb; g_sk_tail_ntail = nt; g_sk_tail_dev = dev;
     return hipSuccess;
 }
@@ -4305,17 +4348,20 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         LnFold lf{};
         int grid = tiles;
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
-            const int cus = device_cus(), ntail = cus > 0 ? tiles % cus : 0, nk = K / PBK;
+            // a product of less than one round (tiles <= CUs: the per-rank batches of a data-parallel re-rank) is cut whole
+            const int cus = device_cus(), nk = K / PBK;
+            const int ntail = cus <= 0 ? 0 : (tiles > cus ? tiles % cus : tiles), pad = (ntail + 7) & ~7;
             // Measured (tools/gpu_r03_splitk.sh): a slice pays ~5 us to leave its 256 KB of partials and the last arrival ~9 us per
-            // 256 KB it reads back (one CU pulls 50-60 GB/s), so the cut only pays where half a tile's main loop is worth more:
-            // long-K products (K >= 2048: FFN-down), two slices.  Cutting the K = 768 products (S = 2..4) made the forward SLOWER
-            // (12.53 vs 12.26 ms); the general form stays reachable through vf_debug_splitk_tail(2).
+            // 256 KB it reads back from memory (one CU pulls 50-60 GB/s), so the cut only pays where half a tile's main loop is
+            // worth more: long-K products (K >= 2048: FFN-down), two slices.  Cutting the K = 768 products (S = 2..4) made the
+            // forward SLOWER (12.53 vs 12.26 ms); the general form stays reachable through vf_debug_splitk_tail(2).
             const int mode = g_splitk_tail.load(std::memory_order_relaxed);
-            int S = ntail > 0 ? std::min(std::min(cus / ntail, nk / 2), 4) : 0;
-            if (mode == 1) S = (nk >= 32 && S >= 2) ? 2 : 0;
-            if (S >= 2 && tiles > cus && splitk_tail_on() && sk_tail_ensure((size_t)ntail * S * PBM * PBN * sizeof(float), ntail) == hipSuccess) {
-                lf.sk_ws = g_sk_tail_ws; lf.sk_cnt = g_sk_tail_cnt; lf.sk_nfull = tiles - ntail; lf.sk_S = S;
-                grid = tiles - ntail + ntail * S;
+            int S = ntail > 0 ? std::min(std::min(cus / pad, nk / 2), 4) : 0;
+            if (mode == 1) S = (nk >= 32 && S >= 2 && tiles > cus) ? 2 : 0;
+            if (S >= 2 && splitk_tail_on() && sk_tail_ensure((size_t)ntail * S * PBM * PBN * sizeof(float), ntail) == hipSuccess) {
+                lf.sk_ws = g_sk_tail_ws; lf.sk_cnt = g_sk_tail_cnt; lf.sk_nfull = tiles - ntail; lf.sk_S = S; lf.sk_ntail = ntail;
+                lf.sk_stat = g_sk_tail_cnt + 2 * (size_t)g_sk_tail_ntail; lf.sk_dbg = g_sk_dbg.load(std::memory_order_relaxed);
+                grid = tiles - ntail + pad * S;
             }
         }
         hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3(grid), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf);
