@@ -1,0 +1,17 @@
+#!/bin/bash
+# where does k_scan_wide's launch go?  timing builds (results invalid) of the configs[4] shard (1.25M x 1024 e4m3, 1024 queries, k = 1000)
+set -o pipefail
+mkdir -p gpurun_out
+: > gpurun_out/r03_wide_ablate.log
+for tag in shipped noepi noepi_nobar noepi_noq noepi_noops noepi_nosib; do
+  L=""; nv=""
+  if [ $tag != shipped ]; then L="$PWD/veritasfi_amd/lib/libvf_w_$tag.so"; nv="--no-verify"; fi
+  echo -n "$tag: " >> gpurun_out/r03_wide_ablate.log
+  VF_LIB_PATH=$L timeout -k 10 300 python3 bench.py --rows 1250000 --dim 1024 --batch 1024 --k 1000 --corpus-dtype fp8 --no-cpu-baseline --no-rerank --no-llm --no-c4 --steps 30 --warmup 3 --no-verify 2>/dev/null | grep -a "^{" | python3 -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); r = d['roofline']
+    print('launch ms', r.get('avg_launch_ms'), 'TFLOP/s', r.get('achieved'), 'cand/query', d['search_stats']['candidates_per_query'])
+" >> gpurun_out/r03_wide_ablate.log 2>&1 || echo failed >> gpurun_out/r03_wide_ablate.log
+done
+cat gpurun_out/r03_wide_ablate.log

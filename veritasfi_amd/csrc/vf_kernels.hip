@@ -1625,6 +1625,9 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         const int ql = nt * kQueryTile + r31;
         const int t = tau_lds[ql];
         tb[nt] = (qg0 + ql) < a.nq ? (t <= 0 ? -INFINITY : (float)t) : INFINITY;
+#if defined(VF_WIDE_NOCAND)
+        tb[nt] = INFINITY;   // timing experiments: the filter runs, nothing passes (results invalid)
+#endif
     }
     for (u32 done = 0u;; done += (u32)kWideLaneList) {
         // Pass 1, straight-line over this lane's 128 scores: a passing score is NOTED -- its value in the lane's
@@ -1648,23 +1651,42 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         if (done == 0u && __ballot(cnt != 0u) == 0ull) return;
 #pragma unroll
         for (int w = 0; w < 4; ++w) lane_mk[w] = mk[w];
-        // Pass 2, dynamic loops (the code exists once): walk the set bits in the same order, claim a stage slot per
-        // noted score; the candidate that claims the last slot of a block of R publishes that block and refreshes
-        // one threshold (below).
+        // Pass 2, ONE dynamic loop (the code exists once): every lane walks its set bits in the same order and the wave moves
+        // in lockstep, "each lane's next noted score" per trip.  The wave claims the stage slots of ALL its noted scores of
+        // this round with one LDS atomic and a trip hands them out by ballot rank (round 3: a per-candidate LDS atomic in a
+        // divergent loop cost a third of this path at the 8-GPU shard size, profiles/r03_wide_ablation_1250k.log); the
+        // candidate that gets the last slot of a block of R publishes that block and refreshes one threshold (below).
+        const u32 mine = cnt > done ? (cnt - done < (u32)kWideLaneList ? cnt - done : (u32)kWideLaneList) : 0u;
+        const u32 total = wave_sum_u32(mine);
+        u32 run = 0u;
+        if (lane == 0) run = atomicAdd(stage_cnt, total);
+        run = (u32)__builtin_amdgcn_readfirstlane((int)run);
         u32 idx = 0u;
-        for (int w = 0; w < 4; ++w) {
-            u32 mw = lane_mk[w];
-            while (mw) {
-                const int bpos = __builtin_ctz(mw);
+        int w = 0;
+        u32 mw = lane_mk[0];
+        for (;;) {
+            // this lane's next noted score of THIS round (scores of other rounds are stepped over: o wraps for idx < done)
+            bool take = false;
+            int bpos = 0, wq = 0;
+            for (;;) {
+                while (mw == 0u && w < 3) { ++w; mw = lane_mk[w]; }
+                if (mw == 0u) break;
+                bpos = __builtin_ctz(mw);
                 mw &= mw - 1u;
+                wq = w;
                 const u32 o = idx - done;
                 ++idx;
-                if (o >= (u32)kWideLaneList) continue;   // another round's (also covers idx < done: o wraps)
-                const float sc = lane_sc[o];
-                const int ql = (2 * w + (bpos >> 4)) * kQueryTile + r31, reg = bpos & 15;
+                if (o < (u32)kWideLaneList) { take = true; break; }
+                if (idx >= done + (u32)kWideLaneList) { mw = 0u; w = 3; break; }   // everything further belongs to later rounds
+            }
+            const unsigned long long bal = __ballot(take);
+            if (bal == 0ull) break;
+            if (take) {
+                const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                const float sc = lane_sc[idx - 1u - done];
+                const int ql = (2 * wq + (bpos >> 4)) * kQueryTile + r31, reg = bpos & 15;
                 const u32 row = (u32)(t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
                 const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
-                const u32 slot = atomicAdd(stage_cnt, 1u);
                 if (slot < (u32)a.stage_cap) {
                     stage_ent[slot] = make_uint4(row, key, (u32)ql | (bin << 8), 1u);
                 } else {   // stage full (the first tiles after a loose seed, or hostile data): straight to the global list
@@ -1676,6 +1698,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
                 }
                 if ((slot & Rm1) == Rm1) { need = true; myslot = slot; myq = ql; }
             }
+            run += (u32)__popcll(bal);
         }
         if (__ballot(cnt > done + (u32)kWideLaneList) == 0ull) break;
     }
@@ -1796,7 +1819,7 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
     // last barrier), fetch chunk c + 3's into registers, 32 MFMAs on chunk c while the fragment ring runs on into
     // chunk c + 1's buffer (written during chunk c - 1, visible since the last barrier), ONE barrier.
 #ifndef VF_WIDE_EXP
-#define VF_WIDE_EXP 0   /* timing experiments (results invalid): bit 0 no query-chunk traffic, bit 1 no corpus loads, bit 2 no barrier */
+#define VF_WIDE_EXP 0   /* timing experiments (results invalid): bit 0 no query-chunk traffic, bit 1 no corpus loads, bit 2 no barrier, bit 3 no epilogue, bit 4 no sibling pacing / flush */
 #endif
 #define VF_CHUNK(STG, CC)                                                     \
     do {                                                                      \
@@ -1859,6 +1882,14 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
 #pragma unroll
         for (int m = 0; m < kWideM; ++m) {
             myrow[m] = nxrow[m];
+            if (VF_WIDE_EXP & 8) {   // keep the accumulators alive at the price of 128 adds
+                float sm = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < kWideNT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sm += acc[m][nt][e];
+                if (sm == 12345.678f) a.s0[0] = sm;
+            } else
             wide_epilogue<MODE>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, (long long)rg * swg + (t0 + m * kRowTile - lo), jt_e,
                                 lane_e, ctl_e, (uint2*)(ctl_e + kWideCtl + (size_t)a.stage_cap * 16 + (size_t)tid * ((kWideLaneList + 4) * 4)),
                                 m == 0 && (st & (kWideWaves - 1)) == wid);
@@ -1867,7 +1898,7 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
         }
-        if (MODE == kModeMain) {
+        if (MODE == kModeMain && !(VF_WIDE_EXP & 16)) {
             // The J workgroups that scan the same rows (one XCD, dispatch permitting) read them once from HBM only while they
             // stay within an L2's reach of each other (8 row groups x 256 KB per super-tile against 4 MB): left alone they
             // drift and the shard was read 1.33 times.  Each publishes the super-tiles it has finished and waits (bounded --
