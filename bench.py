@@ -356,8 +356,8 @@ def c4_chain(args, torch, vf, corpus):
     """BASELINE configs[3], text leg, end to end for ONE query: embed_query (bge-base shape) -> exact top-100 over a
     5M x 768 corpus -> 100 (query, passage) pairs x 512 tokens through the cross-encoder (bge-reranker-base shape) ->
     rank_chunk (time score + fusion + chunk similarity matrix + greedy bundle selection) -> the 20 best.  Stage and
-    whole-chain p50 over 8 requests.  The table / figure encoders the config names do not exist in the reference
-     and are not built."""
+    whole-chain p50 over 8 requests.  The figure encoder the config names (CLIP ViT-L/14 -> 768-d) is timed beside the chain
+    (vf_vit_*, 64 images per call); the reference holds neither image nor table model."""
     import numpy as np
     from datetime import datetime
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -400,7 +400,23 @@ def c4_chain(args, torch, vf, corpus):
                 for key, v in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, (t5 - t4) - (t4 - t3), chain)):
                     stages[key].append(v * 1e3)
     e_enc.close(); r_enc.close()
-    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20,
+    figure = None
+    try:      # the figure leg of the config: images -> the same 768-wide space (random-init ViT-L/14 geometry, seeded pixels)
+        from bench_vision import random_vit, flops_per_image
+        v_enc, v_cfg = random_vit("vit-l-14")
+        px = np.random.default_rng(1).standard_normal((64, 3, v_cfg["image"], v_cfg["image"]), dtype=np.float32)
+        v_enc.forward(px)
+        ts = []
+        for _ in range(5):
+            t0 = clock(); out = v_enc.forward(px); ts.append(clock() - t0)
+        v_enc.close()
+        p50 = float(np.median(ts))
+        figure = {"shape": "vit-l-14 (24 layers, 257 tokens, 768-d projection)", "images": 64, "p50_ms": round(p50 * 1e3, 3),
+                  "images_per_s": round(64 / p50, 1), "tflops": round(flops_per_image(v_cfg) * 64 / p50 / 1e12, 1),
+                  "frac": round(flops_per_image(v_cfg) * 64 / p50 / 2.5e15, 4), "out_dim": int(out.shape[1]), "pcie_inclusive": True}
+    except Exception as e:  # noqa: BLE001
+        figure = {"error": f"{type(e).__name__}: {e}"}
+    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20, "figure_encoder": figure,
             "p50_ms": {k: round(float(np.median(v)), 3) for k, v in stages.items()},
             "what": "configs[3] text leg: embed_query (bert-base shape, ~20 tokens) -> vf_index_search top-100 (host entry) -> "
                     "HipReranker.compute_score over 100 pairs of ~512 tokens (xlmr-base shape) -> rank_chunk (re-embeds the 100 "

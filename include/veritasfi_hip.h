@@ -268,6 +268,31 @@ int vf_reranker_score(vf_encoder* rr, const int32_t* ids, const int32_t* mask, c
                       int32_t t, float* out_scores);
 int vf_reranker_destroy(vf_encoder* rr);
 
+/* ---- vision tower (CLIP-style ViT): the "figure encoder" of BASELINE configs[3] -------------------------------------------
+ * The reference holds no image model; the contract is transformers' CLIPVisionModelWithProjection (the model family the
+ * config names): image_embeds = visual_projection(post_layernorm(last_hidden_state[:, 0])).  Patch embedding without bias,
+ * class token, learned positions, pre_layrnorm, PRE-LayerNorm layers, head dim 64 (ViT-B/32, B/16, L/14), at most 511
+ * patches per image.  The caller's image processor has already resized and normalised the pixels. */
+typedef struct vf_vit vf_vit;
+typedef struct vf_vit_config {
+    int32_t image, patch, channels; /* 224, 14, 3 */
+    int32_t hidden, layers, heads, ffn;
+    int32_t proj_dim;               /* width of the joint space (768 for ViT-L/14) */
+    int32_t act;                    /* 0 erf-GELU, 1 quick-GELU x * sigmoid(1.702 x) (CLIP's default) */
+    int32_t normalize;              /* 1: L2-normalise the projected vector */
+    float ln_eps;
+} vf_vit_config;
+/* Weight blobs (host), in this order.  Kp = channels*patch*patch rounded up to 64.  fp16: patch[H,Kp] (Conv2d weight
+ * flattened [H, c*p*p], zero-padded columns) class[H] pos[(P+1),H], then per layer Wqkv[3H,H] (q rows, k rows, v rows)
+ * Wo[H,H] W1[F,H] W2[H,F], then proj[proj_dim,H].  fp32: pre_ln_gamma[H] pre_ln_beta[H], then per layer ln1_gamma[H]
+ * ln1_beta[H] bqkv[3H] bo[H] ln2_gamma[H] ln2_beta[H] b1[F] b2[H], then post_ln_gamma[H] post_ln_beta[H]. */
+int vf_vit_weight_sizes(const vf_vit_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
+int vf_vit_create(vf_vit** out, const vf_vit_config* cfg, const void* w_fp16, int64_t n_fp16, const float* w_fp32,
+                  int64_t n_fp32, int32_t device_id);
+/* pixels [b, channels, image, image] fp32 host -> out [b, proj_dim] fp32 host */
+int vf_vit_forward(vf_vit* vit, const float* pixels, int32_t b, float* out);
+int vf_vit_destroy(vf_vit* vit);
+
 #ifdef __cplusplus
 }
 #endif

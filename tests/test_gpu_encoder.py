@@ -490,10 +490,10 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
 
 
 @pytest.mark.parametrize("kind", [1, 2, 3, 5, 6, 7, 8])
-@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("epi", [0, 1, 2, 11])
 def test_gemm_kernels_match_torch(vf, kind, epi):
     """Every GEMM kernel (1 = LDS-DMA 128x256 with two workgroups per CU, 2 = 256x256, 3 = register-staged 128x128) x every
-    epilogue (bias, bias + erf-GELU, bias + residual) against torch fp32 on the same fp16 operands, at a shape with a
+    epilogue (bias, bias + erf-GELU, bias + residual, bias + quick-GELU) against torch fp32 on the same fp16 operands, at a shape with a
     ragged tile grid for the XCD-aware tile order (M = 1792 -> 14 / 7 m-tiles, N = 768, K = 320 -> 5 / 10 K-steps)."""
     import ctypes
     import torch
@@ -525,6 +525,8 @@ def test_gemm_kernels_match_torch(vf, kind, epi):
         ref = A.float() @ W.float().T + bias
         if epi == 1:
             ref = torch.nn.functional.gelu(ref)
+        if epi == 11:                                  # quick-GELU, the vision tower's activation
+            ref = ref * torch.sigmoid(1.702 * ref)
         del_big = M * N > 8_000_000
         if epi == 2:
             ref = ref.half().float() + R.float()   # the kernels round the biased product to fp16 before adding the residual

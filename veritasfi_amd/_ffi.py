@@ -36,6 +36,13 @@ class DecoderConfig(ctypes.Structure):
     ]
 
 
+class VitConfig(ctypes.Structure):
+    _fields_ = [
+        ("image", c_i32), ("patch", c_i32), ("channels", c_i32), ("hidden", c_i32), ("layers", c_i32), ("heads", c_i32),
+        ("ffn", c_i32), ("proj_dim", c_i32), ("act", c_i32), ("normalize", c_i32), ("ln_eps", c_f32),
+    ]
+
+
 class SearchStats(ctypes.Structure):
     _fields_ = [
         ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
@@ -93,6 +100,10 @@ SIGNATURES = {
     "vf_decoder_forward": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, c_i32, vp]),
     "vf_decoder_forward_hidden": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp]),
     "vf_decoder_destroy": (ctypes.c_int, [vp]),
+    "vf_vit_weight_sizes": (ctypes.c_int, [ctypes.POINTER(VitConfig), p_i64, p_i64]),
+    "vf_vit_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(VitConfig), vp, c_i64, vp, c_i64, c_i32]),
+    "vf_vit_forward": (ctypes.c_int, [vp, vp, c_i32, vp]),
+    "vf_vit_destroy": (ctypes.c_int, [vp]),
 }
 
 _lib = None

@@ -200,7 +200,8 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 
        EPI_LNA = 7,            // C = rstd_m (A.W'^T - mean_m colsum(W')_n) + c_n : A is the RAW pre-LayerNorm sum, W' = W diag(gamma)
        EPI_LNA_GELU = 8,       // ... + GELU
        EPI_RES_STATS = 9,      // C = A.W^T + b + R (R already normalised), and the row sums (sum, sum of squares) of C
-       EPI_LNRES_STATS = 10 }; // C = A.W^T + b + LayerNorm(R) from the raw R and its row sums, and the row sums of C   // k_gemm8p_tn only: EPI_BIAS_RESIDUAL + the LayerNorm of finished row tiles in the same launch (LnTail)   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
+       EPI_LNRES_STATS = 10,
+       EPI_BIAS_QGELU = 11 };  // C = quick_gelu(A.W^T + b): x sigmoid(1.702 x), the vision tower's activation (CLIP) // C = A.W^T + b + LayerNorm(R) from the raw R and its row sums, and the row sums of C   // k_gemm8p_tn only: EPI_BIAS_RESIDUAL + the LayerNorm of finished row tiles in the same launch (LnTail)   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
 
 // exact-GELU x Phi(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2), with the complementary error function as
 // exp2 of a polynomial:  -log2 erfc(a / sqrt 2) = a (c1 + a (c2 + a (c3 + a (c4 + a c5)))), fitted on [0, 6] with the
@@ -248,6 +249,15 @@ __device__ __forceinline__ f2v gelu_erf2(f2v x) {
     const f2v relu = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
     return relu - a * e;
 }
+// quick-GELU x sigmoid(1.702 x) = max(x, 0) - |x| sigmoid(-1.702 |x|): the same shape as the forms above (no cancellation,
+// large |x| needs no clamp: exp2 overflows to +inf, its reciprocal is 0)
+constexpr float kQGelu = 1.702f * 1.4426950408889634f;
+__device__ __forceinline__ float quick_gelu(float x) {
+    const float a = fabsf(x);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kQGelu * a));
+    return __builtin_fmaf(-a, s, fmaxf(x, 0.0f));
+}
+__device__ __forceinline__ f2v quick_gelu2(f2v x) { return f2v{quick_gelu(x[0]), quick_gelu(x[1])}; }
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
 
 template <int EPI>
@@ -358,6 +368,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const half_t* __restrict__ A, c
                 const long long m = m0 + wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 float v = acc[mt][nt][reg] + bv;
                 if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
                 if (EPI == EPI_BIAS_RESIDUAL) v += (float)R[m * N + n];
                 if (EPI == EPI_RESIDUAL_F32) ((float*)C)[m * N + n] = v + ((const float*)R)[m * N + n];
                 else C[m * N + n] = (half_t)v;
@@ -471,6 +482,7 @@ __global__ __launch_bounds__(256) void k_gemm_splitk(const half_t* __restrict__ 
     for (int e = 0; e < 16; ++e) {
         float x = v[e] + (bias ? bias[n0 + c0 + e] : 0.f);
         if (EPI == EPI_BIAS_GELU) x = gelu_erf(x);
+        if (EPI == EPI_BIAS_QGELU) x = quick_gelu(x);
         o[e >> 3][e & 7] = (half_t)x;
     }
     if (EPI == EPI_BIAS_RESIDUAL) {
@@ -591,6 +603,7 @@ __global__ __launch_bounds__(LTHREADS) void k_gemm256_tn(const half_t* __restric
                 const int row = wr * 128 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 float v = acc[mt][nt][reg] + bv;
                 if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
                 Es[row * LBN + col] = (half_t)v;
             }
     }
@@ -720,6 +733,7 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma_tn(const half_t* __res
                 const int row = wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 float v = acc[mt][nt][reg] + bv;
                 if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
                 Es[row * DBN + col] = (half_t)v;
             }
     }
@@ -863,6 +877,7 @@ __global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma16_tn(const half_t* __r
                 const int row = wr * 64 + mt * 16 + 4 * kb + reg;
                 float v = acc[mt][nt][reg] + bv;
                 if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
                 Es[row * BN + col] = (half_t)v;
             }
     }
@@ -985,6 +1000,7 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t*
             float v = sum[e];
             v += bias ? bias[n0 + c0 + e] : 0.f;
             if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
             if (EPI == EPI_BIAS_RESIDUAL) v += (float)rpre[e];
             o[e] = (half_t)v;
         }
@@ -2016,6 +2032,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
                     v[0] = acc[mi][ni][reg] + bv; v[1] = acc[mi][ni][reg + 1] + bv;
                 }
                 if (EPI == EPI_BIAS_GELU || EPI == EPI_LNA_GELU) v = gelu_erf2(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu2(v);
                 Es[row * PBN + col] = (half_t)v[0];
                 Es[(row + 1) * PBN + col] = (half_t)v[1];
             }
@@ -2263,6 +2280,10 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict
                 if (EPI == EPI_BIAS_GELU) {
                     v0 = gelu_erf2(v0);
                     v1 = gelu_erf2(v1);
+                }
+                if (EPI == EPI_BIAS_QGELU) {
+                    v0 = quick_gelu2(v0);
+                    v1 = quick_gelu2(v1);
                 }
                 pk[mi][ni][0] = (half_t)v0[0];
                 pk[mi][ni][1] = (half_t)v0[1];
@@ -3899,10 +3920,12 @@ static hipError_t configure_once() {
     hipError_t er = hipSuccess;
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 #ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
 #endif
@@ -3910,10 +3933,13 @@ static hipError_t configure_once() {
 #ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
 #endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_QGELU, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
 #ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_QGELU, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
 #endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
@@ -3922,6 +3948,7 @@ static hipError_t configure_once() {
 #endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
 #ifdef VF_EXPERIMENTS
@@ -3936,6 +3963,7 @@ static hipError_t configure_once() {
 #ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
 #endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -5349,6 +5377,296 @@ extern "C" int vf_decoder_forward_hidden(vf_decoder* d, const int32_t* ids, cons
     return VF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Vision tower (CLIP-style ViT): the "figure encoder" BASELINE configs[3] names next to the text encoder.  The reference
+// holds no image model (grep -ri "clip\|vit" /root/reference: nothing), so the contract is the third-party model the
+// config names -- transformers' CLIPVisionModelWithProjection: patch embedding (a strided convolution = a product over
+// unfolded patches), class token + learned positions, LayerNorm, PRE-LayerNorm transformer layers (x += Wo attn(LN1 x);
+// x += W2 act(W1 LN2 x)), LayerNorm of the class token, linear projection to the joint space (768 for ViT-L/14).
+// Everything runs on the encoder's kernels: the products (gemm<EPI>), k_attention2 with the key-padding mask for the
+// rows that pad 257 / 197 / 50 tokens to a multiple of 32, k_layernorm.  New here: the patch unfold, the embedding
+// assembly + first LayerNorm, the quick-GELU epilogue of the products (EPI_BIAS_QGELU: x sigmoid(1.702 x), CLIP's
+// activation), and the class-token head.
+// ------------------------------------------------------------------------------------------------
+struct vf_vit {
+    vf_vit_config cfg{};
+    int device = 0;
+    int P = 0, T = 0, Tp = 0, Kp = 0;     // patches per image, tokens (P + 1), tokens padded to 32, patch length padded to 64
+    half_t* w16 = nullptr;
+    float* w32 = nullptr;
+    size_t o_patch = 0, o_cls = 0, o_pos = 0, o_layers = 0, o_proj = 0, layer16 = 0;
+    size_t f_zero = 0, f_pre = 0, f_layers = 0, f_post = 0, layer32 = 0;
+    int cap_b = 0;
+    float* d_pix = nullptr;
+    half_t *patches = nullptr, *emb = nullptr, *x = nullptr, *y = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *hbuf = nullptr;
+    int* d_mask = nullptr;
+    float* d_out = nullptr;
+    std::mutex mu;
+};
+
+static size_t vit_n16(const vf_vit_config& c) {
+    const size_t H = c.hidden, F = c.ffn, g = c.image / c.patch, P = g * g, Kp = ((size_t)c.channels * c.patch * c.patch + 63) / 64 * 64;
+    return H * Kp + H + (P + 1) * H + (size_t)c.layers * (3 * H * H + H * H + F * H + H * F) + (size_t)c.proj_dim * H;
+}
+static size_t vit_n32(const vf_vit_config& c) {
+    const size_t H = c.hidden, F = c.ffn;
+    return 2 * H + (size_t)c.layers * (2 * H + 3 * H + H + 2 * H + F + H) + 2 * H;
+}
+extern "C" int vf_vit_weight_sizes(const vf_vit_config* cfg, int64_t* n_fp16, int64_t* n_fp32) {
+    if (!cfg || !n_fp16 || !n_fp32) return fail(VF_EINVAL, "vf_vit_weight_sizes: null argument");
+    if (cfg->patch <= 0 || cfg->image <= 0) return fail(VF_EINVAL, "vf_vit_weight_sizes: bad config");
+    *n_fp16 = (int64_t)vit_n16(*cfg);
+    *n_fp32 = (int64_t)vit_n32(*cfg);
+    return VF_OK;
+}
+
+// pixels [B][C][S][S] fp32 -> patches [B P][Kp] fp16, element (c, i, j) of a patch at c p p + i p + j (the Conv2d weight's own
+// flattening); columns >= C p p and rows >= B P (up to rows_p) are zero
+__global__ __launch_bounds__(256) void k_vit_unfold(const float* __restrict__ pix, int B, int C, int S, int p, int Kp, int rows_p,
+                                                    half_t* __restrict__ out) {
+    const int g = S / p, P = g * g, K = C * p * p;
+    const long long n = (long long)rows_p * Kp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int row = (int)(i / Kp), k = (int)(i - (long long)row * Kp);
+        float v = 0.f;
+        if (row < B * P && k < K) {
+            const int b = row / P, pi = row - b * P, py = pi / g, px = pi - py * g;
+            const int c = k / (p * p), r = k - c * p * p, iy = r / p, ix = r - iy * p;
+            v = pix[(((long long)b * C + c) * S + (py * p + iy)) * S + (px * p + ix)];
+        }
+        out[i] = (half_t)v;
+    }
+}
+
+// token rows: [cls + pos 0 | patch embeddings + pos 1..P | zero rows up to Tp], then the first LayerNorm (half a wave per row,
+// k_layernorm's arithmetic: fp32 statistics over the fp32 sums); mask[b][t] = t < T
+__global__ __launch_bounds__(256) void k_vit_embed(const half_t* __restrict__ emb, const half_t* __restrict__ cls,
+                                                   const half_t* __restrict__ pos, const float* __restrict__ g,
+                                                   const float* __restrict__ bta, float eps, int B, int P, int Tp, int H,
+                                                   half_t* __restrict__ x, int* __restrict__ mask) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    if (row >= B * Tp) return;
+    const int b = row / Tp, t = row - b * Tp;
+    if (l32 == 0) mask[row] = t <= P ? 1 : 0;
+    half_t* dst = x + (long long)row * H;
+    if (t > P) {
+        for (int c = l32; c < H; c += 32) dst[c] = (half_t)0.f;
+        return;
+    }
+    const half_t* src = t == 0 ? cls : emb + ((long long)b * P + (t - 1)) * H;
+    float sum = 0.f, sq = 0.f;
+    for (int c = l32; c < H; c += 32) {
+        const float v = (float)src[c] + (float)pos[(long long)t * H + c];
+        sum += v;
+    }
+#pragma unroll
+    for (int o = 16; o; o >>= 1) sum += __shfl_xor(sum, o, 32);
+    const float mean = sum / (float)H;
+    for (int c = l32; c < H; c += 32) {
+        const float v = (float)src[c] + (float)pos[(long long)t * H + c] - mean;
+        sq += v * v;
+    }
+#pragma unroll
+    for (int o = 16; o; o >>= 1) sq += __shfl_xor(sq, o, 32);
+    const float rstd = rsqrtf(sq / (float)H + eps);
+    for (int c = l32; c < H; c += 32) {
+        const float v = (float)src[c] + (float)pos[(long long)t * H + c];
+        dst[c] = (half_t)((v - mean) * rstd * g[c] + bta[c]);
+    }
+}
+
+// one workgroup per image: LayerNorm of the class token's row, then out[d] = <Wproj[d], ln> (no bias), optionally L2-normalised
+__global__ __launch_bounds__(256) void k_vit_head(const half_t* __restrict__ x, int Tp, int H, const float* __restrict__ g,
+                                                  const float* __restrict__ bta, float eps, const half_t* __restrict__ Wp, int D,
+                                                  int normalize, float* __restrict__ out) {
+    extern __shared__ float sm[];   // [H] normalised class token, [256] reduction
+    float* red = sm + H;
+    const int tid = threadIdx.x;
+    const half_t* row = x + (long long)blockIdx.x * Tp * H;
+    float s = 0.f;
+    for (int c = tid; c < H; c += 256) s += (float)row[c];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = red[0] / (float)H;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < H; c += 256) { const float v = (float)row[c] - mean; q += v * v; }
+    red[tid] = q;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float rstd = rsqrtf(red[0] / (float)H + eps);
+    __syncthreads();
+    for (int c = tid; c < H; c += 256) sm[c] = ((float)row[c] - mean) * rstd * g[c] + bta[c];
+    __syncthreads();
+    float nrm = 0.f;
+    float* o_ = out + (long long)blockIdx.x * D;
+    for (int d = tid; d < D; d += 256) {
+        const half_t* w = Wp + (long long)d * H;
+        float acc = 0.f;
+        for (int c = 0; c < H; c += 8) {
+            const h8 wv = *(const h8*)(w + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[e], sm[c + e], acc);
+        }
+        o_[d] = acc;
+        nrm += acc * acc;
+    }
+    if (!normalize) return;
+    red[tid] = nrm;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = red[0] > 0.f ? rsqrtf(red[0]) : 0.f;
+    for (int d = tid; d < D; d += 256) o_[d] *= inv;
+}
+
+static void vit_free_ws(vf_vit* v) {
+    void* p[] = {v->d_pix, v->patches, v->emb, v->x, v->y, v->t, v->qkv, v->ctx, v->hbuf, v->d_mask, v->d_out};
+    for (void* q : p) if (q) (void)hipFree(q);
+    v->d_pix = nullptr; v->patches = v->emb = v->x = v->y = v->t = v->qkv = v->ctx = v->hbuf = nullptr;
+    v->d_mask = nullptr; v->d_out = nullptr; v->cap_b = 0;
+}
+
+extern "C" int vf_vit_destroy(vf_vit* v) {
+    if (!v) return VF_OK;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    (void)hipSetDevice(v->device);
+    (void)hipDeviceSynchronize();
+    vit_free_ws(v);
+    if (v->w16) (void)hipFree(v->w16);
+    if (v->w32) (void)hipFree(v->w32);
+    delete v;
+    if (have_prev) (void)hipSetDevice(prev);
+    return VF_OK;
+}
+
+extern "C" int vf_vit_create(vf_vit** out, const vf_vit_config* cfg, const void* w16, int64_t n16, const float* w32, int64_t n32,
+                             int32_t device_id) {
+    if (!out) return fail(VF_EINVAL, "vf_vit_create: null out");
+    *out = nullptr;
+    if (!cfg || !w16 || !w32) return fail(VF_EINVAL, "vf_vit_create: null argument");
+    const vf_vit_config& c = *cfg;
+    if (c.hidden <= 0 || c.hidden % 128 != 0 || c.hidden > 1024) return fail(VF_EUNSUPPORTED, "vit: hidden must be a multiple of 128, <= 1024");
+    if (c.heads <= 0 || c.hidden % c.heads || c.hidden / c.heads != 64) return fail(VF_EUNSUPPORTED, "vit: head dim must be 64");
+    if (c.ffn <= 0 || c.ffn % 128 != 0) return fail(VF_EUNSUPPORTED, "vit: ffn must be a multiple of 128");
+    if (c.layers <= 0 || c.channels <= 0 || c.patch <= 0 || c.image <= 0 || c.image % c.patch) return fail(VF_EINVAL, "vit: bad image / patch / layers");
+    if (c.proj_dim <= 0 || c.act < 0 || c.act > 1 || c.normalize < 0 || c.normalize > 1) return fail(VF_EINVAL, "vit: bad proj_dim / act / normalize");
+    const int g = c.image / c.patch, P = g * g, T = P + 1, Tp = (T + 31) / 32 * 32;
+    if (Tp > kEncResidentT) return fail(VF_EUNSUPPORTED, "vit: more than 511 patches per image");
+    if ((size_t)n16 != vit_n16(c) || (size_t)n32 != vit_n32(c))
+        return fail(VF_EINVAL, "vf_vit_create: weight blob sizes do not match the config (see vf_vit_weight_sizes)");
+    int ndev = 0;
+    VFT_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(VF_EINVAL, "vf_vit_create: bad device_id");
+    int prev = 0;
+    VFT_HIP(hipGetDevice(&prev));
+    struct Back { int d; ~Back() { (void)hipSetDevice(d); } } back{prev};
+    VFT_HIP(hipSetDevice(device_id));
+    vf_vit* v = new (std::nothrow) vf_vit();
+    if (!v) return fail(VF_ENOMEM, "host allocation failed");
+    v->cfg = c; v->device = device_id; v->P = P; v->T = T; v->Tp = Tp;
+    v->Kp = (c.channels * c.patch * c.patch + 63) / 64 * 64;
+    const size_t H = c.hidden, F = c.ffn;
+    v->o_patch = 0; v->o_cls = H * (size_t)v->Kp; v->o_pos = v->o_cls + H; v->o_layers = v->o_pos + (size_t)T * H;
+    v->layer16 = 3 * H * H + H * H + F * H + H * F;
+    v->o_proj = v->o_layers + (size_t)c.layers * v->layer16;
+    v->f_pre = 0; v->f_layers = 2 * H; v->layer32 = 2 * H + 3 * H + H + 2 * H + F + H;
+    v->f_post = v->f_layers + (size_t)c.layers * v->layer32;
+    hipError_t er = hipMalloc((void**)&v->w16, (size_t)n16 * 2);
+    if (er == hipSuccess) er = hipMalloc((void**)&v->w32, (size_t)n32 * 4);
+    if (er == hipSuccess) er = hipMemcpy(v->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(v->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = configure_once();
+    if (er == hipSuccess) {   // log2(e) / sqrt(64) into the query projection, as the text encoder does (k_attention2 expects it)
+        const float qs = 0.125f * 1.4426950408889634f;
+        for (int l = 0; l < c.layers; ++l) {
+            hipLaunchKernelGGL(k_scale_half, dim3((unsigned)((H * H + 255) / 256)), dim3(256), 0, 0, v->w16 + v->o_layers + (size_t)l * v->layer16, (long long)(H * H), qs);
+            hipLaunchKernelGGL(k_scale_float, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, 0, v->w32 + v->f_layers + (size_t)l * v->layer32 + 2 * H, (long long)H, qs);
+        }
+        er = hipDeviceSynchronize();
+    }
+    if (er != hipSuccess) {
+        const std::string msg = std::string("vf_vit_create: ") + hipGetErrorString(er);
+        vf_vit_destroy(v);
+        return fail(VF_EHIP, msg);
+    }
+    *out = v;
+    return VF_OK;
+}
+
+static int vit_ensure_ws(vf_vit* v, int B) {
+    if (B <= v->cap_b) return VF_OK;
+    vit_free_ws(v);
+    const vf_vit_config& c = v->cfg;
+    const size_t H = c.hidden, F = c.ffn;
+    const size_t Mp = ((size_t)B * v->Tp + 255) / 256 * 256, Rp = ((size_t)B * v->P + 255) / 256 * 256;
+    VFT_HIP(hipMalloc((void**)&v->d_pix, (size_t)B * c.channels * c.image * c.image * 4));
+    VFT_HIP(hipMalloc((void**)&v->patches, Rp * v->Kp * 2));
+    VFT_HIP(hipMalloc((void**)&v->emb, Rp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->x, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->y, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->t, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->qkv, Mp * 3 * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->ctx, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->hbuf, Mp * F * 2));
+    VFT_HIP(hipMalloc((void**)&v->d_mask, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&v->d_out, (size_t)B * c.proj_dim * 4));
+    // rows past B Tp are read by the products: keep them finite
+    VFT_HIP(hipMemset(v->x, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->y, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->t, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->qkv, 0, Mp * 3 * H * 2));
+    VFT_HIP(hipMemset(v->ctx, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->hbuf, 0, Mp * F * 2));
+    VFT_HIP(hipMemset(v->d_mask, 0, Mp * 4));
+    v->cap_b = B;
+    return VF_OK;
+}
+
+// pixels [b][channels][image][image] fp32 host (already resized / normalised by the caller's image processor) -> out [b][proj_dim]
+extern "C" int vf_vit_forward(vf_vit* v, const float* pixels, int32_t b, float* out) {
+    if (!v) return fail(VF_EINVAL, "vf_vit_forward: null handle");
+    if (b < 0) return fail(VF_EINVAL, "vf_vit_forward: negative batch");
+    if (b == 0) return VF_OK;
+    if (!pixels || !out) return fail(VF_EINVAL, "vf_vit_forward: null buffer");
+    std::lock_guard<std::mutex> lk(v->mu);
+    int prev = 0;
+    VFT_HIP(hipGetDevice(&prev));
+    struct Back { int d; ~Back() { (void)hipSetDevice(d); } } back{prev};
+    VFT_HIP(hipSetDevice(v->device));
+    VFT_TRY(vit_ensure_ws(v, b));
+    const vf_vit_config& c = v->cfg;
+    const int H = c.hidden, F = c.ffn, P = v->P, Tp = v->Tp, Kp = v->Kp;
+    const int M = b * Tp, Mp = (M + 255) / 256 * 256, Rp = (b * P + 255) / 256 * 256;
+    hipStream_t st = nullptr;
+    VFT_HIP(hipMemcpyAsync(v->d_pix, pixels, (size_t)b * c.channels * c.image * c.image * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_vit_unfold, dim3(2048), dim3(256), 0, st, v->d_pix, b, c.channels, c.image, c.patch, Kp, Rp, v->patches);
+    VFT_HIP(gemm<EPI_BIAS>(v->patches, v->w16 + v->o_patch, nullptr, nullptr, v->emb, Rp, H, Kp, st));
+    hipLaunchKernelGGL(k_vit_embed, dim3((M + 7) / 8), dim3(256), 0, st, v->emb, v->w16 + v->o_cls, v->w16 + v->o_pos, v->w32 + v->f_pre,
+                       v->w32 + v->f_pre + H, c.ln_eps, b, P, Tp, H, v->x, v->d_mask);
+    for (int l = 0; l < c.layers; ++l) {
+        const half_t* w = v->w16 + v->o_layers + (size_t)l * v->layer16;
+        const float* f = v->w32 + v->f_layers + (size_t)l * v->layer32;
+        const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
+        const float *g1 = f, *b1n = g1 + H, *bqkv = b1n + H, *bo = bqkv + 3 * H, *g2 = bo + H, *b2n = g2 + H, *b1 = b2n + H, *b2 = b1 + F;
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, v->x, g1, b1n, c.ln_eps, M, H, v->t);
+        VFT_HIP(gemm<EPI_BIAS>(v->t, Wqkv, bqkv, nullptr, v->qkv, Mp, 3 * H, H, st));
+        launch_attention2<0>(v->qkv, v->d_mask, b, Tp, c.heads, v->ctx, st);
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->ctx, Wo, bo, v->x, v->y, Mp, H, H, st));
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, v->y, g2, b2n, c.ln_eps, M, H, v->t);
+        if (c.act == 0) VFT_HIP(gemm<EPI_BIAS_GELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st));
+        else VFT_HIP(gemm<EPI_BIAS_QGELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st));
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->hbuf, W2, b2, v->y, v->x, Mp, H, F, st));
+    }
+    hipLaunchKernelGGL(k_vit_head, dim3(b), dim3(256), (size_t)(H + 256) * sizeof(float), st, v->x, Tp, H, v->w32 + v->f_post, v->w32 + v->f_post + H,
+                       c.ln_eps, v->w16 + v->o_proj, c.proj_dim, c.normalize, v->d_out);
+    VFT_HIP(hipGetLastError());
+    VFT_HIP(hipMemcpyAsync(out, v->d_out, (size_t)b * c.proj_dim * 4, hipMemcpyDeviceToHost, st));
+    VFT_HIP(hipStreamSynchronize(st));
+    return VF_OK;
+}
+
 // Test hook (not part of the public header; tools/bench_gemm.py and the GEMM parity test bind it):
 // C[M][N] = epi(A[M][K] . W[N][K]^T + bias [, + R]) on device pointers, fp16 in/out, fp32 accumulation.
 extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, const void* R, void* C, int M, int N, int K,
@@ -5373,6 +5691,7 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     }
     if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st, kind);
     else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st, kind);
+    else if (epi == EPI_BIAS_QGELU) er = gemm<EPI_BIAS_QGELU>(a, w, bias, r, c, M, N, K, st, kind);
     else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st, kind);
     return er == hipSuccess ? 0 : -1;
 }
