@@ -469,13 +469,23 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
         assert rc == 0
         torch.cuda.synchronize()
         return C
+    L.vf_debug_splitk_stats.restype = ctypes.c_int
+    L.vf_debug_splitk_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    stats = (ctypes.c_uint * 2)()
     was = L.vf_debug_splitk_tail(2)                         # the general form (the default cuts long-K products only)
     try:
+        run()                                               # (the first split launch allocates the workspace)
+        L.vf_debug_splitk_stats(stats, -1)                  # reset the read-back counters
         c1, c2 = run(), run()
+        assert L.vf_debug_splitk_stats(stats, -1) == 1
         L.vf_debug_splitk_tail(0)
         c0 = run()
     finally:
         L.vf_debug_splitk_tail(was)
+    # every cut tile is summed by exactly one workgroup per launch; the slices of a tile share an XCD (dispatch indices
+    # congruent modulo 8), so the read-back normally goes through that XCD's L2 -- either way the result is the same
+    print("split-K read-backs through L2 / from memory:", stats[0], stats[1])
+    assert stats[0] + stats[1] == 2 * ntail
     assert torch.equal(c1, c2), "the split-K tail is not deterministic"
     ref = A[-2048:].float() @ W.float().T + bias          # the tail tiles are the LAST dispatch indices: their rows are checked ...
     if epi == 1:
