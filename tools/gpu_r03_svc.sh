@@ -1,4 +1,7 @@
 #!/bin/bash
+# (the A/B partner is built here first and travels with the snapshot:
+#   VF_BUILD_FLAGS="-DVF_SCAN2_SERVICE=1" VF_BUILD_LIB=libvf_nosvc.so VF_BUILD_TAG=_nosvc python -m veritasfi_amd.build
+#  -- the name dates from the run in which the service wave was the default build and this library the four-wave form)
 # A/B of k_scan2's service wave (VF_SCAN2_SERVICE=0 build in lib/libvf_nosvc.so): parity first, then timing at 1M..10M rows
 set -o pipefail
 mkdir -p gpurun_out

@@ -1,4 +1,7 @@
 #!/bin/bash
+# (build the timing libraries first, here, before gpurun -- they travel with the snapshot:
+#   for cfg in noepi:-DVF_WIDE_EXP=8 noepi_nobar:-DVF_WIDE_EXP=12 noepi_noq:-DVF_WIDE_EXP=9 noepi_noops:-DVF_WIDE_EXP=11 noepi_nosib:-DVF_WIDE_EXP=24 nocand:-DVF_WIDE_NOCAND; do
+#     VF_BUILD_FLAGS="${cfg#*:}" VF_BUILD_LIB=libvf_w_${cfg%%:*}.so VF_BUILD_TAG=_w_${cfg%%:*} python -m veritasfi_amd.build; done )
 # where does k_scan_wide's launch go?  timing builds (results invalid) of the configs[4] shard (1.25M x 1024 e4m3, 1024 queries, k = 1000)
 set -o pipefail
 mkdir -p gpurun_out
