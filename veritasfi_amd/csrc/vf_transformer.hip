@@ -4361,7 +4361,11 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // vs 508 / 270 / 291): what it hides -- load latency at the tile seams -- is not what the forward waits for, and its
     // static tile schedule gives up the dispatcher's balancing.  The epilogue still runs on the waves that own the MFMAs.
 #ifdef VF_EXPERIMENTS
-    if (big_ok && K % PBK == 0 && K >= 2 * PBK && kind == 8) {
+    // VF_GEMM_8Q_MASK (experiment): take the persistent kernel for the products whose epilogue bit is set (1 bias, 2 GELU, 4 residual)
+    static const int q_mask = getenv("VF_GEMM_8Q_MASK") ? atoi(getenv("VF_GEMM_8Q_MASK")) : 0;
+    const bool q_pick = kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min &&
+                        ((EPI == EPI_BIAS && (q_mask & 1)) || (EPI == EPI_BIAS_GELU && (q_mask & 2)) || (EPI == EPI_BIAS_RESIDUAL && (q_mask & 4)));
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 8 || q_pick)) {
         const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
         hipLaunchKernelGGL(k_gemm8q_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), QLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
