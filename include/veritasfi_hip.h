@@ -291,6 +291,9 @@ int vf_vit_create(vf_vit** out, const vf_vit_config* cfg, const void* w_fp16, in
                   int64_t n_fp32, int32_t device_id);
 /* pixels [b, channels, image, image] fp32 host -> out [b, proj_dim] fp32 host */
 int vf_vit_forward(vf_vit* vit, const float* pixels, int32_t b, float* out);
+/* the same on raw bytes: pixels [b, 3, image, image] uint8 host (resized / cropped by the caller), normalised on the device as
+ * (x / 255 - mean[c]) / std[c] -- the image processor's rescale + normalize; a quarter of the PCIe bytes */
+int vf_vit_forward_u8(vf_vit* vit, const unsigned char* pixels, const float* mean3, const float* std3, int32_t b, float* out);
 int vf_vit_destroy(vf_vit* vit);
 
 #ifdef __cplusplus

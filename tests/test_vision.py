@@ -88,6 +88,12 @@ def test_image_embeddings_surface_and_errors(vf):
     assert np.allclose(np.linalg.norm(np.asarray(out), axis=1), 1.0, atol=1e-4)
     assert np.allclose(emb.embed_image(px[3]), out[3], atol=1e-6)
     assert emb.embed_images(px[:0]) == []
+    # raw bytes, normalised on the device = the processor's rescale + normalize on the host, then the float entry
+    from veritasfi_amd.vision import CLIP_MEAN, CLIP_STD
+    u8 = np.random.default_rng(5).integers(0, 256, (6, 3, 32, 32), dtype=np.uint8)
+    host = (u8.astype(np.float32) / 255.0 - np.asarray(CLIP_MEAN, np.float32)[None, :, None, None]) / np.asarray(CLIP_STD, np.float32)[None, :, None, None]
+    a, b = enc.forward_u8(u8), enc.forward(host)
+    assert np.abs(a - b).max() < 2e-3 and np.allclose(np.asarray(emb.embed_images(u8)), a, atol=1e-6)
     with pytest.raises(ValueError):
         enc.forward(px[:, :, :16])                 # wrong image size
     enc.close()

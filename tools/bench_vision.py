@@ -44,20 +44,26 @@ def main():
     ap.add_argument("--shape", default="vit-l-14", choices=sorted(SHAPES))
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--u8", action="store_true", help="raw uint8 pixels, normalised on the device")
     a = ap.parse_args()
     enc, cfg = random_vit(a.shape)
-    px = np.random.default_rng(1).standard_normal((a.batch, 3, cfg["image"], cfg["image"]), dtype=np.float32)
-    enc.forward(px)
+    if a.u8:
+        px = np.random.default_rng(1).integers(0, 256, (a.batch, 3, cfg["image"], cfg["image"]), dtype=np.uint8)
+        fwd = enc.forward_u8
+    else:
+        px = np.random.default_rng(1).standard_normal((a.batch, 3, cfg["image"], cfg["image"]), dtype=np.float32)
+        fwd = enc.forward
+    fwd(px)
     ts = []
     for _ in range(a.iters):
         t0 = time.perf_counter()
-        out = enc.forward(px)
+        out = fwd(px)
         ts.append(time.perf_counter() - t0)
     assert np.isfinite(out).all()
     p50 = float(np.median(ts))
     print(json.dumps({"shape": a.shape, "batch": a.batch, "p50_ms": round(p50 * 1e3, 3), "images_per_s": round(a.batch / p50, 1),
                       "tflops_at_p50": round(flops_per_image(cfg) * a.batch / p50 / 1e12, 1),
-                      "frac_of_2.5PF": round(flops_per_image(cfg) * a.batch / p50 / 2.5e15, 4), "pcie_inclusive": True}))
+                      "frac_of_2.5PF": round(flops_per_image(cfg) * a.batch / p50 / 2.5e15, 4), "pcie_inclusive": True, "pixels": "uint8" if a.u8 else "fp32"}))
     enc.close()
 
 

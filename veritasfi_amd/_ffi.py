@@ -103,6 +103,7 @@ SIGNATURES = {
     "vf_vit_weight_sizes": (ctypes.c_int, [ctypes.POINTER(VitConfig), p_i64, p_i64]),
     "vf_vit_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(VitConfig), vp, c_i64, vp, c_i64, c_i32]),
     "vf_vit_forward": (ctypes.c_int, [vp, vp, c_i32, vp]),
+    "vf_vit_forward_u8": (ctypes.c_int, [vp, vp, vp, vp, c_i32, vp]),
     "vf_vit_destroy": (ctypes.c_int, [vp]),
 }
 

@@ -5426,7 +5426,11 @@ extern "C" int vf_vit_weight_sizes(const vf_vit_config* cfg, int64_t* n_fp16, in
 
 // pixels [B][C][S][S] fp32 -> patches [B P][Kp] fp16, element (c, i, j) of a patch at c p p + i p + j (the Conv2d weight's own
 // flattening); columns >= C p p and rows >= B P (up to rows_p) are zero
-__global__ __launch_bounds__(256) void k_vit_unfold(const float* __restrict__ pix, int B, int C, int S, int p, int Kp, int rows_p,
+// (PIX = unsigned char: raw 0..255 pixels, normalised here as (x / 255 - mean[c]) / std[c] = x * sc[c] + sh[c] -- a quarter of the
+// PCIe bytes of fp32 pixels, which at 200 images per call is a fifth of the whole forward)
+template <typename PIX>
+__global__ __launch_bounds__(256) void k_vit_unfold(const PIX* __restrict__ pix, int B, int C, int S, int p, int Kp, int rows_p,
+                                                    float sc0, float sc1, float sc2, float sh0, float sh1, float sh2,
                                                     half_t* __restrict__ out) {
     const int g = S / p, P = g * g, K = C * p * p;
     const long long n = (long long)rows_p * Kp;
@@ -5436,7 +5440,8 @@ __global__ __launch_bounds__(256) void k_vit_unfold(const float* __restrict__ pi
         if (row < B * P && k < K) {
             const int b = row / P, pi = row - b * P, py = pi / g, px = pi - py * g;
             const int c = k / (p * p), r = k - c * p * p, iy = r / p, ix = r - iy * p;
-            v = pix[(((long long)b * C + c) * S + (py * p + iy)) * S + (px * p + ix)];
+            v = (float)pix[(((long long)b * C + c) * S + (py * p + iy)) * S + (px * p + ix)];
+            if constexpr (sizeof(PIX) == 1) v = v * (c == 0 ? sc0 : c == 1 ? sc1 : sc2) + (c == 0 ? sh0 : c == 1 ? sh1 : sh2);
         }
         out[i] = (half_t)v;
     }
@@ -5628,12 +5633,22 @@ static int vit_ensure_ws(vf_vit* v, int B) {
     return VF_OK;
 }
 
-// pixels [b][channels][image][image] fp32 host (already resized / normalised by the caller's image processor) -> out [b][proj_dim]
-extern "C" int vf_vit_forward(vf_vit* v, const float* pixels, int32_t b, float* out) {
+// pixels [b][channels][image][image] host -> out [b][proj_dim]: fp32 already resized / normalised by the caller's image
+// processor (u8 == nullptr), or raw bytes normalised on the device with the processor's mean / std (three channels)
+static int vit_forward_impl(vf_vit* v, const float* pixels, const unsigned char* u8, const float* mean, const float* stdv, int32_t b,
+                            float* out) {
     if (!v) return fail(VF_EINVAL, "vf_vit_forward: null handle");
     if (b < 0) return fail(VF_EINVAL, "vf_vit_forward: negative batch");
     if (b == 0) return VF_OK;
-    if (!pixels || !out) return fail(VF_EINVAL, "vf_vit_forward: null buffer");
+    if ((!pixels && !u8) || !out) return fail(VF_EINVAL, "vf_vit_forward: null buffer");
+    float sc[3] = {1.f, 1.f, 1.f}, sh[3] = {0.f, 0.f, 0.f};
+    if (u8) {
+        if (v->cfg.channels != 3 || !mean || !stdv) return fail(VF_EINVAL, "vf_vit_forward_u8: three channels with mean / std");
+        for (int c = 0; c < 3; ++c) {
+            if (!(stdv[c] > 0.f)) return fail(VF_EINVAL, "vf_vit_forward_u8: std must be positive");
+            sc[c] = 1.0f / (255.0f * stdv[c]); sh[c] = -mean[c] / stdv[c];
+        }
+    }
     std::lock_guard<std::mutex> lk(v->mu);
     int prev = 0;
     VFT_HIP(hipGetDevice(&prev));
@@ -5644,8 +5659,16 @@ extern "C" int vf_vit_forward(vf_vit* v, const float* pixels, int32_t b, float* 
     const int H = c.hidden, F = c.ffn, P = v->P, Tp = v->Tp, Kp = v->Kp;
     const int M = b * Tp, Mp = (M + 255) / 256 * 256, Rp = (b * P + 255) / 256 * 256;
     hipStream_t st = nullptr;
-    VFT_HIP(hipMemcpyAsync(v->d_pix, pixels, (size_t)b * c.channels * c.image * c.image * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_vit_unfold, dim3(2048), dim3(256), 0, st, v->d_pix, b, c.channels, c.image, c.patch, Kp, Rp, v->patches);
+    const size_t npix = (size_t)b * c.channels * c.image * c.image;
+    if (u8) {
+        VFT_HIP(hipMemcpyAsync(v->d_pix, u8, npix, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_vit_unfold<unsigned char>, dim3(2048), dim3(256), 0, st, (const unsigned char*)v->d_pix, b, c.channels, c.image, c.patch, Kp, Rp,
+                           sc[0], sc[1], sc[2], sh[0], sh[1], sh[2], v->patches);
+    } else {
+        VFT_HIP(hipMemcpyAsync(v->d_pix, pixels, npix * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_vit_unfold<float>, dim3(2048), dim3(256), 0, st, (const float*)v->d_pix, b, c.channels, c.image, c.patch, Kp, Rp,
+                           1.f, 1.f, 1.f, 0.f, 0.f, 0.f, v->patches);
+    }
     VFT_HIP(gemm<EPI_BIAS>(v->patches, v->w16 + v->o_patch, nullptr, nullptr, v->emb, Rp, H, Kp, st));
     hipLaunchKernelGGL(k_vit_embed, dim3((M + 7) / 8), dim3(256), 0, st, v->emb, v->w16 + v->o_cls, v->w16 + v->o_pos, v->w32 + v->f_pre,
                        v->w32 + v->f_pre + H, c.ln_eps, b, P, Tp, H, v->x, v->d_mask);
@@ -5669,6 +5692,13 @@ extern "C" int vf_vit_forward(vf_vit* v, const float* pixels, int32_t b, float* 
     VFT_HIP(hipMemcpyAsync(out, v->d_out, (size_t)b * c.proj_dim * 4, hipMemcpyDeviceToHost, st));
     VFT_HIP(hipStreamSynchronize(st));
     return VF_OK;
+}
+extern "C" int vf_vit_forward(vf_vit* v, const float* pixels, int32_t b, float* out) {
+    return vit_forward_impl(v, pixels, nullptr, nullptr, nullptr, b, out);
+}
+extern "C" int vf_vit_forward_u8(vf_vit* v, const unsigned char* pixels, const float* mean3, const float* std3, int32_t b, float* out) {
+    if (!pixels) return fail(VF_EINVAL, "vf_vit_forward_u8: null buffer");
+    return vit_forward_impl(v, nullptr, pixels, mean3, std3, b, out);
 }
 
 // Test hook (not part of the public header; tools/bench_gemm.py and the GEMM parity test bind it):
