@@ -743,6 +743,52 @@ def test_c5_shape(vf, oracle):
     assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
 
 
+@pytest.mark.gpu
+def test_c5_10m_sharding_invariance_and_subset(vf, oracle):
+    """BASELINE configs[4] at FULL size on one GPU: 10M x 1024 e4m3 rows (the corpus bench.py times), 1024 queries, k = 1000
+    through k_scan_wide.  (i) A size-independent property: the result over the whole corpus equals the merge of the results
+    over the config's eight 1.25M-row shards, bit for bit -- the product's merge and the oracle's; (ii) four of the queries
+    against the oracle run over the decoded host copy, shard by shard.  No candidate list may overflow."""
+    import torch
+    import bench
+    n, d, nq, k, G = 10_000_000, 1024, 1024, 1000, 8
+    dev = torch.device("cuda", 0)
+    corpus = bench.make_shard(torch, 0, n, d, dev, "fp8")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    q = torch.randn((nq, d), generator=g, device=dev, dtype=torch.float32)
+    with vf.DenseIndex(corpus) as ix:
+        ids, sc = ix.search_device(q, k)
+        ids, sc = ids.clone(), sc.clone()
+        st = ix.stats()
+    torch.cuda.synchronize()
+    print("C5 full-size stats", st)
+    assert st["path"] == 1 and st["wide_launches"] >= 1 and st["overflowed"] == 0 and st["n_queries"] == nq
+    pick = [0, 341, 682, 1023]
+    qh = q[pick].cpu().numpy()
+    parts_i, parts_s, want_i, want_s = [], [], [], []
+    for r in range(G):
+        lo, hi = vf.shard_bounds(n, G, r)
+        with vf.DenseIndex(corpus[lo:hi], id_offset=lo) as sx:
+            i, s = sx.search_device(q, k)
+            parts_i.append(i.clone()); parts_s.append(s.clone())
+            assert sx.stats()["overflowed"] == 0
+        rows = bench.host_rows(torch, corpus, lo, hi)            # decoded e4m3 values as fp16 (exact), 2.6 GB at a time
+        oi, os_ = oracle.search(rows, qh, k, id_offset=lo)
+        want_i.append(oi); want_s.append(os_)
+        del rows
+    mi, ms = vf.merge_topk_device(torch.stack(parts_i).contiguous(), torch.stack(parts_s).contiguous(), k)
+    torch.cuda.synchronize()
+    ids, sc, mi, ms = ids.cpu().numpy(), sc.cpu().numpy(), mi.cpu().numpy(), ms.cpu().numpy()
+    assert np.array_equal(mi, ids) and np.array_equal(_bits(ms), _bits(sc)), "eight shards merged != the whole corpus"
+    omi, oms = oracle.merge_topk(torch.stack(parts_i).cpu().numpy(), torch.stack(parts_s).cpu().numpy(), k)
+    assert np.array_equal(omi, ids) and np.array_equal(_bits(oms), _bits(sc))
+    wi, ws = oracle.merge_topk(np.stack(want_i), np.stack(want_s), k)
+    assert np.array_equal(ids[pick], wi) and np.array_equal(_bits(sc[pick]), _bits(ws))
+    for r in pick:
+        assert_ranked(ids[r], sc[r])
+
+
 # ---- N > 1 on ONE GPU: two fresh processes, real shards, the default packed exchange ------------------------------------
 _WORLD2_WORKER = r"""
 import os, sys
