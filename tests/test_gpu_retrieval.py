@@ -585,6 +585,18 @@ def test_c3_10m_subset(vf, oracle):
     wi, ws = oracle.merge_topk(np.stack(parts_i), np.stack(parts_s), k)
     assert np.array_equal(ids[pick], wi)
     assert np.array_equal(_bits(sc[pick]), _bits(ws))
+    # BASELINE configs[2]'s partitioning at full size: the eight 1.25M-row shards (a different launch policy: CU-partitioned
+    # streams, overlapping scans) merged by the product == the whole corpus, bit for bit, all 64 queries
+    sh_i, sh_s = [], []
+    for r in range(8):
+        lo, hi = vf.shard_bounds(n, 8, r)
+        with vf.DenseIndex(corpus[lo:hi], id_offset=lo) as sx:
+            i, s_ = sx.search_device(q, k)
+            sh_i.append(i.clone()); sh_s.append(s_.clone())
+            assert sx.stats()["overflowed"] == 0
+    mi, ms = vf.merge_topk_device(torch.stack(sh_i).contiguous(), torch.stack(sh_s).contiguous(), k)
+    torch.cuda.synchronize()
+    assert np.array_equal(mi.cpu().numpy(), ids) and np.array_equal(_bits(ms.cpu().numpy()), _bits(sc))
 
 
 @pytest.mark.parametrize("n,d,nq,k,want_kernel", [
