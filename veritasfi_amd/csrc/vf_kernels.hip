@@ -1279,11 +1279,15 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
         for (int sg = 0; sg < kRing; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S >= kRing: scan2_stage_cap)
     }
     {   // query image -> LDS verbatim; control block + candidate stage zeroed
-        const uint4* srcq = (const uint4*)a.qimg;
-        uint4* dst = (uint4*)img;
-        const int nvec = (a.dp >> 3) * QN;
-#pragma unroll 4
-        for (int i = tid; i < nvec; i += kScan2Threads) dst[i] = srcq[i];
+        // (by LDS-DMA like everything else here: 1 KB per wave instruction, no register hop; the image is 32 or 64 queries x
+        //  dp / 8 sixteen-byte units = a multiple of 256 units, and wave w of the streaming four takes every fourth KB)
+        const char* srcq = (const char*)a.qimg;
+        const int nkb = ((a.dp >> 3) * QN) >> 6;
+        const unsigned img_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(img));
+        const int wu = __builtin_amdgcn_readfirstlane(wid);   // (M0 is scalar: make the wave index uniform for the compiler)
+        if (wu < kScan2Waves)
+            for (int c = wu; c < nkb; c += kScan2Waves) dma16(srcq + ((long long)c << 10) + (lane << 4), img_l + ((unsigned)c << 10));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share (and its ring) has landed; the barrier below covers the others'
         uint4* z = (uint4*)ctl;
         const int nz = kCtlBytes / 16 + a.stage_cap;
         for (int i = tid; i < nz; i += kScan2Threads) z[i] = make_uint4(0u, (i == 0) ? (u32)kScan2Waves : 0u, 0u, 0u);
