@@ -761,11 +761,12 @@ def main():
                 traffic = round(rec["hbm_bytes_per_launch"])
             elif args.corpus_dtype == "f16" and not devs and stats.get("scan_kernel") == 2:
                 # a rank of the 8-GPU configuration (or a one-GPU run of its shard size): the PMC passes of that shard size
-                tf2 = os.path.join("profiles", "pmc_traffic_scan2_1250k.json")
-                rec2 = json.load(open(os.path.join(ROOT, tf2)))
-                w2 = rec2["workload"]
-                if (w2["rows"], w2["dim"], w2["batch"], w2["k"]) == (hi - lo if world > 1 else args.rows, args.dim, args.batch, args.k):
-                    traffic, traffic_file = round(rec2["hbm_bytes_per_launch"]), tf2
+                for tag in ("1250k", "2500k", "5000k"):      # the per-GPU shards of 10M rows on 8 / 4 / 2 GPUs
+                    tf2 = os.path.join("profiles", f"pmc_traffic_scan2_{tag}.json")
+                    rec2 = json.load(open(os.path.join(ROOT, tf2)))
+                    w2 = rec2["workload"]
+                    if (w2["rows"], w2["dim"], w2["batch"], w2["k"]) == (hi - lo, args.dim, args.batch, args.k):
+                        traffic, traffic_file = round(rec2["hbm_bytes_per_launch"]), tf2
         except (OSError, KeyError, ValueError):
             pass
         esz = 2 if args.corpus_dtype == "f16" else 1
