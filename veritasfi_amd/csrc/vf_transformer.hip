@@ -2078,6 +2078,147 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     }
 }
 
+#ifdef VF_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------
+// k_gemm4w_tn (EXPERIMENT, round 3): the 256 x 256 tile on FOUR waves -- one per SIMD, wave tile 128 x 128 = 8 x 8 MFMA
+// 16x16x32 tiles (256 accumulator registers), the layout the vendor library's kernels use on this chip
+// (profiles/r03_vendor_kernels.txt).  Against k_gemm8p_tn: two thirds of the LDS fragment traffic (each A / B fragment feeds
+// eight MFMAs instead of four), ONE barrier per 32-deep K step instead of eight per 64, no partner wave to cover a stall.
+//  * a K step (32 deep) is one 32-KB slot: A 256 rows x 64 B | W 256 rows x 64 B, k_gemm_dma16_tn's row swizzle;
+//    FOUR slots form a ring; at step j: wait for this wave's DMA of step j + 1, barrier (now everybody's has landed and
+//    everybody is done with slot j - 1), issue the DMA of step j + 3 into slot (j - 1) & 3, read the 16 fragments of step
+//    j + 1 into the second register set while the 64 MFMAs of step j run on the first;
+//  * epilogue through LDS as in k_gemm8p_tn (the four slots are exactly the 256 x 256 fp16 image).
+// Requires M % 256 == 0, N % 256 == 0, K % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int WBM = 256, WBN = 256, WBK = 32, WTHREADS = 256, WSLOT = (WBM + WBN) * 64, WLDS = 4 * WSLOT;
+
+template <int EPI>
+__global__ __launch_bounds__(WTHREADS) void k_gemm4w_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                          half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 1, wc = wid & 1;
+    int mt_idx, nt_idx;
+    {   // XCD-contiguous, n-major groups of 4 m-tiles (k_gemm8p_tn's order)
+        const int Mt = M / WBM, Nt = N / WBN, nwg = Mt * Nt;
+        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        constexpr int GM = 4;
+        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
+        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+        nt_idx = r / gm;
+        mt_idx = g * GM + (r - nt_idx * gm);
+    }
+    const long long m0 = (long long)mt_idx * WBM, n0 = (long long)nt_idx * WBN;
+    // one DMA instruction fills 16 rows x 64 B; wave w stages rows [64 w, 64 w + 64) of A and of W: 4 + 4 instructions per step
+    const half_t* a_src[4];
+    const half_t* w_src[4];
+    const int drow = lane >> 2, dpc = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wid * 64 + j * 16 + drow;
+        a_src[j] = A + (m0 + row) * K + (dpc ^ swz16(row)) * 8;
+        w_src[j] = W + (n0 + row) * K + (dpc ^ swz16(row)) * 8;
+    }
+    auto stage = [&](int slot, int kt) {
+        char* ab = smem + slot * WSLOT + (wid * 64) * 64;
+        char* wb = ab + WBM * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * WBK),
+                                             (__attribute__((address_space(3))) void*)(ab + j * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * WBK),
+                                             (__attribute__((address_space(3))) void*)(wb + j * 1024), 16, 0, 0);
+    };
+    f4v acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+    const int pc = (kb ^ swz16(r15)) * 16;   // tile offsets are multiples of 16 rows: (row >> 2) & 3 does not change
+    const char* a_row = smem + (wr * 128 + r15) * 64 + pc;
+    const char* w_row = smem + WBM * 64 + (wc * 128 + r15) * 64 + pc;
+    const int nk = K / WBK;   // even (K % 64 == 0)
+    stage(0, 0);
+    stage(1, 1 < nk ? 1 : nk - 1);
+    stage(2, 2 < nk ? 2 : nk - 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // step 0 of this wave's DMA has landed ...
+    __builtin_amdgcn_s_barrier();                       // ... and everybody's
+    // Fragment registers: two sets of 8 A + 8 B fragments (128 VGPRs); the set of step j + 1 is read from LDS while the 64
+    // MFMAs of step j run.  The MFMAs are inline assembly with the accumulators pinned to AGPRs ("+a"): left to itself the
+    // register allocator split the 256 accumulators across both files and moved them back and forth inside the loop.
+    h8 Fa0[8], Fb0[8], Fa1[8], Fb1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { Fa0[t] = *(const h8*)(a_row + t * 1024); Fb0[t] = *(const h8*)(w_row + t * 1024); }
+#define VFT_MFMA4W(ACC, AF, BF) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(AF), "v"(BF))
+#define VFT_STEP4W(J, FAC, FBC, FAN, FBN)                                                                 \
+    {   /* the barrier sits in the MIDDLE of the step: the matrix pipe still has the first half's MFMAs to chew on   \
+           while the wave waits, and the next step's fragment reads (behind the barrier: that slot is only then     \
+           known to have landed everywhere) have the second half to come back */                                     \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                  \
+            _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) VFT_MFMA4W(acc[mt][nt], FAC[mt], FBC[nt]);   \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* this wave's DMA of step J + 1 has landed */  \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        stage(((J) + 3) & 3, (J) + 3 < nk ? (J) + 3 : nk - 1);   /* past the end: re-reads the last step (unused) */ \
+        const char* an_ = a_row + (((J) + 1) & 3) * WSLOT;                                                \
+        const char* wn_ = w_row + (((J) + 1) & 3) * WSLOT;                                                \
+        _Pragma("unroll") for (int nt = 4; nt < 8; ++nt) {                                                \
+            FAN[2 * (nt - 4)] = *(const h8*)(an_ + (2 * (nt - 4)) * 1024);                                \
+            FAN[2 * (nt - 4) + 1] = *(const h8*)(an_ + (2 * (nt - 4) + 1) * 1024);                        \
+            FBN[2 * (nt - 4)] = *(const h8*)(wn_ + (2 * (nt - 4)) * 1024);                                \
+            FBN[2 * (nt - 4) + 1] = *(const h8*)(wn_ + (2 * (nt - 4) + 1) * 1024);                        \
+            _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) VFT_MFMA4W(acc[mt][nt], FAC[mt], FBC[nt]);   \
+        }                                                                                                 \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        VFT_STEP4W(kt, Fa0, Fb0, Fa1, Fb1)
+        VFT_STEP4W(kt + 1, Fa1, Fb1, Fa0, Fb0)
+    }
+#undef VFT_STEP4W
+#undef VFT_MFMA4W
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the vector unit reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy DMAs
+    __syncthreads();
+    half_t* Es = (half_t*)smem;                         // [256][256] fp16 image = the four slots
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const int col = wc * 128 + nt * 16 + r15;
+        const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg += 2) {
+                const int row = wr * 128 + mt * 16 + 4 * kb + reg;
+                f2v v = {acc[mt][nt][reg] + bv, acc[mt][nt][reg + 1] + bv};
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf2(v);
+                if (EPI == EPI_BIAS_QGELU) v = quick_gelu2(v);
+                Es[row * WBN + col] = (half_t)v[0];
+                Es[(row + 1) * WBN + col] = (half_t)v[1];
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = tid + WTHREADS * i, row = c >> 5, cc = c & 31;   // 32 chunks of 8 halves per 256-wide row
+        h8 o = *(const h8*)(Es + row * WBN + cc * 8);
+        const long long off = (m0 + row) * N + n0 + cc * 8;
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const h8 r = *(const h8*)(R + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+        }
+        *(h8*)(C + off) = o;
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // k_gemm8q_tn: the 8-phase kernel made PERSISTENT, with a seamless pipeline across its tiles.  k_gemm8p_tn spends about
 // half of a K = 768 tile outside its main loop (first DMAs in front, epilogue behind, nothing else on the CU).  Here a
@@ -3961,6 +4102,10 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
 #ifdef VF_EXPERIMENTS
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
@@ -4365,6 +4510,12 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     static const int q_mask = getenv("VF_GEMM_8Q_MASK") ? atoi(getenv("VF_GEMM_8Q_MASK")) : 0;
     const bool q_pick = kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min &&
                         ((EPI == EPI_BIAS && (q_mask & 1)) || (EPI == EPI_BIAS_GELU && (q_mask & 2)) || (EPI == EPI_BIAS_RESIDUAL && (q_mask & 4)));
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL) {
+        if (big_ok && K % 64 == 0 && K >= 128 && kind == 9) {   // experiment: four waves, 128 x 128 wave tiles
+            hipLaunchKernelGGL(k_gemm4w_tn<EPI>, dim3((M / WBM) * (N / WBN)), dim3(WTHREADS), WLDS, st, A, W, bias, R, C, M, N, K);
+            return hipGetLastError();
+        }
+    }
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 8 || q_pick)) {
         const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
         hipLaunchKernelGGL(k_gemm8q_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), QLDS, st, A, W, bias, R, C, M, N, K);
