@@ -1608,6 +1608,7 @@ struct LnFold {
     int sk_ntail;            // tail tiles (the sliced part of the grid is padded to 8 tiles x sk_S: the excess workgroups leave)
     unsigned* sk_stat;       // [4] read-backs through L2 / from memory, (timing experiments: bit 0 of sk_dbg skips the partial stores, bit 1 the read-back)
     int sk_dbg;
+    int loop2;               // main loop in TWO phases of 32 MFMAs per K-tile instead of four of 16 (see k_gemm8p_tn)
 };
 
 struct LnTail {
@@ -1731,6 +1732,10 @@ __global__ __launch_bounds__(256) void k_layernorm_rest(const half_t* y, const f
 //  LDS rows are 128 B = 8 chunks of 16 B; chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7) (the DMA lanes
 //  fetch the matching logical chunk): a ds_read_b128 lane group of the 16x16x32 operand read (8 rows at k-block kb,
 //  8 rows at kb + 1) then touches 16 distinct 16-byte slots of the 256-byte bank row.
+//  Round 3: the default main loop runs TWO phases per K-tile instead of four -- quadrants (m0,n0) (m0,n1), then (m1,n1) (m1,n0):
+//  32 MFMAs behind every hand-over between the wave halves, four barriers per K-tile instead of eight (LnFold::loop2; the
+//  invariants are written out at the loop).  The four-phase loop described above stays selectable (VF_GEMM_8P_LOOP2=0) and
+//  is what the LayerNorm-fold instances run.
 //  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128.
 // ------------------------------------------------------------------------------------------------
 constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLDS = 2 * 4 * PSLOT + PSLOT;
@@ -1848,6 +1853,52 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
 #define VFT_PHASE_TAIL()                                                                   \
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);
+    if (lf.loop2) {
+        // TWO phases per K-tile (round 3): X = quadrants (m0,n0) (m0,n1) on A_m0, B_n0, B_n1 (16 fragment reads, 32 MFMAs),
+        // Y = (m1,n1) (m1,n0) on A_m1 (8 reads, 32 MFMAs): four barriers per K-tile instead of eight, twice the matrix work
+        // behind each hand-over between the wave halves.  Every fragment read has COMPLETED before the barrier that follows it
+        // (lgkmcnt(0) in front of the barrier, in the shadow of the partner half's 32 MFMAs), so a slot may be restaged by
+        // whoever passes the next barrier: X(kt) restages half-tile 4 kt + 7 (its slot, A_m1 of the other buffer, was read in
+        // Y(kt - 1)), Y(kt) the three half-tiles 4 kt + 8 .. + 10 (read in X(kt)).  Landed-guarantees, one phase ahead for the
+        // half that reads one barrier later: X waits until half-tiles <= 4 kt + 3 of this wave's DMA are in (vmcnt(6): 4 kt + 4
+        // .. + 6 may fly), Y until <= 4 kt + 6 (vmcnt(2): only 4 kt + 7 may fly).
+        for (int g = 0; g < 7; ++g) stage(g);
+        if (wr == 1) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 14 issued, 8 may fly: half-tiles 0 .. 2 of this wave landed
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* base = smem + (kt & 1) * (4 * PSLOT);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(4 * kt + 7);
+            VFT_READ_B(B0f, base + 1 * PSLOT)
+            VFT_READ_B(B1f, base + 2 * PSLOT)
+            VFT_READ_A(base + 0 * PSLOT)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            VFT_QUAD(0, 0, B0f)
+            VFT_QUAD(0, 1, B1f)
+            VFT_PHASE_TAIL()
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(4 * kt + 8);
+            stage(4 * kt + 9);
+            stage(4 * kt + 10);
+            VFT_READ_A(base + 3 * PSLOT)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            VFT_QUAD(1, 1, B1f)
+            VFT_QUAD(1, 0, B0f)
+            VFT_PHASE_TAIL()
+        }
+    } else {
     for (int g = 0; g < 6; ++g) stage(g);
     if (wr == 1) {   // waves 4..7 run one barrier behind; the other half reads half-tiles 0 and 1 right after this barrier
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 12 issued, 8 may still fly: half-tiles 0, 1 of this wave landed
@@ -1880,6 +1931,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         VFT_PHASE_MID()
         VFT_QUAD(1, 0, B0f)
         VFT_PHASE_TAIL()
+    }
     }
 #undef VFT_READ_A
 #undef VFT_READ_B
@@ -4423,6 +4475,9 @@ static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bia
 }
 
 static long long p8_min_wgs();   // tiles from which the 8-phase kernel is the default (defined with the LnFold helpers)
+static std::atomic<int> g_loop2{getenv("VF_GEMM_8P_LOOP2") ? atoi(getenv("VF_GEMM_8P_LOOP2")) : 1};   // default: the two-phase loop (round 3: 2-7 % on the products, 0.7-2 % on the forward)
+extern "C" int vf_debug_gemm_8p_loop2(int on) { return on >= 0 ? g_loop2.exchange(on ? 1 : 0) : g_loop2.load(); }   // A/B: two-phase main loop of k_gemm8p_tn
+static LnFold lf_plain() { LnFold l{}; l.loop2 = g_loop2.load(std::memory_order_relaxed); return l; }
 static int device_cus();
 
 // split-K tail of the 8-phase products: one fp32 workspace + counters per device, grown on demand (forwards of one device
@@ -4482,7 +4537,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: 8-phase, the 128 x 256 DMA kernel or the 128 x 128 one
         static const long long p8f_min = getenv("VF_GEMM_8P_F32_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_F32_MIN_WGS")) : 256;   // (Qwen3-4B shape, 320 tiles: 66.4 vs 68.9 ms per forward)
         if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8f_min))) {
-            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, LnFold{});
+            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf_plain());
             return hipGetLastError();
         }
         if (dma_ok && (long long)(M / DBM) * (N / DBN) >= dma_min && kind != 3) {
@@ -4528,7 +4583,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         // Round 3: the tiles of the partial last round are cut along K instead (LnFold::sk_*): S slices per tail tile so that
         // the slices still fit one round, each at least two K-tiles long.
         const int tiles = (N / PBN) * (M / PBM);
-        LnFold lf{};
+        LnFold lf = lf_plain();
         int grid = tiles;
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
             // a product of less than one round (tiles <= CUs: the per-rank batches of a data-parallel re-rank) is cut whole
@@ -4590,9 +4645,9 @@ static bool gemm_gated(const half_t* A, const half_t* Wgu, half_t* C, int M, int
     *er = hipSuccess;
     if (off || M % PBM || N % PBN || F % 128 || K % PBK || K < 2 * PBK || (long long)(M / PBM) * (N / PBN) < 384) return false;
     if (act_kind == 1)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, LnFold{});
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, lf_plain());
     else
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, LnFold{});
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, lf_plain());
     *er = hipGetLastError();
     return true;
 }
