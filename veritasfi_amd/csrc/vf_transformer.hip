@@ -1751,6 +1751,15 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(lt.next + ((lt.gen + 1u) & 63u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     constexpr bool RES16 = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN || EPI == EPI_RES_STATS || EPI == EPI_LNRES_STATS;
+    // Operands swapped (D = W_frag x A_frag): a lane then owns FOUR CONSECUTIVE COLUMNS of one output row instead of one column
+    // of four rows, and the epilogue moves the tile into its LDS image with 32 eight-byte writes per lane instead of 128
+    // two-byte ones (round 3; the fp32-residual form always worked this way, straight from the registers).
+#ifdef VF_8P_SWAP_EPILOGUE   // A/B builds only: measured SLOWER inside the forward ("operand order and power")
+    constexpr bool SWAP16 = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL;
+#else
+    constexpr bool SWAP16 = false;
+#endif
+    constexpr bool SWAP = SWAP16 || EPI == EPI_RESIDUAL_F32;
     constexpr bool LNA = EPI == EPI_LNA || EPI == EPI_LNA_GELU, STATS = EPI == EPI_RES_STATS || EPI == EPI_LNRES_STATS;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
@@ -1833,11 +1842,14 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
         DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
     }
+#ifdef VF_8P_QUAD_T_INNER   /* A/B builds: consecutive MFMAs share the W fragment instead of the A fragment */
+#define VFT_QUAD_LOOPS _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int t = 0; t < 4; ++t)
+#else
+#define VFT_QUAD_LOOPS _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u)
+#endif
 #define VFT_QUAD(MQ, NQ, BF)                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
-                acc[(MQ) * 4 + t][(NQ) * 2 + u] = EPI == EPI_RESIDUAL_F32                                                     \
+    VFT_QUAD_LOOPS                                                                         \
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = SWAP                                                                        \
                     ? __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0) \
                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[t][ks], BF[u][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
 #define VFT_PHASE_HEAD(G)                                                                  \
@@ -2044,6 +2056,43 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         for (int i = 0; i < 8; ++i) {
             const int c = tid + PTHREADS * i, row = c >> 4, cc = c & 15;   // 16 chunks of 8 halves per 128-wide row
             *(h8*)(C + (m0 + row) * NO + (long long)nt_idx * 128 + cc * 8) = *(const h8*)(Eg + row * 128 + cc * 8);
+        }
+        return;
+    }
+    if constexpr (SWAP16) {
+        // swapped layout: lane (r15, kb) of tile (mi, ni) holds row wr 128 + mi 16 + r15, columns wc 64 + ni 16 + 4 kb .. + 3.
+        // Image rows are 528 bytes (256 halves + 8): the 16 lanes of a ds_write_b64 group (one kb, rows r15 = 0 .. 15) land 16
+        // bytes apart, and the 16-byte row reads below stay aligned.  135 KB of the 144.
+        constexpr int ES = PBN + 8;
+        half_t* Es2 = (half_t*)smem;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = wc * 64 + ni * 16 + 4 * kb;
+            f4v bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *(const f4v*)(bias + n0 + col);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int row = wr * 128 + mi * 16 + r15;
+                f2v v0 = {acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]};
+                f2v v1 = {acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]};
+                if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); }
+                if (EPI == EPI_BIAS_QGELU) { v0 = quick_gelu2(v0); v1 = quick_gelu2(v1); }
+                const h4 o = {(half_t)v0[0], (half_t)v0[1], (half_t)v1[0], (half_t)v1[1]};
+                *(h4*)(Es2 + row * ES + col) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
+            h8 o = *(const h8*)(Es2 + row * ES + cc * 8);
+            const long long off = (m0 + row) * N + n0 + cc * 8;
+            if (EPI == EPI_BIAS_RESIDUAL) {
+                const h8 r = *(const h8*)(R + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+            }
+            *(h8*)(C + off) = o;
         }
         return;
     }
