@@ -25,7 +25,6 @@ chain for one query, the embed loop, per-request latencies, the host-buffer entr
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -91,11 +90,9 @@ def launch_ranks(args):
             print(f"bench.py: --gpus {args.gpus} asked for, {seen} GPU(s) visible -- refusing to run a smaller job under "
                   f"that name", file=sys.stderr)
             return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d store picks (and keeps) a free port -- no bind/close/re-bind race with other jobs
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
@@ -597,19 +594,25 @@ def main():
             dist.all_gather_into_tensor(g_blob, buckets[(i // E) % nbuckets][0])
             merged[0] = vf.merge_topk_packed_device(g_blob, world, E * args.batch, args.k, m_ids, m_sc)
 
-    def run(steps):
+    def run(steps, stamps=None):
+        # stamps: host time after each batch's search_end (it waits for that batch's results) -- the intervals between
+        # consecutive completions are the per-step times of the pipelined loop (p50_ms_per_step)
         pending = []
         for i in range(steps):
             slot = i % nslots
             if len(pending) == nslots:
                 ps, pi = pending.pop(0)
                 finish(ps, pi, False)
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
             oi, osc = views(i)
             index.search_begin(slot, qpool[i % len(qpool)], args.k, oi, osc)
             pending.append((slot, i))
         while pending:
             ps, pi = pending.pop(0)
             finish(ps, pi, not pending)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
 
     def fence():
         for dv in (devs or []):
@@ -629,9 +632,13 @@ def main():
         fence()
         index.set_option("profile", 1)  # resets the HIP-event accumulators
         t0 = time.perf_counter()
-        run(args.steps)
+        stamps = []
+        run(args.steps, stamps)
         fence()
         elapsed = time.perf_counter() - t0
+    import numpy as np
+    gaps = np.diff(np.asarray([t0] + stamps)) * 1e3 if len(stamps) == args.steps else None
+    p50_step_ms = None if gaps is None or len(gaps) < 3 else float(np.median(gaps[1:]))   # (the first gap holds the pipeline fill)
     torch.cuda.current_stream(device).wait_stream(side)
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -804,7 +811,7 @@ def main():
                       "traffic_source": None if traffic is None else f"{traffic_file} (rocprofv3 --pmc passes of this workload, "
                                                                      "committed; not re-measured in this run)",
                       "kernel": kname, "bytes_per_launch": prof["scan_bytes_per_launch"],
-                      "cus_used_by_the_scan": 256 - stats.get("aux_cus", 0)}
+                      "cus_used_by_the_scan": torch.cuda.get_device_properties(device).multi_processor_count - stats.get("aux_cus", 0)}
             if prof_timed is None:
                 roof = dict(common, achieved=round(iso_gbs, 1), frac=round(iso_gbs / HBM_PEAK_GBS, 4), avg_launch_ms=round(iso_ms, 4),
                             launches_timed=prof["scan_launches"],
@@ -833,8 +840,13 @@ def main():
             "metric": "queries/sec top-100 over 10Mx768 corpus" if (args.rows, args.dim, args.k) == (10_000_000, 768, 100)
                       else f"queries/sec top-{args.k} over {args.rows}x{args.dim} corpus", "value": round(qps, 1), "unit": "queries/s",
             "n_gpus": len(devs) if devs else world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "p50_ms_per_step": None if p50_step_ms is None else round(p50_step_ms, 4),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16" if args.corpus_dtype == "f16" else "fp8-e4m3 rows, f16 MFMA", "data": "synthetic",
+            "inputs": f"corpus: torch device generator, N(0,1) per {GEN_CHUNK}-row chunk c seeded 1234 + c, rounded to the storage dtype "
+                      "(SURVEY 8d names a host default_rng(1234); at 15 GB the corpus is built where it lives -- the CPU baseline "
+                      "reads the same rows back); queries: torch device generator seed 4321, fp32",
             "config": {"workload": f"{args.rows}x{args.dim} {'fp16' if args.corpus_dtype == 'f16' else 'fp8-e4m3'} corpus, batch-{args.batch} queries, exact cosine "
                                    f"top-{args.k}, " + (f"row-sharded over devices {devs} behind ONE handle in one process (peer copies + merge)" if devs else
                                                         f"row-sharded over {world} GPU(s) + RCCL all-gather of per-shard top-k"),

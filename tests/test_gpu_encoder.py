@@ -15,6 +15,9 @@ _ROOT = ROOT
 # decoder test measured on an MI355X (profiles/r03_decoder_errors.jsonl: largest 1 - cos 7.2e-7, largest relative error of a
 # last-token embedding 1.35e-3, largest "Yes"-logit error 7.8e-4 on logits of magnitude 0.3 - 0.8): ~2-4x those.
 DEC_COS_TOL, DEC_REL_TOL, DEC_LOGIT_TOL = 3e-6, 3e-3, 2.5e-3
+# full-depth models (18 / 36 layers at the real widths): ~3x what the first GPU run measured (profiles/r04_decoder_errors.jsonl)
+FULL_GEMMA_COS_TOL, FULL_GEMMA_REL_TOL, FULL_GEMMA_LOGIT_TOL = 1e-4, 3e-2, 3e-2
+FULL_QWEN_COS_TOL, FULL_QWEN_REL_TOL = 1e-4, 3e-2
 
 
 @pytest.fixture(scope="module")
@@ -257,7 +260,7 @@ def test_reranker_matches_torch_fp32(vf, hidden, layers, heads, ffn, b, t):
     rr.close()
     print("reranker logits", ref[:4], got[:4], np.abs(ref - got).max())
     assert got.shape == (b,)
-    assert np.abs(ref - got).max() < 2.5e-3 * max(1.0, np.abs(ref).max())   # measured 7e-4
+    assert np.abs(ref - got).max() < 1e-3 * max(1.0, np.abs(ref).max())   # measured 7e-4; the bar of DESIGN.md section 2 (logits: 1e-3 relative)
     assert np.array_equal(np.argsort(-ref), np.argsort(-got)) or np.abs(ref - got).max() < np.min(np.diff(np.sort(ref)))
 
 
@@ -785,6 +788,106 @@ def test_gemma_style_decoder_matches_hf_fp32(vf, b, t, left_pad):
               logit_scale=np.abs(want_logit).max())
     assert one_minus_cos < DEC_COS_TOL and rel < DEC_REL_TOL, (one_minus_cos, rel)
     assert lerr < DEC_LOGIT_TOL, (got_logit, want_logit)
+
+
+# ---- FULL-DEPTH parity of the reference's configured decoder models (round-3 review, item 3): the real layer counts and
+#      widths, vocabulary cut to 4096, against HF fp32 ON THE GPU (torch is plumbing in tests; the HF model is created there, so
+#      neither 2 nor 3.6 billion fp32 parameters pass through host memory at once) ------------------------------------------
+def _full_depth_rows(vf, n_rows=4, lo=64, hi=300, vocab=4096, seed=21):
+    """Left-padded rows of lo..hi tokens built by the product's own input builder (the reference's get_inputs layout:
+    bos + "A: " query + sep + "B: " passage + sep + prompt, experiments/profile/stress_test.py:97-146) on the stub tokenizer,
+    token ids folded into the cut vocabulary."""
+    tok = _StubLLMTokenizer()
+    rng = np.random.default_rng(seed)
+    words = ["revenue", "lotus", "margin", "battery", "delivery", "2023", "guidance", "segment", "cash", "vehicle", "emira", "eletre"]
+    sent = lambda n: " ".join(words[int(i)] for i in rng.integers(0, len(words), n))
+    targets = np.linspace(lo, hi, n_rows).astype(int)
+    pairs = [[sent(8), sent(max(4, int(t) - 40))] for t in targets]
+    rows = vf.build_llm_reranker_inputs(pairs, tok, max_length=1024)
+    width = -(-max(len(r) for r in rows) // 32) * 32
+    ids = np.zeros((len(rows), width), np.int64)
+    mask = np.zeros((len(rows), width), np.int64)
+    for i, r in enumerate(rows):
+        ids[i, width - len(r):] = (np.asarray(r, np.int64) * 37 + 11) % (vocab - 8) + 5      # spread over the cut vocabulary
+        mask[i, width - len(r):] = 1
+    return ids, mask, tok
+
+
+def _round_params_to_fp16(model, gain_noise):
+    import torch
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.dim() == 1 and gain_noise:
+                p_.add_(torch.randn_like(p_) * gain_noise)
+            p_.copy_(p_.half().float())
+
+
+def test_full_depth_gemma_2b_geometry_yes_logit(vf):
+    """bge-reranker-v2-gemma's geometry (config/example.yaml:9): 18 layers, hidden 2048, 8 query heads on ONE kv head of
+    dim 256, GeGLU 16384, embeddings x sqrt(2048) -- the model bench.py times as `rerank_llm`.  The score the reference takes
+    (logits[:, -1, yes], stress_test.py:197,212-225) and the last-token hidden state against HF fp32."""
+    import torch
+    from transformers import GemmaConfig, GemmaForCausalLM
+    from veritasfi_amd.retrieval import last_token_pool
+    ids, mask, tok = _full_depth_rows(vf)
+    yes = int((tok("Yes")["input_ids"][0] * 37 + 11) % (4096 - 8) + 5)
+    torch.manual_seed(31)
+    cfg = GemmaConfig(vocab_size=4096, hidden_size=2048, intermediate_size=16384, num_hidden_layers=18, num_attention_heads=8,
+                      num_key_value_heads=1, head_dim=256, max_position_embeddings=2048, rope_theta=10000.0)
+    with torch.device("cuda"):
+        model = GemmaForCausalLM(cfg).eval()
+    _round_params_to_fp16(model, 0.1)
+    tid, tm = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    with torch.no_grad():
+        out = model(input_ids=tid, attention_mask=tm, output_hidden_states=True)
+        want_h = last_token_pool(out.hidden_states[-1], tm).float().cpu().numpy()
+        want_logit = out.logits[:, -1, yes].float().cpu().numpy()
+    del out
+    sc = vf.HipDecoder.from_hf(model, score_token=yes)
+    got_logit = sc.forward(ids, mask)
+    sc.close()
+    emb = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    got_h = emb.forward(ids, mask)
+    emb.close()
+    del model
+    torch.cuda.empty_cache()
+    one_minus_cos, rel = _embedding_errors(got_h, want_h)
+    lerr = float(np.abs(got_logit - want_logit).max())
+    _measured("full_depth_gemma_2b", one_minus_cos=one_minus_cos, rel=rel, logit_abs_err=lerr, logit_scale=np.abs(want_logit).max(),
+              rows=ids.shape[0], width=ids.shape[1], layers=18)
+    assert one_minus_cos < FULL_GEMMA_COS_TOL and rel < FULL_GEMMA_REL_TOL, (one_minus_cos, rel)
+    assert lerr < FULL_GEMMA_LOGIT_TOL * max(1.0, float(np.abs(want_logit).max())), (got_logit, want_logit)
+
+
+def test_full_depth_qwen3_embedding_4b_geometry_last_token(vf):
+    """Qwen3-Embedding-4B's geometry (step3_mul.py:384, the reference's default embedder): 36 layers, hidden 2560, 32 query
+    / 8 kv heads of dim 128, SwiGLU 9728, q/k-norm, RoPE theta 1e6.  last_token_pool embeddings (step3_mul.py:181-209)
+    against HF fp32."""
+    import torch
+    from transformers import Qwen3Config, Qwen3Model
+    from veritasfi_amd.retrieval import last_token_pool
+    ids, mask, _ = _full_depth_rows(vf, seed=22)
+    torch.manual_seed(32)
+    cfg = Qwen3Config(vocab_size=4096, hidden_size=2560, intermediate_size=9728, num_hidden_layers=36, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, max_position_embeddings=4096, rope_theta=1000000.0,
+                      tie_word_embeddings=False)
+    with torch.device("cuda"):
+        model = Qwen3Model(cfg).eval()
+    _round_params_to_fp16(model, 0.1)
+    tid, tm = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    with torch.no_grad():
+        hs = model(input_ids=tid, attention_mask=tm).last_hidden_state
+        want = last_token_pool(hs, tm).float().cpu().numpy()
+    del hs
+    dec = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+    got = dec.forward(ids, mask)
+    dec.close()
+    del model
+    torch.cuda.empty_cache()
+    one_minus_cos, rel = _embedding_errors(got, want)
+    _measured("full_depth_qwen3_embedding_4b", one_minus_cos=one_minus_cos, rel=rel, rows=ids.shape[0], width=ids.shape[1], layers=36)
+    assert got.shape == (ids.shape[0], 2560)
+    assert one_minus_cos < FULL_QWEN_COS_TOL and rel < FULL_QWEN_REL_TOL, (one_minus_cos, rel)
 
 
 def test_decoder_embedder_drop_in(vf):

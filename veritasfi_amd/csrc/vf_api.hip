@@ -129,6 +129,7 @@ struct vf_index {
     int d = 0, dp = 0, dtype = 0;  // dtype: how rows are HELD in HBM (VF_DTYPE_F32 / _F16 / _FP8_E4M3)
     int64_t id_offset = 0;
     int n_cu = 256;
+    int64_t aux_applied = -1;   // the CU split the first slot's streams were created with (-1: no slot yet); fixed from then on
     bool owns_rows = false;
     void* rows_orig = nullptr;        // as given (fp32 or fp16), [n][d]
     void* rows_scan = nullptr;    // fp16 [n][dp]; may alias rows_orig
@@ -216,6 +217,7 @@ static int build_common(vf_index* ix) {
 // 0.362 ms per batch, 2.5M 0.717 -> 0.682, 5M 1.280 -> 1.269, 10M no change; profiles/r03_scan2_sweep.log).
 constexpr int64_t kSplitMaxRows = 6'000'000;
 static int64_t resolved_aux(const vf_index* ix) {
+    if (ix->aux_applied >= 0) return ix->aux_applied;   // what the existing scan streams are masked with (0 if masking failed)
     int64_t a = ix->aux_cus >= 0 ? ix->aux_cus : (ix->n <= kSplitMaxRows ? 32 : 0);
     if (a <= 0 || ix->n_cu < 64 || a * 2 > ix->n_cu) return 0;
     return a;
@@ -232,14 +234,18 @@ static int ensure_slot(vf_index* ix, Slot& s) {
     // leaves `aux_cus` CUs alone (mask bits interleave over the 8 XCDs: bits [0, n_cu - aux) = all but the last aux / 8 CUs
     // of every XCD; tools/ubench/cu_mask_probe.hip); everything else runs on an unmasked stream and finds those CUs free.
     s.scan_stream = s.stream;
-    if (const int64_t aux = resolved_aux(ix)) {
+    int64_t aux = resolved_aux(ix);
+    if (aux) {
         const int words = (ix->n_cu + 31) / 32;
         std::vector<uint32_t> mask(words, 0u);
         for (int b = 0; b < ix->n_cu - (int)aux; ++b) mask[b / 32] |= 1u << (b % 32);
         hipStream_t ms = nullptr;
         if (hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, mask.data()) == hipSuccess && ms) s.scan_stream = ms;
-        else (void)hipGetLastError();   // no CU masking on this stack: one stream, as before
+        else { (void)hipGetLastError(); if (ix->aux_applied < 0) aux = 0; }   // no CU masking on this stack: one stream, whole-chip grids
     }
+    // the split is a property of the streams: plans, stats and the overlap decision use what was APPLIED here, whatever the
+    // option is set to later (vf_index_set_option rejects a change once slots exist)
+    if (ix->aux_applied < 0) ix->aux_applied = aux;
     VF_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
     VF_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     VF_HIP(hipEventCreateWithFlags(&s.ev_scan, hipEventDisableTiming));
@@ -547,6 +553,8 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
     else if (s == "aux_cus") {   // takes effect for slots created afterwards (set it before the first search)
         if (!in_range(-1, 128)) return fail(VF_EINVAL, "aux_cus must be -1 (auto) or in [0, 128]");
+        if (ix->aux_applied >= 0 && value != ix->aux_cus)
+            return fail(VF_EINVAL, "aux_cus is fixed once the first search has created the scan streams: set it before searching");
         ix->aux_cus = value;
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }

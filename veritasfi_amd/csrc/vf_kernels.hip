@@ -840,7 +840,6 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
     if (a.debug & 2) return;  // timing experiment: never publish / refresh
     if constexpr (!PUBLISH) return;
     if (need) {
-        const u32 blk = (base + total) / R - 1u;  // the block this wave completed
         // (1) refresh one tau from what is published so far (two dependent L2 reads)
         const int nb = wave_tau_two_level(a.hist_coarse + qq * 64, a.hist + (long long)qq * kHistBins, a.kprime, lane);
         if (lane == 0 && nb > 0) {
@@ -851,6 +850,9 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
         //     Entries other waves claimed but have not written yet read w == 0 (the stage is zeroed at
         //     kernel start) and are skipped: the histogram then under-counts, which only makes tau
         //     less tight.
+        //     EVERY block this wave completed is published (round 4): with small blocks (refresh_every scaled down to 4 for
+        //     one or two queries) a wave's candidates can span several blocks, and the ones in the middle used to be lost.
+        for (u32 blk = base / R; blk < (base + total) / R; ++blk)
         for (u32 j = (u32)lane; j < R; j += 64u) {
             const u32 idx = blk * R + j;
             if (idx >= (u32)a.stage_cap) break;
@@ -1143,12 +1145,12 @@ constexpr int kScan2Waves = 4, kScan2Threads = (kScan2Waves + (kScan2Service ? 1
 
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
 }
 __device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {

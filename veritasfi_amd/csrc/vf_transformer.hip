@@ -1611,6 +1611,14 @@ struct LnFold {
     int loop2;               // main loop in TWO phases of 32 MFMAs per K-tile instead of four of 16 (see k_gemm8p_tn)
 };
 
+// split-K tail workspace of one handle (see gws_ensure)
+struct GemmWs {
+    float* ws = nullptr;
+    unsigned* cnt = nullptr;     // [kSkMaxTiles][2] arrivals + XCD mask, then 4 statistics words
+    size_t bytes = 0;
+};
+constexpr int kSkMaxTiles = 256;
+
 struct LnTail {
     half_t* x;               // LayerNorm output [M][N]
     const float* g;
@@ -2344,7 +2352,7 @@ __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, const c
     const unsigned long long ua = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
                                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(ua), "s"(base)
                  : "memory");
@@ -2981,7 +2989,7 @@ __device__ __forceinline__ void a2_read_v(h8 (&vf)[2][2], const char* Vs, int kt
 __device__ __forceinline__ void a2_dma16(const void* g, const char* lds) {
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(g), "s"(base)
                  : "memory");
@@ -4151,6 +4159,8 @@ __global__ __launch_bounds__(64) void k_token_logit(const half_t* x, const int* 
 // handle + C ABI
 // ------------------------------------------------------------------------------------------------
 using namespace vft;
+static hipError_t gws_ensure(GemmWs& g);
+static void gws_free(GemmWs& g);
 
 // Opt every kernel into its dynamic LDS size (idempotent; cheap).
 // VF_EXPERIMENTS (VF_BUILD_FLAGS="-DVF_EXPERIMENTS" python -m veritasfi_amd.build --force) compiles the measured-and-rejected
@@ -4270,6 +4280,7 @@ constexpr int kEncResidentT = 512;   // longest sequence whose K / V^T fit the r
 constexpr int kEncMaxT = 8192;       // longest sequence the encoder takes (streaming attention beyond kEncResidentT)
 
 struct vf_encoder {
+    GemmWs gws;
     vf_encoder_config cfg{};
     int device = 0;
     half_t* w16 = nullptr;   // all fp16 matrices
@@ -4359,6 +4370,7 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     enc_free_ws(e);
+    gws_free(e->gws);
     if (e->gstream) (void)hipStreamDestroy(e->gstream);
     if (e->w16) (void)hipFree(e->w16);
     if (e->w32) (void)hipFree(e->w32);
@@ -4491,6 +4503,7 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
     VFT_HIP(hipMemset(e->ctx, 0, Mp * H * 2));
     VFT_HIP(hipMemset(e->hbuf, 0, Mp * F * 2));
     e->cap_tokens = tokens; e->cap_b = B;
+    VFT_HIP(gws_ensure(e->gws));
     return VF_OK;
 }
 
@@ -4529,48 +4542,68 @@ extern "C" int vf_debug_gemm_8p_loop2(int on) { return on >= 0 ? g_loop2.exchang
 static LnFold lf_plain() { LnFold l{}; l.loop2 = g_loop2.load(std::memory_order_relaxed); return l; }
 static int device_cus();
 
-// split-K tail of the 8-phase products: one fp32 workspace + counters per device, grown on demand (forwards of one device
-// are serialised by their handles' streams; two handles on one device share it only if they run on the same stream order --
-// they do: every forward runs on the NULL stream or a captured graph replayed on it)
-static float* g_sk_tail_ws = nullptr;
-static unsigned* g_sk_tail_cnt = nullptr;
-static size_t g_sk_tail_bytes = 0;
-static int g_sk_tail_ntail = 0, g_sk_tail_dev = -1;
+// Split-K tail of the 8-phase products: fp32 partials + arrival counters.  The workspace belongs to a HANDLE (round 4: it
+// used to be process-global, which raced between handles on different threads / devices): each encoder / decoder / vision
+// handle allocates its own in *_ensure_ws -- never inside gemm(), so a forward under stream capture never allocates --
+// and passes it down; launches of one handle are serialised by its mutex and stream, and the buffer is freed only at destroy.
+// Sized for the largest cut gemm() makes: tail tiles x slices <= the CU count, 256 KB of partials each.
 static std::atomic<int> g_splitk_tail{getenv("VF_NO_SPLITK_TAIL") ? 0 : getenv("VF_SPLITK_TAIL") ? std::min(2, std::max(0, atoi(getenv("VF_SPLITK_TAIL")))) : 1};
 extern "C" int vf_debug_splitk_tail(int on) { return on >= 0 ? g_splitk_tail.exchange(on > 2 ? 2 : on) : g_splitk_tail.load(); }   // 0 off, 1 long-K products only (default), 2 every product with a partial last round
 static std::atomic<int> g_sk_dbg{0};
-// read-backs served by the slices' own L2 / from memory since the last call (and the timing-experiment switches of LnFold::sk_dbg)
+static bool splitk_tail_on() { return g_splitk_tail.load(std::memory_order_relaxed) != 0; }
+static std::mutex g_gws_mu;
+static std::vector<GemmWs*> g_gws_all;    // every live workspace (statistics hook only)
+static hipError_t gws_ensure(GemmWs& g) {   // current device = the handle's
+    if (g.ws) return hipSuccess;
+    const size_t nb = (size_t)std::max(device_cus(), kSkMaxTiles) * PBM * PBN * sizeof(float);
+    hipError_t e = hipMalloc((void**)&g.ws, nb);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.cnt, ((size_t)kSkMaxTiles * 2 + 4) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(g.cnt, 0, ((size_t)kSkMaxTiles * 2 + 4) * sizeof(unsigned));
+    if (e != hipSuccess) {
+        if (g.ws) (void)hipFree(g.ws);
+        if (g.cnt) (void)hipFree(g.cnt);
+        g.ws = nullptr; g.cnt = nullptr;
+        return e;
+    }
+    g.bytes = nb;
+    std::lock_guard<std::mutex> lk(g_gws_mu);
+    g_gws_all.push_back(&g);
+    return hipSuccess;
+}
+static void gws_free(GemmWs& g) {           // the owner has synchronised its device
+    {
+        std::lock_guard<std::mutex> lk(g_gws_mu);
+        g_gws_all.erase(std::remove(g_gws_all.begin(), g_gws_all.end(), &g), g_gws_all.end());
+    }
+    if (g.ws) (void)hipFree(g.ws);
+    if (g.cnt) (void)hipFree(g.cnt);
+    g.ws = nullptr; g.cnt = nullptr; g.bytes = 0;
+}
+// read-backs served by the slices' own L2 / from memory since the last call, summed over the live workspaces of the current
+// device (and the timing-experiment switches of LnFold::sk_dbg)
 extern "C" int vf_debug_splitk_stats(unsigned* out2, int dbg) {
     if (dbg >= 0) g_sk_dbg.store(dbg);
-    if (!g_sk_tail_cnt || !out2) return 0;
+    if (!out2) return 0;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    unsigned* p = g_sk_tail_cnt + 2 * (size_t)g_sk_tail_ntail;
-    if (hipMemcpy(out2, p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return hipMemset(p, 0, 4 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
-}
-static bool splitk_tail_on() { return g_splitk_tail.load(std::memory_order_relaxed) != 0; }
-static hipError_t sk_tail_ensure(size_t bytes, int ntail) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev == g_sk_tail_dev && bytes <= g_sk_tail_bytes && ntail <= g_sk_tail_ntail) return hipSuccess;
-    e = hipDeviceSynchronize();   // nobody is using the old buffers
-    if (e != hipSuccess) return e;
-    if (g_sk_tail_ws) (void)hipFree(g_sk_tail_ws);
-    if (g_sk_tail_cnt) (void)hipFree(g_sk_tail_cnt);
-    g_sk_tail_ws = nullptr; g_sk_tail_cnt = nullptr; g_sk_tail_bytes = 0; g_sk_tail_ntail = 0; g_sk_tail_dev = -1;
-    const size_t nb = std::max(bytes, g_sk_tail_bytes);
-    const int nt = std::max(ntail, 256);
-    if ((e = hipMalloc((void**)&g_sk_tail_ws, nb)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&g_sk_tail_cnt, ((size_t)nt * 2 + 4) * sizeof(unsigned))) != hipSuccess) return e;   // arrivals + XCD mask per tile, then 4 statistics words
-    if ((e = hipMemset(g_sk_tail_cnt, 0, ((size_t)nt * 2 + 4) * sizeof(unsigned))) != hipSuccess) return e;
-    g_sk_tail_bytes = nb; g_sk_tail_ntail = nt; g_sk_tail_dev = dev;
-    return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_gws_mu);
+    out2[0] = out2[1] = 0;
+    int seen = 0;
+    for (GemmWs* g : g_gws_all) {
+        hipPointerAttribute_t at{};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipPointerGetAttributes(&at, g->cnt) != hipSuccess || at.device != dev) { (void)hipGetLastError(); continue; }
+        unsigned v[2] = {0, 0};
+        unsigned* p = g->cnt + 2 * (size_t)kSkMaxTiles;
+        if (hipMemcpy(v, p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemset(p, 0, 4 * sizeof(unsigned)) != hipSuccess) return -1;
+        out2[0] += v[0]; out2[1] += v[1]; ++seen;
+    }
+    return seen ? 1 : 0;
 }
 
 template <int EPI>
 static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N,
-                       int K, hipStream_t st, int force_kind = 0) {
+                       int K, hipStream_t st, int force_kind = 0, GemmWs* gws = nullptr) {
     // Tile choice (VF_GEMM_KIND overrides for A/B runs: 5 = DMA 128x256 with 16x16x32 MFMAs (the default large-problem
     // kernel), 6 = its 128-wide instance, 1 = 128x256 with 32x32x16 MFMAs, 2 = 256x256, 3 = 128x128):
     //  * 128 x 256 DMA tiles, two workgroups per CU, when they give at least VF_GEMM_DMA_MIN_WGS workgroups
@@ -4645,9 +4678,9 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
             const int mode = g_splitk_tail.load(std::memory_order_relaxed);
             int S = ntail > 0 ? std::min(std::min(cus / pad, nk / 2), 4) : 0;
             if (mode == 1) S = (nk >= 32 && S >= 2 && tiles > cus) ? 2 : 0;
-            if (S >= 2 && splitk_tail_on() && sk_tail_ensure((size_t)ntail * S * PBM * PBN * sizeof(float), ntail) == hipSuccess) {
-                lf.sk_ws = g_sk_tail_ws; lf.sk_cnt = g_sk_tail_cnt; lf.sk_nfull = tiles - ntail; lf.sk_S = S; lf.sk_ntail = ntail;
-                lf.sk_stat = g_sk_tail_cnt + 2 * (size_t)g_sk_tail_ntail; lf.sk_dbg = g_sk_dbg.load(std::memory_order_relaxed);
+            if (S >= 2 && splitk_tail_on() && gws && gws->ws && ntail <= kSkMaxTiles && (size_t)ntail * S * PBM * PBN * sizeof(float) <= gws->bytes) {
+                lf.sk_ws = gws->ws; lf.sk_cnt = gws->cnt; lf.sk_nfull = tiles - ntail; lf.sk_S = S; lf.sk_ntail = ntail;
+                lf.sk_stat = gws->cnt + 2 * (size_t)kSkMaxTiles; lf.sk_dbg = g_sk_dbg.load(std::memory_order_relaxed);
                 grid = tiles - ntail + pad * S;
             }
         }
@@ -4985,7 +5018,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             lf.stats_in = e->stats_b; lf.colsum = f32;
             VFT_HIP(gemm8p_fold<EPI_LNA>(e->x, f16, f32 + 3 * H, nullptr, e->qkv, Mp, 3 * H, H, lf, st));
         }
-        else VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st));
+        else VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st, 0, &e->gws));
         static const bool att_stream = getenv("VF_ATT_STREAM") != nullptr;  // A/B switch: streaming kernel on the BERT path
         // Sequences longer than 512 tokens (bge-m3 = XLM-R-large with an 8194-entry position table: config/example.yaml:3,
         // src/utils/ragManager.py:50) cannot keep K and V^T of a head resident in LDS: they take the streaming kernel
@@ -5036,10 +5069,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         }
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
         else if ((fused_ln = gemm_residual_ln(e, e->ctx, Wo, bo, e->x, e->y, g1, b1n, Mp, H, H, st, &ler))) VFT_HIP(ler);
-        else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st));
+        else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st, 0, &e->gws));
         if (!fused_ln) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, M, F, H, st));
-        else VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st));
+        else VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st, 0, &e->gws));
         fused_ln = false;
         if (skinny) {
             VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, M, H, F, st, e->sk_part, e->sk_cnt));
@@ -5051,7 +5084,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         } else if ((fused_ln = gemm_residual_ln(e, e->hbuf, W2, b2, e->x, e->y, g2, b2n, Mp, H, F, st, &ler))) {
             VFT_HIP(ler);
         } else {
-            VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st));
+            VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st, 0, &e->gws));
         }
         if (!fused_ln) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
     }
@@ -5269,6 +5302,7 @@ extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e)
 constexpr int kDecMaxT = 4096;  // the reference truncates at max_length=4096 (step3_mul.py:200); streaming attention has no residency limit, the RoPE table is sized for this
 
 struct vf_decoder {
+    GemmWs gws;
     vf_decoder_config cfg{};
     int device = 0;
     half_t* w16 = nullptr;
@@ -5338,6 +5372,7 @@ extern "C" int vf_decoder_destroy(vf_decoder* d) {
     (void)hipSetDevice(d->device);
     (void)hipDeviceSynchronize();
     dec_free_ws(d);
+    gws_free(d->gws);
     if (d->w16) (void)hipFree(d->w16);
     if (d->w32) (void)hipFree(d->w32);
     if (d->d_flag) (void)hipFree(d->d_flag);
@@ -5413,6 +5448,7 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, nullptr, c.rope_theta, kDecMaxT, c.head_dim, d->rope);
     VFT_HIP(hipGetLastError());
     d->cap_tokens = tokens; d->cap_b = B; d->rope_T = kDecMaxT;
+    VFT_HIP(gws_ensure(d->gws));
     return VF_OK;
 }
 
@@ -5436,7 +5472,7 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         const float* P = d->w32 + d->f_layers + (size_t)l * d->layer32;
         const float *ln1 = P, *ln2 = P + H, *qn = P + 2 * H, *kn = qn + DH;
         hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3((M + 7) / 8), dim3(256), 0, st, px, ln1, woff, c.rms_eps, M, H, d->n);
-        VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st));
+        VFT_HIP(gemm<EPI_BIAS>(d->n, Wqkv, nullptr, nullptr, d->qkv, Mp, QKV, H, st, 0, &d->gws));
         hipLaunchKernelGGL(k_qknorm_rope, dim3((M + 256 / (DH / 16) - 1) / (256 / (DH / 16)), 3), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
                            qn, kn, c.rms_eps, c.qk_norm, d->rope, pos);
         if (DH == 64) {
@@ -5475,7 +5511,7 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         hipLaunchKernelGGL(k_rmsnorm<half_t>, dim3((M + 7) / 8), dim3(256), 0, st, px, ln2, woff, c.rms_eps, M, H, d->n);
         hipError_t ger = hipSuccess;
         if (!gemm_gated(d->n, Wgu, d->act, Mp, F, H, c.act, st, &ger)) {   // gate / up products and the activation in one launch
-            VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st));
+            VFT_HIP(gemm<EPI_BIAS>(d->n, Wgu, nullptr, nullptr, d->gu, Mp, 2 * F, H, st, 0, &d->gws));
             hipLaunchKernelGGL(k_swiglu, dim3(((F >> 3) + 255) / 256, M < 32768 ? M : 32768), dim3(256), 0, st, d->gu, (long long)M, F, c.act,
                                d->act);
         }
@@ -5648,6 +5684,7 @@ extern "C" int vf_decoder_forward_hidden(vf_decoder* d, const int32_t* ids, cons
 // activation), and the class-token head.
 // ------------------------------------------------------------------------------------------------
 struct vf_vit {
+    GemmWs gws;
     vf_vit_config cfg{};
     int device = 0;
     int P = 0, T = 0, Tp = 0, Kp = 0;     // patches per image, tokens (P + 1), tokens padded to 32, patch length padded to 64
@@ -5798,6 +5835,7 @@ extern "C" int vf_vit_destroy(vf_vit* v) {
     (void)hipSetDevice(v->device);
     (void)hipDeviceSynchronize();
     vit_free_ws(v);
+    gws_free(v->gws);
     if (v->w16) (void)hipFree(v->w16);
     if (v->w32) (void)hipFree(v->w32);
     delete v;
@@ -5885,6 +5923,7 @@ static int vit_ensure_ws(vf_vit* v, int B) {
     VFT_HIP(hipMemset(v->hbuf, 0, Mp * F * 2));
     VFT_HIP(hipMemset(v->d_mask, 0, Mp * 4));
     v->cap_b = B;
+    VFT_HIP(gws_ensure(v->gws));
     return VF_OK;
 }
 
@@ -5924,7 +5963,7 @@ static int vit_forward_impl(vf_vit* v, const float* pixels, const unsigned char*
         hipLaunchKernelGGL(k_vit_unfold<float>, dim3(2048), dim3(256), 0, st, (const float*)v->d_pix, b, c.channels, c.image, c.patch, Kp, Rp,
                            1.f, 1.f, 1.f, 0.f, 0.f, 0.f, v->patches);
     }
-    VFT_HIP(gemm<EPI_BIAS>(v->patches, v->w16 + v->o_patch, nullptr, nullptr, v->emb, Rp, H, Kp, st));
+    VFT_HIP(gemm<EPI_BIAS>(v->patches, v->w16 + v->o_patch, nullptr, nullptr, v->emb, Rp, H, Kp, st, 0, &v->gws));
     hipLaunchKernelGGL(k_vit_embed, dim3((M + 7) / 8), dim3(256), 0, st, v->emb, v->w16 + v->o_cls, v->w16 + v->o_pos, v->w32 + v->f_pre,
                        v->w32 + v->f_pre + H, c.ln_eps, b, P, Tp, H, v->x, v->d_mask);
     for (int l = 0; l < c.layers; ++l) {
@@ -5933,13 +5972,13 @@ static int vit_forward_impl(vf_vit* v, const float* pixels, const unsigned char*
         const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
         const float *g1 = f, *b1n = g1 + H, *bqkv = b1n + H, *bo = bqkv + 3 * H, *g2 = bo + H, *b2n = g2 + H, *b1 = b2n + H, *b2 = b1 + F;
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, v->x, g1, b1n, c.ln_eps, M, H, v->t);
-        VFT_HIP(gemm<EPI_BIAS>(v->t, Wqkv, bqkv, nullptr, v->qkv, Mp, 3 * H, H, st));
+        VFT_HIP(gemm<EPI_BIAS>(v->t, Wqkv, bqkv, nullptr, v->qkv, Mp, 3 * H, H, st, 0, &v->gws));
         launch_attention2<0>(v->qkv, v->d_mask, b, Tp, c.heads, v->ctx, st);
-        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->ctx, Wo, bo, v->x, v->y, Mp, H, H, st));
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->ctx, Wo, bo, v->x, v->y, Mp, H, H, st, 0, &v->gws));
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, v->y, g2, b2n, c.ln_eps, M, H, v->t);
-        if (c.act == 0) VFT_HIP(gemm<EPI_BIAS_GELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st));
+        if (c.act == 0) VFT_HIP(gemm<EPI_BIAS_GELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st, 0, &v->gws));
         else VFT_HIP(gemm<EPI_BIAS_QGELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st));
-        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->hbuf, W2, b2, v->y, v->x, Mp, H, F, st));
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->hbuf, W2, b2, v->y, v->x, Mp, H, F, st, 0, &v->gws));
     }
     hipLaunchKernelGGL(k_vit_head, dim3(b), dim3(256), (size_t)(H + 256) * sizeof(float), st, v->x, Tp, H, v->w32 + v->f_post, v->w32 + v->f_post + H,
                        c.ln_eps, v->w16 + v->o_proj, c.proj_dim, c.normalize, v->d_out);
@@ -5970,6 +6009,13 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;
+    // the hook's own split-K workspace: one per device, never freed, calls serialised (a test hook, not a serving path)
+    static std::mutex hook_mu;
+    static GemmWs hook_ws[16];
+    std::lock_guard<std::mutex> hook_lk(hook_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || gws_ensure(hook_ws[dev]) != hipSuccess) return -1;
+    GemmWs* gws = &hook_ws[dev];
     if (epi == EPI_GATED_SILU || epi == EPI_GATED_GELU) {   // W = [gate rows (N / 2) | up rows (N / 2)], C is M x N / 2
         if (!gemm_gated(a, w, c, M, N / 2, K, epi == EPI_GATED_GELU, st, &er)) return -2;
         return er == hipSuccess ? 0 : -1;
@@ -5978,10 +6024,10 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
         er = gemm<EPI_RESIDUAL_F32>(a, w, nullptr, r, c, M, N, K, st, kind);
         return er == hipSuccess ? 0 : -1;
     }
-    if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st, kind);
-    else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st, kind);
-    else if (epi == EPI_BIAS_QGELU) er = gemm<EPI_BIAS_QGELU>(a, w, bias, r, c, M, N, K, st, kind);
-    else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st, kind);
+    if (epi == EPI_BIAS) er = gemm<EPI_BIAS>(a, w, bias, r, c, M, N, K, st, kind, gws);
+    else if (epi == EPI_BIAS_GELU) er = gemm<EPI_BIAS_GELU>(a, w, bias, r, c, M, N, K, st, kind, gws);
+    else if (epi == EPI_BIAS_QGELU) er = gemm<EPI_BIAS_QGELU>(a, w, bias, r, c, M, N, K, st, kind, gws);
+    else er = gemm<EPI_BIAS_RESIDUAL>(a, w, bias, r, c, M, N, K, st, kind, gws);
     return er == hipSuccess ? 0 : -1;
 }
 
