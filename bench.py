@@ -367,8 +367,10 @@ def c4_chain(args, torch, vf, corpus):
     rr = vf.HipReranker(HashTokenizer(r_cfg["vocab"]), r_enc, max_length=512)
     rng = np.random.default_rng(5)
     passages = [sentence(rng, 470) for _ in range(256)]       # chunk texts by id (mod 256): ~512 tokens per pair
-    stages = {k: [] for k in ("embed_query", "search_top100", "rerank_100x512", "similarity_mtx", "fuse_select", "chain")}
+    stages = {k: [] for k in ("embed_query", "search_top100", "rerank_100x512", "rerank_tokenize_stand_in", "rerank_device_call",
+                              "similarity_mtx", "similarity_mtx_rows", "fuse_select", "chain", "chain_rows")}
     clock = time.perf_counter
+    r_tok = rr.tokenizer
     with vf.DenseIndex(corpus[:n]) as ix:
         for it in range(10):
             question = sentence(rng, 16)
@@ -377,12 +379,20 @@ def c4_chain(args, torch, vf, corpus):
             t1 = clock()
             ids, _ = ix.search(qv, 100)
             t2 = clock()
-            chunks = [{"page_content": passages[int(i) % 256] + f" #{int(i)}", "bundle_id": j // 2,
+            chunks = [{"page_content": passages[int(i) % 256] + f" #{int(i)}", "bundle_id": j // 2, "row_id": int(i),
                        "metadata": {"date_published": f"2024-{1 + j % 12:02d}-{1 + j % 28:02d}"}} for j, i in enumerate(ids[0])]
-            scores = rr.compute_score([[question, c["page_content"]] for c in chunks], batch_size=8)
+            pairs = [[question, c["page_content"]] for c in chunks]
+            scores = rr.compute_score(pairs, batch_size=8)
             t3 = clock()
+            # the same call split: the tokenizer (a Python stand-in here; third-party, as upstream) and the library call
+            enc_in = r_tok([p[0] for p in pairs], [p[1] for p in pairs], padding=True, truncation=True, max_length=512, return_tensors="np")
+            t3a = clock()
+            r_enc.forward(enc_in["input_ids"], enc_in["attention_mask"])
+            t3b = clock()
             mtx = vf.compute_similarity_mtx(emb, [c["page_content"] for c in chunks], as_torch=False)
             t4 = clock()
+            mtx_rows = vf.compute_similarity_mtx(emb, [c["page_content"] for c in chunks], as_torch=False, index=ix, row_ids=ids[0])
+            t4r = clock()
 
             class _Cached:      # rank_chunk calls compute_score itself; the stage split above already paid for it once
                 def compute_score(self, pairs, batch_size=8):
@@ -392,11 +402,36 @@ def c4_chain(args, torch, vf, corpus):
             tc = clock()
             picked2 = vf.rank_chunk(chunks, question, datetime(2024, 6, 15), rr, emb, 20)
             chain = (t2 - t0) + (clock() - tc)
-            assert picked2 == picked and len(picked) <= 20 and mtx.shape == (100, 100)
+            tc = clock()
+            picked3 = vf.rank_chunk(chunks, question, datetime(2024, 6, 15), rr, emb, 20, similarity_index=ix)
+            chain_rows = (t2 - t0) + (clock() - tc)
+            assert picked2 == picked and len(picked) <= 20 and mtx.shape == mtx_rows.shape == (100, 100) and len(picked3) <= 20
             if it >= 2:
-                for key, v in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, (t5 - t4) - (t4 - t3), chain)):
+                for key, v in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t3a - t3, t3b - t3a, t4 - t3b, t4r - t4, (t5 - t4r) - (t4 - t3b), chain, chain_rows)):
                     stages[key].append(v * 1e3)
     e_enc.close(); r_enc.close()
+    mixed = None
+    try:      # the query side of the figure leg: the same question through the CLIP TEXT tower (ViT-L/14's: 12 x 768, 77 positions)
+        from bench_vision import ClipHashTokenizer, random_clip_text
+        t_enc, t_cfg = random_clip_text("vit-l-14")
+        cemb = vf.HipClipTextEmbeddings(ClipHashTokenizer(t_cfg["vocab"]), t_enc)
+        cemb.embed_query(sentence(rng, 16))
+        ts = []
+        for _ in range(8):
+            qn = sentence(rng, 16)
+            t0 = clock(); cv = cemb.embed_query(qn); ts.append(clock() - t0)
+        docs = [sentence(rng, 30) for _ in range(256)]
+        cemb.embed_documents(docs)
+        t0 = clock(); cemb.embed_documents(docs); tb = clock() - t0
+        t_enc.close()
+        mixed = {"clip_text_tower": "vit-l-14 text tower (12 layers, 768 wide, 77 positions, 768-d projection), random weights",
+                 "embed_query_p50_ms": round(float(np.median(ts)) * 1e3, 3), "embed_256_captions_ms": round(tb * 1e3, 3),
+                 "out_dim": len(cv),
+                 "what": "a query is embedded by BOTH towers (the text embedder above and this one); each vector searches the rows of its "
+                         "own space in ONE 768-wide matrix (veritasfi_amd.mixed.MixedModalIndex: text + table-as-text rows | figure rows); "
+                         "tests/test_gpu_retrieval.py::test_c4_mixed_modality_index_text_table_figure runs it at 5M rows against the oracle"}
+    except Exception as e:  # noqa: BLE001
+        mixed = {"error": f"{type(e).__name__}: {e}"}
     figure = None
     try:      # the figure leg of the config: images -> the same 768-wide space (random-init ViT-L/14 geometry, seeded pixels)
         from bench_vision import random_vit, flops_per_image
@@ -413,12 +448,15 @@ def c4_chain(args, torch, vf, corpus):
                   "frac": round(flops_per_image(v_cfg) * 64 / p50 / 2.5e15, 4), "out_dim": int(out.shape[1]), "pcie_inclusive": True}
     except Exception as e:  # noqa: BLE001
         figure = {"error": f"{type(e).__name__}: {e}"}
-    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20, "figure_encoder": figure,
+    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20, "figure_encoder": figure, "mixed_modality": mixed,
             "p50_ms": {k: round(float(np.median(v)), 3) for k, v in stages.items()},
             "what": "configs[3] text leg: embed_query (bert-base shape, ~20 tokens) -> vf_index_search top-100 (host entry) -> "
                     "HipReranker.compute_score over 100 pairs of ~512 tokens (xlmr-base shape) -> rank_chunk (re-embeds the 100 "
                     "chunks in ONE batched call for the similarity matrix, vf_fuse_rank, greedy selection); chain = embed + "
-                    "search + rank_chunk with the real scorer; random weights, hash tokenizer stand-in (no checkpoints offline)"}
+                    "search + rank_chunk with the real scorer; chain_rows = the same with the similarity matrix taken from the corpus rows "
+                    "by id (vf_cosine_matrix_rows, opt-in: rank_chunk(..., similarity_index=ix)) instead of re-embedding the 100 chunks; "
+                    "rerank_100x512 = rerank_tokenize_stand_in (a Python whitespace-hash tokenizer standing in for the third-party one) + "
+                    "rerank_device_call (HipEncoder.forward: H2D, forward, D2H); random weights (no checkpoints offline)"}
 
 
 def rerank_p50_sharded(args, device):

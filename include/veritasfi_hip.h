@@ -157,6 +157,11 @@ int vf_index_destroy(vf_index* idx);
  * src/utils/ensembleRetriever.py:275-279 (compute_similarity_mtx after the embed loop):
  * x [n,d] fp32 host -> out [n,n] fp32 host, canonical cosine of every row pair. */
 int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out, int32_t device_id);
+/* The same matrix for n rows ALREADY in the index, picked by global id (out [n,n] fp32 host, n <= 4096): what vf_cosine_matrix
+ * returns for those rows' values, without re-embedding the chunk texts (ensembleRetriever.py:275 embeds each of the n
+ * retrieved chunks again; their embeddings are rows of the HBM-resident corpus).  Valid when the embedder treats documents and
+ * queries alike (the reference embeds both with embed_query, :275 and faissRetriever.py:33).  Single-device handles. */
+int vf_cosine_matrix_rows(vf_index* idx, const int64_t* ids, int32_t n, float* out);
 
 /* experiments/retriever/step3_mul.py:275 (similarities_matrix = cosine_similarity(E, C)):
  * a [na,d], b [nb,d] fp32 host -> out [na,nb] fp32 host. */
@@ -295,6 +300,33 @@ int vf_vit_forward(vf_vit* vit, const float* pixels, int32_t b, float* out);
  * (x / 255 - mean[c]) / std[c] -- the image processor's rescale + normalize; a quarter of the PCIe bytes */
 int vf_vit_forward_u8(vf_vit* vit, const unsigned char* pixels, const float* mean3, const float* std3, int32_t b, float* out);
 int vf_vit_destroy(vf_vit* vit);
+
+/* ---- CLIP text tower: the QUERY side of the figure leg (BASELINE configs[3]) ------------------------------------------------
+ * Figure rows are CLIP image embeddings (vf_vit_*); a text query can only be compared with them after going through the same
+ * model's text tower -- transformers' CLIPTextModelWithProjection: text_embeds = text_projection(final_layer_norm(h)[eos]).
+ * Token + learned position embeddings, PRE-LayerNorm layers with CAUSAL attention plus the key-padding mask, head dim 64,
+ * at most 512 positions (CLIP: 77).  The reference has no counterpart (its ingest embeds text only, src/load_data.py:98-128);
+ * the embedder surface it would be injected through is the one of src/utils/ragManager.py:50 (embed_query / embed_documents). */
+typedef struct vf_clip_text vf_clip_text;
+typedef struct vf_clip_text_config {
+    int32_t vocab, max_pos;         /* 49408, 77 */
+    int32_t hidden, layers, heads, ffn; /* ViT-L/14's text tower: 768, 12, 12, 3072 */
+    int32_t proj_dim;               /* width of the joint space (768 for ViT-L/14) */
+    int32_t act;                    /* 0 erf-GELU, 1 quick-GELU */
+    int32_t eos_token_id;           /* 2 (legacy configs of the published checkpoints): pool at argmax(ids); else at the first such id */
+    int32_t normalize;              /* 1: L2-normalise the projected vector */
+    float ln_eps;
+} vf_clip_text_config;
+/* Weight blobs (host), in this order.  fp16: token[vocab,H] pos[max_pos,H], then per layer Wqkv[3H,H] (q rows, k rows, v rows)
+ * Wo[H,H] W1[F,H] W2[H,F], then proj[proj_dim,H].  fp32: per layer ln1_gamma[H] ln1_beta[H] bqkv[3H] bo[H] ln2_gamma[H]
+ * ln2_beta[H] b1[F] b2[H], then final_ln_gamma[H] final_ln_beta[H]. */
+int vf_clip_text_weight_sizes(const vf_clip_text_config* cfg, int64_t* n_fp16, int64_t* n_fp32);
+int vf_clip_text_create(vf_clip_text** out, const vf_clip_text_config* cfg, const void* w_fp16, int64_t n_fp16, const float* w_fp32,
+                        int64_t n_fp32, int32_t device_id);
+/* ids [b, t] int32 host, right-padded, t <= max_pos; mask [b, t] (1 = token) or NULL (every position valid: what the HF
+ * pipeline passes) -> out [b, proj_dim] fp32 host */
+int vf_clip_text_forward(vf_clip_text* ct, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, float* out);
+int vf_clip_text_destroy(vf_clip_text* ct);
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,10 @@ _ROOT = ROOT
 # last-token embedding 1.35e-3, largest "Yes"-logit error 7.8e-4 on logits of magnitude 0.3 - 0.8): ~2-4x those.
 DEC_COS_TOL, DEC_REL_TOL, DEC_LOGIT_TOL = 3e-6, 3e-3, 2.5e-3
 # full-depth models (18 / 36 layers at the real widths): ~3x what the first GPU run measured (profiles/r04_decoder_errors.jsonl)
-FULL_GEMMA_COS_TOL, FULL_GEMMA_REL_TOL, FULL_GEMMA_LOGIT_TOL = 1e-4, 3e-2, 3e-2
-FULL_QWEN_COS_TOL, FULL_QWEN_REL_TOL = 1e-4, 3e-2
+# measured: gemma-2b geometry 1 - cos 9.5e-7, relative error 1.5e-3, "Yes"-logit error 2.9e-3 on logits of magnitude 1.9 (1.5e-3
+# relative); Qwen3-Embedding-4B geometry 1 - cos 4.5e-6, relative error 2.5e-3
+FULL_GEMMA_COS_TOL, FULL_GEMMA_REL_TOL, FULL_GEMMA_LOGIT_TOL = 3e-6, 4.5e-3, 5e-3
+FULL_QWEN_COS_TOL, FULL_QWEN_REL_TOL = 1.5e-5, 7.5e-3
 
 
 @pytest.fixture(scope="module")

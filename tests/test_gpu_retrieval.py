@@ -343,6 +343,50 @@ def test_small_dense_ops(vf, oracle):
     assert np.array_equal(order, R.fuse_and_rank(rer, t))
 
 
+def test_cosine_matrix_of_index_rows_by_id(vf, oracle):
+    """vf_cosine_matrix_rows: the similarity matrix of retrieved chunks from the corpus rows in HBM (round-3 review, item 6) ==
+    the canonical cosine matrix of those rows' values, bit for bit, for fp32 / fp16 / e4m3 corpora, with an id offset,
+    duplicates in the id list, and the error paths."""
+    from oracle import ref_numpy as R
+    import torch
+    rng = np.random.default_rng(31)
+    c32 = rng.standard_normal((30_000, 768)).astype(np.float32)
+    ids = rng.integers(0, 30_000, 100)
+    ids[7] = ids[3]                                                   # the same chunk twice: cosine exactly as for a pair of equal rows
+    for rows, vals, off in ((c32, c32, 0), (c32.astype(np.float16), c32.astype(np.float16).astype(np.float32), 1_000_000)):
+        with vf.DenseIndex(rows, id_offset=off) as ix:
+            m = ix.cosine_matrix_rows(ids + off)
+            assert m.shape == (100, 100) and np.array_equal(_bits(m), _bits(oracle.cosine(vals[ids], vals[ids])))
+            assert np.array_equal(_bits(m), _bits(vf.cosine_matrix(vals[ids])))
+            assert ix.cosine_matrix_rows([]).shape == (0, 0)
+            with pytest.raises(RuntimeError, match="outside the index"):
+                ix.cosine_matrix_rows([off - 1])
+            with pytest.raises(RuntimeError, match="outside the index"):
+                ix.cosine_matrix_rows([off + 30_000])
+    codes = _e4m3_codes(20_000, 256, 33)
+    dec = R.decode_e4m3(codes).astype(np.float32)
+    sel = rng.integers(0, 20_000, 40)
+    with vf.DenseIndex.from_e4m3(codes) as ix:
+        assert np.array_equal(_bits(ix.cosine_matrix_rows(sel)), _bits(oracle.cosine(dec[sel], dec[sel])))
+    # the opt-in route of compute_similarity_mtx / rank_chunk equals the re-embed route when the rows ARE the chunks' embeddings
+    table = rng.standard_normal((500, 128)).astype(np.float32)
+
+    class FakeEmb:
+        def embed_documents(self, texts):
+            return [table[int(t)].tolist() for t in texts]
+
+    picked = [int(i) for i in rng.integers(0, 500, 60)]
+    with vf.DenseIndex(table) as ix:
+        a = vf.compute_similarity_mtx(FakeEmb(), [str(i) for i in picked], as_torch=False)
+        b = vf.compute_similarity_mtx(FakeEmb(), [str(i) for i in picked], as_torch=False, index=ix, row_ids=picked)
+        assert np.array_equal(_bits(a), _bits(b))
+        with pytest.raises(ValueError):
+            vf.compute_similarity_mtx(FakeEmb(), ["1", "2"], index=ix, row_ids=[1])
+    with vf.DenseIndex(c32[:4000], device_ids=[0, 0]) as grp:          # rows on several devices: refused, not guessed
+        with pytest.raises(RuntimeError, match="sharded"):
+            grp.cosine_matrix_rows([1, 2])
+
+
 def test_drop_in_classes(vf, oracle):
     """FaissRetriever / compute_similarity_mtx / select_top_chunks with the reference's call shapes."""
     rng = np.random.default_rng(28)
@@ -732,6 +776,96 @@ def test_c4_5m_end_to_end(vf, oracle):
     want = R.rank_chunk([c["bundle_id"] for c in chunks], scores, ts, embs, 20, 0.9)
     assert got == want and 0 < len(got) <= 10
     e_enc.close(); r_enc.close()
+
+
+def test_c4_mixed_modality_index_text_table_figure(vf, oracle):
+    """configs[3] as ONE index at the configured size: 5M x 768 rows in HBM, one id space -- text rows (the bench's corpus),
+    2000 TABLE rows embedded from table-as-text by HipEmbeddings (the reference's own route for tables: every chunk goes
+    through embed_documents, src/load_data.py:120-128; table-transformer is an upstream detector, not an embedder) and a
+    250k-row FIGURE segment in CLIP's joint space holding 256 real ViT-L/14-geometry image embeddings.  One text query is
+    embedded by BOTH towers (bge-base shape; CLIP ViT-L/14's text tower), each vector searches its own space: top-100 of
+    each against the oracle over the host copy of that space's rows (ids and score bits); a table's own text and a figure's
+    own image find their rows; the text hits and the best figure hits (by caption) go through the cross-encoder and
+    rank_chunk keeps at most 20, equal to the oracle's restatement fed with the same model outputs."""
+    import sys
+    import torch
+    import bench
+    from datetime import datetime
+    from oracle import ref_numpy as R
+    from veritasfi_amd.mixed import MixedModalIndex, MixedModalRetriever, TEXT_SPACE, CLIP_SPACE
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _synth import HashTokenizer, sentence
+    from bench_rerank import random_encoder
+    from bench_vision import ClipHashTokenizer, random_clip_text, random_vit
+    n, d, k = 5_000_000, 768, 100
+    n_fig, n_tab, n_img = 250_000, 2000, 256
+    fig_lo, tab_lo = n - n_fig, n - n_fig - n_tab
+    dev = torch.device("cuda", 0)
+    corpus = bench.make_shard(torch, 0, n, d, dev, "f16")
+    e_enc, e_cfg = random_encoder("bert-base", head=0)
+    r_enc, r_cfg = random_encoder("xlmr-base", head=1, vocab=32000)
+    t_enc, t_cfg = random_clip_text("vit-l-14", vocab=8192)
+    v_enc, v_cfg = random_vit("vit-l-14")
+    emb = vf.HipEmbeddings(HashTokenizer(e_cfg["vocab"]), e_enc, max_length=512, batch_size=100)
+    cemb = vf.HipClipTextEmbeddings(ClipHashTokenizer(t_cfg["vocab"]), t_enc)
+    rr = vf.HipReranker(HashTokenizer(r_cfg["vocab"]), r_enc, max_length=512)
+    rng = np.random.default_rng(7)
+    # tables as text: "header | header ... ; cell | cell ..." rows, embedded by the TEXT embedder
+    tables = [" ; ".join(" | ".join(sentence(rng, 3).split()) for _ in range(4)) + f" table{j}" for j in range(n_tab)]
+    tvec = np.asarray(emb.embed_documents(tables), np.float32)
+    assert tvec.shape == (n_tab, d)
+    corpus[tab_lo:fig_lo] = torch.from_numpy(tvec.astype(np.float16)).to(dev)
+    # figures: seeded "images" through the vision tower; the rest of the figure segment keeps synthetic CLIP-space rows
+    px = np.random.default_rng(8).standard_normal((n_img, 3, v_cfg["image"], v_cfg["image"]), dtype=np.float32)
+    ivec = np.concatenate([v_enc.forward(px[i:i + 64]) for i in range(0, n_img, 64)])
+    assert ivec.shape == (n_img, d) and np.isfinite(ivec).all()
+    corpus[fig_lo:fig_lo + n_img] = torch.from_numpy(ivec.astype(np.float16)).to(dev)
+    segments = {"text": (0, tab_lo), "table": (tab_lo, fig_lo), "figure": (fig_lo, n)}
+    question = sentence(rng, 16)
+    with MixedModalIndex(corpus, segments) as mix:
+        assert mix.ranges == {TEXT_SPACE: (0, fig_lo), CLIP_SPACE: (fig_lo, n)}
+        hits = MixedModalRetriever(mix, emb, cemb).invoke([question], k)
+        (ti, ts_), (fi, fs) = hits[TEXT_SPACE], hits[CLIP_SPACE]
+        assert ti.shape == fi.shape == (1, k) and ti.max() < fig_lo and fi.min() >= fig_lo       # each vector met its own space only
+        assert set(mix.modality_of(ti).ravel()) <= {"text", "table"} and set(mix.modality_of(fi).ravel()) == {"figure"}
+        # exactness of both searches against the oracle over the host copies (1.25M-row pieces)
+        qv = {TEXT_SPACE: np.asarray([emb.embed_query(question)], np.float32), CLIP_SPACE: np.asarray([cemb.embed_query(question)], np.float32)}
+        for sp, (lo, hi), (gi, gs) in ((TEXT_SPACE, (0, fig_lo), (ti, ts_)), (CLIP_SPACE, (fig_lo, n), (fi, fs))):
+            pi, ps = [], []
+            for a in range(lo, hi, 1_250_000):
+                rows = corpus[a:min(hi, a + 1_250_000)].cpu().numpy()
+                i_, s_ = oracle.search(rows, qv[sp], k, id_offset=a)
+                pi.append(i_); ps.append(s_)
+                del rows
+            wi, ws = oracle.merge_topk(np.stack(pi), np.stack(ps), k)
+            assert np.array_equal(gi, wi) and np.array_equal(_bits(gs), _bits(ws)), sp
+        # a table's own text finds its row (same embedder, fp16-rounded row: cosine ~ 1); a figure's own image finds its row
+        probe = [17, 1234, 1999]
+        pt = mix.search({TEXT_SPACE: np.asarray(emb.embed_documents([tables[j] for j in probe]), np.float32)}, 5)[TEXT_SPACE]
+        assert pt[0][:, 0].tolist() == [tab_lo + j for j in probe] and np.all(pt[1][:, 0] > 0.9995)
+        pf = mix.search({CLIP_SPACE: ivec[[3, 100, 255]]}, 5)[CLIP_SPACE]
+        assert pf[0][:, 0].tolist() == [fig_lo + 3, fig_lo + 100, fig_lo + 255] and np.all(pf[1][:, 0] > 0.9995)
+    del corpus
+    # re-rank: the 100 text-space hits by content, the 20 best figure hits by caption; rank_chunk keeps <= 20
+    passages = [sentence(rng, 470) for _ in range(64)]
+    def content(i):
+        i = int(i)
+        if i >= fig_lo:
+            return f"figure caption {sentence(np.random.default_rng(i), 24)} #{i}"
+        return tables[i - tab_lo] if i >= tab_lo else passages[i % 64] + f" #{i}"
+    picked = list(ti[0]) + list(fi[0][:20])
+    chunks = [{"page_content": content(i), "bundle_id": j // 2, "modality": str(mix.modality_of([i])[0]),
+               "metadata": {"date_published": f"2024-{1 + j % 12:02d}-{1 + j % 28:02d}"}} for j, i in enumerate(picked)]
+    qt = datetime(2024, 6, 15)
+    got = vf.rank_chunk(chunks, question, qt, rr, emb, chunk_topk=20)
+    scores = rr.compute_score([[question, c["page_content"]] for c in chunks], batch_size=8)
+    assert len(scores) == 120 and np.isfinite(scores).all()
+    tsc = vf.time_scores(qt, [c["metadata"]["date_published"] for c in chunks])
+    embs = np.asarray(emb.embed_documents([c["page_content"] for c in chunks]), np.float32)
+    want = R.rank_chunk([c["bundle_id"] for c in chunks], scores, tsc, embs, 20, 0.9)
+    assert got == want and 0 < len(got) <= 10
+    for h in (e_enc, r_enc, t_enc, v_enc):
+        h.close()
 
 
 # ---- BASELINE configs[4] shape: fp8-e4m3 rows, d = 1024, B = 1024 queries, k = 1000 -------------------------------------

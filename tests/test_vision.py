@@ -99,3 +99,130 @@ def test_image_embeddings_surface_and_errors(vf):
     enc.close()
     with pytest.raises(RuntimeError):
         enc.forward(px)
+
+
+# ---- CLIP TEXT tower (round 4): the query side of the figure leg ------------------------------------------------------------
+def _clip_text(hidden, layers, heads, ffn, proj, act, vocab=1000, max_pos=77, eos=2, seed=1):
+    import torch
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    torch.manual_seed(seed)
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=ffn, num_hidden_layers=layers,
+                         num_attention_heads=heads, max_position_embeddings=max_pos, projection_dim=proj, hidden_act=act,
+                         eos_token_id=eos, bos_token_id=1, pad_token_id=0)
+    m = CLIPTextModelWithProjection(cfg).eval()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n.endswith("bias"):
+                p_.normal_(0.0, 0.05)
+            elif "layer_norm" in n:
+                p_.normal_(1.0, 0.1)
+            elif "embedding" in n:
+                p_.normal_(0.0, 0.3)
+            elif p_.dim() >= 2:
+                p_.normal_(0.0, 0.06)
+            p_.copy_(p_.half().float())
+    return m
+
+
+def _text_batch(rng, b, t, vocab, eos):
+    """CLIP tokenizer shaped rows: bos, words, eos, then padding (the published tokenizer pads with the EOS id; with the legacy
+    eos_token_id == 2 the pooled position is argmax(ids), so the real end-of-text id is the largest of the vocabulary)."""
+    ids = np.zeros((b, t), np.int64)
+    mask = np.zeros((b, t), np.int64)
+    eot = vocab - 1 if eos == 2 else eos
+    for i in range(b):
+        n = t - 2 if i == 0 else int(rng.integers(1, t - 2))          # row 0 fills the window
+        words = rng.integers(3, vocab - 1, n)
+        if eos != 2:
+            words[words == eos] = 3
+        row = [1, *words.tolist(), eot]
+        ids[i, :len(row)] = row
+        ids[i, len(row):] = eot if eos != 2 else 0                     # pad: EOS id (new configs) or 0 (below every real id)
+        mask[i, :len(row)] = 1
+    return ids, mask
+
+
+def test_text_pack_layout_matches_the_header_sizes():
+    from veritasfi_amd.vision import pack_hf_clip_text
+    m = _clip_text(128, 2, 2, 256, 64, "quick_gelu", vocab=300, max_pos=40)
+    cfg, w16, w32 = pack_hf_clip_text(m)
+    H, F, L, V, P, D = 128, 256, 2, 300, 40, 64
+    assert cfg["act"] == 1 and cfg["proj_dim"] == D and cfg["eos_token_id"] == 2 and cfg["max_pos"] == P
+    assert w16.size == V * H + P * H + L * (3 * H * H + H * H + F * H + H * F) + D * H
+    assert w32.size == L * (2 * H + 3 * H + H + 2 * H + F + H) + 2 * H
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [
+    dict(hidden=128, layers=2, heads=2, ffn=256, proj=64, act="quick_gelu", eos=2, batch=5, t=20, max_pos=40),
+    dict(hidden=256, layers=3, heads=4, ffn=512, proj=128, act="gelu", eos=999, batch=9, t=77, max_pos=77),       # new-style eos id: first occurrence
+    dict(hidden=512, layers=4, heads=8, ffn=2048, proj=512, act="quick_gelu", eos=2, batch=16, t=77, max_pos=77),  # ViT-B/32's text tower, 4 of 12 layers
+    dict(hidden=768, layers=12, heads=12, ffn=3072, proj=768, act="quick_gelu", eos=2, batch=12, t=77, max_pos=77),  # ViT-L/14's text tower at full depth: 768-d joint space
+])
+def test_text_tower_matches_clip_fp32(vf, shape):
+    """text_embeds of CLIPTextModelWithProjection (fp32, CPU, same fp16-rounded weights): causal attention, EOS pooling under both
+    eos conventions, with and without the attention mask (the HF pipeline passes none), a smaller batch on the same handle."""
+    import torch
+    from veritasfi_amd.vision import HipClipTextEncoder
+    s = dict(shape)
+    batch, t, eos = s.pop("batch"), s.pop("t"), s["eos"]
+    m = _clip_text(**s)
+    rng = np.random.default_rng(17)
+    ids, mask = _text_batch(rng, batch, t, 1000, eos)
+    with torch.no_grad():
+        want = m(input_ids=torch.from_numpy(ids)).text_embeds.numpy()
+        want_masked = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).text_embeds.numpy()
+    enc = HipClipTextEncoder.from_hf(m)
+    try:
+        got = enc.forward(ids)
+        got_masked = enc.forward(ids, mask)
+        again = enc.forward(ids[: max(1, batch // 2)])
+    finally:
+        enc.close()
+    assert got.shape == want.shape == (batch, s["proj"])
+    scale = float(np.abs(want).max())
+    err = float(np.abs(got - want).max()) / scale
+    err_m = float(np.abs(got_masked - want_masked).max()) / scale
+    cos = float(np.min(np.sum(got * want, 1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))))
+    print("text tower", shape, "max err / max|embed|", err, "masked", err_m, "min cosine", cos)
+    assert err < 6e-3 and err_m < 6e-3 and cos > 0.9999      # the vision tower's tolerances (fp16 operands and residual stream)
+    assert np.array_equal(again, got[: again.shape[0]])
+
+
+class _WordTokenizer:
+    """CLIPTokenizer-shaped stand-in (no vocabulary files offline): bos, one id per word, eot = the largest id, zero padding."""
+    def __init__(self, vocab=1000):
+        self.vocab = vocab
+
+    def __call__(self, texts, padding="max_length", truncation=True, max_length=77, return_tensors="np"):
+        ids = np.zeros((len(texts), max_length), np.int64)
+        mask = np.zeros_like(ids)
+        for i, tx in enumerate(texts):
+            w = [3 + (sum(map(ord, x)) * 31 + len(x)) % (self.vocab - 5) for x in tx.split()][: max_length - 2]
+            row = [1, *w, self.vocab - 1]
+            ids[i, :len(row)], mask[i, :len(row)] = row, 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+@pytest.mark.gpu
+def test_clip_text_embeddings_surface_and_errors(vf):
+    """embed_query / embed_documents (the ragManager.py:50 embedder surface) over the text tower, and a figure leg served by it:
+    FaissRetriever(figure_rows, HipClipTextEmbeddings).invoke([text]) searches CLIP space with a CLIP query vector."""
+    from veritasfi_amd.vision import HipClipTextEmbeddings, HipClipTextEncoder
+    m = _clip_text(128, 2, 2, 256, 64, "quick_gelu")
+    enc = HipClipTextEncoder.from_hf(m, normalize=True)
+    emb = HipClipTextEmbeddings(_WordTokenizer(), enc, batch_size=3)
+    docs = [f"figure {i} quarterly deliveries by region chart {i % 4}" for i in range(8)]
+    vecs = np.asarray(emb.embed_documents(docs), np.float32)
+    assert vecs.shape == (8, 64) and np.allclose(np.linalg.norm(vecs, axis=1), 1.0, atol=1e-4)
+    q = emb.embed_query(docs[5])
+    assert isinstance(q, list) and isinstance(q[0], float) and np.allclose(q, vecs[5], atol=1e-6)
+    assert emb.embed_documents([]) == []
+    fr = vf.FaissRetriever(vecs.tolist(), emb)                      # rows in CLIP space, queries through the CLIP text tower
+    I, D = fr.invoke([docs[2], docs[7]], 3)
+    assert I[0, 0] == 2 and I[1, 0] == 7 and np.all(D[:, 0] > 0.999)
+    with pytest.raises(ValueError):
+        enc.forward(np.zeros((2, 78), np.int64))                    # beyond max_pos
+    enc.close()
+    with pytest.raises(RuntimeError):
+        enc.forward(np.zeros((1, 8), np.int64))

@@ -1,5 +1,7 @@
 """Synthetic stand-ins shared by the harnesses: there are no tokenizer files or checkpoints offline, so texts are
 tokenised by a deterministic whitespace hash and models are random-init encoders of a named shape."""
+import itertools
+
 import numpy as np
 
 WORDS = ["revenue", "segment", "filing", "quarter", "margin", "vehicle", "delivery", "guidance", "capex", "cash",
@@ -29,17 +31,26 @@ class HashTokenizer:
         a = [a] if isinstance(a, str) else list(a)
         b = [None] * len(a) if b is None else ([b] if isinstance(b, str) else list(b))
         rows = []
+        cache, slow = self._cache, self._tok
+        def toks(text):           # one dict lookup per word; the Python-level hash runs once per distinct word
+            words = text.split()
+            try:
+                return list(map(cache.__getitem__, words))
+            except KeyError:
+                return [cache[w] if w in cache else slow(w) for w in words]
         for x, y in zip(a, b):
-            t = [self.bos] + [self._tok(w) for w in x.split()] + [self.sep]
+            t = [self.bos] + toks(x) + [self.sep]
             if y is not None:
-                t += [self.sep] + [self._tok(w) for w in y.split()] + [self.sep]
+                t += [self.sep] + toks(y)[:max_length] + [self.sep]
             rows.append(t[:max_length])
         width = max(len(r) for r in rows)
         ids = np.full((len(rows), width), self.pad, np.int64)
         mask = np.zeros((len(rows), width), np.int64)
-        for i, r in enumerate(rows):
-            ids[i, :len(r)] = r
-            mask[i, :len(r)] = 1
+        lens = np.fromiter(map(len, rows), np.int64, len(rows))
+        flat = np.fromiter(itertools.chain.from_iterable(rows), np.int64, int(lens.sum()))
+        keep = np.arange(width)[None, :] < lens[:, None]
+        ids[keep] = flat
+        mask[keep] = 1
         if return_tensors == "pt":
             import torch
             return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}

@@ -33,6 +33,56 @@ def random_vit(shape, seed=0):
     return HipVisionEncoder(cfg, w16, w32), cfg
 
 
+TEXT_SHAPES = {"vit-l-14": dict(vocab=49408, max_pos=77, hidden=768, layers=12, heads=12, ffn=3072, proj_dim=768),
+               "vit-b-16": dict(vocab=49408, max_pos=77, hidden=512, layers=12, heads=8, ffn=2048, proj_dim=512)}
+
+
+def random_clip_text(shape, seed=1, vocab=None):
+    """The TEXT tower of the same CLIP model (vf_clip_text_*): ViT-L/14's is 12 layers x 768 wide, 77 positions, 768-d projection."""
+    from veritasfi_amd import _ffi
+    from veritasfi_amd.vision import HipClipTextEncoder
+    import ctypes
+    cfg = dict(TEXT_SHAPES[shape], act=1, eos_token_id=2, normalize=1, ln_eps=1e-5)
+    if vocab:
+        cfg["vocab"] = vocab
+    c = _ffi.ClipTextConfig(**cfg)
+    n16, n32 = _ffi.c_i64(0), _ffi.c_i64(0)
+    _ffi.check(_ffi.lib().vf_clip_text_weight_sizes(ctypes.byref(c), ctypes.byref(n16), ctypes.byref(n32)))
+    rng = np.random.default_rng(seed)
+    w16 = (rng.standard_normal(n16.value, dtype=np.float32) * 0.03).astype(np.float16)
+    w32 = np.zeros(n32.value, np.float32)
+    H, F, L = cfg["hidden"], cfg["ffn"], cfg["layers"]
+    per = 2 * H + 3 * H + H + 2 * H + F + H
+    for l in range(L):
+        o = l * per
+        w32[o:o + H] = 1.0
+        w32[o + 6 * H:o + 7 * H] = 1.0
+    w32[L * per:L * per + H] = 1.0
+    return HipClipTextEncoder(cfg, w16, w32), cfg
+
+
+class ClipHashTokenizer:
+    """CLIPTokenizer's call shape (padding="max_length", 77 positions, bos / eot, the eot id the LARGEST of the vocabulary so
+    that the legacy argmax pooling finds it) over a whitespace hash -- no vocabulary files offline."""
+    def __init__(self, vocab=49408):
+        self.vocab, self.bos, self.eot = vocab, vocab - 2, vocab - 1
+
+    def __call__(self, texts, padding="max_length", truncation=True, max_length=77, return_tensors="np", **_):
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        ids = np.zeros((len(texts), max_length), np.int64)
+        mask = np.zeros_like(ids)
+        for i, tx in enumerate(texts):
+            w = []
+            for x in tx.split()[: max_length - 2]:
+                h = 2166136261
+                for ch in x.encode():
+                    h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+                w.append(1 + h % (self.vocab - 3))
+            row = [self.bos, *w, self.eot]
+            ids[i, :len(row)], mask[i, :len(row)] = row, 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
 def flops_per_image(cfg):
     T = (cfg["image"] // cfg["patch"]) ** 2 + 1
     H, F, L = cfg["hidden"], cfg["ffn"], cfg["layers"]

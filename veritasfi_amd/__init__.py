@@ -26,7 +26,8 @@ from .sharded import ShardedRetriever, ShardedScorer, shard_bounds  # noqa: F401
 from .encoder import (HipDecoder, HipDecoderEmbeddings, HipDecoderModel, HipEmbeddings, HipEncoder, HipLLMReranker, HipModel,  # noqa: F401
                       HipReranker, build_llm_reranker_inputs, pack_hf_decoder_weights, pack_hf_weights)
 from .rank import rank_chunk  # noqa: F401
-from .vision import HipImageEmbeddings, HipVisionEncoder, pack_hf_clip_vision  # noqa: F401
+from .vision import (HipClipTextEmbeddings, HipClipTextEncoder, HipImageEmbeddings, HipVisionEncoder, pack_hf_clip_text,  # noqa: F401
+                     pack_hf_clip_vision)
 from .ensemble import EnsembleRetriever  # noqa: F401
 
 __version__ = "0.1.0"

@@ -43,6 +43,13 @@ class VitConfig(ctypes.Structure):
     ]
 
 
+class ClipTextConfig(ctypes.Structure):
+    _fields_ = [
+        ("vocab", c_i32), ("max_pos", c_i32), ("hidden", c_i32), ("layers", c_i32), ("heads", c_i32), ("ffn", c_i32),
+        ("proj_dim", c_i32), ("act", c_i32), ("eos_token_id", c_i32), ("normalize", c_i32), ("ln_eps", c_f32),
+    ]
+
+
 class SearchStats(ctypes.Structure):
     _fields_ = [
         ("path", c_i64), ("n_queries", c_i64), ("candidates", c_i64), ("max_candidates", c_i64),
@@ -81,6 +88,7 @@ SIGNATURES = {
     "vf_index_debug_read": (ctypes.c_int, [vp, c_i32, vp, c_i64]),
     "vf_index_destroy": (ctypes.c_int, [vp]),
     "vf_cosine_matrix": (ctypes.c_int, [vp, c_i32, c_i32, vp, c_i32]),
+    "vf_cosine_matrix_rows": (ctypes.c_int, [vp, vp, c_i32, vp]),
     "vf_cosine_scores": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32]),
     "vf_merge_topk_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
     "vf_merge_topk_packed_device": (ctypes.c_int, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
@@ -105,6 +113,10 @@ SIGNATURES = {
     "vf_vit_forward": (ctypes.c_int, [vp, vp, c_i32, vp]),
     "vf_vit_forward_u8": (ctypes.c_int, [vp, vp, vp, vp, c_i32, vp]),
     "vf_vit_destroy": (ctypes.c_int, [vp]),
+    "vf_clip_text_weight_sizes": (ctypes.c_int, [ctypes.POINTER(ClipTextConfig), p_i64, p_i64]),
+    "vf_clip_text_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(ClipTextConfig), vp, c_i64, vp, c_i64, c_i32]),
+    "vf_clip_text_forward": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp]),
+    "vf_clip_text_destroy": (ctypes.c_int, [vp]),
 }
 
 _lib = None

@@ -1324,6 +1324,38 @@ extern "C" int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out
     return vf_cosine_scores(x, n, x, n, d, out, device_id);
 }
 
+// Cosine matrix of rows ALREADY in the index, picked by id (round 4): compute_similarity_mtx re-embeds the n retrieved chunk
+// texts (src/utils/ensembleRetriever.py:265-281: n encoder forwards upstream, one batched forward here -- 19 ms for 100 chunks
+// of 512 tokens); when the chunks came out of this index and the embedder treats documents and queries alike, their
+// embeddings are rows of the HBM-resident corpus: gather + canonical normalise (the index's own norms) + dot16.
+extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n, float* out) {
+    DeviceGuard restore_callers_device;
+    if (!ix) return fail(VF_EINVAL, "vf_cosine_matrix_rows: null handle");
+    if (n < 0) return fail(VF_EINVAL, "vf_cosine_matrix_rows: negative n");
+    if (n == 0) return VF_OK;
+    if (!ids || !out) return fail(VF_EINVAL, "vf_cosine_matrix_rows: null buffer");
+    if (!ix->shards.empty()) return fail(VF_EUNSUPPORTED, "vf_cosine_matrix_rows: the rows of a sharded handle live on several devices");
+    if (n > 4096) return fail(VF_EINVAL, "vf_cosine_matrix_rows: n must be <= 4096");
+    std::vector<long long> sel((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int64_t r = ids[i] - ix->id_offset;
+        if (r < 0 || r >= ix->n) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
+        sel[(size_t)i] = r;
+    }
+    std::lock_guard<std::mutex> lk(ix->mu);
+    VF_HIP(hipSetDevice(ix->device));
+    DevBuf dsel, xn, dout;
+    auto done = [&](int code) { dsel.release(); xn.release(); dout.release(); return code; };
+    int rc;
+    if ((rc = dsel.ensure((size_t)n * 8)) || (rc = xn.ensure((size_t)n * ix->d * 4)) || (rc = dout.ensure((size_t)n * n * 4))) return done(rc);
+    hipError_t e = hipMemcpy(dsel.p, sel.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_normalize_rows_gather(ix->rows_orig, ix->dtype, dsel.as<long long>(), n, ix->d, ix->norm, xn.as<float>(), nullptr);
+    if (e == hipSuccess) e = launch_dense_dot16(xn.as<float>(), n, xn.as<float>(), n, ix->d, dout.as<float>(), n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n * n * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(fail(VF_EHIP, std::string("vf_cosine_matrix_rows: ") + hipGetErrorString(e)));
+    return done(VF_OK);
+}
+
 extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts, int32_t nparts, int32_t nq,
                                     int32_t k, int64_t* d_ids, float* d_scores, int32_t device_id, void* stream) {
     DeviceGuard restore_callers_device;

@@ -97,6 +97,8 @@ hipError_t launch_prep_queries(const float* q, int nq, int d, int dp, int qn_til
                                float* qn, _Float16* qimg, hipStream_t s);
 hipError_t launch_normalize_rows(const void* rows, int dt /* VF_DTYPE_* */, long long row0, long long nrows, int d,
                                  const float* norm, float* out, hipStream_t s);
+hipError_t launch_normalize_rows_gather(const void* rows, int dt, const long long* sel /*device, local row numbers*/, int nsel, int d,
+                                        const float* norm, float* out, hipStream_t s);
 hipError_t launch_dense_dot16(const float* qn, int nq, const float* cn, long long nrows, int d,
                               float* out, long long out_stride, hipStream_t s);
 hipError_t launch_sort_rows(const float* scores, long long score_stride, int nq, int n, int k,

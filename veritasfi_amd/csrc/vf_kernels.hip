@@ -227,6 +227,25 @@ hipError_t launch_normalize_rows(const void* rows, int dt, long long row0, long 
     return hipGetLastError();
 }
 
+// the same for rows PICKED by index: out[i] = canonical normalisation of row sel[i] (vf_cosine_matrix_rows)
+__global__ __launch_bounds__(256) void k_normalize_rows_gather(const void* rows, int dt, const long long* sel, int nsel, int d,
+                                                                const float* norm, float* out) {
+    const long long total = (long long)nsel * d;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d, row = sel[r];
+        out[i] = load_elem(rows, dt, row * (long long)d + (i - r * d)) * canon_inv(norm[row]);
+    }
+}
+
+hipError_t launch_normalize_rows_gather(const void* rows, int dt, const long long* sel, int nsel, int d, const float* norm,
+                                        float* out, hipStream_t s) {
+    if (nsel <= 0) return hipSuccess;
+    long long blocks = ((long long)nsel * d + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_normalize_rows_gather, dim3((unsigned)blocks), dim3(256), 0, s, rows, dt, sel, nsel, d, norm, out);
+    return hipGetLastError();
+}
+
 // out[q * out_stride + r] = dot16(qn[q], cn[r]); one 16-lane group per row, looping over queries.
 __global__ __launch_bounds__(256) void k_dense_dot16(const float* qn, int nq, const float* cn, long long nrows, int d,
                                                       float* out, long long out_stride) {

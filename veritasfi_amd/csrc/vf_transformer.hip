@@ -2585,6 +2585,199 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_gemm9_tn (round 4): the PERSISTENT two-phase kernel with an LDS-FREE, BARRIER-FREE epilogue.
+//
+// What the numbers of round 3 say: a 256 x 256 tile of k_gemm8p_tn costs T(K) = 10 us + 0.0217 us x K -- the main
+// loop moves its 64 KB per K-tile at 47 GB/s per CU = 12 TB/s chip-wide, i.e. AT the L2 -> LDS ceiling, and the fixed 10 us per
+// tile (37 % of a K = 768 tile) are the epilogue: every workgroup of a round reaches it together, 256 x 128 KB of output
+// meet the memory system as one burst (32 MB at ~4 TB/s = 8 us) while every matrix pipe idles, then 256 new workgroups are
+// dispatched and wait for their first loads.  The persistent 8-phase experiment (k_gemm8q_tn) kept the loads of the next
+// tile in flight but still moved the tile through LDS in four barrier-separated passes.  Here:
+//  * the tile leaves STRAIGHT FROM THE ACCUMULATORS: operands swapped (D = W_frag x A_frag), and the W rows a wave stages
+//    are PERMUTED so that lane (r15, kb) owns, for row r15 of every 16-row block, columns 8 kb .. 8 kb + 7 and 32 + 8 kb ..
+//    + 7 of the wave's 64: two 16-byte stores per 16 x 64 block whose four kb lanes write one aligned 64-byte segment
+//    each.  No LDS image, no barrier: the epilogue is ~200 VALU instructions and 16 fire-and-forget stores per lane;
+//  * the stores DRAIN UNDER THE NEXT TILE'S MAIN LOOP: the stage sequence runs on into the next tile (its first seven
+//    half-tiles are issued before the epilogue, as in k_gemm8q_tn), the first K-tile's counted waits leave the 16 stores in
+//    flight (vmcnt is in order and counts stores);
+//  * the one-barrier stagger between the two wave halves is never rebalanced: a half runs its epilogue while the other
+//    still issues the last (or already the first) 32 MFMAs -- no wave waits for another one between tiles;
+//  * residual rows are fetched into the (dead) fragment registers at the start of the epilogue; the bias of a tile arrives
+//    by one LDS-DMA during its first K-tile, double-buffered by tile parity.
+// Main loop, slot discipline and landed-guarantees are k_gemm8p_tn's two-phase loop (see there); q_stage maps half-tiles past
+// the end of K to the next tile (or the dump slot).  Requires M, N % 256 == 0, K % 64 == 0, K >= 256; gridDim.x a multiple of
+// 8 or the tile count.
+// ------------------------------------------------------------------------------------------------
+constexpr int RLDS = PLDS + 2048;   // + two tiles' bias (2 x 256 floats)
+
+template <int EPI>
+__global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                         const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                         half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + 2 x bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
+    const int Mt = M / PBM, Nt = N / PBN, ntiles = Mt * Nt;
+    float* bias_lds = (float*)(smem + PLDS);
+    unsigned voff[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = 16 * wid + 8 * j + (lane >> 3);          // LDS row of the half-tile
+        const int lc = (lane & 7) ^ ((i >> 1) & 7);            // logical 16-byte chunk this lane fetches
+        const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
+        // W rows, permuted: LDS row 32 w' + 16 u + jj of B_n0 (n-block u, MFMA column jj) holds column 8 (jj >> 2) + 4 u + (jj & 3)
+        // of wave w''s first 32; B_n1 the same of its second 32
+        const int jj = i & 15, u = (i >> 4) & 1;
+        const int bn0 = (i >> 5) * 64 + 8 * (jj >> 2) + 4 * u + (jj & 3), bn1 = bn0 + 32;
+        voff[0][j] = (unsigned)((am0 * K + lc * 8) * 2);
+        voff[1][j] = (unsigned)((bn0 * K + lc * 8) * 2);
+        voff[2][j] = (unsigned)((bn1 * K + lc * 8) * 2);
+        voff[3][j] = (unsigned)((am1 * K + lc * 8) * 2);
+    }
+    const int nk = K / PBK, G = 4 * nk;
+    int mt_c, nt_c, mt_n = 0, nt_n = 0;
+    int orig = blockIdx.x;
+    q_tile_of(orig, Mt, Nt, mt_c, nt_c);
+    bool has_next = orig + (int)gridDim.x < ntiles;
+    if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
+    int ktg = 0;   // K-tiles consumed by this workgroup so far: LDS buffer of local K-tile kt is (ktg + kt) & 1
+#define VF9_STAGE(S_, G_) q_stage<S_>(smem, wid, A, W, K, (G_), G, nk, ktg, has_next, mt_c, nt_c, mt_n, nt_n, voff[S_][0], voff[S_][1]);
+    f4v acc[8][4];
+    const int swz = (r15 >> 1) & 7;
+    const int a_off = (wr * 64 + r15) * 128, b_off = (wc * 32 + r15) * 128;
+    const int c0 = ((0 + kb) ^ swz) * 16, c1 = ((4 + kb) ^ swz) * 16;   // k-steps 0 and 1
+    h8 Af[4][2], B0f[2][2], B1f[2][2];
+#define VF9_READ_A(SLOTBASE)                                                              \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+        Af[t][0] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c0);                       \
+        Af[t][1] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c1);                       \
+    }
+#define VF9_READ_B(DSTF, SLOTBASE)                                                         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                        \
+        DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
+        DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
+    }
+#define VF9_QUAD(MQ, NQ, BF)                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
+#define VF9_MID()                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+    __builtin_amdgcn_s_barrier();                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    __builtin_amdgcn_s_setprio(1);
+#define VF9_TAIL()                                                                         \
+    __builtin_amdgcn_s_setprio(0);                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    VF9_STAGE(0, 0) VF9_STAGE(1, 1) VF9_STAGE(2, 2) VF9_STAGE(3, 3) VF9_STAGE(0, 4) VF9_STAGE(1, 5) VF9_STAGE(2, 6)
+    if (wr == 1) {   // waves 4..7 run one barrier behind, from here to the end of the kernel
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 14 issued, 8 may fly: half-tiles 0 .. 2 of this wave landed
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int it = 0;; ++it) {
+        const long long m0 = (long long)mt_c * PBM, n0 = (long long)nt_c * PBN;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* base = smem + ((ktg + kt) & 1) * (4 * PSLOT);
+            // the first K-tile after an epilogue: its 16 stores are younger than every DMA this tile waits for and stay in flight
+            const bool relaxed = kt == 0 && it > 0;
+            if (relaxed) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            VF9_STAGE(3, 4 * kt + 7)
+            if (kt == 0 && wid == 0 && bias) dma16s(bias + n0, (unsigned)lane * 16u, (const char*)(bias_lds + (it & 1) * 256));
+            VF9_READ_B(B0f, base + 1 * PSLOT)
+            VF9_READ_B(B1f, base + 2 * PSLOT)
+            VF9_READ_A(base + 0 * PSLOT)
+            VF9_MID()
+            VF9_QUAD(0, 0, B0f)
+            VF9_QUAD(0, 1, B1f)
+            VF9_TAIL()
+            if (relaxed) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            VF9_STAGE(0, 4 * kt + 8)
+            VF9_STAGE(1, 4 * kt + 9)
+            VF9_STAGE(2, 4 * kt + 10)
+            VF9_READ_A(base + 3 * PSLOT)
+            VF9_MID()
+            VF9_QUAD(1, 1, B1f)
+            VF9_QUAD(1, 0, B0f)
+            VF9_TAIL()
+        }
+        ktg += nk;
+        // ---- epilogue, straight from the registers: lane (r15, kb) of block mi holds row wr 128 + mi 16 + r15, and for
+        // hf = 0, 1 the eight columns wc 64 + hf 32 + 8 kb .. + 7: acc[mi][2 hf][0..3], acc[mi][2 hf + 1][0..3]
+        const long long col0 = n0 + wc * 64 + 8 * kb;
+        h8 rr[8][2];
+        if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    rr[mi][hf] = *(const h8*)(R + (m0 + wr * 128 + mi * 16 + r15) * N + col0 + hf * 32);
+        }
+        float bv[2][8];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f4v b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (bias) {
+                const float* bl = bias_lds + (it & 1) * 256 + wc * 64 + hf * 32 + 8 * kb;
+                b0 = *(const f4v*)bl; b1 = *(const f4v*)(bl + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[hf][e] = b0[e]; bv[hf][4 + e] = b1[e]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            half_t* crow = C + (m0 + wr * 128 + mi * 16 + r15) * N + col0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                h8 o;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f4v a4 = acc[mi][2 * hf + q];
+                    f2v v0 = {a4[0] + bv[hf][4 * q + 0], a4[1] + bv[hf][4 * q + 1]};
+                    f2v v1 = {a4[2] + bv[hf][4 * q + 2], a4[3] + bv[hf][4 * q + 3]};
+                    if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); }
+                    if (EPI == EPI_BIAS_QGELU) { v0 = quick_gelu2(v0); v1 = quick_gelu2(v1); }
+                    if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+                        // the LDS-image epilogues round acc + bias to fp16 before the residual joins in fp32: keep that order
+                        v0[0] = (float)(half_t)v0[0] + (float)rr[mi][hf][4 * q + 0]; v0[1] = (float)(half_t)v0[1] + (float)rr[mi][hf][4 * q + 1];
+                        v1[0] = (float)(half_t)v1[0] + (float)rr[mi][hf][4 * q + 2]; v1[1] = (float)(half_t)v1[1] + (float)rr[mi][hf][4 * q + 3];
+                    }
+                    o[4 * q + 0] = (half_t)v0[0]; o[4 * q + 1] = (half_t)v0[1];
+                    o[4 * q + 2] = (half_t)v1[0]; o[4 * q + 3] = (half_t)v1[1];
+                }
+                *(h8*)(crow + hf * 32) = o;
+            }
+        }
+        if (!has_next) break;
+        orig += gridDim.x;
+        mt_c = mt_n;
+        nt_c = nt_n;
+        has_next = orig + (int)gridDim.x < ntiles;
+        if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
+    }
+#undef VF9_READ_A
+#undef VF9_READ_B
+#undef VF9_QUAD
+#undef VF9_MID
+#undef VF9_TAIL
+#undef VF9_STAGE
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused attention.  grid (ceil(T/128), heads, B), 256 threads; wave w handles queries
 // [qb*128 + 32w, +32) of sequence b, head hd; K [T][64] and V^T [64][T] of that (b, head) live in LDS.
 // S^T = K Q^T is computed with the KEY on the MFMA row, so a lane holds 16 key scores of ONE query
@@ -4198,6 +4391,10 @@ static hipError_t configure_once() {
 #ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
 #endif
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
@@ -4539,6 +4736,8 @@ static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bia
 static long long p8_min_wgs();   // tiles from which the 8-phase kernel is the default (defined with the LnFold helpers)
 static std::atomic<int> g_loop2{getenv("VF_GEMM_8P_LOOP2") ? atoi(getenv("VF_GEMM_8P_LOOP2")) : 1};   // default: the two-phase loop (round 3: 2-7 % on the products, 0.7-2 % on the forward)
 extern "C" int vf_debug_gemm_8p_loop2(int on) { return on >= 0 ? g_loop2.exchange(on ? 1 : 0) : g_loop2.load(); }   // A/B: two-phase main loop of k_gemm8p_tn
+static std::atomic<int> g_gemm9{-1};   // -1: VF_GEMM_9 decides; 0 / 1: forced by the test hook
+extern "C" int vf_debug_gemm9(int on) { return g_gemm9.exchange(on < 0 ? -1 : (on ? 1 : 0)); }   // A/B: the persistent register-epilogue kernel as the default large product
 static LnFold lf_plain() { LnFold l{}; l.loop2 = g_loop2.load(std::memory_order_relaxed); return l; }
 static int device_cus();
 
@@ -4659,6 +4858,16 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         return hipGetLastError();
     }
 #endif
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL) {
+        // round 4: the persistent two-phase kernel with the register-direct epilogue (k_gemm9_tn)
+        static const int p9 = getenv("VF_GEMM_9") ? atoi(getenv("VF_GEMM_9")) : 0;
+        const int p9_now = g_gemm9.load(std::memory_order_relaxed) >= 0 ? g_gemm9.load(std::memory_order_relaxed) : p9;
+        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+            const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
+            hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K);
+            return hipGetLastError();
+        }
+    }
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
@@ -5779,11 +5988,12 @@ __global__ __launch_bounds__(256) void k_vit_embed(const half_t* __restrict__ em
 // one workgroup per image: LayerNorm of the class token's row, then out[d] = <Wproj[d], ln> (no bias), optionally L2-normalised
 __global__ __launch_bounds__(256) void k_vit_head(const half_t* __restrict__ x, int Tp, int H, const float* __restrict__ g,
                                                   const float* __restrict__ bta, float eps, const half_t* __restrict__ Wp, int D,
-                                                  int normalize, float* __restrict__ out) {
+                                                  int normalize, float* __restrict__ out, const int* __restrict__ rowsel = nullptr) {
     extern __shared__ float sm[];   // [H] normalised class token, [256] reduction
     float* red = sm + H;
     const int tid = threadIdx.x;
-    const half_t* row = x + (long long)blockIdx.x * Tp * H;
+    // the pooled row: the class token (row 0) of an image, or row rowsel[b] of a text sequence (CLIP's EOS-token pooling)
+    const half_t* row = x + ((long long)blockIdx.x * Tp + (rowsel ? rowsel[blockIdx.x] : 0)) * H;
     float s = 0.f;
     for (int c = tid; c < H; c += 256) s += (float)row[c];
     red[tid] = s;
@@ -5981,7 +6191,7 @@ static int vit_forward_impl(vf_vit* v, const float* pixels, const unsigned char*
         VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->hbuf, W2, b2, v->y, v->x, Mp, H, F, st, 0, &v->gws));
     }
     hipLaunchKernelGGL(k_vit_head, dim3(b), dim3(256), (size_t)(H + 256) * sizeof(float), st, v->x, Tp, H, v->w32 + v->f_post, v->w32 + v->f_post + H,
-                       c.ln_eps, v->w16 + v->o_proj, c.proj_dim, c.normalize, v->d_out);
+                       c.ln_eps, v->w16 + v->o_proj, c.proj_dim, c.normalize, v->d_out, (const int*)nullptr);
     VFT_HIP(hipGetLastError());
     VFT_HIP(hipMemcpyAsync(out, v->d_out, (size_t)b * c.proj_dim * 4, hipMemcpyDeviceToHost, st));
     VFT_HIP(hipStreamSynchronize(st));
@@ -5995,6 +6205,228 @@ extern "C" int vf_vit_forward_u8(vf_vit* v, const unsigned char* pixels, const f
     return vit_forward_impl(v, nullptr, pixels, mean3, std3, b, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// CLIP TEXT tower (round 4): the query side of the figure leg.  Figure rows live in CLIP's joint space (vf_vit_* above); a
+// text query reaches them only through the SAME model's text tower -- transformers' CLIPTextModelWithProjection:
+// token + learned position embeddings (no LayerNorm), PRE-LayerNorm layers with CAUSAL attention (and the key-padding
+// mask), final_layer_norm, the hidden state at the EOS token, text_projection (no bias) into the joint space (768 for
+// ViT-L/14).  Kernels: the vision tower's products / k_layernorm / quick-GELU epilogue, the decoder family's causal
+// streaming attention at head dim 64 (k_attention_stream2<64, true>: softmax scale passed, nothing folded into Wq), and
+// k_vit_head reading row eos[b] instead of row 0.
+// ------------------------------------------------------------------------------------------------
+struct vf_clip_text {
+    GemmWs gws;
+    vf_clip_text_config cfg{};
+    int device = 0;
+    half_t* w16 = nullptr;
+    float* w32 = nullptr;
+    size_t o_tok = 0, o_pos = 0, o_layers = 0, o_proj = 0, layer16 = 0;
+    size_t f_layers = 0, f_final = 0, layer32 = 0;
+    int cap_tokens = 0, cap_b = 0;
+    half_t *x = nullptr, *y = nullptr, *t = nullptr, *qkv = nullptr, *ctx = nullptr, *hbuf = nullptr;
+    int *d_ids = nullptr, *d_mask_in = nullptr, *d_mask = nullptr, *d_eos = nullptr;
+    float* d_out = nullptr;
+    std::mutex mu;
+};
+
+static size_t ct_n16(const vf_clip_text_config& c) {
+    const size_t H = c.hidden, F = c.ffn;
+    return (size_t)c.vocab * H + (size_t)c.max_pos * H + (size_t)c.layers * (3 * H * H + H * H + F * H + H * F) + (size_t)c.proj_dim * H;
+}
+static size_t ct_n32(const vf_clip_text_config& c) {
+    const size_t H = c.hidden, F = c.ffn;
+    return (size_t)c.layers * (2 * H + 3 * H + H + 2 * H + F + H) + 2 * H;
+}
+extern "C" int vf_clip_text_weight_sizes(const vf_clip_text_config* cfg, int64_t* n_fp16, int64_t* n_fp32) {
+    if (!cfg || !n_fp16 || !n_fp32) return fail(VF_EINVAL, "vf_clip_text_weight_sizes: null argument");
+    if (cfg->vocab <= 0 || cfg->max_pos <= 0 || cfg->hidden <= 0 || cfg->layers <= 0 || cfg->ffn <= 0 || cfg->proj_dim <= 0)
+        return fail(VF_EINVAL, "vf_clip_text_weight_sizes: bad config");
+    *n_fp16 = (int64_t)ct_n16(*cfg);
+    *n_fp32 = (int64_t)ct_n32(*cfg);
+    return VF_OK;
+}
+
+// rows [b][Tp]: x = fp16(token[id] + position[t]) for t < T, zero rows and mask 0 beyond; mask[b][t] = the caller's mask
+__global__ __launch_bounds__(256) void k_clip_text_embed(const int* __restrict__ ids, const int* __restrict__ mask_in,
+                                                         const half_t* __restrict__ tok, const half_t* __restrict__ pos, int B, int T,
+                                                         int Tp, int H, int vocab, half_t* __restrict__ x, int* __restrict__ mask) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    if (row >= B * Tp) return;
+    const int b = row / Tp, t = row - b * Tp;
+    half_t* dst = x + (long long)row * H;
+    if (t >= T) {
+        if (l32 == 0) mask[row] = 0;
+        for (int c = l32 * 8; c < H; c += 256) *(h8*)(dst + c) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        return;
+    }
+    int id = ids[b * T + t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    if (l32 == 0) mask[row] = mask_in[b * T + t] ? 1 : 0;
+    const half_t* e = tok + (long long)id * H;
+    const half_t* p = pos + (long long)t * H;
+    for (int c = l32 * 8; c < H; c += 256) {
+        const h8 ev = *(const h8*)(e + c), pv = *(const h8*)(p + c);
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)((float)ev[i] + (float)pv[i]);
+        *(h8*)(dst + c) = o;
+    }
+}
+
+static void ct_free_ws(vf_clip_text* v) {
+    void* p[] = {v->x, v->y, v->t, v->qkv, v->ctx, v->hbuf, v->d_ids, v->d_mask_in, v->d_mask, v->d_eos, v->d_out};
+    for (void* q : p) if (q) (void)hipFree(q);
+    v->x = v->y = v->t = v->qkv = v->ctx = v->hbuf = nullptr;
+    v->d_ids = v->d_mask_in = v->d_mask = v->d_eos = nullptr; v->d_out = nullptr; v->cap_tokens = v->cap_b = 0;
+}
+
+extern "C" int vf_clip_text_destroy(vf_clip_text* v) {
+    if (!v) return VF_OK;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    (void)hipSetDevice(v->device);
+    (void)hipDeviceSynchronize();
+    ct_free_ws(v);
+    gws_free(v->gws);
+    if (v->w16) (void)hipFree(v->w16);
+    if (v->w32) (void)hipFree(v->w32);
+    delete v;
+    if (have_prev) (void)hipSetDevice(prev);
+    return VF_OK;
+}
+
+extern "C" int vf_clip_text_create(vf_clip_text** out, const vf_clip_text_config* cfg, const void* w16, int64_t n16, const float* w32,
+                                   int64_t n32, int32_t device_id) {
+    if (!out) return fail(VF_EINVAL, "vf_clip_text_create: null out");
+    *out = nullptr;
+    if (!cfg || !w16 || !w32) return fail(VF_EINVAL, "vf_clip_text_create: null argument");
+    const vf_clip_text_config& c = *cfg;
+    if (c.hidden <= 0 || c.hidden % 128 != 0 || c.hidden > 1024) return fail(VF_EUNSUPPORTED, "clip text: hidden must be a multiple of 128, <= 1024");
+    if (c.heads <= 0 || c.hidden % c.heads || c.hidden / c.heads != 64) return fail(VF_EUNSUPPORTED, "clip text: head dim must be 64");
+    if (c.ffn <= 0 || c.ffn % 128 != 0) return fail(VF_EUNSUPPORTED, "clip text: ffn must be a multiple of 128");
+    if (c.layers <= 0 || c.vocab <= 0 || c.max_pos <= 0 || c.max_pos > 512) return fail(VF_EINVAL, "clip text: bad layers / vocab / max_pos (<= 512)");
+    if (c.proj_dim <= 0 || c.act < 0 || c.act > 1 || c.normalize < 0 || c.normalize > 1) return fail(VF_EINVAL, "clip text: bad proj_dim / act / normalize");
+    if ((size_t)n16 != ct_n16(c) || (size_t)n32 != ct_n32(c))
+        return fail(VF_EINVAL, "vf_clip_text_create: weight blob sizes do not match the config (see vf_clip_text_weight_sizes)");
+    int ndev = 0;
+    VFT_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(VF_EINVAL, "vf_clip_text_create: bad device_id");
+    int prev = 0;
+    VFT_HIP(hipGetDevice(&prev));
+    struct Back { int d; ~Back() { (void)hipSetDevice(d); } } back{prev};
+    VFT_HIP(hipSetDevice(device_id));
+    vf_clip_text* v = new (std::nothrow) vf_clip_text();
+    if (!v) return fail(VF_ENOMEM, "host allocation failed");
+    v->cfg = c; v->device = device_id;
+    const size_t H = c.hidden, F = c.ffn;
+    v->o_tok = 0; v->o_pos = (size_t)c.vocab * H; v->o_layers = v->o_pos + (size_t)c.max_pos * H;
+    v->layer16 = 3 * H * H + H * H + F * H + H * F;
+    v->o_proj = v->o_layers + (size_t)c.layers * v->layer16;
+    v->f_layers = 0; v->layer32 = 2 * H + 3 * H + H + 2 * H + F + H;
+    v->f_final = (size_t)c.layers * v->layer32;
+    hipError_t er = hipMalloc((void**)&v->w16, (size_t)n16 * 2);
+    if (er == hipSuccess) er = hipMalloc((void**)&v->w32, (size_t)n32 * 4);
+    if (er == hipSuccess) er = hipMemcpy(v->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(v->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = configure_once();
+    if (er != hipSuccess) {
+        const std::string msg = std::string("vf_clip_text_create: ") + hipGetErrorString(er);
+        vf_clip_text_destroy(v);
+        return fail(VF_EHIP, msg);
+    }
+    *out = v;
+    return VF_OK;
+}
+
+static int ct_ensure_ws(vf_clip_text* v, int B, int Tp) {
+    int tokens = (B * Tp + 255) / 256 * 256;
+    if (tokens <= v->cap_tokens && B <= v->cap_b) return VF_OK;
+    tokens = std::max(tokens, v->cap_tokens); B = std::max(B, v->cap_b);
+    ct_free_ws(v);
+    const size_t H = v->cfg.hidden, F = v->cfg.ffn, Mp = tokens;
+    VFT_HIP(hipMalloc((void**)&v->x, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->y, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->t, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->qkv, Mp * 3 * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->ctx, Mp * H * 2));
+    VFT_HIP(hipMalloc((void**)&v->hbuf, Mp * F * 2));
+    VFT_HIP(hipMalloc((void**)&v->d_ids, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&v->d_mask_in, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&v->d_mask, Mp * 4));
+    VFT_HIP(hipMalloc((void**)&v->d_eos, (size_t)B * 4));
+    VFT_HIP(hipMalloc((void**)&v->d_out, (size_t)B * v->cfg.proj_dim * 4));
+    // rows past B Tp are read by the products: keep them finite
+    VFT_HIP(hipMemset(v->x, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->y, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->t, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->qkv, 0, Mp * 3 * H * 2));
+    VFT_HIP(hipMemset(v->ctx, 0, Mp * H * 2));
+    VFT_HIP(hipMemset(v->hbuf, 0, Mp * F * 2));
+    VFT_HIP(hipMemset(v->d_mask, 0, Mp * 4));
+    v->cap_tokens = tokens; v->cap_b = B;
+    VFT_HIP(gws_ensure(v->gws));
+    return VF_OK;
+}
+
+// ids / mask [b][t] int32 host (right-padded, as CLIP's tokenizer pads; mask == nullptr: every token valid -- what the HF
+// pipeline does, its tokenizer pads with the EOS id and passes no mask) -> out [b][proj_dim] fp32 host.
+// The pooled position follows transformers: eos_token_id == 2 (the published checkpoints' legacy config): argmax of the ids,
+// first maximum; otherwise the FIRST position holding eos_token_id (a row without one pools position 0, as argmax of zeros does).
+extern "C" int vf_clip_text_forward(vf_clip_text* v, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, float* out) {
+    if (!v) return fail(VF_EINVAL, "vf_clip_text_forward: null handle");
+    if (b < 0 || t < 0) return fail(VF_EINVAL, "vf_clip_text_forward: negative sizes");
+    if (b == 0) return VF_OK;
+    if (!ids || !out) return fail(VF_EINVAL, "vf_clip_text_forward: null buffer");
+    const vf_clip_text_config& c = v->cfg;
+    if (t == 0 || t > c.max_pos) return fail(VF_EINVAL, "vf_clip_text_forward: t must be in [1, max_pos]");
+    std::vector<int> eos((size_t)b), ones;
+    for (int i = 0; i < b; ++i) {
+        const int32_t* r = ids + (size_t)i * t;
+        int at = 0;
+        if (c.eos_token_id == 2) { for (int j = 1; j < t; ++j) if (r[j] > r[at]) at = j; }
+        else { for (int j = 0; j < t; ++j) if (r[j] == c.eos_token_id) { at = j; break; } }
+        eos[(size_t)i] = at;
+    }
+    if (!mask) { ones.assign((size_t)b * t, 1); mask = ones.data(); }
+    std::lock_guard<std::mutex> lk(v->mu);
+    int prev = 0;
+    VFT_HIP(hipGetDevice(&prev));
+    struct Back { int d; ~Back() { (void)hipSetDevice(d); } } back{prev};
+    VFT_HIP(hipSetDevice(v->device));
+    const int Tp = (t + 31) / 32 * 32;
+    VFT_TRY(ct_ensure_ws(v, b, Tp));
+    const int H = c.hidden, F = c.ffn;
+    const int M = b * Tp, Mp = (M + 255) / 256 * 256;
+    hipStream_t st = nullptr;
+    VFT_HIP(hipMemcpyAsync(v->d_ids, ids, (size_t)b * t * 4, hipMemcpyHostToDevice, st));
+    VFT_HIP(hipMemcpyAsync(v->d_mask_in, mask, (size_t)b * t * 4, hipMemcpyHostToDevice, st));
+    VFT_HIP(hipMemcpyAsync(v->d_eos, eos.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_clip_text_embed, dim3((M + 7) / 8), dim3(256), 0, st, v->d_ids, v->d_mask_in, v->w16 + v->o_tok, v->w16 + v->o_pos, b, t,
+                       Tp, H, c.vocab, v->x, v->d_mask);
+    const dim3 agrid((Tp + 127) / 128, c.heads, b);
+    for (int l = 0; l < c.layers; ++l) {
+        const half_t* w = v->w16 + v->o_layers + (size_t)l * v->layer16;
+        const float* f = v->w32 + v->f_layers + (size_t)l * v->layer32;
+        const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
+        const float *g1 = f, *b1n = g1 + H, *bqkv = b1n + H, *bo = bqkv + 3 * H, *g2 = bo + H, *b2n = g2 + H, *b1 = b2n + H, *b2 = b1 + F;
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, v->x, g1, b1n, c.ln_eps, M, H, v->t);
+        VFT_HIP(gemm<EPI_BIAS>(v->t, Wqkv, bqkv, nullptr, v->qkv, Mp, 3 * H, H, st, 0, &v->gws));
+        hipLaunchKernelGGL((k_attention_stream2<64, true>), agrid, dim3(256), sizeof(AttnStream2Lds<64>), st, v->qkv, v->d_mask, Tp, 3 * H, c.heads,
+                           c.heads, 0.125f, v->ctx, H, (const int*)nullptr);
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->ctx, Wo, bo, v->x, v->y, Mp, H, H, st, 0, &v->gws));
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, v->y, g2, b2n, c.ln_eps, M, H, v->t);
+        if (c.act == 0) VFT_HIP(gemm<EPI_BIAS_GELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st, 0, &v->gws));
+        else VFT_HIP(gemm<EPI_BIAS_QGELU>(v->t, W1, b1, nullptr, v->hbuf, Mp, F, H, st, 0, &v->gws));
+        VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(v->hbuf, W2, b2, v->y, v->x, Mp, H, F, st, 0, &v->gws));
+    }
+    hipLaunchKernelGGL(k_vit_head, dim3(b), dim3(256), (size_t)(H + 256) * sizeof(float), st, v->x, Tp, H, v->w32 + v->f_final, v->w32 + v->f_final + H,
+                       c.ln_eps, v->w16 + v->o_proj, c.proj_dim, c.normalize, v->d_out, (const int*)v->d_eos);
+    VFT_HIP(hipGetLastError());
+    VFT_HIP(hipMemcpyAsync(out, v->d_out, (size_t)b * c.proj_dim * 4, hipMemcpyDeviceToHost, st));
+    VFT_HIP(hipStreamSynchronize(st));
+    return VF_OK;
+}
+
 // Test hook (not part of the public header; tools/bench_gemm.py and the GEMM parity test bind it):
 // C[M][N] = epi(A[M][K] . W[N][K]^T + bias [, + R]) on device pointers, fp16 in/out, fp32 accumulation.
 extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, const void* R, void* C, int M, int N, int K,
@@ -6004,8 +6436,9 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     if (M % 128 || N % 128 || K % 64) return -2;
     if ((kind == 1 || kind == 5) && (M % DBM || N % DBN)) return -2;
     if (kind == 6 && (M % DBM || N % 128)) return -2;
-    if ((kind == 2 || kind == 7 || kind == 8) && (M % LBM || N % LBN)) return -2;
+    if ((kind == 2 || kind == 7 || kind == 8 || kind == 10) && (M % LBM || N % LBN)) return -2;
     if ((kind == 7 || kind == 8) && K < 128) return -2;
+    if (kind == 10 && (K < 256 || (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_QGELU && epi != EPI_BIAS_RESIDUAL))) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;

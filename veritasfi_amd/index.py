@@ -257,6 +257,16 @@ class DenseIndex:
     def set_option(self, name: str, value: int) -> None:
         _ffi.check(_ffi.lib().vf_index_set_option(self._h, name.encode(), int(value)), "vf_index_set_option")
 
+    def cosine_matrix_rows(self, ids) -> np.ndarray:
+        """[n, n] canonical cosine matrix of rows already in this index, picked by global id (``vf_cosine_matrix_rows``): the
+        similarity matrix of retrieved chunks without re-embedding their texts."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64).ravel()
+        out = np.empty((ids.size, ids.size), np.float32)
+        if ids.size:
+            _ffi.check(_ffi.lib().vf_cosine_matrix_rows(self._h, ids.ctypes.data, int(ids.size), out.ctypes.data),
+                       "vf_cosine_matrix_rows")
+        return out
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             _ffi.lib().vf_index_destroy(self._h)

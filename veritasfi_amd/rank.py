@@ -24,8 +24,11 @@ from .similarity import compute_similarity_mtx, fuse_and_rank
 
 
 def rank_chunk(chunks, question: str, query_time: datetime, reranker, embedding_fn, chunk_topk: int,
-               similar_threshhold: float = 0.9, reranker_lock=None, device_id: int = 0):
-    """chunks: list of dicts with 'page_content', 'bundle_id', 'metadata'['date_published' = 'YYYY-MM-DD']."""
+               similar_threshhold: float = 0.9, reranker_lock=None, device_id: int = 0, similarity_index=None,
+               row_id_key: str = "row_id"):
+    """chunks: list of dicts with 'page_content', 'bundle_id', 'metadata'['date_published' = 'YYYY-MM-DD'].
+    similarity_index (opt-in, see compute_similarity_mtx): the DenseIndex the chunks were retrieved from, each chunk carrying its
+    row as chunk[row_id_key] -- the similarity matrix then comes from the corpus rows in HBM instead of re-embedding n texts."""
     bundle_map = {}
     for idx, chunk in enumerate(chunks):
         bundle_map.setdefault(chunk["bundle_id"], []).append(idx)
@@ -40,7 +43,11 @@ def rank_chunk(chunks, question: str, query_time: datetime, reranker, embedding_
     with (reranker_lock if reranker_lock is not None else contextlib.nullcontext()):  # :450
         reranker_scores = reranker.compute_score(pairs, batch_size=8)
     _, ranked_indices = fuse_and_rank(reranker_scores, time_scores, device_id)       # :454-457
-    similar_mtx = compute_similarity_mtx(embedding_fn, chunk_content_list, device_id, as_torch=False)  # :462
+    if similarity_index is not None:
+        similar_mtx = compute_similarity_mtx(embedding_fn, chunk_content_list, device_id, as_torch=False, index=similarity_index,
+                                             row_ids=[chunk[row_id_key] for chunk in chunks])
+    else:
+        similar_mtx = compute_similarity_mtx(embedding_fn, chunk_content_list, device_id, as_torch=False)  # :462
     selected_indices = []
     current_size = 0
     for idx in ranked_indices:                                                        # :464-481

@@ -21,11 +21,21 @@ def _embed_all(embedding_fn, chunks):
     return np.asarray([embedding_fn.embed_query(c) for c in chunks], dtype=np.float32)
 
 
-def compute_similarity_mtx(embedding_fn, chunks, device_id: int = 0, as_torch: bool = True):
+def compute_similarity_mtx(embedding_fn, chunks, device_id: int = 0, as_torch: bool = True, index=None, row_ids=None):
     """ensembleRetriever.py:265-281.  Returns an [n, n] tensor the caller indexes as
-    ``similar_mtx[idx, selected_indices] > 0.9`` (vllmManager.py:476)."""
+    ``similar_mtx[idx, selected_indices] > 0.9`` (vllmManager.py:476).
+
+    Default: the reference's route -- embed the n chunk texts (ONE batched call here) and take the canonical cosine.
+    ``index=`` + ``row_ids=`` (explicit opt-in): the chunks came out of that ``DenseIndex`` and ``row_ids[i]`` is chunk i's row
+    -- their embeddings are already in HBM, so the matrix is ``index.cosine_matrix_rows(row_ids)`` and nothing is embedded
+    again.  The same matrix whenever the corpus rows ARE ``embed_documents(chunk texts)`` and the embedder treats documents and
+    queries alike (the reference embeds both with ``embed_query``); an embedder with a query instruction must keep the default."""
     if len(chunks) == 0:
         mtx = np.zeros((0, 0), dtype=np.float32)
+    elif index is not None:
+        if row_ids is None or len(row_ids) != len(chunks):
+            raise ValueError("row_ids must name one index row per chunk")
+        mtx = index.cosine_matrix_rows(row_ids)
     else:
         mtx = _index.cosine_matrix(_embed_all(embedding_fn, chunks), device_id)
     if as_torch:

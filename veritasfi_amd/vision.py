@@ -1,4 +1,7 @@
-"""Image encoder on the GPU: the vision tower of a CLIP-style model ("figure encoder" of BASELINE.json configs[3]).
+"""CLIP-style towers on the GPU: the vision tower ("figure encoder" of BASELINE.json configs[3]) and, since round 4, the TEXT
+tower of the same model -- the only way a text query reaches figure rows, which live in CLIP's joint space and not in the text
+embedder's (``HipClipTextEncoder`` / ``HipClipTextEmbeddings`` at the end of this file; transformers'
+``CLIPTextModelWithProjection`` is the contract: ``text_embeds = text_projection(final_layer_norm(h)[eos])``).
 
 The reference has no image model to mirror (``grep -ri "clip\\|vit" /root/reference`` finds nothing); the contract is the
 third-party model the config names, transformers' ``CLIPVisionModelWithProjection``:
@@ -146,3 +149,113 @@ class HipImageEmbeddings:
 
     def embed_image(self, image):
         return self.embed_images([image] if self.image_processor is not None else np.asarray(image)[None])[0]
+
+
+# ---- text tower ---------------------------------------------------------------------------------------------------------
+def pack_hf_clip_text(model, normalize=False):
+    """Flatten a HF ``CLIPTextModelWithProjection`` into the two blobs ``vf_clip_text_create`` takes (layout:
+    include/veritasfi_hip.h).  Returns (cfg, w16, w32)."""
+    sd = model.state_dict()
+    c = model.config
+    H, F, L = c.hidden_size, c.intermediate_size, c.num_hidden_layers
+    act = {"gelu": ACT_GELU, "quick_gelu": ACT_QUICK_GELU}.get(c.hidden_act)
+    if act is None:
+        raise ValueError(f"activation {c.hidden_act!r} is not implemented (gelu, quick_gelu)")
+    w16 = [_np16(sd["text_model.embeddings.token_embedding.weight"]), _np16(sd["text_model.embeddings.position_embedding.weight"])]
+    w32 = []
+    for l in range(L):
+        p = f"text_model.encoder.layers.{l}."
+        w16 += [_np16(sd[p + "self_attn.q_proj.weight"]), _np16(sd[p + "self_attn.k_proj.weight"]),
+                _np16(sd[p + "self_attn.v_proj.weight"]), _np16(sd[p + "self_attn.out_proj.weight"]),
+                _np16(sd[p + "mlp.fc1.weight"]), _np16(sd[p + "mlp.fc2.weight"])]
+        w32 += [_np32(sd[p + "layer_norm1.weight"]), _np32(sd[p + "layer_norm1.bias"]),
+                _np32(sd[p + "self_attn.q_proj.bias"]), _np32(sd[p + "self_attn.k_proj.bias"]),
+                _np32(sd[p + "self_attn.v_proj.bias"]), _np32(sd[p + "self_attn.out_proj.bias"]),
+                _np32(sd[p + "layer_norm2.weight"]), _np32(sd[p + "layer_norm2.bias"]),
+                _np32(sd[p + "mlp.fc1.bias"]), _np32(sd[p + "mlp.fc2.bias"])]
+    w16 += [_np16(sd["text_projection.weight"])]
+    w32 += [_np32(sd["text_model.final_layer_norm.weight"]), _np32(sd["text_model.final_layer_norm.bias"])]
+    cfg = dict(vocab=c.vocab_size, max_pos=c.max_position_embeddings, hidden=H, layers=L, heads=c.num_attention_heads, ffn=F,
+               proj_dim=c.projection_dim, act=act, eos_token_id=int(c.eos_token_id), normalize=int(bool(normalize)),
+               ln_eps=float(c.layer_norm_eps))
+    return cfg, np.ascontiguousarray(np.concatenate(w16)), np.ascontiguousarray(np.concatenate(w32))
+
+
+class HipClipTextEncoder:
+    """Handle over ``vf_clip_text_*``.  ``forward(input_ids, attention_mask=None)`` -> text_embeds [b, proj_dim] fp32."""
+
+    def __init__(self, cfg: dict, w16: np.ndarray, w32: np.ndarray, device_id: int = 0):
+        L = _ffi.lib()
+        self.cfg = dict(cfg)
+        c = _ffi.ClipTextConfig(**cfg)
+        n16, n32 = _ffi.c_i64(0), _ffi.c_i64(0)
+        _ffi.check(L.vf_clip_text_weight_sizes(ctypes.byref(c), ctypes.byref(n16), ctypes.byref(n32)), "vf_clip_text_weight_sizes")
+        w16 = np.ascontiguousarray(w16, dtype=np.float16)
+        w32 = np.ascontiguousarray(w32, dtype=np.float32)
+        if w16.size != n16.value or w32.size != n32.value:
+            raise ValueError(f"weight blobs have {w16.size}/{w32.size} elements, config needs {n16.value}/{n32.value}")
+        self._h = _ffi.vp()
+        _ffi.check(L.vf_clip_text_create(ctypes.byref(self._h), ctypes.byref(c), w16.ctypes.data, w16.size, w32.ctypes.data,
+                                         w32.size, int(device_id)), "vf_clip_text_create")
+        self.out_dim = int(cfg["proj_dim"])
+
+    @classmethod
+    def from_hf(cls, model, normalize=False, device_id: int = 0):
+        return cls(*pack_hf_clip_text(model, normalize), device_id=device_id)
+
+    def forward(self, input_ids, attention_mask=None) -> np.ndarray:
+        if self._h is None:
+            raise RuntimeError("HipClipTextEncoder is closed")
+        if hasattr(input_ids, "detach"):
+            input_ids = input_ids.detach().cpu().numpy()
+        if hasattr(attention_mask, "detach"):
+            attention_mask = attention_mask.detach().cpu().numpy()
+        ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        if ids.ndim != 2 or ids.shape[1] < 1 or ids.shape[1] > self.cfg["max_pos"]:
+            raise ValueError(f"input_ids must be [b, 1..{self.cfg['max_pos']}], got {ids.shape}")
+        mp = None
+        if attention_mask is not None:
+            m = np.ascontiguousarray(attention_mask, dtype=np.int32)
+            if m.shape != ids.shape:
+                raise ValueError("attention_mask must have the shape of input_ids")
+            mp = m.ctypes.data
+        out = np.empty((ids.shape[0], self.out_dim), np.float32)
+        _ffi.check(_ffi.lib().vf_clip_text_forward(self._h, ids.ctypes.data, mp, ids.shape[0], ids.shape[1], out.ctypes.data),
+                   "vf_clip_text_forward")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _ffi.lib().vf_clip_text_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipClipTextEmbeddings:
+    """The embedder surface of src/utils/ragManager.py:50 (``embed_query(str) -> list[float]``, ``embed_documents(list[str]) ->
+    list[list[float]]``) over the CLIP text tower: what a figure-leg ``FaissRetriever(figure_rows, HipClipTextEmbeddings(...))``
+    takes as its ``embedding_fn``.  ``tokenizer``: HF-style callable (``padding="max_length"``, ``truncation=True``,
+    ``max_length``) returning ``input_ids`` and ``attention_mask``; tokenisation stays third-party, as for the text embedder."""
+
+    def __init__(self, tokenizer, encoder: HipClipTextEncoder, batch_size: int = 256, pass_mask: bool = False):
+        self.tokenizer, self.encoder, self.batch_size, self.pass_mask = tokenizer, encoder, int(batch_size), bool(pass_mask)
+        self.max_length = int(encoder.cfg["max_pos"])
+
+    def _embed(self, texts):
+        out = []
+        for i in range(0, len(texts), self.batch_size):
+            enc = self.tokenizer(list(texts[i:i + self.batch_size]), padding="max_length", truncation=True, max_length=self.max_length,
+                                 return_tensors="np")
+            out.append(self.encoder.forward(enc["input_ids"], enc["attention_mask"] if self.pass_mask else None))
+        return np.concatenate(out) if out else np.zeros((0, self.encoder.out_dim), np.float32)
+
+    def embed_documents(self, texts):
+        return self._embed(list(texts)).tolist()
+
+    def embed_query(self, text):
+        return self._embed([text])[0].tolist()
