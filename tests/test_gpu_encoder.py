@@ -504,7 +504,7 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
     assert err < 2e-2 and d01 < 1.6e-2      # fp16 output of O(10) values: one ulp is 7.8e-3
 
 
-@pytest.mark.parametrize("kind", [1, 2, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("kind", [1, 2, 3, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("epi", [0, 1, 2, 11])
 def test_gemm_kernels_match_torch(vf, kind, epi):
     """Every GEMM kernel (1 = LDS-DMA 128x256 with two workgroups per CU, 2 = 256x256, 3 = register-staged 128x128) x every
@@ -523,12 +523,16 @@ def test_gemm_kernels_match_torch(vf, kind, epi):
     shapes = [(1792, 768, 320), (512, 1024, 3072)]
     if kind == 9:
         shapes = [(1792, 768, 320), (512, 1024, 3072), (2560, 512, 128), (1024, 256, 64 * 7)]   # (K = 320: 10 steps; 128: the minimum)
+    if kind == 10:
+        # k_gemm9_tn (persistent, register-direct epilogue; K >= 256): fewer tiles than CUs, 320 / 384 tiles on 256 workgroups with odd
+        # and even K-tile counts (LDS buffer parity alternates between a workgroup's tiles), an exact three rounds, a long K
+        shapes = [(1792, 768, 320), (512, 1024, 3072), (10240, 2048, 320), (6144, 4096, 256), (16384, 3072, 448), (51200, 768, 768)]
     if kind == 8:
         # the persistent 8-phase kernel: more tiles than workgroups (320 and 384 on 256: the cross-tile pipeline, odd and
         # minimal K-tile counts so the LDS buffer parity alternates between a workgroup's tiles), and an exact 3 rounds
         shapes += [(10240, 2048, 320), (6144, 4096, 128), (16384, 3072, 192)]
     for (M, N, K) in shapes:
-        if kind in (7, 8, 9) and (M % 256 or N % 256):   # the 8-phase kernels (and the four-wave experiment) take 256 x 256 tiles only
+        if kind in (7, 8, 9, 10) and (M % 256 or N % 256):   # the 8-phase kernels (and the four-wave experiment) take 256 x 256 tiles only
             M, N = (M + 255) // 256 * 256, (N + 255) // 256 * 256
         A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
         W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()

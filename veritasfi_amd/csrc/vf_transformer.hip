@@ -2358,6 +2358,15 @@ __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, const c
                  : "memory");
 }
 
+// the same with the LDS byte address and the 64-bit global base already in scalar registers (k_gemm9_tn keeps both as running state)
+__device__ __forceinline__ void dma16u(unsigned long long ua, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(ua), "s"(lds_addr)
+                 : "memory");
+}
+
 [[maybe_unused]] constexpr int QLDS = PLDS + 1024;   // + one tile's bias (256 floats)
 
 // tile of a dispatch index: XCD-contiguous, n-major groups of 4 m-tiles (as k_gemm8p_tn)
@@ -2608,41 +2617,81 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict
 // the end of K to the next tile (or the dump slot).  Requires M, N % 256 == 0, K % 64 == 0, K >= 256; gridDim.x a multiple of
 // 8 or the tile count.
 // ------------------------------------------------------------------------------------------------
-constexpr int RLDS = PLDS + 2048;   // + two tiles' bias (2 x 256 floats)
+constexpr int RLDS = PLDS + 2048 + 1024;   // + two tiles' bias (2 x 256 floats) + wall-clock stamps of 16 tiles (debug)
+constexpr int k9StampTiles = 16, k9Stamps = 6;
 
 template <int EPI>
 __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                         half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + 2 x bias
+                                                         half_t* __restrict__ C, int M, int N, int K, int stagger_ticks, unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + 2 x bias + stamps
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
     const int Mt = M / PBM, Nt = N / PBN, ntiles = Mt * Nt;
     float* bias_lds = (float*)(smem + PLDS);
-    unsigned voff[4][2];
+    // Per-lane byte offsets of the first DMA instruction of A_m0 and of B_n0 inside a tile's A / W panel.  The second instruction of
+    // a half-tile fetches the rows 8 further down, whose swizzle differs: it keeps its own offset; A_m1 (+ 64 rows) and B_n1 (+ 32
+    // rows) enter through the scalar base.
+    unsigned voffA[2], voffW[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = 16 * wid + 8 * j + (lane >> 3);          // LDS row of the half-tile
         const int lc = (lane & 7) ^ ((i >> 1) & 7);            // logical 16-byte chunk this lane fetches
-        const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
+        const int am0 = i < 64 ? i : 64 + i;                   // A_m0: rows {0..63, 128..191}; A_m1: + 64
         // W rows, permuted: LDS row 32 w' + 16 u + jj of B_n0 (n-block u, MFMA column jj) holds column 8 (jj >> 2) + 4 u + (jj & 3)
         // of wave w''s first 32; B_n1 the same of its second 32
         const int jj = i & 15, u = (i >> 4) & 1;
-        const int bn0 = (i >> 5) * 64 + 8 * (jj >> 2) + 4 * u + (jj & 3), bn1 = bn0 + 32;
-        voff[0][j] = (unsigned)((am0 * K + lc * 8) * 2);
-        voff[1][j] = (unsigned)((bn0 * K + lc * 8) * 2);
-        voff[2][j] = (unsigned)((bn1 * K + lc * 8) * 2);
-        voff[3][j] = (unsigned)((am1 * K + lc * 8) * 2);
+        const int bn0 = (i >> 5) * 64 + 8 * (jj >> 2) + 4 * u + (jj & 3);
+        voffA[j] = (unsigned)((am0 * K + lc * 8) * 2);
+        voffW[j] = (unsigned)((bn0 * K + lc * 8) * 2);
     }
-    const int nk = K / PBK, G = 4 * nk;
-    int mt_c, nt_c, mt_n = 0, nt_n = 0;
+    const unsigned long long a_m1_bytes = (unsigned long long)64 * K * 2, b_n1_bytes = (unsigned long long)32 * K * 2;
+    const int nk = K / PBK;
+    int mt_c, nt_c;
     int orig = blockIdx.x;
     q_tile_of(orig, Mt, Nt, mt_c, nt_c);
     bool has_next = orig + (int)gridDim.x < ntiles;
-    if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
     int ktg = 0;   // K-tiles consumed by this workgroup so far: LDS buffer of local K-tile kt is (ktg + kt) & 1
-#define VF9_STAGE(S_, G_) q_stage<S_>(smem, wid, A, W, K, (G_), G, nk, ktg, has_next, mt_c, nt_c, mt_n, nt_n, voff[S_][0], voff[S_][1]);
+    // ---- the STAGE CURSOR: half-tiles are staged strictly in sequence (A_m0, B_n0, B_n1, A_m1 of K-tile 0, then of K-tile 1, ...,
+    // running on into the workgroup's next tile), 1.75 K-tiles ahead of the MFMAs.  Its state lives in scalar registers and
+    // moves by a few scalar adds per half-tile (the first version recomputed tile, K-tile and slot of every half-tile from its
+    // index: ~45 scalar instructions per stage call, 180 in front of every K-tile's first barrier).
+    unsigned long long st_a, st_w;          // byte addresses of the K-tile being staged: row 0 of the tile's A / W panel, its first k
+    int st_kt = 0, st_orig = orig;          // that K-tile's index in its tile; the dispatch index of the tile being staged
+    unsigned st_slot;                       // LDS byte address of that K-tile's buffer + this wave's 2 KB piece (toggles by 64 KB)
+    bool st_dump = false;                   // past the workgroup's last tile: the stage calls go on re-reading into the dump slot
+    const unsigned lds_smem = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem);
+    const unsigned lds0 = lds_smem + (unsigned)(16 * wid * 128);
+    {
+        const unsigned long long a0 = (unsigned long long)(A + (long long)mt_c * PBM * K), w0 = (unsigned long long)(W + (long long)nt_c * PBN * K);
+        st_a = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a0);
+        st_w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w0);
+        st_slot = lds0;
+    }
+    auto stage_advance = [&]() {            // after A_m1: on to the next K-tile (of this tile, of the next one, or of the dump)
+        st_slot = lds0 + ((st_slot - lds0) ^ (4u * PSLOT));
+        if (st_dump) return;
+        if (++st_kt < nk) { st_a += PBK * 2; st_w += PBK * 2; return; }
+        st_kt = 0;
+        st_orig += (int)gridDim.x;
+        if (st_orig < ntiles) {
+            int mt_, nt_;
+            q_tile_of(st_orig, Mt, Nt, mt_, nt_);
+            st_a = (unsigned long long)A + (unsigned long long)((long long)mt_ * PBM * K) * 2ull;
+            st_w = (unsigned long long)W + (unsigned long long)((long long)nt_ * PBN * K) * 2ull;
+        } else {
+            st_dump = true;                 // keep the last K-tile's addresses: valid memory, landing in the dump slot
+        }
+    };
+#define VF9_STAGE(S_, G_)                                                                                              \
+    {                                                                                                                  \
+        const unsigned dst_ = st_dump ? lds0 + 8u * PSLOT : st_slot + (unsigned)(S_) * PSLOT;                          \
+        const unsigned long long b_ = (S_) == 0 ? st_a : (S_) == 3 ? st_a + a_m1_bytes : (S_) == 1 ? st_w : st_w + b_n1_bytes; \
+        dma16u(b_, ((S_) == 0 || (S_) == 3) ? voffA[0] : voffW[0], dst_);                                              \
+        dma16u(b_, ((S_) == 0 || (S_) == 3) ? voffA[1] : voffW[1], dst_ + 1024u);                                      \
+        if ((S_) == 3) stage_advance();                                                                                \
+    }
     f4v acc[8][4];
     const int swz = (r15 >> 1) & 7;
     const int a_off = (wr * 64 + r15) * 128, b_off = (wc * 32 + r15) * 128;
@@ -2658,11 +2707,17 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
         DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
         DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
     }
-#define VF9_QUAD(MQ, NQ, BF)                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
-                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
+#ifndef VF9_ORDER
+#define VF9_ORDER 1
+#endif
+#if VF9_ORDER == 0     /* consecutive MFMAs share the A fragment (second operand), the W fragment alternates */
+#define VF9_QUAD_LOOPS _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u)
+#else                  /* consecutive MFMAs share the W fragment (FIRST operand) over four A fragments */
+#define VF9_QUAD_LOOPS _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int t = 0; t < 4; ++t)
+#endif
+#define VF9_QUAD(MQ, NQ, BF, ZERO_)   /* ZERO_ (literal): a tile's first K-tile starts from C = 0 at its first k-step: no accumulator is ever cleared */ \
+    VF9_QUAD_LOOPS                                                                         \
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], ((ZERO_) && ks == 0) ? f4v{0.f, 0.f, 0.f, 0.f} : acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
 #define VF9_MID()                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
@@ -2673,108 +2728,259 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);
     VF9_STAGE(0, 0) VF9_STAGE(1, 1) VF9_STAGE(2, 2) VF9_STAGE(3, 3) VF9_STAGE(0, 4) VF9_STAGE(1, 5) VF9_STAGE(2, 6)
+    // DESYNCHRONISE the workgroups.  Tiles take the same time everywhere, so workgroups that start together reach every epilogue
+    // together: 256 x 128 KB of stores meet the memory system as one burst, the store acknowledgements come back at the HBM
+    // write rate (~8 us for 32 MB) and -- vmcnt being in order -- every wave's next stage waits behind them (measured: T(K) =
+    // 8 us + 1.5 us per K-tile with or without the LDS-free epilogue; profiles/r04_gemm9_k_sweep.log).  Spread over a tile's
+    // time, a third of the chip writes while two thirds compute and the write-back cache absorbs each tile.  The workgroups
+    // with the SMALLER tile count (blockIdx >= ntiles % grid) take their offsets for free: they end before the others anyway.
+    if (stagger_ticks > 0) {
+        const int G_ = (int)gridDim.x, rem = ntiles % G_, b = (int)blockIdx.x;
+        int num = 0, den = 1;
+        if (rem != 0) { if (b >= rem) { num = ((b - rem) >> 3) + 1; den = ((G_ - rem + 7) >> 3) + 1; } }
+        else if (ntiles >= 2 * G_) { num = b >> 3; den = 2 * ((G_ + 7) >> 3); }       // exact rounds: half a tile's spread
+        const unsigned long long wait = (unsigned long long)stagger_ticks * (unsigned)num / (unsigned)den;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     if (wr == 1) {   // waves 4..7 run one barrier behind, from here to the end of the kernel
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 14 issued, 8 may fly: half-tiles 0 .. 2 of this wave landed
         __builtin_amdgcn_s_barrier();
     }
-    for (int it = 0;; ++it) {
+    unsigned long long* stamps = (unsigned long long*)(smem + PLDS + 2048);   // [16 tiles][6], written by lane 0 of wave 0 (LDS: no vmcnt traffic)
+#define VF9_STAMP(SLOT_)                                                                                              \
+    if (dbg && wid == 0 && lane == 0 && it < k9StampTiles) stamps[it * k9Stamps + (SLOT_)] = __builtin_amdgcn_s_memrealtime();
+    if (dbg && wid == 0) { for (int i = lane; i < k9StampTiles * k9Stamps; i += 64) stamps[i] = 0ull; }
+    // ---- the epilogue in TWO HALVES that ride INSIDE the MFMA blocks of the main loop.  Phase X of a K-tile touches only the
+    // accumulators of the wave's first 64 rows (acc[0..3]), phase Y only those of its second 64 (acc[4..7]).  After X of the LAST
+    // K-tile acc[0..3] are final: they are converted and stored between the 32 MFMAs of that K-tile's Y (which never touches
+    // them); acc[4..7] are final after that Y and leave between the MFMAs of the NEXT tile's first X.  Each micro-step clears the four
+    // registers it has converted (the MFMAs always accumulate in place: starting a tile from C = 0 instead made the allocator open new
+    // live ranges for the accumulators and spill), so no accumulator is copied.  History (profiles/r04_gemm9_*.log): the whole
+    // epilogue between two tiles made the two wave halves take turns at it under the one-barrier stagger (first K-tile of a tile 4.4
+    // us instead of 1.6, + 2.2 us epilogue: 5 of a tile's 25 us); the halves placed in front of their phase's barrier did the same
+    // to a lesser degree (every barrier interval with a half in it stretched to that half's length) -- only work issued in the
+    // shadow of the wave's OWN MFMAs is free.
+    // lane (r15, kb) of block mi holds row wr 128 + mi 16 + r15 and, for hf = 0, 1, the eight columns wc 64 + hf 32 + 8 kb .. + 7:
+    // acc[mi][2 hf][0..3], acc[mi][2 hf + 1][0..3].  Residual rows are loaded by VF9_EPI_LOAD_R at the TOP of the phase, before
+    // its stage DMAs (vmcnt is in order: loads issued after them would wait for them), and used a few hundred cycles later.
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    h8 rr[4][2];
+#define VF9_EPI_LOAD_R(MH_, M0_, N0_)                                                                                  \
+    if constexpr (EPI == EPI_BIAS_RESIDUAL) {                                                                          \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                                               \
+            _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_)                                                        \
+                rr[t_][hf_] = *(const h8*)(R + ((M0_) + wr * 128 + (4 * (MH_) + t_) * 16 + r15) * N + (N0_) + wc * 64 + 8 * kb + hf_ * 32); \
+    }
+#define VF9_EPI_HALF(MH_, M0_, N0_, PAR_)                                                                              \
+    {                                                                                                                  \
+        f2v bv_[2][4];                                                                                                 \
+        _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                                          \
+            f4v b0_ = {0.f, 0.f, 0.f, 0.f}, b1_ = b0_;                                                                 \
+            if (bias) {                                                                                                \
+                const float* bl_ = bias_lds + (PAR_) * 256 + wc * 64 + hf_ * 32 + 8 * kb;                              \
+                b0_ = *(const f4v*)bl_; b1_ = *(const f4v*)(bl_ + 4);                                                  \
+            }                                                                                                          \
+            bv_[hf_][0] = f2v{b0_[0], b0_[1]}; bv_[hf_][1] = f2v{b0_[2], b0_[3]};                                      \
+            bv_[hf_][2] = f2v{b1_[0], b1_[1]}; bv_[hf_][3] = f2v{b1_[2], b1_[3]};                                      \
+        }                                                                                                              \
+        half_t* cbase_ = C + ((M0_) + wr * 128 + (4 * (MH_)) * 16 + r15) * N + (N0_) + wc * 64 + 8 * kb;               \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                             \
+            const int mi_ = 4 * (MH_) + t_;                                                                            \
+            _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                                      \
+                u4v o_;                                                                                                \
+                _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                     \
+                    const f4v a4_ = acc[mi_][2 * hf_ + q_];                                                            \
+                    f2v v0_ = f2v{a4_[0], a4_[1]} + bv_[hf_][2 * q_], v1_ = f2v{a4_[2], a4_[3]} + bv_[hf_][2 * q_ + 1]; \
+                    if (EPI == EPI_BIAS_GELU) { v0_ = gelu_erf2(v0_); v1_ = gelu_erf2(v1_); }                          \
+                    if (EPI == EPI_BIAS_QGELU) { v0_ = quick_gelu2(v0_); v1_ = quick_gelu2(v1_); }                     \
+                    h2v p0_ = __builtin_convertvector(v0_, h2v), p1_ = __builtin_convertvector(v1_, h2v);              \
+                    if constexpr (EPI == EPI_BIAS_RESIDUAL) {   /* (the LDS-image epilogues round acc + bias to fp16 before the residual joins: same order) */ \
+                        const h8 r8_ = rr[t_][hf_];                                                                    \
+                        p0_ = __builtin_convertvector(__builtin_convertvector(p0_, f2v) + f2v{(float)r8_[4 * q_ + 0], (float)r8_[4 * q_ + 1]}, h2v); \
+                        p1_ = __builtin_convertvector(__builtin_convertvector(p1_, f2v) + f2v{(float)r8_[4 * q_ + 2], (float)r8_[4 * q_ + 3]}, h2v); \
+                    }                                                                                                  \
+                    o_[2 * q_] = __builtin_bit_cast(unsigned, p0_); o_[2 * q_ + 1] = __builtin_bit_cast(unsigned, p1_); \
+                }                                                                                                      \
+                *(u4v*)(cbase_ + (long long)t_ * 16 * N + hf_ * 32) = o_;                                              \
+            }                                                                                                          \
+            _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) acc[mi_][b_] = f4v{0.f, 0.f, 0.f, 0.f}; \
+        }                                                                                                              \
+    }
+    // The 32 MFMAs of a phase with the epilogue half threaded between them, in the order the hardware should issue it: after every
+    // second MFMA one micro-step (bias add + fp16 conversion of four accumulator registers: ~4 VALU instructions, issued in the
+    // shadow of the MFMA before them), after every fourth a 16-byte store.  sched_barrier(0) pins each group: left alone the
+    // scheduler hoists the conversions to the top of the block and spills the fragments.  (bias: 16 floats, read once per block.)
+    // MFMA order inside a quadrant: VF9_ORDER (k-step, then the W fragment u, then the four A fragments t).
+    u4v ob_;
+    f2v bvp_[4];
+    f4v bq0_, bq1_;
+    half_t* cb_ = C;
+    const float* bl_ = bias_lds;
+#define VF9_STEP(N_, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)                                                    \
+    {                                                                                                                  \
+        constexpr int r16_ = (N_) & 15, ks_ = r16_ >> 3, u_ = (r16_ >> 2) & 1, t_ = r16_ & 3;                           \
+        if ((N_) < 16) acc[(MQ_) * 4 + t_][(NQA_) * 2 + u_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BFA_[u_][ks_], Af[t_][ks_], acc[(MQ_) * 4 + t_][(NQA_) * 2 + u_], 0, 0, 0); \
+        else acc[(MQ_) * 4 + t_][(NQB_) * 2 + u_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BFB_[u_][ks_], Af[t_][ks_], acc[(MQ_) * 4 + t_][(NQB_) * 2 + u_], 0, 0, 0); \
+        if ((EON_) && (N_) == 8 && bias) { bq0_ = *(const f4v*)(bl_ + 32); bq1_ = *(const f4v*)(bl_ + 36); }   /* the second column half's bias, 8 MFMAs ahead */ \
+        if ((EON_) && (N_) == 15) {                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+            bvp_[0] = f2v{bq0_[0], bq0_[1]}; bvp_[1] = f2v{bq0_[2], bq0_[3]}; bvp_[2] = f2v{bq1_[0], bq1_[1]}; bvp_[3] = f2v{bq1_[2], bq1_[3]}; \
+        }                                                                                                              \
+        if ((EON_) && ((N_) & 1)) {       /* pieces in the order hf 0: t 0..3, then hf 1: t 0..3 */                    \
+            constexpr int j_ = (N_) >> 1, p_ = j_ >> 1, ehf_ = p_ >> 2, et_ = p_ & 3, eq_ = j_ & 1;                     \
+            const f4v a4_ = acc[4 * (MH_) + et_][2 * ehf_ + eq_];                                                      \
+            f2v v0_ = f2v{a4_[0], a4_[1]} + bvp_[2 * eq_], v1_ = f2v{a4_[2], a4_[3]} + bvp_[2 * eq_ + 1];               \
+            if (EPI == EPI_BIAS_GELU) { v0_ = gelu_erf2(v0_); v1_ = gelu_erf2(v1_); }                                  \
+            if (EPI == EPI_BIAS_QGELU) { v0_ = quick_gelu2(v0_); v1_ = quick_gelu2(v1_); }                             \
+            acc[4 * (MH_) + et_][2 * ehf_ + eq_] = f4v{0.f, 0.f, 0.f, 0.f};   /* ready for the next tile: the MFMAs always accumulate in place */ \
+            ob_[2 * eq_] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0_, h2v));                            \
+            ob_[2 * eq_ + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1_, h2v));                        \
+            if (eq_ == 1) *(u4v*)(cb_ + (long long)et_ * 16 * N + ehf_ * 32) = ob_;                                    \
+        }                                                                                                              \
+        if ((EON_) && ((N_) & 1)) __builtin_amdgcn_sched_barrier(0);                                                   \
+    }
+#define VF9_BLOCK(MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_, M0_, N0_, PAR_)                                       \
+    {                                                                                                                  \
+        if (EON_) {                                                                                                    \
+            bq0_ = f4v{0.f, 0.f, 0.f, 0.f}; bq1_ = bq0_;                                                               \
+            bl_ = bias_lds + (PAR_) * 256 + wc * 64 + 8 * kb;                                                          \
+            if (bias) { bq0_ = *(const f4v*)bl_; bq1_ = *(const f4v*)(bl_ + 4); }                                      \
+            cb_ = C + ((M0_) + wr * 128 + (4 * (MH_)) * 16 + r15) * N + (N0_) + wc * 64 + 8 * kb;                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+            bvp_[0] = f2v{bq0_[0], bq0_[1]}; bvp_[1] = f2v{bq0_[2], bq0_[3]}; bvp_[2] = f2v{bq1_[0], bq1_[1]}; bvp_[3] = f2v{bq1_[2], bq1_[3]}; \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                              \
+        VF9_STEP(0, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(1, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
+        VF9_STEP(2, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(3, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
+        VF9_STEP(4, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(5, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
+        VF9_STEP(6, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(7, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
+        VF9_STEP(8, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(9, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
+        VF9_STEP(10, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(11, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(12, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(13, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(14, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(15, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(16, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(17, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(18, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(19, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(20, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(21, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(22, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(23, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(24, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(25, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(26, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(27, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(28, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(29, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+        VF9_STEP(30, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(31, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
+    }
+    // one K-tile.  FIRST_: 0 = no, 1 = a tile's first K-tile (accumulators start from C = 0), 2 = the same with the PREVIOUS tile's
+    // second half leaving between phase X's MFMAs.  LAST_: this tile's first half leaves between phase Y's MFMAs.  All literals.
+    // Counted waits (vmcnt is in order and counts the epilogue's stores).  Queue around a tile boundary, oldest first:
+    // X(nk-1): 2 DMAs | Y(nk-1): 6 DMAs, 8 stores | X(0): 2 DMAs, 8 stores | Y(0): 6 DMAs | X(1): 2 DMAs ...
+    //   X(0) needs the DMAs of X(nk-1) landed  -> 6 + 8 may fly;   Y(0) those of Y(nk-1) -> 8 + 2 + 8 may fly;
+    //   X(1) those of X(0) -> 8 + 6 may fly (the first eight stores are older: they have had two phases);  Y(1): as ever.
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+#ifndef VF9_EPI_SPLIT
+#define VF9_EPI_SPLIT 0   /* (unused by the current placement; the wave-half split measured slower: first K-tile 5.6 vs 4.9 us) */
+#endif
+#ifndef VF9_EPI_IN_X
+#define VF9_EPI_IN_X 0   /* 1: the second half's epilogue threaded through the MFMAs of the next tile's first phase (VF9_BLOCK's micro-steps).  Built and
+                            inspected in round 4: with 128 accumulators + 64 fragment registers live the allocator spills 60-120 registers around the block,
+                            in every arrangement tried (peeled K-tiles, C = 0 starts, opaque zeros); 0 = both halves in front of their phase's barrier */
+#endif
+    // One loop body for every K-tile (first is a wave-uniform run-time flag: peeling the first K-tile into a copy of its own let the
+    // compiler fold the cleared accumulators into C = 0 MFMAs with fresh destinations, and the allocator spilled).
+    // BOTH halves of a tile's epilogue run in the NEXT tile's first K-tile, each in front of the barrier of the phase that is about to
+    // overwrite its accumulators: acc[0..3] (final since X of the last K-tile) in front of X(0), acc[4..7] (final since Y of the last
+    // K-tile) in front of Y(0).  One phase earlier -- right behind the MFMAs that finish them -- a half first had to wait for those
+    // MFMAs to drain through the pipe it shares with the other wave half (first K-tile 4.9 us instead of 1.5; profiles/r04_gemm9_*.log).
+    long long m0p = 0, n0p = 0;   // the previous tile
+    int it = 0;
+    for (;; ++it) {
         const long long m0 = (long long)mt_c * PBM, n0 = (long long)nt_c * PBN;
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+        VF9_STAMP(0)
         for (int kt = 0; kt < nk; ++kt) {
+            if (kt == 1) { VF9_STAMP(1) }
+            if (kt == 2) { VF9_STAMP(2) }
             const char* base = smem + ((ktg + kt) & 1) * (4 * PSLOT);
-            // the first K-tile after an epilogue: its 16 stores are younger than every DMA this tile waits for and stay in flight
-            const bool relaxed = kt == 0 && it > 0;
-            if (relaxed) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            const bool first = kt == 0 && it > 0, second = kt == 1 && it > 0;
+            // Counted waits (vmcnt is in order and counts the epilogue's stores).  Queue around a tile boundary, oldest first:
+            // X(nk-1): 2 DMAs | Y(nk-1): 6 DMAs | X(0): 2 DMAs, 8 stores | Y(0): 6 DMAs, 8 stores | X(1): 2 DMAs | Y(1): 6 DMAs ...
+            //   X(0) needs the DMAs of X(nk-1): as ever (6);   Y(0) those of Y(nk-1) -> 2 + 8 may fly;   X(1) those of X(0) -> 8 + 6 + 8;
+            //   Y(1) those of Y(0) -> 8 + 2 (the first eight stores are older: three phases old);   X(2): as ever (the second eight: three phases).
+            // (the residual form stores BEFORE it stages -- X(0): 8 stores, 2 DMAs | Y(0): 8 stores, 6 DMAs -- so X(1) may leave 8 + 6 in
+            // flight and Y(1) is as ever)
+            if (second) { if constexpr (EPI == EPI_BIAS_RESIDUAL) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            VF9_STAGE(3, 4 * kt + 7)
-            if (kt == 0 && wid == 0 && bias) dma16s(bias + n0, (unsigned)lane * 16u, (const char*)(bias_lds + (it & 1) * 256));
+            if constexpr (EPI == EPI_BIAS_RESIDUAL) {   // residual rows first, consumed at once: nothing younger to wait behind, no register held across the stage
+                if (first) { VF9_EPI_LOAD_R(0, m0p, n0p) VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            VF9_STAGE(3, 0)
+            if (kt == 0 && wid == 0 && bias) dma16u((unsigned long long)(bias + n0), (unsigned)lane * 16u, lds_smem + (unsigned)PLDS + (unsigned)(it & 1) * 1024u);
+            if constexpr (EPI != EPI_BIAS_RESIDUAL) {
+                if (first) { VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }   // (before the fragment reads: their 64 registers are dead here)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             VF9_READ_B(B0f, base + 1 * PSLOT)
             VF9_READ_B(B1f, base + 2 * PSLOT)
             VF9_READ_A(base + 0 * PSLOT)
             VF9_MID()
-            VF9_QUAD(0, 0, B0f)
-            VF9_QUAD(0, 1, B1f)
+            VF9_BLOCK(0, B0f, 0, B1f, 1, 0, 0, 1, m0p, n0p, 0)
             VF9_TAIL()
-            if (relaxed) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            if (first || (second && EPI != EPI_BIAS_RESIDUAL)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            VF9_STAGE(0, 4 * kt + 8)
-            VF9_STAGE(1, 4 * kt + 9)
-            VF9_STAGE(2, 4 * kt + 10)
+            if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+                if (first) { VF9_EPI_LOAD_R(1, m0p, n0p) VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            VF9_STAGE(0, 0)
+            VF9_STAGE(1, 0)
+            VF9_STAGE(2, 0)
+            if constexpr (EPI != EPI_BIAS_RESIDUAL) {
+                if (first) { VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }   // (the A fragments are dead here)
+            }
+            __builtin_amdgcn_sched_barrier(0);
             VF9_READ_A(base + 3 * PSLOT)
             VF9_MID()
-            VF9_QUAD(1, 1, B1f)
-            VF9_QUAD(1, 0, B0f)
+            VF9_BLOCK(1, B1f, 1, B0f, 0, 0, 0, 0, m0, n0, 0)
             VF9_TAIL()
         }
         ktg += nk;
-        // ---- epilogue, straight from the registers: lane (r15, kb) of block mi holds row wr 128 + mi 16 + r15, and for
-        // hf = 0, 1 the eight columns wc 64 + hf 32 + 8 kb .. + 7: acc[mi][2 hf][0..3], acc[mi][2 hf + 1][0..3]
-        const long long col0 = n0 + wc * 64 + 8 * kb;
-        h8 rr[8][2];
-        if constexpr (EPI == EPI_BIAS_RESIDUAL) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-                    rr[mi][hf] = *(const h8*)(R + (m0 + wr * 128 + mi * 16 + r15) * N + col0 + hf * 32);
-        }
-        float bv[2][8];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            f4v b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-            if (bias) {
-                const float* bl = bias_lds + (it & 1) * 256 + wc * 64 + hf * 32 + 8 * kb;
-                b0 = *(const f4v*)bl; b1 = *(const f4v*)(bl + 4);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { bv[hf][e] = b0[e]; bv[hf][4 + e] = b1[e]; }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            half_t* crow = C + (m0 + wr * 128 + mi * 16 + r15) * N + col0;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                h8 o;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const f4v a4 = acc[mi][2 * hf + q];
-                    f2v v0 = {a4[0] + bv[hf][4 * q + 0], a4[1] + bv[hf][4 * q + 1]};
-                    f2v v1 = {a4[2] + bv[hf][4 * q + 2], a4[3] + bv[hf][4 * q + 3]};
-                    if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); }
-                    if (EPI == EPI_BIAS_QGELU) { v0 = quick_gelu2(v0); v1 = quick_gelu2(v1); }
-                    if constexpr (EPI == EPI_BIAS_RESIDUAL) {
-                        // the LDS-image epilogues round acc + bias to fp16 before the residual joins in fp32: keep that order
-                        v0[0] = (float)(half_t)v0[0] + (float)rr[mi][hf][4 * q + 0]; v0[1] = (float)(half_t)v0[1] + (float)rr[mi][hf][4 * q + 1];
-                        v1[0] = (float)(half_t)v1[0] + (float)rr[mi][hf][4 * q + 2]; v1[1] = (float)(half_t)v1[1] + (float)rr[mi][hf][4 * q + 3];
-                    }
-                    o[4 * q + 0] = (half_t)v0[0]; o[4 * q + 1] = (half_t)v0[1];
-                    o[4 * q + 2] = (half_t)v1[0]; o[4 * q + 3] = (half_t)v1[1];
-                }
-                *(h8*)(crow + hf * 32) = o;
-            }
-        }
+        VF9_STAMP(3)
+        m0p = m0; n0p = n0;
         if (!has_next) break;
         orig += gridDim.x;
-        mt_c = mt_n;
-        nt_c = nt_n;
+        q_tile_of(orig, Mt, Nt, mt_c, nt_c);
         has_next = orig + (int)gridDim.x < ntiles;
-        if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
     }
+    // the last tile's epilogue
+    VF9_EPI_LOAD_R(0, m0p, n0p)
+    VF9_EPI_HALF(0, m0p, n0p, it & 1)
+    // the last tile's second half
+    VF9_EPI_LOAD_R(1, m0p, n0p)
+    VF9_EPI_HALF(1, m0p, n0p, it & 1)
+    VF9_STAMP(4)
+#undef VF9_BLOCK
+#undef VF9_STEP
+#undef VF9_EPI_HALF
+#undef VF9_EPI_LOAD_R
+#undef VF9_STAMP
 #undef VF9_READ_A
 #undef VF9_READ_B
 #undef VF9_QUAD
+#undef VF9_QUAD_LOOPS
 #undef VF9_MID
 #undef VF9_TAIL
 #undef VF9_STAGE
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
+    if (dbg && wid == 0) {                           // every store acknowledged: the workgroup's end; then the stamps leave LDS
+        if (lane == 0) stamps[(k9StampTiles - 1) * k9Stamps + 5] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int i = lane; i < k9StampTiles * k9Stamps; i += 64) dbg[(long long)blockIdx.x * (k9StampTiles * k9Stamps) + i] = stamps[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4736,6 +4942,9 @@ static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bia
 static long long p8_min_wgs();   // tiles from which the 8-phase kernel is the default (defined with the LnFold helpers)
 static std::atomic<int> g_loop2{getenv("VF_GEMM_8P_LOOP2") ? atoi(getenv("VF_GEMM_8P_LOOP2")) : 1};   // default: the two-phase loop (round 3: 2-7 % on the products, 0.7-2 % on the forward)
 extern "C" int vf_debug_gemm_8p_loop2(int on) { return on >= 0 ? g_loop2.exchange(on ? 1 : 0) : g_loop2.load(); }   // A/B: two-phase main loop of k_gemm8p_tn
+static std::atomic<unsigned long long*> g_gemm9_dbg{nullptr};
+// test hook: device buffer [workgroups][16 tiles][6] for k_gemm9_tn's wall-clock stamps (100 MHz), or null (tools/gemm9_stamps.py)
+extern "C" void vf_debug_gemm9_stamps(void* buf) { g_gemm9_dbg.store((unsigned long long*)buf); }
 static std::atomic<int> g_gemm9{-1};   // -1: VF_GEMM_9 decides; 0 / 1: forced by the test hook
 extern "C" int vf_debug_gemm9(int on) { return g_gemm9.exchange(on < 0 ? -1 : (on ? 1 : 0)); }   // A/B: the persistent register-epilogue kernel as the default large product
 static LnFold lf_plain() { LnFold l{}; l.loop2 = g_loop2.load(std::memory_order_relaxed); return l; }
@@ -4860,11 +5069,19 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
 #endif
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL) {
         // round 4: the persistent two-phase kernel with the register-direct epilogue (k_gemm9_tn)
-        static const int p9 = getenv("VF_GEMM_9") ? atoi(getenv("VF_GEMM_9")) : 0;
+        // Default for K < 4096 (VF_GEMM_9=0 switches it off).  In the 100-pair forward, per layer (profiles/r04_rerank_layer_8p_vs_gemm9.txt):
+        // 768 wide: QKV 167 vs 188 us, out projection 82 vs 87, FFN-up + GELU 235 vs 271, FFN-down (K = 3072) 231 vs 235; 1024 wide: 277 vs
+        // 281, 129 vs 127, 408 vs 408 -- and FFN-down (K = 4096, 800 tiles = 3.1 rounds) 391 vs 360: there the 8-phase kernel's split-K
+        // tail is worth more than the persistent pipeline, so long-K products stay with it.
+        static const int p9 = getenv("VF_GEMM_9") ? atoi(getenv("VF_GEMM_9")) : 1;
+        static const int p9_kmax = getenv("VF_GEMM_9_KMAX") ? atoi(getenv("VF_GEMM_9_KMAX")) : 4096;
         const int p9_now = g_gemm9.load(std::memory_order_relaxed) >= 0 ? g_gemm9.load(std::memory_order_relaxed) : p9;
-        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && K < p9_kmax && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
             const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
-            hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K);
+            // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
+            static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
+            const int ticks = tiles > ncu ? (int)((150ll * (K / PBK) + 200) * stg / 100) : 0;
+            hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, ticks, g_gemm9_dbg.load(std::memory_order_relaxed));
             return hipGetLastError();
         }
     }
