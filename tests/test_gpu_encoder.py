@@ -30,17 +30,6 @@ def vf():
     return m
 
 
-def _experiments_built():
-    """The shipped library holds one kernel per operation; the measured-and-rejected ones (persistent one-query forward,
-    LayerNorm in the products' tail, first-generation attention, the other GEMM tilings) are compiled in only with
-    VF_BUILD_FLAGS=-DVF_EXPERIMENTS."""
-    import ctypes
-    from veritasfi_amd import _ffi
-    L = _ffi.lib()
-    L.vf_debug_experiments.restype = ctypes.c_int
-    return L.vf_debug_experiments() == 1
-
-
 def _hf_bert(hidden, layers, heads, ffn, vocab=1000, seed=0):
     import torch
     from transformers import BertConfig, BertModel
@@ -106,101 +95,6 @@ def test_embedding_encoder_matches_torch_fp32(vf, name, hidden, layers, heads, f
     # max |d emb| 2.3e-4, hidden mean 1.0e-3 / max 1.3e-2 at 12 layers -- asserted at ~3x that
     assert cos.min() > 0.99999 and err < 8e-4
     assert herr.mean() < 3e-3 and herr.max() < 4e-2
-
-
-@pytest.mark.parametrize("hidden,layers,heads,ffn,b,t", [
-    (768, 12, 12, 3072, 1, 32),     # BERT-base shape, one query string (faissRetriever.py:33)
-    (768, 4, 12, 3072, 1, 40),      # padded to 64 tokens: four row tiles
-    (768, 4, 12, 3072, 2, 32),      # two short strings: one sequence per (head, sequence) workgroup
-    (1024, 6, 16, 4096, 1, 64),     # XLM-R-large / bge-m3 shape: the largest LDS image (64 rows x 1024)
-    (256, 3, 4, 1024, 1, 20),       # fewer column tiles than workgroups everywhere
-])
-def test_one_query_persistent_forward(vf, hidden, layers, heads, ffn, b, t):
-    """k_sq_forward (all layers of a <= 64-token forward in one persistent launch, grid barriers between phases; an
-    experiment, off by default) against torch fp32, against the launch-per-product path, and run phase by phase (no barrier)
-    -- the last two must agree bit for bit with each other, and with the launch-per-product path up to the summation order
-    of the K splits."""
-    import ctypes, torch
-    from veritasfi_amd import _ffi
-    if not _experiments_built():
-        pytest.skip("k_sq_forward is an experiment kernel: build with VF_BUILD_FLAGS=-DVF_EXPERIMENTS")
-    L = _ffi.lib()
-    L.vf_debug_sq_mode.restype = ctypes.c_int
-    L.vf_debug_sq_mode.argtypes = [ctypes.c_int]
-    model = _hf_bert(hidden, layers, heads, ffn)
-    rng = np.random.default_rng(11)
-    ids, mask = _batch(rng, b, t, 1000)
-    mask[0, t - 3:] = 0                                  # some padding in every case
-    with torch.no_grad():
-        ref_h = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state.numpy()
-    ref = ref_h[:, 0] / np.linalg.norm(ref_h[:, 0], axis=1, keepdims=True)
-    enc = vf.HipEncoder.from_hf(model, pooling=0, normalize=True)
-    out, hid = {}, {}
-    try:
-        for mode in (0, 1, 2):
-            L.vf_debug_sq_mode(mode)
-            out[mode] = [enc.forward(ids, mask) for _ in range(3)]      # replays of the captured graph too
-            hid[mode] = enc.hidden_states(ids, mask)
-    finally:
-        L.vf_debug_sq_mode(0)
-        enc.close()
-    valid = mask.astype(bool)
-    for mode in (0, 1, 2):
-        for o in out[mode]:
-            assert np.array_equal(o, out[mode][0])                      # deterministic
-        err = np.abs(out[mode][0] - ref).max()
-        herr = np.abs(hid[mode] - ref_h)[valid]
-        print("mode", mode, "max|d emb|", err, "hidden mean/max", herr.mean(), herr.max())
-        assert err < 8e-4 and herr.mean() < 3e-3 and herr.max() < 4e-2
-    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(hid[1][valid], hid[2][valid])
-    assert np.abs(hid[1] - hid[0])[valid].max() < 2e-2
-
-
-def test_layernorm_in_the_tail_of_the_residual_products(vf):
-    """From 384 tiles up the o-proj / FFN-down products CAN carry their LayerNorm (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>: extra
-    workgroups of the same launch normalise finished row tiles, hand-off by write-through stores + an agent-scope counter;
-    an experiment, off by default -- it measured no faster).  Same arithmetic as the separate LayerNorm launch: the
-    embeddings and every hidden state must be bit-identical with the tail switched off, and match torch fp32; a second
-    shape (ragged, packed rows) restarts the counters."""
-    import ctypes, torch
-    from veritasfi_amd import _ffi
-    if not _experiments_built():
-        pytest.skip("the LayerNorm-in-the-tail epilogue is an experiment kernel: build with VF_BUILD_FLAGS=-DVF_EXPERIMENTS")
-    L = _ffi.lib()
-    L.vf_debug_ln_tail.restype = ctypes.c_longlong
-    L.vf_debug_ln_tail.argtypes = [ctypes.c_int]
-    model = _hf_bert(768, 2, 12, 3072)
-    rng = np.random.default_rng(21)
-    b, t = 64, 512                                           # 32768 rows: 128 x 3 = 384 tiles
-    ids, mask = _batch(rng, b, t, 1000, ragged=False)
-    enc = vf.HipEncoder.from_hf(model, pooling=0, normalize=True)
-    try:
-        L.vf_debug_ln_tail(1)
-        n0 = L.vf_debug_ln_tail(-1)
-        got = [enc.forward(ids, mask) for _ in range(3)]     # generations 1..12 of the counters
-        hid = enc.hidden_states(ids[:, :], mask)
-        fused_calls = L.vf_debug_ln_tail(-1) - n0
-        L.vf_debug_ln_tail(0)
-        ref = enc.forward(ids, mask)
-        ref_h = enc.hidden_states(ids, mask)
-        L.vf_debug_ln_tail(1)
-        # a different row count on the same handle (the counters restart), ragged: packed rows
-        ids2, mask2 = _batch(np.random.default_rng(22), 160, 512, 1000)
-        mask2[:, 400:] = 0
-        a = enc.forward(ids2, mask2)
-        L.vf_debug_ln_tail(0)
-        a_ref = enc.forward(ids2, mask2)
-    finally:
-        L.vf_debug_ln_tail(0)
-        enc.close()
-    assert fused_calls == 4 * 2 * 2, fused_calls             # 4 forwards x 2 layers x 2 products
-    for g in got:
-        assert np.array_equal(g, ref)
-    assert np.array_equal(hid, ref_h)
-    assert np.array_equal(a, a_ref)
-    with torch.no_grad():
-        want = model(input_ids=torch.from_numpy(ids[:4]), attention_mask=torch.from_numpy(mask[:4])).last_hidden_state.numpy()
-    assert np.abs(hid[:4] - want).max() < 4e-2
 
 
 def test_pooling_variants(vf):
@@ -504,35 +398,27 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
     assert err < 2e-2 and d01 < 1.6e-2      # fp16 output of O(10) values: one ulp is 7.8e-3
 
 
-@pytest.mark.parametrize("kind", [1, 2, 3, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("kind", [3, 5, 7, 10])
 @pytest.mark.parametrize("epi", [0, 1, 2, 11])
 def test_gemm_kernels_match_torch(vf, kind, epi):
-    """Every GEMM kernel (1 = LDS-DMA 128x256 with two workgroups per CU, 2 = 256x256, 3 = register-staged 128x128) x every
-    epilogue (bias, bias + erf-GELU, bias + residual, bias + quick-GELU) against torch fp32 on the same fp16 operands, at a shape with a
+    """Every GEMM kernel (3 = register-staged 128x128, 5 = LDS-DMA 128x256 with two workgroups per CU, 7 = 8-phase 256x256, 10 = the
+    persistent k_gemm9_tn) x every epilogue (bias, bias + erf-GELU, bias + residual, bias + quick-GELU) against torch fp32 on the same fp16 operands, at a shape with a
     ragged tile grid for the XCD-aware tile order (M = 1792 -> 14 / 7 m-tiles, N = 768, K = 320 -> 5 / 10 K-steps)."""
     import ctypes
     import torch
     from veritasfi_amd import _ffi
-    if kind in (1, 2, 6, 8, 9) and not _experiments_built():
-        pytest.skip("GEMM kinds 1, 2, 6, 8, 9 are experiment kernels: build with VF_BUILD_FLAGS=-DVF_EXPERIMENTS")
     L = _ffi.lib()
     L.vf_debug_gemm.restype = ctypes.c_int
     L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(100 * kind + epi)
     shapes = [(1792, 768, 320), (512, 1024, 3072)]
-    if kind == 9:
-        shapes = [(1792, 768, 320), (512, 1024, 3072), (2560, 512, 128), (1024, 256, 64 * 7)]   # (K = 320: 10 steps; 128: the minimum)
     if kind == 10:
         # k_gemm9_tn (persistent, register-direct epilogue; K >= 256): fewer tiles than CUs, 320 / 384 tiles on 256 workgroups with odd
         # and even K-tile counts (LDS buffer parity alternates between a workgroup's tiles), an exact three rounds, a long K
         shapes = [(1792, 768, 320), (512, 1024, 3072), (10240, 2048, 320), (6144, 4096, 256), (16384, 3072, 448), (51200, 768, 768)]
-    if kind == 8:
-        # the persistent 8-phase kernel: more tiles than workgroups (320 and 384 on 256: the cross-tile pipeline, odd and
-        # minimal K-tile counts so the LDS buffer parity alternates between a workgroup's tiles), and an exact 3 rounds
-        shapes += [(10240, 2048, 320), (6144, 4096, 128), (16384, 3072, 192)]
     for (M, N, K) in shapes:
-        if kind in (7, 8, 9, 10) and (M % 256 or N % 256):   # the 8-phase kernels (and the four-wave experiment) take 256 x 256 tiles only
+        if kind in (7, 10) and (M % 256 or N % 256):   # the 8-phase and the persistent kernel take 256 x 256 tiles only
             M, N = (M + 255) // 256 * 256, (N + 255) // 256 * 256
         A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
         W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()
@@ -1085,7 +971,7 @@ def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, 
     ref = reference(qkv, mask, b, t, heads, rows=rows)
     valid = mask.reshape(b, t)[:rows].reshape(-1).bool()
     vmax = float(qkv[:, 2 * heads * 64:].float().abs().max())
-    kinds = (2, 1, 3, 4) if _experiments_built() else (2, 4)   # k_attention2, [first generation, register-staged streaming,] LDS-DMA streaming
+    kinds = (2, 4)   # k_attention2, the LDS-DMA streaming kernel
     for kind in kinds:
         ctx = torch.full((b * t, heads * 64), float("nan"), dtype=torch.float16, device=dev)
         run(L, kind, qkv, mask, b, t, heads, ctx)
@@ -1099,7 +985,7 @@ def test_attention_kernels_match_fp32_softmax(vf, b, t, heads, ragged, growing, 
     c2 = torch.zeros(b * t, heads * 64, dtype=torch.float16, device=dev)
     c3 = torch.zeros_like(c2)
     run(L, 2, qkv, mask, b, t, heads, c2)
-    run(L, 3 if _experiments_built() else 4, qkv, mask, b, t, heads, c3)
+    run(L, 4, qkv, mask, b, t, heads, c3)
     torch.cuda.synchronize()
     allv = mask.bool()
     assert float((c2.float()[allv] - c3.float()[allv]).abs().max()) <= 1.5e-3 * vmax

@@ -28,13 +28,8 @@ def main():
         for t in (32, 64):
             ids = rng.integers(5, cfg["vocab"], size=(1, t)).astype(np.int32)
             mask = np.ones_like(ids)
-            res = {}
-            for name, mode in (("launch_per_product", 0), ("persistent", 1)):      # A/B through the test hook
-                L.vf_debug_sq_mode(mode)
-                res[name] = p50(lambda: enc.forward(ids, mask))
-            L.vf_debug_sq_mode(0)
-            print(json.dumps({"case": "embed_query", "model_shape": shape, "tokens": t, "p50_ms": res["launch_per_product"][0],
-                              "min_ms": res["launch_per_product"][1], "persistent_experiment_p50_ms": res["persistent"][0]}), flush=True)
+            m, lo = p50(lambda: enc.forward(ids, mask))
+            print(json.dumps({"case": "embed_query", "model_shape": shape, "tokens": t, "p50_ms": m, "min_ms": lo}), flush=True)
         enc.close()
     c = rng.standard_normal((10_000, 1024)).astype(np.float32)
     ix = vf.DenseIndex(c)

@@ -132,9 +132,7 @@ __device__ __forceinline__ void ln_finish(float (&v)[4][8], float s, int l32, in
 
 __global__ __launch_bounds__(256) void k_embed_ln(const int* ids, const int* pos, const int* tts, const half_t* word,
                                                    const half_t* posw, const half_t* typew, const float* g,
-                                                   const float* bta, float eps, int M, int H, half_t* out,
-                                                   unsigned* zero2 = nullptr) {
-    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;   // k_sq_forward's barrier words
+                                                   const float* bta, float eps, int M, int H, half_t* out) {
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= M) return;
     const h8* w = (const h8*)(word + (long long)ids[row] * H);
@@ -195,13 +193,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* y, const float*
 // GEMM operands are fp16.
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_RESIDUAL_F32 = 3,
        EPI_GATED_SILU = 4, EPI_GATED_GELU = 5,
-       EPI_BIAS_RESIDUAL_LN = 6,
+       /* 6: was the LayerNorm-in-the-tail experiment (deleted in round 4) */
        // LayerNorm folded into the products around it (k_gemm8p_tn only; LnFold, DESIGN.md 7 "LayerNorm without a launch"):
        EPI_LNA = 7,            // C = rstd_m (A.W'^T - mean_m colsum(W')_n) + c_n : A is the RAW pre-LayerNorm sum, W' = W diag(gamma)
        EPI_LNA_GELU = 8,       // ... + GELU
        EPI_RES_STATS = 9,      // C = A.W^T + b + R (R already normalised), and the row sums (sum, sum of squares) of C
        EPI_LNRES_STATS = 10,
-       EPI_BIAS_QGELU = 11 };  // C = quick_gelu(A.W^T + b): x sigmoid(1.702 x), the vision tower's activation (CLIP) // C = A.W^T + b + LayerNorm(R) from the raw R and its row sums, and the row sums of C   // k_gemm8p_tn only: EPI_BIAS_RESIDUAL + the LayerNorm of finished row tiles in the same launch (LnTail)   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
+       EPI_BIAS_QGELU = 11 };  // C = quick_gelu(A.W^T + b): x sigmoid(1.702 x), the vision tower's activation (CLIP) // C = A.W^T + b + LayerNorm(R) from the raw R and its row sums, and the row sums of C   // k_gemm8p_tn only: C[M][N/2] = act(A.Wgate^T) * (A.Wup^T), W = [gate rows | up rows]
 
 // exact-GELU x Phi(x) = max(x, 0) - (|x| / 2) erfc(|x| / sqrt 2), with the complementary error function as
 // exp2 of a polynomial:  -log2 erfc(a / sqrt 2) = a (c1 + a (c2 + a (c3 + a (c4 + a c5)))), fitted on [0, 6] with the
@@ -498,132 +496,10 @@ __global__ __launch_bounds__(256) void k_gemm_splitk(const half_t* __restrict__ 
     if (tid == 0) __hip_atomic_store(counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 }
 
-// ------------------------------------------------------------------------------------------------
-// Large-tile GEMM: 256 x 256 output tile per 512-thread workgroup (8 waves as 2 (M) x 4 (N), each 128 x 64 =
-// 4 x 2 MFMA 32x32 tiles, 128 accumulator VGPRs), BK = 64, two LDS buffers of 64 KB (A 256x64 + W 256x64 fp16).
-// Operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write): a wave
-// instruction fills 1 KB = 8 rows x 128 B linearly; the 16-byte chunk a lane FETCHES is XOR-swizzled
-// (chunk ^ ((row >> 1) & 7)) and the fragment reads apply the same involution, which makes the ds_read_b128
-// of 16 consecutive rows hit 16 distinct 16-byte slots (conflict-free) without padding.  Per K-tile: stage the
-// next tile, 32 MFMAs per wave on the current one, vmcnt(0) + barrier (the guide's minimum two-phase form).
-// Twice the FLOP per operand byte of the 128 x 128 kernel.  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0.
-// ------------------------------------------------------------------------------------------------
-constexpr int LBM = 256, LBN = 256, LTHREADS = 512;
-
-template <int EPI>
-__global__ __launch_bounds__(LTHREADS) void k_gemm256_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
-                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // ONE array: [2][A 256x64 | W 256x64] fp16 = 128 KB
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r31 = lane & 31, h = lane >> 5, wr = wid >> 2, wc = wid & 3;
-    int mt_idx, nt_idx;
-    {   // XCD-contiguous, n-major groups of 4 m-tiles (same idea as k_gemm_tn; 32 workgroups per XCD at a time)
-        const int Mt = M / LBM, Nt = N / LBN, nwg = Mt * Nt;
-        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        constexpr int GM = 4;
-        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
-        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
-        nt_idx = r / gm;
-        mt_idx = g * GM + (r - nt_idx * gm);
-    }
-    const long long m0 = (long long)mt_idx * LBM, n0 = (long long)nt_idx * LBN;
-    // staging: the A tile is 32 wave-instructions (8 rows each), the W tile 32 more; wave w issues A rows
-    // [32w, 32w+32) and W rows [32w, 32w+32): 4 + 4 instructions per K-tile.
-    // lane l of an instruction lands at LDS slot l: row (l >> 3) of the 8, physical chunk l & 7, and fetches the
-    // LOGICAL chunk (l & 7) ^ ((row >> 1) & 7) of that row.
-    const int srow8 = lane >> 3, spc = lane & 7;
-    const half_t* a_src[4];
-    const half_t* w_src[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wid * 32 + j * 8 + srow8;
-        const int lc = spc ^ ((row >> 1) & 7);
-        a_src[j] = A + (m0 + row) * K + lc * 8;
-        w_src[j] = W + (n0 + row) * K + lc * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* abase = smem + buf * 65536 + (wid * 32) * 128;          // A rows of this wave
-        char* wbase = smem + buf * 65536 + 32768 + (wid * 32) * 128;  // W rows of this wave
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * GBK),
-                                             (__attribute__((address_space(3))) void*)(abase + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * GBK),
-                                             (__attribute__((address_space(3))) void*)(wbase + j * 1024), 16, 0, 0);
-        }
-    };
-    f16v acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    // fragment addresses: row = wr*128 + mt*32 + r31 (A) / wc*64 + nt*32 + r31 (W); chunk (2 ks + h) ^ ((row >> 1) & 7)
-    const int swz = (r31 >> 1) & 7;  // wr*128, mt*32, wc*64, nt*32 are multiples of 16: they do not change (row >> 1) & 7
-    const char* a_row = smem + (wr * 128 + r31) * 128;
-    const char* w_row = smem + 32768 + (wc * 64 + r31) * 128;
-    const int nk = K / GBK;
-    stage(0, 0);
-    __syncthreads();  // (emits the vmcnt(0) the LDS-DMA needs)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        stage(buf ^ 1, kt + 1 < nk ? kt + 1 : kt);
-        const char* ab = a_row + buf * 65536;
-        const char* wb = w_row + buf * 65536;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int pc = ((2 * ks + h) ^ swz) * 16;
-            h8 af[4], wf[2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = *(const h8*)(ab + t * 32 * 128 + pc);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) wf[t] = *(const h8*)(wb + t * 32 * 128 + pc);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [256][256] fp16 image (128 KB = the operand buffers),
-    // then 16-byte row chunks out (residual added in fp32 on the vector side)
-    half_t* Es = (half_t*)smem;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = wc * 64 + nt * 32 + r31;
-        const float bv = bias ? bias[n0 + col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = wr * 128 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float v = acc[mt][nt][reg] + bv;
-                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
-                Es[row * LBN + col] = (half_t)v;
-            }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = tid + LTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
-        h8 o = *(const h8*)(Es + row * LBN + cc * 8);
-        const long long off = (m0 + row) * N + n0 + cc * 8;
-        if (EPI == EPI_BIAS_RESIDUAL) {
-            const h8 r = *(const h8*)(R + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
-        }
-        *(h8*)(C + off) = o;
-    }
-}
+constexpr int LBM = 256, LBN = 256;   // the 256 x 256 tile of the 8-phase / persistent kernels
 
 // ------------------------------------------------------------------------------------------------
-// k_gemm_dma_tn: 128 (M) x 256 (N) tile, 4 waves (2 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles), BK = 32,
+// k_gemm_dma16_tn: 128 (M) x 256 (N) tile, 4 waves (2 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles), BK = 32,
 // THREE 24 KB LDS slots filled by LDS-DMA (72 KB per workgroup), so that TWO workgroups share a CU.
 // The two are independent: one's barrier bubbles, DMA tail and whole epilogue (the output's HBM write) run
 // under the other's MFMAs -- the overlap a single lock-stepped 128 KB workgroup per CU cannot have.
@@ -635,125 +511,8 @@ __global__ __launch_bounds__(LTHREADS) void k_gemm256_tn(const half_t* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr int DBM = 128, DBN = 256, DBK = 32, DTHREADS = 256, DSLOT = 24576, DLDS = 3 * DSLOT;
 
-template <int EPI>
-__global__ __launch_bounds__(DTHREADS, 2) void k_gemm_dma_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
-                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 slots x [A 128x32 | W 256x32] fp16
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r31 = lane & 31, h = lane >> 5, wr = wid >> 1, wc = wid & 1;
-    int mt_idx, nt_idx;
-    {   // XCD-contiguous, n-major groups of 8 m-tiles (64 workgroups resident per XCD)
-        const int Mt = M / DBM, Nt = N / DBN, nwg = Mt * Nt;
-        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        constexpr int GM = 8;
-        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
-        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
-        nt_idx = r / gm;
-        mt_idx = g * GM + (r - nt_idx * gm);
-    }
-    const long long m0 = (long long)mt_idx * DBM, n0 = (long long)nt_idx * DBN;
-    // one DMA instruction fills 16 rows x 64 B; the A tile is 8 of them (wave w: rows [32w, 32w+32)), the W tile 16
-    // (wave w: rows [64w, 64w+64)).  lane l -> row l >> 2 of the 16, physical chunk l & 3.
-    const half_t* a_src[2];
-    const half_t* w_src[4];
-    const int drow = lane >> 2, dpc = lane & 3;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wid * 32 + j * 16 + drow;
-        a_src[j] = A + (m0 + row) * K + (dpc ^ ((row >> 2) & 3)) * 8;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wid * 64 + j * 16 + drow;
-        w_src[j] = W + (n0 + row) * K + (dpc ^ ((row >> 2) & 3)) * 8;
-    }
-    auto stage = [&](int slot, int kt) {
-        char* abase = smem + slot * DSLOT + (wid * 32) * 64;
-        char* wbase = smem + slot * DSLOT + 8192 + (wid * 64) * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * DBK),
-                                             (__attribute__((address_space(3))) void*)(abase + j * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * DBK),
-                                             (__attribute__((address_space(3))) void*)(wbase + j * 1024), 16, 0, 0);
-    };
-    f16v acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const int swz = (r31 >> 2) & 3;  // tile offsets are multiples of 32 rows: they do not change (row >> 2) & 3
-    const char* a_row = smem + (wr * 64 + r31) * 64;
-    const char* w_row = smem + 8192 + (wc * 128 + r31) * 64;
-    const int nk = K / DBK;
-    stage(0, 0);
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nslot = slot == 2 ? 0 : slot + 1;
-        stage(nslot, kt + 1 < nk ? kt + 1 : nk - 1);            // past the end: re-reads the last tile (unused)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // stage kt landed (this wave's DMA)
-        __builtin_amdgcn_s_barrier();                           // ... and every wave's
-        const char* ab = a_row + slot * DSLOT;
-        const char* wb = w_row + slot * DSLOT;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pc = ((2 * ks + h) ^ swz) * 16;
-            h8 af[2], wf[4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) af[t] = *(const h8*)(ab + t * 32 * 64 + pc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *(const h8*)(wb + t * 32 * 64 + pc);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
-        }
-        slot = nslot;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the trailing dummy stage before LDS is reused
-    __syncthreads();
-    // epilogue through LDS: fp16(acc + bias [+GELU]) into a [128][256] fp16 image (64 KB of the 72), then 16-byte
-    // row chunks out (residual added in fp32 on the vector side)
-    half_t* Es = (half_t*)smem;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = wc * 128 + nt * 32 + r31;
-        const float bv = bias ? bias[n0 + col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float v = acc[mt][nt][reg] + bv;
-                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                if (EPI == EPI_BIAS_QGELU) v = quick_gelu(v);
-                Es[row * DBN + col] = (half_t)v;
-            }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = tid + DTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
-        h8 o = *(const h8*)(Es + row * DBN + cc * 8);
-        const long long off = (m0 + row) * N + n0 + cc * 8;
-        if (EPI == EPI_BIAS_RESIDUAL) {
-            const h8 r = *(const h8*)(R + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
-        }
-        *(h8*)(C + off) = o;
-    }
-}
-
-// 16x16x32 variant of the kernel above (the guide measures that MFMA shape at 1.12-1.15x the FLOP/s of 32x32x16 with
-// operands from LDS).  Lane (r = lane & 15, kb = lane >> 4) reads rows r of a 16-row tile at k-block kb, so the chunk
+// The kernel described above, with 16x16x32 MFMAs (the guide measures that MFMA shape at 1.12-1.15x the FLOP/s of 32x32x16 with
+// operands from LDS; the 32x32x16 form of round 1 measured 4-6 % slower and is gone).  Lane (r = lane & 15, kb = lane >> 4) reads rows r of a 16-row tile at k-block kb, so the chunk
 // swizzle is re-derived for that map: physical chunk = c ^ f(row), f = {0, 3, 2, 1}[(row >> 2) & 3], which gives every
 // ds_read_b128 lane group ({0-3, 12-15, 20-27} ...) 16 distinct 16-byte slots.
 __device__ __forceinline__ int swz16(int row) { return (0x6C >> (2 * ((row >> 2) & 3))) & 3; }   // 0b01'10'11'00 -> 0, 3, 2, 1
@@ -1009,576 +768,18 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void k_gemm_skinny(const half_t*
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sq_forward: EVERY layer of a one-query forward (B T <= 64 tokens) in ONE persistent launch.
-// With separate launches such a forward is ~90 dependent kernels of 5-8 us that each move a few hundred KB: the time is
-// kernel boundaries and dependent memory round trips, not work.  Here one workgroup per CU stays resident and a layer is
-// FOUR phases separated by a grid barrier (one agent-scope arrive counter, polled):
-//   P1  per (head, sequence): LayerNorm of the previous layer's FFN sum on load (rows -> LDS, fp16, k_layernorm's
-//       arithmetic), the head's 192 QKV columns (12 waves = 12 column tiles of 16, W streamed straight into MFMA B
-//       operands), then the head's attention out of LDS (S^T = K Q^T so that the probabilities come out in the A-operand
-//       layout of P V; keys of an operand are permuted the same way on both sides);   -> ctx
-//   P2  per 16 output columns: ctx Wo^T + b + residual   (waves split K; fp32 partials meet in LDS)   -> y
-//   P3  per 16 columns: LayerNorm(y) on load, W1, erf-GELU                                            -> hbuf
-//   P4  per 16 columns: hbuf W2^T + b + residual                                                      -> y
-// The residual of P2 / P4 is the LayerNorm OUTPUT of the rows P1 / P3 normalised: instead of publishing those rows, one
-// workgroup of P1 / P3 publishes the row statistics (mean, rstd) and the consumer recomputes its 16 columns from the
-// pre-LayerNorm sum -- the same arithmetic, hence the same fp16 values.  The final LayerNorm and the pooling stay
-// separate launches.
-// Hand-off between workgroups (the XCDs' L2s are not coherent with each other): every activation store is a 16- or 8-byte
-// sc1 (write-through) buffer store, every activation load an sc1 buffer load; a workgroup arrives (one lane, agent-scope
-// atomic add) after every wave's s_waitcnt vmcnt(0) and a workgroup barrier, and loads only behind the barrier that follows
-// the poll (MI355X_MICROARCH.md, hand-off table, first row).  A cache-wide release / acquire fence per wave and barrier
-// was measured at ~60 us per barrier.  Weights never change: a phase's first weight operands are fetched BEFORE its
-// barrier wait, so their latency hides behind the slowest workgroup of the previous phase.
-// Every wait is bounded: a barrier that does not complete within ~1 s raises bar[1] and lets the grid drain.
-// Requires H % 256 == 0, F % 256 == 0, head dim 64, T in {32, 64}; grid <= the number of CUs (all workgroups resident).
+// Buffer-resource accesses with explicit cache policy (the hand-over forms of MI355X_MICROARCH.md): 16- / 8-byte loads and
+// stores with sc1 (memory side), used by the split-K tail of the 8-phase products.  (The persistent all-layers one-query
+// forward these were written for -- k_sq_forward, rounds 2-3: correct, 20-40 % slower than a launch per product -- is gone;
+// its measurements stay in DESIGN.md section 7.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kSqWaves = 12, kSqThreads = kSqWaves * 64, kSqHead = 1024, kSqRedSlots = 6;
-constexpr unsigned kSqSpinLimit = 1u << 20;
-
-struct SqParams {
-    const half_t* w16;            // first layer's fp16 blob  [Wqkv | Wo | W1 | W2]
-    const float* w32;             // first layer's fp32 blob  [bqkv | bo | g1 | b1n | b1 | b2 | g2 | b2n]
-    long long layer16, layer32;   // per-layer strides
-    int H, F, heads, layers, B, T;
-    float eps;
-    int q_folded;
-    const int* mask;
-    half_t *x, *y, *ctx, *hbuf;
-    float* stats;                 // [2][64][2]: (mean, rstd) of the rows P1 normalised, then of the rows P3 normalised
-    unsigned* bar;                // [0] barrier arrivals, [1] timeout (both zeroed by the launch before this one)
-    unsigned* timeout;            // host-mapped flag
-    int nsleep;                   // poll period of the barrier wait, in units of 512 cycles
-    unsigned long long* stamps;   // diagnostics (vf_debug_sq_stamps): [phase][workgroup][4] s_memrealtime clocks, or nullptr
-};
-__device__ __forceinline__ void sq_stamp(const SqParams& p, int ph, int which) {
-    if (p.stamps && threadIdx.x == 0) p.stamps[((long long)ph * gridDim.x + blockIdx.x) * 4 + which] = __builtin_amdgcn_s_memrealtime();
-}
-
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t sq_rsrc_t;
 __device__ __forceinline__ sq_rsrc_t sq_rsrc(const void* q) { return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, 0x7ffffff0, 0x00020000); }
-// sc1 (aux bit 16) accesses; byte offsets
 __device__ __forceinline__ h8 sq_ld8(sq_rsrc_t r, int off) { return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16)); }
-__device__ __forceinline__ h4 sq_ld4(sq_rsrc_t r, int off) { return __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16)); }
 __device__ __forceinline__ void sq_st8(sq_rsrc_t r, int off, h8 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), r, off, 0, 16); }
-__device__ __forceinline__ void sq_st4(sq_rsrc_t r, int off, h4 v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2v, v), r, off, 0, 16); }
 
-// workgroup barrier for LDS traffic only (no wait for outstanding global stores)
-__device__ __forceinline__ void sq_lds_sync() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ void sq_arrive(const SqParams& p) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have reached memory
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sq_wait(const SqParams& p, unsigned target) {
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            for (int i = 0; i < p.nsleep; ++i) __builtin_amdgcn_s_sleep(8);
-            if ((++spins & 1023u) == 0 && (spins > kSqSpinLimit || __hip_atomic_load(p.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(p.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// rows [r0, r0 + nrows) of src -> the LDS image xs (row stride ld halves); g != nullptr: LayerNorm on the way (half a
-// wave per row, exactly k_layernorm's arithmetic) and, with stats != nullptr, (mean, rstd) of row r to stats[2 (r0 + r)].
-// NR rounds of 24 rows; the loads of all rounds are issued before the first row is reduced (one memory round trip).
-template <int NR>
-__device__ __forceinline__ void sq_rows_to_lds(sq_rsrc_t src, int r0, int nrows, int H, const float* g, const float* bta,
-                                               float eps, half_t* xs, int ld, float* stats, int tid) {
-    const int hw = tid >> 5, l32 = tid & 31, nch = H >> 3;
-    h8 raw[NR][4];
-#pragma unroll
-    for (int rd = 0; rd < NR; ++rd) {
-        const int r = hw + rd * (kSqThreads / 32);
-        if (r < nrows) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (l32 + 32 * i < nch) raw[rd][i] = sq_ld8(src, ((r0 + r) * H + (l32 + 32 * i) * 8) * 2);
-        }
-    }
-    // statistics per row (the opaque copies keep the compiler from holding a second, fp32 copy of the rows: this code runs
-    // next to the registers of prefetched weights), then chunk by chunk: gamma / beta once, applied to every round's row
-    float mean[NR], rstd[NR];
-#pragma unroll
-    for (int rd = 0; rd < NR; ++rd) {
-        mean[rd] = 0.f; rstd[rd] = 1.f;
-        const int r = hw + rd * (kSqThreads / 32);
-        if (g && r < nrows) {
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (l32 + 32 * i < nch) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sum += (float)raw[rd][i][e];
-                }
-            mean[rd] = half_wave_sum(sum) / H;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                i4v bits = __builtin_bit_cast(i4v, raw[rd][i]);
-                asm volatile("" : "+v"(bits));
-                raw[rd][i] = __builtin_bit_cast(h8, bits);
-                if (l32 + 32 * i < nch) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = (float)raw[rd][i][e] - mean[rd]; q += d * d; }
-                }
-            }
-            rstd[rd] = rsqrtf(half_wave_sum(q) / H + eps);
-            if (stats && l32 == 0) {
-                const float2 mr = {mean[rd], rstd[rd]};
-                __hip_atomic_store((unsigned long long*)(stats + 2 * (r0 + r)), __builtin_bit_cast(unsigned long long, mr),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = l32 + 32 * i;
-        if (c < nch) {
-            float gg[8], bb[8];
-            if (g) {
-                const float4 g0 = *(const float4*)(g + c * 8), g1 = *(const float4*)(g + c * 8 + 4);
-                const float4 b0 = *(const float4*)(bta + c * 8), b1 = *(const float4*)(bta + c * 8 + 4);
-                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-            }
-#pragma unroll
-            for (int rd = 0; rd < NR; ++rd) {
-                const int r = hw + rd * (kSqThreads / 32);
-                if (r < nrows) {
-                    h8 o = raw[rd][i];
-                    if (g) {
-                        i4v bits = __builtin_bit_cast(i4v, raw[rd][i]);
-                        asm volatile("" : "+v"(bits));
-                        const h8 x = __builtin_bit_cast(h8, bits);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)x[e] - mean[rd]) * rstd[rd] * gg[e] + bb[e]);
-                    }
-                    *(h8*)(xs + r * ld + c * 8) = o;
-                }
-            }
-        }
-    }
-}
-
-// The residual of thread (row, columns c .. c + 3) of a P2 / P4 tile: the LayerNorm output the producing phase normalised,
-// recomputed from the pre-LayerNorm sum y and the published row statistics (or, in the first layer, the embedding rows x).
-struct SqRes { h4 y; float2 mr; float4 g, b; };
-__device__ __forceinline__ void sq_res_load(SqRes& r, bool ln, sq_rsrc_t src, int row, int H, int c, const float* stats,
-                                            const float* g, const float* bta) {
-    r.y = sq_ld4(src, (row * H + c) * 2);
-    r.mr = float2{0.f, 1.f};
-    r.g = float4{1.f, 1.f, 1.f, 1.f};
-    r.b = float4{0.f, 0.f, 0.f, 0.f};
-    if (ln) {
-        const unsigned long long v = __hip_atomic_load((const unsigned long long*)(stats + 2 * row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.mr = __builtin_bit_cast(float2, v);
-        r.g = *(const float4*)(g + c);
-        r.b = *(const float4*)(bta + c);
-    }
-}
-__device__ __forceinline__ void sq_res_value(const SqRes& r, bool ln, float (&out)[4]) {
-    const float gg[4] = {r.g.x, r.g.y, r.g.z, r.g.w}, bb[4] = {r.b.x, r.b.y, r.b.z, r.b.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        out[e] = ln ? (float)(half_t)(((float)r.y[e] - r.mr.x) * r.mr.y * gg[e] + bb[e]) : (float)r.y[e];
-}
-
-// The weight operands of one 16-column tile for this wave: k-steps wid + 12 (c0 + u), u < CH (of 32 halves, < ksteps), of
-// rows n0 .. n0 + 15 of W starting at column k0.  Weights never change: these loads may be issued before the grid barrier.
-template <int CH>
-__device__ __forceinline__ void sq_tile_w(const half_t* W, int ldw, int k0, int ksteps, int n0, int c0, h8 (&bf)[CH], int tid) {
-    const int lane = tid & 63, wid = tid >> 6, r15 = lane & 15, kb = lane >> 4;
-    const half_t* wp = W + (long long)(n0 + r15) * ldw + k0 + kb * 8;
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-        const int s0 = wid + kSqWaves * (c0 + u);
-        const int s = s0 < ksteps ? s0 : (wid < ksteps ? wid : 0);   // clamped: always a valid address
-        bf[u] = *(const h8*)(wp + s * 32);
-    }
-}
-
-// One 16-column tile of C[16 MT][.] = A . W^T over k-steps [0, ksteps) of 32 starting at column k0 of both operands.  The
-// twelve waves take the k-steps round-robin, CH per wave and pass (bf: the first pass's weight operands, see sq_tile_w);
-// their fp32 tiles meet in `red` (six slots: waves 6..11 deposit, waves 0..5 add theirs on top), and thread t < 64 MT
-// returns the sums of row t >> 2, columns 4 (t & 3) .. + 3.  A comes from LDS (ALDS: xs, row stride lda) or through ra.
-template <int MT, int CH, bool ALDS>
-__device__ __forceinline__ void sq_tile(const half_t* A, sq_rsrc_t ra, int lda, const half_t* W, int ldw, int k0, int ksteps,
-                                        int n0, h8 (&bf)[CH], float (*red)[64][17], float (&sum)[4], int tid,
-                                        const SqParams& p, int ph) {
-    const int lane = tid & 63, wid = tid >> 6, r15 = lane & 15, kb = lane >> 4;
-    f4v acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
-    for (int c0 = 0; wid + kSqWaves * c0 < ksteps; c0 += CH) {
-        if (c0) sq_tile_w<CH>(W, ldw, k0, ksteps, n0, c0, bf, tid);
-        h8 af[CH][MT];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int s0 = wid + kSqWaves * (c0 + u);
-            const int s = s0 < ksteps ? s0 : (wid < ksteps ? wid : 0);
-            const int off = r15 * lda + k0 + kb * 8 + s * 32;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-                af[u][t] = ALDS ? *(const h8*)(A + off + t * 16 * lda) : sq_ld8(ra, (off + t * 16 * lda) * 2);
-        }
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-            if (wid + kSqWaves * (c0 + u) < ksteps) {
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][t], bf[u], acc[t], 0, 0, 0);
-            }
-    }
-    if (p.stamps && tid == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0])); sq_stamp(p, ph, 2); }   // diagnostics: this wave's MFMAs are done
-    if (wid >= kSqRedSlots) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) red[wid - kSqRedSlots][t * 16 + 4 * kb + reg][r15] = acc[t][reg];
-    }
-    sq_lds_sync();
-    if (wid < kSqRedSlots) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) red[wid][t * 16 + 4 * kb + reg][r15] += acc[t][reg];
-    }
-    sq_lds_sync();
-    const int row = tid >> 2, c0 = (tid & 3) * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sum[e] = 0.f;
-    if (row < MT * 16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int w = 0; w < kSqRedSlots; ++w) sum[e] += red[w][row][c0 + e];
-    }
-    if (p.stamps && tid == 0) { asm volatile("s_nop 0" :: "v"(sum[0])); sq_stamp(p, ph, 3); }      // diagnostics: reduced
-}
-
-// P1's weight stream of one wave: eight k-steps of its 16 W rows starting at k-step s0
-__device__ __forceinline__ void sq_p1_w(const half_t* wrow, int s0, h8 (&w8)[8]) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w8[q] = *(const h8*)(wrow + (s0 + q) * 32);
-}
-template <int MTS>
-__device__ __forceinline__ void sq_p1_mma(const half_t* xs, int ld, int s0, const h8 (&w8)[8], f4v (&acc)[MTS], int tid) {
-    const int lane = tid & 63, r15 = lane & 15, kb = lane >> 4;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int t = 0; t < MTS; ++t) {
-            const h8 af = *(const h8*)(xs + (16 * t + r15) * ld + kb * 8 + (s0 + q) * 32);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, w8[q], acc[t], 0, 0, 0);
-        }
-}
-
-// MTS: 16-row tiles of ONE sequence (T / 16), MTG: of the whole batch (B T / 16); NB: batches of eight k-steps of the QKV
-// weights a wave holds before P1's barrier wait (3: all of H = 768; later batches are fetched as registers free up)
-template <int MTS, int MTG, int NB>
-__global__ __launch_bounds__(kSqThreads) void k_sq_forward(SqParams p, int ph0, int ph1) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wg = blockIdx.x, nwg = gridDim.x;
-    const int H = p.H, F = p.F, T = MTS * 16, M = MTG * 16, ld = H + 8;
-    constexpr int CH4 = 16 / MTG;                                 // k-steps per wave and pass of the FFN-down product
-    float* mbias = (float*)smem;                                  // [64] key-padding bias of the sequence (0 / -inf)
-    half_t* xs = (half_t*)(smem + kSqHead);                       // [M][ld] normalised rows
-    float (*red)[64][17] = (float (*)[64][17])(smem + kSqHead + (size_t)M * ld * 2);
-    // P1's second life of the xs region
-    half_t* qs = xs;                      // [T][72]
-    half_t* ksm = qs + T * 72;            // [T][72]
-    half_t* vt = ksm + T * 72;            // [64][T + 8]
-    const sq_rsrc_t rx = sq_rsrc(p.x), ry = sq_rsrc(p.y), rctx = sq_rsrc(p.ctx), rhb = sq_rsrc(p.hbuf);
-    float* stats2 = p.stats;              // rows P1 normalised (the previous layer's second LayerNorm)
-    float* stats1 = p.stats + 128;        // rows P3 normalised (this layer's first LayerNorm)
-    unsigned done = 0;                    // barriers passed
-    // Every phase: arrive at the barrier that ends the previous one, THEN fetch this phase's first weights (they do not
-    // depend on it), then wait -- the weight stream's latency hides behind the slowest workgroup of the previous phase.
-    for (int l = ph0 >> 2; l <= (ph1 - 1) >> 2; ++l) {
-        // the lane coordinates are made opaque once per layer: otherwise every address of every phase is computed (LICM) before
-        // the loop and parked in scratch memory, to be fetched back on each phase's critical path
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), r15 = lane & 15, kb = lane >> 4;
-        const half_t* w = p.w16 + (long long)l * p.layer16;
-        const float* f = p.w32 + (long long)l * p.layer32;
-        const half_t *Wqkv = w, *Wo = Wqkv + (long long)3 * H * H, *W1 = Wo + (long long)H * H, *W2 = W1 + (long long)F * H;
-        const float *bqkv = f, *bo = bqkv + 3 * H, *g1 = bo + H, *b1n = g1 + H, *b1 = b1n + H, *b2 = b1 + F;
-        const float* gp = l ? f - p.layer32 + (3 * H + H + 2 * H + F + H) : nullptr;     // previous layer's g2 | b2n
-        if (4 * l >= ph0 && 4 * l < ph1) {
-            // ---- P1: LayerNorm on load, the head's Q K V, its attention
-            const int ph = 4 * l;
-            if (ph > ph0) ++done;
-            if (wg >= p.heads * p.B) {                 // nothing to do in this phase (its own branch: no half-defined registers)
-                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
-            } else {
-                h8 wq[NB][8];
-                const int part = wid >> 2, j = wid & 3, ks = H >> 5;       // ks: a multiple of 8
-                if (ph > ph0) sq_arrive(p);
-                {
-                    const half_t* wrow = Wqkv + (long long)(part * H + (wg % p.heads) * 64 + 16 * j + r15) * H + kb * 8;
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) sq_p1_w(wrow, 8 * q < ks ? 8 * q : 0, wq[q]);
-                }
-                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
-                sq_stamp(p, ph, 0);
-                for (int u = wg; u < p.heads * p.B; u += nwg) {
-                    const int h = u % p.heads, b = u / p.heads;
-                    const int ncol = part * H + h * 64 + 16 * j + r15;
-                    const half_t* wrow = Wqkv + (long long)ncol * H + kb * 8;
-                    const float bias = bqkv[ncol];
-                    if (u != wg) {
-#pragma unroll
-                        for (int q = 0; q < NB; ++q) sq_p1_w(wrow, 8 * q < ks ? 8 * q : 0, wq[q]);
-                    }
-                    if (tid < T) mbias[tid] = p.mask[b * T + tid] ? 0.f : -INFINITY;
-                    sq_rows_to_lds<(MTS * 16 + 23) / 24>(l ? ry : rx, b * T, T, H, gp, gp ? gp + H : nullptr, p.eps, xs, ld,
-                                                         (l && h == 0) ? stats2 : nullptr, tid);
-                    sq_lds_sync();
-                    sq_stamp(p, ph, 2);
-                    f4v acc[MTS];
-#pragma unroll
-                    for (int t = 0; t < MTS; ++t)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
-                    // batches 0 .. NB-1 are in registers; a register set is refilled with batch s + NB as soon as it has been used
-                    for (int s0 = 0; s0 < ks; s0 += 8 * NB) {
-#pragma unroll
-                        for (int q = 0; q < NB; ++q) {
-                            if (s0 + 8 * q < ks) sq_p1_mma<MTS>(xs, ld, s0 + 8 * q, wq[q], acc, tid);
-                            if (s0 + 8 * (q + NB) < ks) sq_p1_w(wrow, s0 + 8 * (q + NB), wq[q]);
-                        }
-                    }
-                    sq_lds_sync();                     // xs is dead: Q, K, V^T take its place
-                    sq_stamp(p, ph, 3);
-#pragma unroll
-                    for (int t = 0; t < MTS; ++t) {
-                        if (part == 2) {
-                            h4 o;
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) o[reg] = (half_t)(acc[t][reg] + bias);
-                            *(h4*)(vt + (16 * j + r15) * (T + 8) + 16 * t + 4 * kb) = o;
-                        } else {
-                            half_t* dst = part == 0 ? qs : ksm;
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) dst[(16 * t + 4 * kb + reg) * 72 + 16 * j + r15] = (half_t)(acc[t][reg] + bias);
-                        }
-                    }
-                    sq_lds_sync();
-                    if (wid < MTS) {
-                        const int i = wid;                 // query tile
-                        f4v st[MTS];
-#pragma unroll
-                        for (int jt = 0; jt < MTS; ++jt) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) st[jt][e] = 0.f;
-#pragma unroll
-                            for (int k2 = 0; k2 < 2; ++k2) {
-                                const h8 a = *(const h8*)(ksm + (16 * jt + r15) * 72 + kb * 8 + 32 * k2);
-                                const h8 bq = *(const h8*)(qs + (16 * i + r15) * 72 + kb * 8 + 32 * k2);
-                                st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, st[jt], 0, 0, 0);
-                            }
-                        }
-                        // st[jt][reg]: key 16 jt + 4 kb + reg, query 16 i + r15
-                        const float sc = p.q_folded ? 1.f : 0.125f * 1.4426950408889634f;
-                        float mx = -INFINITY;
-#pragma unroll
-                        for (int jt = 0; jt < MTS; ++jt)
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) {
-                                st[jt][reg] = st[jt][reg] * sc + mbias[16 * jt + 4 * kb + reg];
-                                mx = fmaxf(mx, st[jt][reg]);
-                            }
-                        mx = fmaxf(mx, __shfl_xor(mx, 16));
-                        mx = fmaxf(mx, __shfl_xor(mx, 32));
-                        if (mx == -INFINITY) mx = 0.f;     // no valid key: every weight is exp2(-inf) = 0
-                        float lsum = 0.f;
-                        h8 ph8[MTS / 2];
-#pragma unroll
-                        for (int jt = 0; jt < MTS; ++jt)
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) {
-                                const half_t hp = (half_t)__builtin_amdgcn_exp2f(st[jt][reg] - mx);
-                                lsum += (float)hp;         // the sum of the weights the product really uses
-                                ph8[jt >> 1][(jt & 1) * 4 + reg] = hp;
-                            }
-                        lsum += __shfl_xor(lsum, 16);
-                        lsum += __shfl_xor(lsum, 32);
-                        f4v o[4];
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[n][e] = 0.f;
-#pragma unroll
-                            for (int s2 = 0; s2 < MTS / 2; ++s2) {
-                                const h4 v0 = *(const h4*)(vt + (16 * n + r15) * (T + 8) + 32 * s2 + 4 * kb);
-                                const h4 v1 = *(const h4*)(vt + (16 * n + r15) * (T + 8) + 32 * s2 + 16 + 4 * kb);
-                                const h8 bv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph8[s2], bv, o[n], 0, 0, 0);
-                            }
-                        }
-                        // o[n][reg]: query 16 i + 4 kb + reg, column 16 n + r15; that query's sum lives in lane 4 kb + reg.
-                        // The tile goes through a wave-private 16 x 72 LDS image so that it leaves as 16-byte write-through stores.
-                        half_t* ot = (half_t*)red + i * (16 * 72);
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const float lq = __shfl(lsum, 4 * kb + reg);
-                            const float inv = lq > 0.f ? 1.f / lq : 0.f;
-#pragma unroll
-                            for (int n = 0; n < 4; ++n) ot[(4 * kb + reg) * 72 + 16 * n + r15] = (half_t)(o[n][reg] * inv);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int rr = q * 8 + (lane >> 3), cc = (lane & 7) * 8;
-                            sq_st8(rctx, ((b * T + 16 * i + rr) * H + h * 64 + cc) * 2, *(const h8*)(ot + rr * 72 + cc));
-                        }
-                    }
-                    sq_lds_sync();                     // before the next unit rewrites the LDS image
-                }
-                sq_stamp(p, ph, 1);
-            }
-        }
-        if (4 * l + 1 >= ph0 && 4 * l + 1 < ph1) {
-            // ---- P2: attention output projection + bias + residual -> y
-            const int ph = 4 * l + 1;
-            if (ph > ph0) ++done;
-            if (wg >= H / 16) {
-                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
-            } else {
-                h8 bf[3];
-                if (ph > ph0) sq_arrive(p);
-                sq_tile_w<3>(Wo, H, 0, H >> 5, wg * 16, 0, bf, tid);
-                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
-                sq_stamp(p, ph, 0);
-                for (int tile = wg; tile < H / 16; tile += nwg) {
-                    const int n0 = tile * 16, row = tid >> 2, c0 = (tid & 3) * 4;
-                    const bool has_row = row < M;
-                    SqRes rs;
-                    float4 bpre = {0.f, 0.f, 0.f, 0.f};
-                    if (has_row) { sq_res_load(rs, l != 0, l ? ry : rx, row, H, n0 + c0, stats2, gp, gp ? gp + H : nullptr); bpre = *(const float4*)(bo + n0 + c0); }
-                    if (tile != wg) sq_tile_w<3>(Wo, H, 0, H >> 5, n0, 0, bf, tid);
-                    float sum[4];
-                    sq_tile<MTG, 3, false>(nullptr, rctx, H, Wo, H, 0, H >> 5, n0, bf, red, sum, tid, p, ph);
-                    if (has_row) {
-                        const float bb[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
-                        float res[4];
-                        sq_res_value(rs, l != 0, res);
-                        h4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (half_t)(sum[e] + bb[e] + res[e]);
-                        sq_st4(ry, (row * H + n0 + c0) * 2, o);
-                    }
-                    sq_lds_sync();
-                }
-                sq_stamp(p, ph, 1);
-            }
-        }
-        if (4 * l + 2 >= ph0 && 4 * l + 2 < ph1) {
-            // ---- P3: LayerNorm(y) on load, FFN up + GELU -> hbuf; workgroup 0 publishes the row statistics (P4's residual)
-            const int ph = 4 * l + 2;
-            if (ph > ph0) ++done;
-            if (wg >= F / 16) {
-                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
-            } else {
-                h8 bf[3];
-                if (ph > ph0) sq_arrive(p);
-                sq_tile_w<3>(W1, H, 0, H >> 5, wg * 16, 0, bf, tid);
-                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
-                sq_stamp(p, ph, 0);
-                bool loaded = false;
-                for (int tile = wg; tile < F / 16; tile += nwg) {
-                    const int n0 = tile * 16, row = tid >> 2, c0 = (tid & 3) * 4;
-                    const bool has_row = row < M;
-                    float4 bpre = {0.f, 0.f, 0.f, 0.f};
-                    if (has_row) bpre = *(const float4*)(b1 + n0 + c0);
-                    if (tile != wg) sq_tile_w<3>(W1, H, 0, H >> 5, n0, 0, bf, tid);
-                    if (!loaded) {
-                        sq_rows_to_lds<(MTG * 16 + 23) / 24>(ry, 0, M, H, g1, b1n, p.eps, xs, ld, wg == 0 ? stats1 : nullptr, tid);
-                        sq_lds_sync();
-                        loaded = true;
-                    }
-                    float sum[4];
-                    sq_tile<MTG, 3, true>(xs, ry, ld, W1, H, 0, H >> 5, n0, bf, red, sum, tid, p, ph);
-                    if (has_row) {
-                        const float bb[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
-                        h4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (half_t)gelu_erf(sum[e] + bb[e]);
-                        sq_st4(rhb, (row * F + n0 + c0) * 2, o);
-                    }
-                    sq_lds_sync();
-                }
-                sq_stamp(p, ph, 1);
-            }
-        }
-        if (4 * l + 3 >= ph0 && 4 * l + 3 < ph1) {
-            // ---- P4: FFN down + bias + residual -> y   (K = F: 16 / MTG k-steps per wave and pass)
-            const int ph = 4 * l + 3;
-            if (ph > ph0) ++done;
-            if (wg >= H / 16) {
-                if (ph > ph0) { sq_arrive(p); sq_wait(p, done * (unsigned)nwg); }
-            } else {
-                h8 bf[CH4];
-                if (ph > ph0) sq_arrive(p);
-                sq_tile_w<CH4>(W2, F, 0, F >> 5, wg * 16, 0, bf, tid);
-                if (ph > ph0) sq_wait(p, done * (unsigned)nwg);
-                sq_stamp(p, ph, 0);
-                for (int tile = wg; tile < H / 16; tile += nwg) {
-                    const int n0 = tile * 16, row = tid >> 2, c0 = (tid & 3) * 4;
-                    const bool has_row = row < M;
-                    SqRes rs;
-                    float4 bpre = {0.f, 0.f, 0.f, 0.f};
-                    if (has_row) { sq_res_load(rs, true, ry, row, H, n0 + c0, stats1, g1, b1n); bpre = *(const float4*)(b2 + n0 + c0); }
-                    if (tile != wg) sq_tile_w<CH4>(W2, F, 0, F >> 5, n0, 0, bf, tid);
-                    float sum[4];
-                    sq_tile<MTG, CH4, false>(nullptr, rhb, F, W2, F, 0, F >> 5, n0, bf, red, sum, tid, p, ph);
-                    if (has_row) {
-                        const float bb[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
-                        float res[4];
-                        sq_res_value(rs, true, res);
-                        h4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (half_t)(sum[e] + bb[e] + res[e]);
-                        sq_st4(ry, (row * H + n0 + c0) * 2, o);
-                    }
-                    sq_lds_sync();
-                }
-                sq_stamp(p, ph, 1);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// LayerNorm in the tail of the residual product (EPI_BIAS_RESIDUAL_LN).  600 tiles on 256 CUs are 2.34 rounds of work in
-// 3: while the last round's 88 tiles run, 168 CUs idle -- and then a LayerNorm launch reads the sums back and writes the
-// rows again (2 x 29 us per layer).  Here the launch carries up to 256 EXTRA workgroups behind its tiles; the dispatcher
-// hands them to the CUs the partial round leaves free, and they normalise the row tiles whose N-tiles have all been stored:
-//   * a tile's workgroup stores its sums write-through (sc1), drains (s_waitcnt vmcnt(0), barrier) and counts itself in
-//     mdone[row tile] (agent-scope add; monotone over calls: generation gen of a row tile is complete at gen * Nt);
-//   * a worker claims units of 64 rows in the order the row tiles' last tiles are dispatched (`order`, built on the
-//     host from the tile map), polls mdone, reads the rows with sc1 loads (MI355X_MICROARCH.md hand-off table, first row),
-//     applies k_layernorm's arithmetic and marks the unit done (= gen);
-//   * every wait is bounded and nothing depends on dispatch order: a worker that times out simply leaves, and the clean-up
-//     launch k_layernorm_rest normalises whatever units are not marked (normally none: it costs one flag read per 8 rows).
-// The residual operand and the LayerNorm output are the SAME buffer (x): a row tile's x rows are rewritten only after all
-// tiles that read them as residual have finished.
 // ------------------------------------------------------------------------------------------------
 // LayerNorm folded into the neighbouring products: a residual product (EPI_RES_STATS / EPI_LNRES_STATS) leaves, per 256-column
 // tile, the sums (sum y, sum y^2) of every row of its fp16 output y; the consumers read the raw y and the n_parts partial
@@ -1619,103 +820,6 @@ struct GemmWs {
 };
 constexpr int kSkMaxTiles = 256;
 
-struct LnTail {
-    half_t* x;               // LayerNorm output [M][N]
-    const float* g;
-    const float* b;
-    float eps;
-    unsigned* mdone;         // [M / 256]
-    unsigned* next;          // [64] claim counters: slot gen % 64; this launch resets slot (gen + 1) % 64
-    unsigned* done;          // [M / 64]
-    const int* order;        // [M / 256]
-    unsigned gen;
-    int ntiles;              // workgroups of the product itself; blockIdx >= ntiles: workers
-    int nowait;              // timing experiment (results invalid): workers do not wait for their row tile
-};
-constexpr int kLnUnitRows = 64, kLnSpinLimit = 4096;
-
-// thread 0: claim the next unit and wait (bounded) for its row tile; returns the unit, or 0xffffffff when there is no more
-// work or the wait timed out (k_layernorm_rest then does what is left)
-__device__ __forceinline__ unsigned ln_tail_claim(const LnTail& lt, int nunits, int upt, unsigned target) {
-    const unsigned u = __hip_atomic_fetch_add(lt.next + (lt.gen & 63u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (u >= (unsigned)nunits) return 0xffffffffu;
-    const int mt = lt.order[u / upt];
-    int spins = 0;
-    while ((int)(__hip_atomic_load(lt.mdone + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > kLnSpinLimit) return 0xffffffffu;
-    }
-    return u;
-}
-
-__device__ __forceinline__ void ln_tail_worker(const LnTail& lt, const half_t* Y, int M, int N, char* smem) {
-    const int tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31, nch = N >> 3;
-    const int Nt = N / 256, upt = 256 / kLnUnitRows, nunits = (M / 256) * upt;
-    unsigned* s_unit = (unsigned*)smem;       // [2]: the unit being normalised / the next one (claimed while the rows load)
-    const sq_rsrc_t ry = sq_rsrc(Y);
-    const unsigned target = lt.nowait ? 0u : lt.gen * (unsigned)Nt;
-    if (tid == 0) s_unit[0] = ln_tail_claim(lt, nunits, upt, target);
-    __syncthreads();
-    for (int it = 0;; ++it) {
-        const unsigned u = s_unit[it & 1];
-        if (u == 0xffffffffu) return;
-        const long long row0 = (long long)lt.order[u / upt] * 256 + (u % upt) * kLnUnitRows;
-        // 16 half-waves x 4 rows, all 16 loads of a lane in flight; the next claim (an atomic and a poll) rides on their latency
-        h8 raw[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (l32 + 32 * i < nch) raw[r][i] = sq_ld8(ry, (int)(((row0 + 4 * hw + r) * N + (l32 + 32 * i) * 8) * 2));
-        if (tid == 0) s_unit[(it + 1) & 1] = ln_tail_claim(lt, nunits, upt, target);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v[4][8];
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (l32 + 32 * i < nch) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { v[i][e] = (float)raw[r][i][e]; sum += v[i][e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-                }
-            }
-            ln_finish(v, sum, l32, nch, N, lt.g, lt.b, lt.eps, lt.x + (row0 + 4 * hw + r) * N);
-        }
-        if (tid == 0) lt.done[u] = lt.gen;                     // (read by the next launch: plain store)
-        __syncthreads();
-    }
-}
-
-// LayerNorm of the 64-row units the tail workers did not mark (done[unit] != gen); y -> x.  One workgroup per unit.
-#ifdef VF_EXPERIMENTS
-__global__ __launch_bounds__(256) void k_layernorm_rest(const half_t* y, const float* g, const float* bta, float eps, int M,
-                                                         int H, half_t* x, const unsigned* done, unsigned gen) {
-    if (done[blockIdx.x] == gen) return;
-    const int l32 = threadIdx.x & 31, nch = H >> 3;
-    for (int row = blockIdx.x * kLnUnitRows + (threadIdx.x >> 5); row < (int)(blockIdx.x + 1) * kLnUnitRows && row < M; row += 8) {
-        const h8* src = (const h8*)(y + (long long)row * H);
-        float v[4][8];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = l32 + 32 * i;
-            if (c < nch) {
-                const h8 a = src[c];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e]; s += v[i][e]; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-            }
-        }
-        ln_finish(v, s, l32, nch, H, g, bta, eps, x + (long long)row * H);
-    }
-}
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // k_gemm8p_tn: 256 x 256 x 64 tiles, 8 waves (2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles,
 // 128 accumulator VGPRs), ONE workgroup per CU, LDS-DMA staging with a counted vmcnt and raw barriers --
@@ -1751,14 +855,10 @@ constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLD
 template <int EPI>
 __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                           const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K, LnTail lt, LnFold lf) {
+                                                          half_t* __restrict__ C, int M, int N, int K, LnFold lf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: [2 K-tiles][4 half-tiles][16 KB] + dump
     const int tid = threadIdx.x, lane = tid & 63;
-    if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) {
-        if ((int)blockIdx.x >= lt.ntiles) { ln_tail_worker(lt, C, M, N, smem); return; }
-        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(lt.next + ((lt.gen + 1u) & 63u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    constexpr bool RES16 = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_LN || EPI == EPI_RES_STATS || EPI == EPI_LNRES_STATS;
+    constexpr bool RES16 = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_RES_STATS || EPI == EPI_LNRES_STATS;
     // Operands swapped (D = W_frag x A_frag): a lane then owns FOUR CONSECUTIVE COLUMNS of one output row instead of one column
     // of four rows, and the epilogue moves the tile into its LDS image with 32 eight-byte writes per lane instead of 128
     // two-byte ones (round 3; the fp32-residual form always worked this way, straight from the registers).
@@ -2177,188 +1277,15 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
             for (int d_ = 16; d_; d_ >>= 1) { sm += __shfl_xor(sm, d_, 32); sq += __shfl_xor(sq, d_, 32); }
             if (cc == 0) *(float2*)(lf.stats_out + ((long long)nt_idx * lf.Mp + m0 + row) * 2) = make_float2(sm, sq);
         }
-        if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) sq_st8(sq_rsrc(C), (int)(off * 2), o);   // write-through: the tail workers read it
-        else *(h8*)(C + off) = o;
-    }
-    if constexpr (EPI == EPI_BIAS_RESIDUAL_LN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's stores have reached memory ...
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(lt.mdone + mt_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the tile counts
-    }
-}
-
-#ifdef VF_EXPERIMENTS
-// ------------------------------------------------------------------------------------------------
-// k_gemm4w_tn (EXPERIMENT, round 3): the 256 x 256 tile on FOUR waves -- one per SIMD, wave tile 128 x 128 = 8 x 8 MFMA
-// 16x16x32 tiles (256 accumulator registers), the layout the vendor library's kernels use on this chip
-// (profiles/r03_vendor_kernels.txt).  Against k_gemm8p_tn: two thirds of the LDS fragment traffic (each A / B fragment feeds
-// eight MFMAs instead of four), ONE barrier per 32-deep K step instead of eight per 64, no partner wave to cover a stall.
-//  * a K step (32 deep) is one 32-KB slot: A 256 rows x 64 B | W 256 rows x 64 B, k_gemm_dma16_tn's row swizzle;
-//    FOUR slots form a ring; at step j: wait for this wave's DMA of step j + 1, barrier (now everybody's has landed and
-//    everybody is done with slot j - 1), issue the DMA of step j + 3 into slot (j - 1) & 3, read the 16 fragments of step
-//    j + 1 into the second register set while the 64 MFMAs of step j run on the first;
-//  * epilogue through LDS as in k_gemm8p_tn (the four slots are exactly the 256 x 256 fp16 image).
-// Requires M % 256 == 0, N % 256 == 0, K % 64 == 0.
-// ------------------------------------------------------------------------------------------------
-constexpr int WBM = 256, WBN = 256, WBK = 32, WTHREADS = 256, WSLOT = (WBM + WBN) * 64, WLDS = 4 * WSLOT;
-
-template <int EPI>
-__global__ __launch_bounds__(WTHREADS) void k_gemm4w_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
-                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 1, wc = wid & 1;
-    int mt_idx, nt_idx;
-    {   // XCD-contiguous, n-major groups of 4 m-tiles (k_gemm8p_tn's order)
-        const int Mt = M / WBM, Nt = N / WBN, nwg = Mt * Nt;
-        const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        constexpr int GM = 4;
-        const int g = p / (GM * Nt), r = p - g * (GM * Nt);
-        const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
-        nt_idx = r / gm;
-        mt_idx = g * GM + (r - nt_idx * gm);
-    }
-    const long long m0 = (long long)mt_idx * WBM, n0 = (long long)nt_idx * WBN;
-    // one DMA instruction fills 16 rows x 64 B; wave w stages rows [64 w, 64 w + 64) of A and of W: 4 + 4 instructions per step
-    const half_t* a_src[4];
-    const half_t* w_src[4];
-    const int drow = lane >> 2, dpc = lane & 3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wid * 64 + j * 16 + drow;
-        a_src[j] = A + (m0 + row) * K + (dpc ^ swz16(row)) * 8;
-        w_src[j] = W + (n0 + row) * K + (dpc ^ swz16(row)) * 8;
-    }
-    auto stage = [&](int slot, int kt) {
-        char* ab = smem + slot * WSLOT + (wid * 64) * 64;
-        char* wb = ab + WBM * 64;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (long long)kt * WBK),
-                                             (__attribute__((address_space(3))) void*)(ab + j * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + (long long)kt * WBK),
-                                             (__attribute__((address_space(3))) void*)(wb + j * 1024), 16, 0, 0);
-    };
-    f4v acc[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
-    const int pc = (kb ^ swz16(r15)) * 16;   // tile offsets are multiples of 16 rows: (row >> 2) & 3 does not change
-    const char* a_row = smem + (wr * 128 + r15) * 64 + pc;
-    const char* w_row = smem + WBM * 64 + (wc * 128 + r15) * 64 + pc;
-    const int nk = K / WBK;   // even (K % 64 == 0)
-    stage(0, 0);
-    stage(1, 1 < nk ? 1 : nk - 1);
-    stage(2, 2 < nk ? 2 : nk - 1);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // step 0 of this wave's DMA has landed ...
-    __builtin_amdgcn_s_barrier();                       // ... and everybody's
-    // Fragment registers: two sets of 8 A + 8 B fragments (128 VGPRs); the set of step j + 1 is read from LDS while the 64
-    // MFMAs of step j run.  The MFMAs are inline assembly with the accumulators pinned to AGPRs ("+a"): left to itself the
-    // register allocator split the 256 accumulators across both files and moved them back and forth inside the loop.
-    h8 Fa0[8], Fb0[8], Fa1[8], Fb1[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { Fa0[t] = *(const h8*)(a_row + t * 1024); Fb0[t] = *(const h8*)(w_row + t * 1024); }
-#define VFT_MFMA4W(ACC, AF, BF) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(AF), "v"(BF))
-#define VFT_STEP4W(J, FAC, FBC, FAN, FBN)                                                                 \
-    {   /* the barrier sits in the MIDDLE of the step: the matrix pipe still has the first half's MFMAs to chew on   \
-           while the wave waits, and the next step's fragment reads (behind the barrier: that slot is only then     \
-           known to have landed everywhere) have the second half to come back */                                     \
-        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                  \
-            _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) VFT_MFMA4W(acc[mt][nt], FAC[mt], FBC[nt]);   \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* this wave's DMA of step J + 1 has landed */  \
-        __builtin_amdgcn_s_barrier();                                                                     \
-        stage(((J) + 3) & 3, (J) + 3 < nk ? (J) + 3 : nk - 1);   /* past the end: re-reads the last step (unused) */ \
-        const char* an_ = a_row + (((J) + 1) & 3) * WSLOT;                                                \
-        const char* wn_ = w_row + (((J) + 1) & 3) * WSLOT;                                                \
-        _Pragma("unroll") for (int nt = 4; nt < 8; ++nt) {                                                \
-            FAN[2 * (nt - 4)] = *(const h8*)(an_ + (2 * (nt - 4)) * 1024);                                \
-            FAN[2 * (nt - 4) + 1] = *(const h8*)(an_ + (2 * (nt - 4) + 1) * 1024);                        \
-            FBN[2 * (nt - 4)] = *(const h8*)(wn_ + (2 * (nt - 4)) * 1024);                                \
-            FBN[2 * (nt - 4) + 1] = *(const h8*)(wn_ + (2 * (nt - 4) + 1) * 1024);                        \
-            _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) VFT_MFMA4W(acc[mt][nt], FAC[mt], FBC[nt]);   \
-        }                                                                                                 \
-    }
-    for (int kt = 0; kt < nk; kt += 2) {
-        VFT_STEP4W(kt, Fa0, Fb0, Fa1, Fb1)
-        VFT_STEP4W(kt + 1, Fa1, Fb1, Fa0, Fb0)
-    }
-#undef VFT_STEP4W
-#undef VFT_MFMA4W
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the vector unit reads them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy DMAs
-    __syncthreads();
-    half_t* Es = (half_t*)smem;                         // [256][256] fp16 image = the four slots
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-        const int col = wc * 128 + nt * 16 + r15;
-        const float bv = bias ? bias[n0 + col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg += 2) {
-                const int row = wr * 128 + mt * 16 + 4 * kb + reg;
-                f2v v = {acc[mt][nt][reg] + bv, acc[mt][nt][reg + 1] + bv};
-                if (EPI == EPI_BIAS_GELU) v = gelu_erf2(v);
-                if (EPI == EPI_BIAS_QGELU) v = quick_gelu2(v);
-                Es[row * WBN + col] = (half_t)v[0];
-                Es[(row + 1) * WBN + col] = (half_t)v[1];
-            }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int c = tid + WTHREADS * i, row = c >> 5, cc = c & 31;   // 32 chunks of 8 halves per 256-wide row
-        h8 o = *(const h8*)(Es + row * WBN + cc * 8);
-        const long long off = (m0 + row) * N + n0 + cc * 8;
-        if (EPI == EPI_BIAS_RESIDUAL) {
-            const h8 r = *(const h8*)(R + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
-        }
         *(h8*)(C + off) = o;
     }
 }
-#endif
+
 
 // ------------------------------------------------------------------------------------------------
-// k_gemm8q_tn: the 8-phase kernel made PERSISTENT, with a seamless pipeline across its tiles.  k_gemm8p_tn spends about
-// half of a K = 768 tile outside its main loop (first DMAs in front, epilogue behind, nothing else on the CU).  Here a
-// workgroup walks tiles blockIdx.x, + gridDim.x, ... and
-//  * the stage sequence simply runs on into the NEXT tile: the last six stage calls of a tile (which k_gemm8p_tn sends to
-//    a dump slot) fetch the next tile's first six half-tiles, so its main loop starts with its pipeline full;
-//  * the MFMA operands are swapped (D = W_frag x A_frag): a lane then owns 4 consecutive COLUMNS of one output row, and the
-//    epilogue packs them (bias / GELU in registers) and moves the tile through 32 KB of LDS -- the two slots the prefetch
-//    does not touch -- in four 64-row passes of 8-byte writes and 16-byte row reads (128 two-byte LDS writes per thread
-//    before);
-//  * the bias of a tile arrives by one LDS-DMA during its main loop; residual rows are loaded up front in the epilogue.
-// All staging goes through inline asm (dma16s): the compiler never sees an LDS-DMA, so it puts no vmcnt(0) in front of the
-// epilogue's LDS traffic; every wait is written here.  vmcnt is in order and counts stores: in the first K-tile after
-// an epilogue the counted waits allow the 16 epilogue stores (younger than the prefetched stages) to stay in flight.
-// Requires M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128; gridDim.x a multiple of 8 or the tile count.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, const char* lds) {
-    // both scalars are wave-uniform by construction; readfirstlane makes that a fact for the register allocator
-    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds);
-    const unsigned long long a = (unsigned long long)sbase;
-    // (readfirstlane returns int: widen through unsigned, or the low half sign-extends into the high one)
-    const unsigned long long ua = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
-                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(ua), "s"(base)
-                 : "memory");
-}
-
-// the same with the LDS byte address and the 64-bit global base already in scalar registers (k_gemm9_tn keeps both as running state)
+// One LDS-DMA instruction (1 KB per wave) from inline asm, so that the compiler never sees an LDS-DMA and puts no vmcnt(0) in front of
+// LDS traffic; every wait is written by hand.  LDS byte address and 64-bit global base are scalars (k_gemm9_tn keeps both as running
+// state); the s_nop covers the M0 write -> LDS-DMA hazard the compiler's recognizer cannot see inside asm.
 __device__ __forceinline__ void dma16u(unsigned long long ua, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -2366,8 +1293,6 @@ __device__ __forceinline__ void dma16u(unsigned long long ua, unsigned voff, uns
                  : "v"(voff), "s"(ua), "s"(lds_addr)
                  : "memory");
 }
-
-[[maybe_unused]] constexpr int QLDS = PLDS + 1024;   // + one tile's bias (256 floats)
 
 // tile of a dispatch index: XCD-contiguous, n-major groups of 4 m-tiles (as k_gemm8p_tn)
 __device__ __forceinline__ void q_tile_of(int orig, int Mt, int Nt, int& mt, int& nt) {
@@ -2378,219 +1303,6 @@ __device__ __forceinline__ void q_tile_of(int orig, int Mt, int Nt, int& mt, int
     const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
     nt = r / gm;
     mt = g * GM + (r - nt * gm);
-}
-
-// Half-tile g (counted from the current tile's first; S = g & 3 is known at every call site): g >= G runs on into the
-// next tile, or -- without one -- re-reads the last K-tile into the dump slot so that the counted waits keep their meaning.
-// Everything by value: a lambda capturing the loop's variables by reference parks them in scratch memory.
-template <int S>
-__device__ __forceinline__ void q_stage(char* smem, int wid, const half_t* A, const half_t* W, int K, int g, int G, int nk, int ktg,
-                                        bool has_next, int mt_c, int nt_c, int mt_n, int nt_n, unsigned o0, unsigned o1) {
-    const bool cur = g < G, real = cur || has_next;
-    const int kt = cur ? (g >> 2) : (real ? (g >> 2) - nk : nk - 1);
-    const int mt = (cur || !has_next) ? mt_c : mt_n, nt = (cur || !has_next) ? nt_c : nt_n;
-    const int slot = real ? ((ktg + (g >> 2)) & 1) * 4 + S : 8;
-    char* dst = smem + slot * PSLOT + (16 * wid) * 128;
-    const half_t* base = (S == 0 || S == 3) ? A + ((long long)mt * PBM) * K : W + ((long long)nt * PBN) * K;
-    base += (long long)kt * PBK;
-    dma16s(base, o0, dst);
-    dma16s(base, o1, dst + 1024);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(PTHREADS) void k_gemm8q_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
-                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                          half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + bias
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
-    const int Mt = M / PBM, Nt = N / PBN, ntiles = Mt * Nt;
-    float* bias_lds = (float*)(smem + PLDS);
-    // ---- staging: wave w issues DMA instructions 2w, 2w+1 of every half-tile: LDS rows 16 w + 8 j + (lane >> 3).
-    //      Per-lane byte offsets inside a tile's A / W panel; the tile and the K-tile enter through the scalar base.
-    unsigned voff[4][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = 16 * wid + 8 * j + (lane >> 3);          // LDS row of the half-tile
-        const int lc = (lane & 7) ^ ((i >> 1) & 7);            // logical 16-byte chunk this lane fetches
-        const int am0 = i < 64 ? i : 64 + i, am1 = am0 + 64;   // A_m0: rows {0..63, 128..191}; A_m1: + 64
-        const int bn0 = (i >> 5) * 64 + (i & 31), bn1 = bn0 + 32;
-        voff[0][j] = (unsigned)((am0 * K + lc * 8) * 2);
-        voff[1][j] = (unsigned)((bn0 * K + lc * 8) * 2);
-        voff[2][j] = (unsigned)((bn1 * K + lc * 8) * 2);
-        voff[3][j] = (unsigned)((am1 * K + lc * 8) * 2);
-    }
-    // K range of this workgroup: all of K, or slice sk_slice of sk_S (whole K-tiles, >= 2 each: the host checks)
-    const int nk = K / PBK, G = 4 * nk;   // K-tiles, half-tiles of one tile
-    int mt_c, nt_c, mt_n = 0, nt_n = 0;
-    int orig = blockIdx.x;
-    q_tile_of(orig, Mt, Nt, mt_c, nt_c);
-    bool has_next = orig + (int)gridDim.x < ntiles;
-    if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
-    int ktg = 0;   // K-tiles consumed by this workgroup so far: LDS buffer of local K-tile kt is (ktg + kt) & 1
-#define VFQ_STAGE(S_, G_) q_stage<S_>(smem, wid, A, W, K, (G_), G, nk, ktg, has_next, mt_c, nt_c, mt_n, nt_n, voff[S_][0], voff[S_][1]);
-    f4v acc[8][4];
-    // fragment addresses inside a half-tile: row = (wave's 64 / 32 rows) + tile * 16 + r15; chunk (4 ks + kb) ^ ((r15 >> 1) & 7)
-    const int swz = (r15 >> 1) & 7;
-    const int a_off = (wr * 64 + r15) * 128, b_off = (wc * 32 + r15) * 128;
-    const int c0 = ((0 + kb) ^ swz) * 16, c1 = ((4 + kb) ^ swz) * 16;   // k-steps 0 and 1
-    h8 Af[4][2], B0f[2][2], B1f[2][2];
-#define VFQ_READ_A(SLOTBASE)                                                              \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
-        Af[t][0] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c0);                       \
-        Af[t][1] = *(const h8*)((SLOTBASE) + a_off + t * 2048 + c1);                       \
-    }
-#define VFQ_READ_B(DSTF, SLOTBASE)                                                         \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                        \
-        DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
-        DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
-    }
-    // operands swapped (W fragment first): tile (m-tile MQ*4+t, n-tile NQ*2+u) comes out TRANSPOSED -- lane (r15, kb)
-    // holds C[row 16 (MQ*4+t) + r15][cols 16 (NQ*2+u) + 4 kb .. + 3]
-#define VFQ_QUAD(MQ, NQ, BF)                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                  \
-                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
-#define VFQ_PHASE_HEAD(S_, G_)                                                             \
-    if (relaxed) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                         \
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                  \
-    __builtin_amdgcn_s_barrier();                                                          \
-    VFQ_STAGE(S_, G_)
-#define VFQ_PHASE_MID()                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    __builtin_amdgcn_s_barrier();                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    __builtin_amdgcn_s_setprio(1);
-#define VFQ_PHASE_TAIL()                                                                   \
-    __builtin_amdgcn_s_setprio(0);                                                         \
-    __builtin_amdgcn_sched_barrier(0);
-    VFQ_STAGE(0, 0) VFQ_STAGE(1, 1) VFQ_STAGE(2, 2) VFQ_STAGE(3, 3) VFQ_STAGE(0, 4) VFQ_STAGE(1, 5)
-    for (int it = 0;; ++it) {
-        const long long m0 = (long long)mt_c * PBM, n0 = (long long)nt_c * PBN;
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
-        // waves 4..7 run one barrier behind; the other half reads half-tiles 0 and 1 right after this barrier.  12 DMAs of this
-        // tile are issued: 8 may still fly (+ the 16 stores of the previous tile's epilogue, younger than all of them)
-        if (wr == 1) {
-            if (it > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* base = smem + ((ktg + kt) & 1) * (4 * PSLOT);
-            const int g0 = 4 * kt + 6;
-            const bool relaxed = kt == 0 && it > 0;   // (see the header: the previous epilogue's stores)
-            // phase 0: quadrant (m0, n0); reads B_n0 then A_m0
-            VFQ_PHASE_HEAD(2, g0)
-            if (kt == 0 && wid == 0 && bias) dma16s(bias + n0, (unsigned)lane * 16u, (const char*)bias_lds);
-            VFQ_READ_B(B0f, base + 1 * PSLOT)
-            VFQ_READ_A(base + 0 * PSLOT)
-            VFQ_PHASE_MID()
-            VFQ_QUAD(0, 0, B0f)
-            VFQ_PHASE_TAIL()
-            // phase 1: quadrant (m0, n1); reads B_n1
-            VFQ_PHASE_HEAD(3, g0 + 1)
-            VFQ_READ_B(B1f, base + 2 * PSLOT)
-            VFQ_PHASE_MID()
-            VFQ_QUAD(0, 1, B1f)
-            VFQ_PHASE_TAIL()
-            // phase 2: quadrant (m1, n1); reads A_m1
-            VFQ_PHASE_HEAD(0, g0 + 2)
-            VFQ_READ_A(base + 3 * PSLOT)
-            VFQ_PHASE_MID()
-            VFQ_QUAD(1, 1, B1f)
-            VFQ_PHASE_TAIL()
-            // phase 3: quadrant (m1, n0); nothing to read
-            VFQ_PHASE_HEAD(1, g0 + 3)
-            VFQ_PHASE_MID()
-            VFQ_QUAD(1, 0, B0f)
-            VFQ_PHASE_TAIL()
-        }
-        if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
-        ktg += nk;
-        // ---- epilogue.  Es: slots 2, 3 of the buffer that holds the (next) K-tile 1 -- the prefetch has filled that
-        // buffer's slots 0, 1 and all of the other buffer, or is still doing so.
-        char* Es = smem + (((ktg + 1) & 1) * 4 + 2) * PSLOT;   // [64 rows][512 B], 16-byte chunk c of row r at c ^ (r & 15)
-        h8 rres[16];
-        if (EPI == EPI_BIAS_RESIDUAL) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = tid + PTHREADS * (i & 3), row = (i >> 2) * 64 + (c >> 5), cc = c & 31;
-                rres[i] = *(const h8*)(R + (m0 + row) * N + n0 + cc * 8);
-            }
-        }
-        __builtin_amdgcn_s_barrier();   // every wave has left the main loop: the tile's last LDS reads are done
-        h4 pk[8][4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            f4v bv = {0.f, 0.f, 0.f, 0.f};
-            if (bias) bv = *(const f4v*)(bias_lds + wc * 64 + ni * 16 + 4 * kb);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                f2v v0 = {acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]};
-                f2v v1 = {acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]};
-                if (EPI == EPI_BIAS_GELU) {
-                    v0 = gelu_erf2(v0);
-                    v1 = gelu_erf2(v1);
-                }
-                if (EPI == EPI_BIAS_QGELU) {
-                    v0 = quick_gelu2(v0);
-                    v1 = quick_gelu2(v1);
-                }
-                pk[mi][ni][0] = (half_t)v0[0];
-                pk[mi][ni][1] = (half_t)v0[1];
-                pk[mi][ni][2] = (half_t)v1[0];
-                pk[mi][ni][3] = (half_t)v1[1];
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {   // rows [64 p, 64 p + 64) of the tile: waves wr == p >> 1, their m-tiles 4 (p & 1) .. + 3
-            if (wr == (p >> 1)) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const int row = t * 16 + r15;                        // in the pass
-                        const int chunk = (wc * 8 + ni * 2 + (kb >> 1)) ^ r15;  // 16-byte chunk of the 512-byte row, swizzled
-                        *(h4*)(Es + row * 512 + chunk * 16 + (kb & 1) * 8) = pk[4 * (p & 1) + t][ni];
-                    }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;   // 32 chunks of 8 halves per 256-wide row
-                h8 o = *(const h8*)(Es + row * 512 + ((cc ^ (row & 15)) * 16));
-                if (EPI == EPI_BIAS_RESIDUAL) {
-                    const h8 r = rres[p * 4 + i];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
-                }
-                *(h8*)(C + (m0 + p * 64 + row) * N + n0 + cc * 8) = o;
-            }
-            __syncthreads();
-        }
-        if (!has_next) break;
-        orig += gridDim.x;
-        mt_c = mt_n;
-        nt_c = nt_n;
-        has_next = orig + (int)gridDim.x < ntiles;
-        if (has_next) q_tile_of(orig + gridDim.x, Mt, Nt, mt_n, nt_n);
-    }
-#undef VFQ_READ_A
-#undef VFQ_READ_B
-#undef VFQ_QUAD
-#undef VFQ_PHASE_HEAD
-#undef VFQ_PHASE_MID
-#undef VFQ_PHASE_TAIL
-#undef VFQ_STAGE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3005,195 +1717,6 @@ __device__ __forceinline__ void halves(float v, float& lo, float& hi) {
     lo = a;
     hi = b;
 }
-
-// S^T tile = K[kt .. kt+32) . Q^T (key on the MFMA row): 4 k-steps of 16 over dh = 64
-__device__ __forceinline__ void attn_qk(f16v& s, const half_t* Ks, const h8 (&qf)[4], int kt, int r31, int h) {
-    f16v z;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) z[e] = 0.f;
-    const half_t* krow = Ks + (kt + r31) * AKLD + h * 8;
-    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow), qf[0], z, 0, 0, 0);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), qf[ks], s, 0, 0, 0);
-}
-
-// online-softmax update with the scores of key tile kt (state 0: all keys valid, 1: mixed) and O^T += V^T P^T
-__device__ __forceinline__ void attn_softmax_pv(const f16v& sc, f16v (&o)[2], float& m_run, float& l_run, const half_t* Vt,
-                                                int vt_ld, const float* mb, int kt, int state, int r31, int h, float LOG2E) {
-    // this tile's V^T fragments first (their LDS latency hides under the softmax):
-    // k-slot j of half h <-> key 16*st + (j&3) + 8*(j>>2) + 4*h
-    h8 vf[2][2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const half_t* vrow = Vt + (mt * 32 + r31) * vt_ld + kt + 16 * st + 4 * h;
-            const h4 lo4 = *(const h4*)(vrow);
-            const h4 hi4 = *(const h4*)(vrow + 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vf[st][mt][e] = lo4[e]; vf[st][mt][4 + e] = hi4[e]; }
-        }
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches (next tile's MFMAs, these reads) above the softmax
-    f16v s = sc;
-    if (state == 1) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) s[reg] += mb[kt + (reg & 3) + 8 * (reg >> 2) + 4 * h];
-    }
-    float tmax = fmaxf(s[0], s[1]);
-#pragma unroll
-    for (int reg = 2; reg < 16; reg += 2) tmax = fmaxf(tmax, fmaxf(s[reg], s[reg + 1]));  // v_max3
-    {
-        float lo, hi;
-        halves(tmax, lo, hi);
-        tmax = fmaxf(lo, hi);
-    }
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // raw v_exp_f32: arguments <= 0, underflow -> 0
-    const float mneg = -m_new * LOG2E;
-    float psum = 0.f;
-    h8 pf[2];
-    // (plain C on purpose: an inline-asm v_add consuming a v_exp_f32 result hides the TRANS -> VALU forwarding hazard
-    // from the compiler's wait-state insertion; measured as placement-dependent accuracy loss)
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[reg], LOG2E, mneg));
-        psum += p;
-        pf[reg >> 3][reg & 7] = (half_t)p;
-    }
-    {
-        float lo, hi;
-        halves(psum, lo, hi);
-        psum = lo + hi;
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (__ballot(alpha != 1.0f) != 0ull) {  // the running max moved for some query of this wave (rare after the first tiles)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
-    }
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][mt], pf[st], o[mt], 0, 0, 0);
-}
-
-#ifdef VF_EXPERIMENTS
-__global__ __launch_bounds__(ATHREADS) void k_attention(const half_t* __restrict__ qkv, const int* __restrict__ mask,
-                                                         int T, int H, int vt_ld, float qs, float ex, half_t* __restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* Ks = (half_t*)smem;                   // [T][AKLD]
-    half_t* Vt = Ks + (size_t)T * AKLD;           // [64][vt_ld]
-    float* mb = (float*)(Vt + (size_t)ADH * vt_ld);  // [T] additive mask
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, hd = blockIdx.x;
-    const long long row0 = (long long)b * T;
-    const int ld = 3 * H;
-    const half_t* Kg = qkv + row0 * ld + H + hd * ADH;
-    const half_t* Vg = qkv + row0 * ld + 2 * H + hd * ADH;
-    // K: verbatim rows.  16-byte chunks: key t, dh [8*kc, +8)
-    for (int c = tid; c < T * 8; c += ATHREADS) {
-        const int t = c >> 3, kc = c & 7;
-        *(uint4*)(Ks + t * AKLD + kc * 8) = *(const uint4*)(Kg + (long long)t * ld + kc * 8);
-    }
-    // V^T: a thread takes an 8-key x 8-dh block (8 loads of 16 B), transposes it in registers and writes
-    // 8 rows of 8 keys (16 B each): 8x fewer LDS stores than element-wise transposition
-    for (int c = tid; c < (T >> 3) * 8; c += ATHREADS) {
-        const int tb = c >> 3, kc = c & 7;  // keys [8*tb, +8), dh [8*kc, +8)
-        h8 blk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) blk[i] = *(const h8*)(Vg + (long long)(tb * 8 + i) * ld + kc * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            h8 rowv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rowv[i] = blk[i][e];
-            *(h8*)(Vt + (kc * 8 + e) * vt_ld + tb * 8) = rowv;
-        }
-    }
-    for (int t = tid; t < T; t += ATHREADS) mb[t] = mask[row0 + t] ? 0.f : -30000.f;
-    __syncthreads();
-    // per 32-key tile: 0 = every key valid (no mask arithmetic), 1 = mixed, 2 = every key masked (tile skipped: its
-    // probabilities underflow to exactly 0 either way).  A sequence with no valid key at all keeps every tile (HF
-    // then attends uniformly; so does the masked path).
-    int* tstate = (int*)(mb + T);
-    if (tid < (T >> 5)) {
-        int nvalid = 0;
-        for (int j = 0; j < 32; ++j) nvalid += mb[tid * 32 + j] == 0.f;
-        tstate[tid] = nvalid == 32 ? 0 : (nvalid == 0 ? 2 : 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        bool any = false;
-        for (int j = 0; j < (T >> 5); ++j) any |= tstate[j] != 2;
-        if (!any) for (int j = 0; j < (T >> 5); ++j) tstate[j] = 1;
-    }
-    __syncthreads();
-    // tile masks in SGPRs (bit i = key tile i): `act` = not fully masked, `mixed` = needs the additive mask
-    unsigned act = 0, mixed = 0;
-    for (int j = 0; j < (T >> 5); ++j) {
-        const int st = __builtin_amdgcn_readfirstlane(tstate[j]);
-        act |= (st != 2 ? 1u : 0u) << j;
-        mixed |= (st == 1 ? 1u : 0u) << j;
-    }
-    // each wave walks 32-query blocks wid, wid + 8, ...
-    for (int q0 = wid * 32; q0 < T; q0 += (ATHREADS / 64) * 32) {
-        // Q fragments (B operand): lane (query r31, half h) holds q[8h + j + 16 ks], scaled by 1/sqrt(64)
-        h8 qf[4];
-        {
-            const half_t* Qg = qkv + (row0 + q0 + r31) * ld + hd * ADH + h * 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                h8 v = *(const h8*)(Qg + ks * 16);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * qs);
-                qf[ks] = v;
-            }
-        }
-        f16v o[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
-        float m_run = -1e30f, l_run = 0.f;
-        // Software pipeline inside the wave: the S^T MFMAs of the NEXT active key tile and the V^T fragments of the
-        // current one are issued before the current tile's softmax, so the matrix pipe and the LDS work under the
-        // VALU chain (max -> exchange -> 16 exp -> exchange) instead of after it.  Two score registers ping-pong
-        // (loop unrolled by two): no register copies, and the prefetch is unconditional (past the last tile it
-        // recomputes the current one; unused).  The tile walk is scalar bit arithmetic: no LDS on the critical path.
-        int kt = __builtin_ctz(act);                      // first active tile (act != 0: see above)
-        f16v sA, sB;
-        attn_qk(sA, Ks, qf, kt * 32, r31, h);
-        while (true) {
-            const unsigned rest = act & (~1u << kt);      // active tiles after kt
-            const int kn = rest ? __builtin_ctz(rest) : kt;
-            attn_qk(sB, Ks, qf, kn * 32, r31, h);
-            attn_softmax_pv(sA, o, m_run, l_run, Vt, vt_ld, mb, kt * 32, (mixed >> kt) & 1, r31, h, ex);
-            if (!rest) break;
-            const unsigned rest2 = act & (~1u << kn);
-            const int kn2 = rest2 ? __builtin_ctz(rest2) : kn;
-            attn_qk(sA, Ks, qf, kn2 * 32, r31, h);
-            attn_softmax_pv(sB, o, m_run, l_run, Vt, vt_ld, mb, kn * 32, (mixed >> kn) & 1, r31, h, ex);
-            if (!rest2) break;
-            kt = kn2;
-        }
-        const float inv = 1.0f / l_run;
-        half_t* dst = ctx + (row0 + q0 + r31) * H + hd * ADH;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                h4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
-                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
-            }
-    }
-}
-#endif
 
 // weight preparation: the attention kernels take scores in log2 units, so log2(e) / sqrt(dh) is folded into the query
 // projection (rows [0, H) of Wqkv and of its bias) once, when the weights are loaded
@@ -3716,213 +2239,8 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
 // ------------------------------------------------------------------------------------------------
 constexpr int SKT = 64;  // keys per tile
 
-template <int DH>
-struct AttnStreamLds {
-    half_t k[2][SKT][DH + 8];
-    half_t vt[2][DH][SKT + 8];
-    float mb[2][SKT];
-    int padded[2];   // the tile holds a masked key (or runs past the sequence's end)
-};
-
-template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void k_attention_stream(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
-                                                           int ld, int heads, int kv_heads, float scale,
-                                                           half_t* __restrict__ ctx, int ctx_ld, const int* __restrict__ seq_off = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    AttnStreamLds<DH>& L = *reinterpret_cast<AttnStreamLds<DH>*>(smem);
-    constexpr int KS = DH / 16;   // k-steps of a QK^T tile
-    constexpr int MT = DH / 32;   // 32-row output tiles of O^T
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r31 = lane & 31, h = lane >> 5;
-    const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
-    const int hk = hd / (heads / kv_heads);
-    // packed sequences (seq_off): sequence b occupies rows [seq_off[b], seq_off[b + 1]); the grid is sized for the longest
-    const long long row0 = seq_off ? (long long)seq_off[b] : (long long)b * Targ;
-    const int T = seq_off ? seq_off[b + 1] - seq_off[b] : Targ;
-    if (qb * 128 >= T) return;
-    const int q_dim = heads * DH, kv_dim = kv_heads * DH;
-    const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
-    const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
-    const int q0 = qb * 128 + wid * 32;
-    const bool wave_active = q0 < T;
-    // tiles this workgroup visits: all of them, or (causal) up to its last query
-    const int last_q = (qb * 128 + 127 < T - 1) ? qb * 128 + 127 : T - 1;
-    const int ntiles = CAUSAL ? (last_q / SKT + 1) : (T + SKT - 1) / SKT;
-    // ---- staging assignment: K tile = SKT rows x DH halves = SKT*DH/8 chunks of 16 B over 256 threads;
-    //      V tile = (SKT/8) x (DH/8) blocks of 8 keys x 8 dh, one per thread of the first SKT*DH/64 threads
-    constexpr int KCH = SKT * DH / 8 / 256;  // chunks per thread (2 at DH = 64, 4 at DH = 128)
-    constexpr int VBLK = SKT * DH / 64;      // 64 or 128
-    h8 rk[KCH];
-    h8 rv[8];
-    float rmb = 0.f;
-    auto fetch = [&](int tile) {
-        const int kt = tile * SKT;
-#pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            const int c = tid + 256 * j, t = c / (DH / 8), kc = c % (DH / 8);
-            const int key = kt + t < T ? kt + t : T - 1;
-            rk[j] = *(const h8*)(Kg + (long long)key * ld + kc * 8);
-        }
-        if (tid < VBLK) {
-            const int tb = tid / (DH / 8), kc = tid % (DH / 8);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int key = kt + tb * 8 + i < T ? kt + tb * 8 + i : T - 1;
-                rv[i] = *(const h8*)(Vg + (long long)key * ld + kc * 8);
-            }
-        }
-        if (tid < SKT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            const int c = tid + 256 * j, t = c / (DH / 8), kc = c % (DH / 8);
-            *(h8*)(&L.k[buf][t][kc * 8]) = rk[j];
-        }
-        if (tid < VBLK) {
-            const int tb = tid / (DH / 8), kc = tid % (DH / 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                h8 rowv;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rowv[i] = rv[i][e];
-                *(h8*)(&L.vt[buf][kc * 8 + e][tb * 8]) = rowv;
-            }
-        }
-        if (tid < SKT) {   // (wave 0 exactly)
-            L.mb[buf][tid] = rmb;
-            const bool any = __ballot(rmb != 0.f) != 0ull;
-            if (tid == 0) L.padded[buf] = any ? 1 : 0;
-        }
-    };
-    // Q fragments (B operand), pre-scaled
-    h8 qf[KS];
-    {
-        const int qrow = q0 + r31 < T ? q0 + r31 : T - 1;
-        const half_t* Qg = qkv + (row0 + qrow) * ld + hd * DH + h * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            h8 v = *(const h8*)(Qg + ks * 16);
-            if (scale > 0.f) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
-            }
-            qf[ks] = v;
-        }
-    }
-    f16v o[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    // scale <= 0: the caller folded log2(e) / sqrt(DH) into Q (the encoder does, at weight load): scores are in log2 units
-    const float LOG2E = scale > 0.f ? 1.4426950408889634f : 1.0f;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1, kt = tile * SKT;
-        if (tile + 1 < ntiles) fetch(tile + 1);
-        const bool visit = wave_active && (!CAUSAL || kt <= q0 + 31);
-        if (visit) {
-            f16v s[2];
-#pragma unroll
-            for (int half_t_ = 0; half_t_ < 2; ++half_t_) {
-                f16v z;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                const half_t* krow = &L.k[buf][half_t_ * 32 + r31][h * 8];
-                s[half_t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow), qf[0], z, 0, 0, 0);
-#pragma unroll
-                for (int ks = 1; ks < KS; ++ks)
-                    s[half_t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), qf[ks], s[half_t_], 0, 0, 0);
-            }
-            // masks, each behind a wave-uniform branch: key padding (and tile tail) only on tiles that hold a masked key
-            // (L.padded, set when the tile was stashed), causal only on tiles that reach past the wave's first query
-            const bool diag = CAUSAL && (kt + SKT - 1 > q0);
-            if (L.padded[buf]) {
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) s[sx][reg] += L.mb[buf][sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
-            }
-            if (diag) {
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int kl = sx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        if (kt + kl > q0 + r31) s[sx][reg] = -30000.f;
-                    }
-            }
-            float tmax = -1e30f;
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, s[sx][reg]);
-            {
-                float lo, hi;
-                halves(tmax, lo, hi);
-                tmax = fmaxf(lo, hi);
-            }
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            const float mneg = -m_new * LOG2E;
-            float psum = 0.f;
-            h8 pf[4];
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[sx][reg], LOG2E, mneg));
-                    psum += p;
-                    pf[sx * 2 + (reg >> 3)][reg & 7] = (half_t)p;
-                }
-            {
-                float lo, hi;
-                halves(psum, lo, hi);
-                psum = lo + hi;
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            // unconditional: behind a "did any maximum move" branch the compiler copies all of O on the path that skips
-            // the multiply (86 v_mov per tile measured) -- more than the multiplies cost
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
-            // O^T[dh, q] += V^T[dh, keys] P^T[keys, q]; k-slot j of half h of 16-key group st <-> key 16 st + (j&3) + 8 (j>>2) + 4 h
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const half_t* vrow = &L.vt[buf][mt * 32 + r31][16 * st + 4 * h];
-                    const h4 lo4 = *(const h4*)(vrow);
-                    const h4 hi4 = *(const h4*)(vrow + 8);
-                    h8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
-                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
-                }
-        }
-        if (tile + 1 < ntiles) stash(buf ^ 1);
-        __syncthreads();
-    }
-    if (wave_active && q0 + r31 < T) {
-        const float inv = 1.0f / l_run;
-        half_t* dst = ctx + (row0 + q0 + r31) * ctx_ld + hd * DH;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                h4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
-                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
-            }
-    }
-}
+// (This first, register-staged generation of the streaming kernel was deleted in round 4; k_attention_stream2 below is the kernel that
+// runs.  The description above is kept because the tile loop, the online softmax and the masks are the ones it introduced.)
 
 // ------------------------------------------------------------------------------------------------
 // k_attention_stream2<CAUSAL>: k_attention_stream at head dim 128 with the operand path of k_attention2 -- K and V tiles
@@ -4217,182 +2535,6 @@ __global__ void k_all_last_set(const int* mask, int B, int T, int Tv, int* out) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_attention_stream256<CAUSAL>: head dim 256 (gemma).  A wave's 32 queries x 256 dims no longer fit in registers
-// next to a 128-register output accumulator, so the workgroup's 128-query Q tile lives in LDS (66 KB, pre-scaled)
-// and K / V stream in 32-key tiles (two register-staged buffers): 139 KB, one workgroup per CU.  Same algebra as
-// k_attention_stream: S^T = K Q^T, online softmax per 32-key tile, O^T += V^T P^T.
-// ------------------------------------------------------------------------------------------------
-struct AttnStream256Lds {
-    half_t q[128][256 + 8];
-    half_t k[2][32][256 + 8];
-    half_t vt[2][256][32 + 4];
-    float mb[2][32];
-};
-
-template <bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attention_stream256(const half_t* __restrict__ qkv, const int* __restrict__ mask, int Targ,
-                                                              int ld, int heads, int kv_heads, float scale,
-                                                              half_t* __restrict__ ctx, int ctx_ld, const int* __restrict__ seq_off = nullptr) {
-    constexpr int DH = 256, KT = 32, KS = DH / 16, MT = DH / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    AttnStream256Lds& L = *reinterpret_cast<AttnStream256Lds*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r31 = lane & 31, h = lane >> 5;
-    const int qb = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
-    const int hk = hd / (heads / kv_heads);
-    const long long row0 = seq_off ? (long long)seq_off[b] : (long long)b * Targ;   // (packed sequences: see k_attention_stream)
-    const int T = seq_off ? seq_off[b + 1] - seq_off[b] : Targ;
-    if (qb * 128 >= T) return;
-    const int q_dim = heads * DH, kv_dim = kv_heads * DH;
-    const half_t* Kg = qkv + row0 * ld + q_dim + hk * DH;
-    const half_t* Vg = qkv + row0 * ld + q_dim + kv_dim + hk * DH;
-    const int q0 = qb * 128 + wid * 32;
-    const bool wave_active = q0 < T;
-    const int last_q = (qb * 128 + 127 < T - 1) ? qb * 128 + 127 : T - 1;
-    const int ntiles = CAUSAL ? (last_q / KT + 1) : (T + KT - 1) / KT;
-    // Q tile -> LDS, scaled: 128 rows x 32 chunks of 16 B, 16 per thread
-    for (int c = tid; c < 128 * (DH / 8); c += 256) {
-        const int r = c / (DH / 8), kc = c % (DH / 8);
-        const int qrow = qb * 128 + r < T ? qb * 128 + r : T - 1;
-        h8 v = *(const h8*)(qkv + (row0 + qrow) * ld + hd * DH + kc * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * scale);
-        *(h8*)(&L.q[r][kc * 8]) = v;
-    }
-    h8 rk[4];   // K tile: 32 rows x 32 chunks = 1024 chunks, 4 per thread
-    h8 rv[8];   // V tile: (32/8) x (256/8) = 128 blocks of 8 keys x 8 dh, threads 0..127
-    float rmb = 0.f;
-    auto fetch = [&](int tile) {
-        const int kt = tile * KT;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = tid + 256 * j, t = c >> 5, kc = c & 31;
-            const int key = kt + t < T ? kt + t : T - 1;
-            rk[j] = *(const h8*)(Kg + (long long)key * ld + kc * 8);
-        }
-        if (tid < 128) {
-            const int tb = tid >> 5, kc = tid & 31;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int key = kt + tb * 8 + i < T ? kt + tb * 8 + i : T - 1;
-                rv[i] = *(const h8*)(Vg + (long long)key * ld + kc * 8);
-            }
-        }
-        if (tid < KT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = tid + 256 * j, t = c >> 5, kc = c & 31;
-            *(h8*)(&L.k[buf][t][kc * 8]) = rk[j];
-        }
-        if (tid < 128) {
-            const int tb = tid >> 5, kc = tid & 31;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {   // rows are 72 B apart: 8-byte stores (a 16-byte store would be misaligned on odd rows)
-                h4 lo4, hi4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { lo4[i] = rv[i][e]; hi4[i] = rv[4 + i][e]; }
-                *(h4*)(&L.vt[buf][kc * 8 + e][tb * 8]) = lo4;
-                *(h4*)(&L.vt[buf][kc * 8 + e][tb * 8 + 4]) = hi4;
-            }
-        }
-        if (tid < KT) L.mb[buf][tid] = rmb;
-    };
-    f16v o[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float LOG2E = 1.4426950408889634f;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    const half_t* qrow_lds = &L.q[wid * 32 + r31][h * 8];
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1, kt = tile * KT;
-        if (tile + 1 < ntiles) fetch(tile + 1);
-        const bool visit = wave_active && (!CAUSAL || kt <= q0 + 31);
-        if (visit) {
-            f16v s;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.f;
-            const half_t* krow = &L.k[buf][r31][h * 8];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(krow + ks * 16), *(const h8*)(qrow_lds + ks * 16), s, 0, 0, 0);
-            const bool diag = CAUSAL && (kt + KT - 1 > q0);
-            float tmax = -1e30f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int kl = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float v = s[reg] + L.mb[buf][kl];
-                if (diag && kt + kl > q0 + r31) v = -30000.f;
-                s[reg] = v;
-                tmax = fmaxf(tmax, v);
-            }
-            {
-                float lo, hi;
-                halves(tmax, lo, hi);
-                tmax = fmaxf(lo, hi);
-            }
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            const float mneg = -m_new * LOG2E;
-            float psum = 0.f;
-            h8 pf[2];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[reg], LOG2E, mneg));
-                psum += p;
-                pf[reg >> 3][reg & 7] = (half_t)p;
-            }
-            {
-                float lo, hi;
-                halves(psum, lo, hi);
-                psum = lo + hi;
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            if (__ballot(alpha != 1.0f) != 0ull) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const half_t* vrow = &L.vt[buf][mt * 32 + r31][16 * st + 4 * h];
-                    const h4 lo4 = *(const h4*)(vrow);
-                    const h4 hi4 = *(const h4*)(vrow + 8);
-                    h8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = lo4[e]; vf[4 + e] = hi4[e]; }
-                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[mt], 0, 0, 0);
-                }
-        }
-        if (tile + 1 < ntiles) stash(buf ^ 1);
-        __syncthreads();
-    }
-    if (wave_active && q0 + r31 < T) {
-        const float inv = 1.0f / l_run;
-        half_t* dst = ctx + (row0 + q0 + r31) * ctx_ld + hd * DH;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                h4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[mt][g4 * 4 + e] * inv);
-                *(h4*)(dst + mt * 32 + 8 * g4 + 4 * h) = v;
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Decoder-only (pre-norm, RMSNorm, RoPE, grouped-query attention, SwiGLU) layer pieces: the family of the models the
 // reference configures by default -- Qwen3-Embedding with last_token_pool (experiments/retriever/step3_mul.py:181-209,
 // :384) and "Yes"-logit LLM re-rankers (experiments/profile/stress_test.py:197,212-225).  GEMMs and the streaming
@@ -4562,41 +2704,20 @@ static hipError_t gws_ensure(GemmWs& g);
 static void gws_free(GemmWs& g);
 
 // Opt every kernel into its dynamic LDS size (idempotent; cheap).
-// VF_EXPERIMENTS (VF_BUILD_FLAGS="-DVF_EXPERIMENTS" python -m veritasfi_amd.build --force) compiles the measured-and-rejected
-// kernels back in: k_gemm256_tn, k_gemm_dma_tn (32x32x16 MFMAs), the 128-wide DMA instance, the persistent k_gemm8q_tn, the
-// all-layers k_sq_forward, LayerNorm in the tail of the residual products, first-generation attention (k_attention, the
-// register-staged k_attention_stream / _stream256).  The shipped library holds ONE kernel per operation and shape class; the
-// VF_* switches and vf_debug_* hooks of the experiments answer "not built" without the flag.
+// The library holds ONE kernel per operation and shape class.  The measured-and-rejected kernels of rounds 1-3 (k_gemm256_tn,
+// k_gemm_dma_tn with 32x32x16 MFMAs, the 128-wide DMA instance, the four-wave k_gemm4w_tn, the persistent k_gemm8q_tn, the all-layers
+// k_sq_forward, LayerNorm in the tail of the residual products, first-generation attention) were deleted in round 4; their
+// measurements stay in DESIGN.md section 7 and profiles/.
 static hipError_t configure_once() {
     hipError_t er = hipSuccess;
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm256_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_QGELU, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_GELU, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_QGELU, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_BIAS_RESIDUAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (DBM + 128) * 64);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
@@ -4606,52 +2727,20 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNRES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm4w_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8q_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_dma16_tn<EPI_RESIDUAL_F32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<4, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_sq_forward<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention2<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<64>));
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStreamLds<128>));
-#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<64>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<128>));
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream2<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream2Lds<256>));
-#ifdef VF_EXPERIMENTS
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attention_stream256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AttnStream256Lds));
-#endif
     return er;
 }
 
@@ -4704,27 +2793,15 @@ struct vf_encoder {
     // split-K GEMM (forwards of <= kSplitMaxRows tokens): fp32 slabs [kSplitMax][kSplitMaxRows][max(3H, F)] + tile counters
     float* sk_part = nullptr;
     unsigned* sk_cnt = nullptr;
-    // LayerNorm in the tail of the residual products (EPI_BIAS_RESIDUAL_LN): per-row-tile completion counters, claim counters,
-    // per-unit done marks, the row tiles in dispatch-completion order; generation counter (host)
-    unsigned *ln_mdone = nullptr, *ln_next = nullptr, *ln_done = nullptr;
-    int* ln_order = nullptr;
-    int ln_cap_mt = 0, ln_mt = 0, ln_nt = 0;
-    unsigned ln_gen = 0;
     // LayerNorm folded into the products (LnFold): gamma-folded copies of Wqkv (layers >= 1) and W1 (fp16, per layer
     // [3H][H] + [F][H]), their column sums and the folded bias vectors (fp32, per layer 3H + 3H + F + F); built on first use.
     // Row-sum partials of the two raw residual sums [H / 256][cap_tokens][2] live with the workspace.
     half_t* fold16 = nullptr;
     float* fold32 = nullptr;
     float *stats_a = nullptr, *stats_b = nullptr;
-    // persistent one-query forward (k_sq_forward): barrier words (+ the published row statistics, 256 bytes in) on the device,
-    // a host-mapped timeout flag
-    unsigned* sq_bar = nullptr;
-    unsigned *sq_flag_h = nullptr, *sq_flag_d = nullptr;
-    int sq_grid = 0;
-    bool sq_ok = false;
     // Small forwards (one query string: faissRetriever.py:33) are ~90 dependent launches of a few microseconds each and
     // run host-bound when launched one by one: they are captured once per shape into a hipGraph and replayed.
-    struct GraphKey { int B, T, Tv, tt, pooling, normalize, sq; bool operator==(const GraphKey& o) const { return B == o.B && T == o.T && Tv == o.Tv && tt == o.tt && pooling == o.pooling && normalize == o.normalize && sq == o.sq; } };
+    struct GraphKey { int B, T, Tv, tt, pooling, normalize; bool operator==(const GraphKey& o) const { return B == o.B && T == o.T && Tv == o.Tv && tt == o.tt && pooling == o.pooling && normalize == o.normalize; } };
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     hipStream_t gstream = nullptr;
@@ -4780,14 +2857,8 @@ extern "C" int vf_encoder_destroy(vf_encoder* e) {
     if (e->d_flag) (void)hipFree(e->d_flag);
     if (e->sk_part) (void)hipFree(e->sk_part);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
-    if (e->ln_mdone) (void)hipFree(e->ln_mdone);
     if (e->fold16) (void)hipFree(e->fold16);
     if (e->fold32) (void)hipFree(e->fold32);
-    if (e->ln_next) (void)hipFree(e->ln_next);
-    if (e->ln_done) (void)hipFree(e->ln_done);
-    if (e->ln_order) (void)hipFree(e->ln_order);
-    if (e->sq_bar) (void)hipFree(e->sq_bar);
-    if (e->sq_flag_h) (void)hipHostFree(e->sq_flag_h);
     delete e;
     return VF_OK;
 }
@@ -4831,28 +2902,9 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
         if (er == hipSuccess) er = hipMalloc((void**)&e->sk_cnt, 4096 * sizeof(unsigned));
         if (er == hipSuccess) er = hipMemset(e->sk_cnt, 0, 4096 * sizeof(unsigned));
     }
-    if (er == hipSuccess) er = hipMalloc((void**)&e->sq_bar, 4096);
-    if (er == hipSuccess) er = hipMemset(e->sq_bar, 0, 4096);
-    if (er == hipSuccess) er = hipHostMalloc((void**)&e->sq_flag_h, sizeof(unsigned), hipHostMallocMapped);
-    if (er == hipSuccess) { *e->sq_flag_h = 0u; er = hipHostGetDevicePointer((void**)&e->sq_flag_d, e->sq_flag_h, 0); }
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = configure_once();
-#ifdef VF_EXPERIMENTS
-    e->q_folded = getenv("VF_ATT_V1") == nullptr;   // A/B switch: the first-generation kernel scales Q itself
-    if (er == hipSuccess && c.hidden % 256 == 0 && c.ffn % 256 == 0) {
-        // persistent one-query forward: every workgroup must be resident (grid <= CUs, one workgroup per CU fits)
-        int cus = 0, nb = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 0;
-        const int grid = cus < 256 ? cus : 256;
-        const size_t lds = kSqHead + (size_t)64 * (c.hidden + 8) * 2 + sizeof(float) * kSqRedSlots * 64 * 17;
-        if (grid >= 1 && lds <= 160 * 1024 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_sq_forward<4, 4, 3>, kSqThreads, lds) == hipSuccess && nb >= 1) {
-            e->sq_ok = true; e->sq_grid = grid;
-        }
-        (void)hipGetLastError();
-    }
-#endif
     if (er == hipSuccess && e->q_folded) {
         const float qs = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(64)
         for (int l = 0; l < c.layers; ++l) {
@@ -5027,7 +3079,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     if constexpr (EPI == EPI_RESIDUAL_F32) {   // fp32 residual epilogue: 8-phase, the 128 x 256 DMA kernel or the 128 x 128 one
         static const long long p8f_min = getenv("VF_GEMM_8P_F32_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_F32_MIN_WGS")) : 256;   // (Qwen3-4B shape, 320 tiles: 66.4 vs 68.9 ms per forward)
         if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8f_min))) {
-            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf_plain());
+            hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, lf_plain());
             return hipGetLastError();
         }
         if (dma_ok && (long long)(M / DBM) * (N / DBN) >= dma_min && kind != 3) {
@@ -5050,23 +3102,6 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // already runs at 328 / 161 / 187 us per layer and the persistent one at 328 / 162 / 184 (XLM-R-large shape: 498 / 258 / 289
     // vs 508 / 270 / 291): what it hides -- load latency at the tile seams -- is not what the forward waits for, and its
     // static tile schedule gives up the dispatcher's balancing.  The epilogue still runs on the waves that own the MFMAs.
-#ifdef VF_EXPERIMENTS
-    // VF_GEMM_8Q_MASK (experiment): take the persistent kernel for the products whose epilogue bit is set (1 bias, 2 GELU, 4 residual)
-    static const int q_mask = getenv("VF_GEMM_8Q_MASK") ? atoi(getenv("VF_GEMM_8Q_MASK")) : 0;
-    const bool q_pick = kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min &&
-                        ((EPI == EPI_BIAS && (q_mask & 1)) || (EPI == EPI_BIAS_GELU && (q_mask & 2)) || (EPI == EPI_BIAS_RESIDUAL && (q_mask & 4)));
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL) {
-        if (big_ok && K % 64 == 0 && K >= 128 && kind == 9) {   // experiment: four waves, 128 x 128 wave tiles
-            hipLaunchKernelGGL(k_gemm4w_tn<EPI>, dim3((M / WBM) * (N / WBN)), dim3(WTHREADS), WLDS, st, A, W, bias, R, C, M, N, K);
-            return hipGetLastError();
-        }
-    }
-    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 8 || q_pick)) {
-        const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
-        hipLaunchKernelGGL(k_gemm8q_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), QLDS, st, A, W, bias, R, C, M, N, K);
-        return hipGetLastError();
-    }
-#endif
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL) {
         // round 4: the persistent two-phase kernel with the register-direct epilogue (k_gemm9_tn)
         // Default for K < 4096 (VF_GEMM_9=0 switches it off).  In the 100-pair forward, per layer (profiles/r04_rerank_layer_8p_vs_gemm9.txt):
@@ -5110,34 +3145,13 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
                 grid = tiles - ntail + pad * S;
             }
         }
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3(grid), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf);
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3(grid), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, lf);
         return hipGetLastError();
     }
     if (dma_ok && (kind == 5 || (kind == 0 && (long long)(M / DBM) * (N / DBN) >= dma_min))) {
         hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 256>), dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
         return hipGetLastError();
     }
-#ifdef VF_EXPERIMENTS
-    // The same kernel with 128-wide N tiles (48 KB LDS, three workgroups per CU).  Measured on the mid-size problems it
-    // was meant for (decoder residual products, 8..32-pair micro-batches): equal or up to 6 % SLOWER than the
-    // register-staged 128 x 128 kernel below, so it is off unless asked for (kind 6 / VF_GEMM_DMA128_MIN_WGS).
-    static const long long dma128_min = getenv("VF_GEMM_DMA128_MIN_WGS") ? atoll(getenv("VF_GEMM_DMA128_MIN_WGS")) : (1ll << 60);
-    if (M % DBM == 0 && N % 128 == 0 && K % DBK == 0 &&
-        (kind == 6 || (kind == 0 && (long long)(M / DBM) * (N / 128) >= dma128_min))) {
-        hipLaunchKernelGGL((k_gemm_dma16_tn<EPI, 128>), dim3((N / 128) * (M / DBM)), dim3(DTHREADS), 3 * (DBM + 128) * 64, st, A, W, bias,
-                           R, C, M, N, K);
-        return hipGetLastError();
-    }
-    if (dma_ok && kind == 1) {
-        hipLaunchKernelGGL(k_gemm_dma_tn<EPI>, dim3((N / DBN) * (M / DBM)), dim3(DTHREADS), DLDS, st, A, W, bias, R, C, M, N, K);
-        return hipGetLastError();
-    }
-    if (big_ok && kind == 2) {
-        hipLaunchKernelGGL(k_gemm256_tn<EPI>, dim3((N / LBN) * (M / LBM)), dim3(LTHREADS), 131072, st, A, W, bias, R, C, M,
-                           N, K);
-        return hipGetLastError();
-    }
-#endif
     const dim3 grid((N / GBN) * (M / GBM));
     const size_t lds = (size_t)2 * (GBM + GBN) * GLD * sizeof(half_t);
     hipLaunchKernelGGL(k_gemm_tn<EPI>, grid, dim3(256), lds, st, A, W, bias, R, C, M, N, K);
@@ -5153,9 +3167,9 @@ static bool gemm_gated(const half_t* A, const half_t* Wgu, half_t* C, int M, int
     *er = hipSuccess;
     if (off || M % PBM || N % PBN || F % 128 || K % PBK || K < 2 * PBK || (long long)(M / PBM) * (N / PBN) < 384) return false;
     if (act_kind == 1)
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, lf_plain());
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_GELU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, lf_plain());
     else
-        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, LnTail{}, lf_plain());
+        hipLaunchKernelGGL(k_gemm8p_tn<EPI_GATED_SILU>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, Wgu, nullptr, nullptr, C, M, N, K, lf_plain());
     *er = hipGetLastError();
     return true;
 }
@@ -5179,105 +3193,8 @@ static hipError_t gemm_skinny(const half_t* A, const half_t* W, const float* bia
     return hipGetLastError();
 }
 
-// OFF by default: measured on the 100-pair re-rank forward it returns nothing (12.21 vs 12.33 ms, 11.96 vs 11.97 on another
-// box): the LayerNorm pass is a full-bandwidth sweep of 157 MB, the K = 768 product it would hide under is itself limited
-// by the memory system (+19 us for the product, -29 for the launch it replaces), and the third of the row tiles that
-// complete in the last round have nothing left to hide under.  VF_LN_TAIL=1 switches it on.
-static std::atomic<int> g_ln_tail{getenv("VF_LN_TAIL") ? 1 : 0};
-static std::atomic<long long> g_ln_tail_calls{0};
-// Test hook: switch the LayerNorm tail on / off at run time (returns the previous setting); -1 returns the number of fused
-// launches so far instead.
-extern "C" long long vf_debug_ln_tail(int on) {
-    if (on < 0) return g_ln_tail_calls.load();
-    return g_ln_tail.exchange(on ? 1 : 0);
-}
-
-// Residual product + LayerNorm in one launch (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, see LnTail) followed by the clean-up launch.
-// Returns false when the shape does not take the 8-phase kernel (the caller then runs the product and k_layernorm).
-static bool gemm_residual_ln(vf_encoder* e, const half_t* A, const half_t* W, const float* bias, half_t* x, half_t* y,
-                             const float* g, const float* b, int Mp, int N, int K, hipStream_t st, hipError_t* er) {
-#ifndef VF_EXPERIMENTS
-    (void)e; (void)A; (void)W; (void)bias; (void)x; (void)y; (void)g; (void)b; (void)Mp; (void)N; (void)K; (void)st; (void)er;
-    return false;   // LayerNorm in the tail of the residual products: an experiment (VF_EXPERIMENTS)
-#else
-    const bool off = g_ln_tail.load(std::memory_order_relaxed) == 0;   // A/B switch: VF_LN_TAIL=1 or vf_debug_ln_tail(1)
-    const long long p8_min = p8_min_wgs();
-    static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
-    *er = hipSuccess;
-    const int Mt = Mp / PBM, Nt = N / PBN;
-    if (off || env_kind != 0 || Mp % PBM || N % PBN || N > 1024 || K % PBK || K < 2 * PBK || (long long)Mt * Nt < p8_min ||
-        (long long)Mp * N * 2 >= (1ll << 31))
-        return false;
-    if (Mt > e->ln_cap_mt) {
-        if (e->ln_mdone) { (void)hipFree(e->ln_mdone); (void)hipFree(e->ln_done); (void)hipFree(e->ln_order); }
-        e->ln_mdone = nullptr; e->ln_done = nullptr; e->ln_order = nullptr; e->ln_cap_mt = 0;
-        hipError_t a = hipMalloc((void**)&e->ln_mdone, (size_t)Mt * sizeof(unsigned));
-        if (a == hipSuccess) a = hipMalloc((void**)&e->ln_done, (size_t)Mt * (PBM / kLnUnitRows) * sizeof(unsigned));
-        if (a == hipSuccess) a = hipMalloc((void**)&e->ln_order, (size_t)Mt * sizeof(int));
-        if (a == hipSuccess && !e->ln_next) a = hipMalloc((void**)&e->ln_next, 64 * sizeof(unsigned));
-        if (a != hipSuccess) { *er = a; return true; }
-        e->ln_cap_mt = Mt; e->ln_mt = 0;
-    }
-    if (Mt != e->ln_mt || Nt != e->ln_nt) {
-        // a new shape: counters restart (generation 0 = nothing done), and the order in which the row tiles complete --
-        // the dispatch index of a tile is 8 (position within its XCD's contiguous range) + XCD; a row tile is complete when
-        // its last-dispatched tile is
-        const int nwg = Mt * Nt, q8 = nwg >> 3, r8 = nwg & 7;
-        std::vector<long long> key(Mt, -1);
-        for (int xcd = 0; xcd < 8; ++xcd) {
-            const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, cnt = xcd < r8 ? q8 + 1 : q8;
-            for (int i = 0; i < cnt; ++i) {
-                const int p = start + i, GM = 4;
-                const int gq = p / (GM * Nt), r = p - gq * (GM * Nt);
-                const int gm = (Mt - gq * GM) < GM ? (Mt - gq * GM) : GM;
-                const int nt = r / gm, mt = gq * GM + (r - nt * gm);
-                const long long orig = (long long)i * 8 + xcd;
-                if (orig > key[mt]) key[mt] = orig;
-            }
-        }
-        std::vector<int> order(Mt);
-        for (int i = 0; i < Mt; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return key[a2] < key[b2]; });
-        hipError_t a = hipMemcpyAsync(e->ln_order, order.data(), (size_t)Mt * sizeof(int), hipMemcpyHostToDevice, st);
-        if (a == hipSuccess) a = hipMemsetAsync(e->ln_mdone, 0, (size_t)Mt * sizeof(unsigned), st);
-        if (a == hipSuccess) a = hipMemsetAsync(e->ln_done, 0, (size_t)Mt * (PBM / kLnUnitRows) * sizeof(unsigned), st);
-        if (a == hipSuccess) a = hipMemsetAsync(e->ln_next, 0, 64 * sizeof(unsigned), st);
-        if (a == hipSuccess) a = hipStreamSynchronize(st);     // (the host vector goes out of scope)
-        if (a != hipSuccess) { *er = a; return true; }
-        e->ln_mt = Mt; e->ln_nt = Nt; e->ln_gen = 0;
-    }
-    LnTail lt{};
-    lt.x = x; lt.g = g; lt.b = b; lt.eps = e->cfg.ln_eps;
-    lt.mdone = e->ln_mdone; lt.next = e->ln_next; lt.done = e->ln_done; lt.order = e->ln_order;
-    lt.gen = ++e->ln_gen; lt.ntiles = Mt * Nt;
-    static const bool nowait = getenv("VF_LN_TAIL_NOWAIT") != nullptr;
-    lt.nowait = nowait ? 1 : 0;
-    static const int env_workers = getenv("VF_LN_TAIL_WORKERS") ? atoi(getenv("VF_LN_TAIL_WORKERS")) : -1;   // experiments
-    const int workers = env_workers >= 0 ? env_workers : std::min(device_cus(), Mt * (PBM / kLnUnitRows));
-    hipLaunchKernelGGL(k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>, dim3(lt.ntiles + workers), dim3(PTHREADS), PLDS, st, A, W, bias, x, y, Mp, N, K, lt, LnFold{});
-    hipLaunchKernelGGL(k_layernorm_rest, dim3(Mp / kLnUnitRows), dim3(256), 0, st, y, g, b, e->cfg.ln_eps, Mp, N, x, e->ln_done, lt.gen);
-    *er = hipGetLastError();
-    g_ln_tail_calls.fetch_add(1, std::memory_order_relaxed);
-    return true;
-#endif
-}
-
-// The persistent one-query forward is an EXPERIMENT, off by default: measured on MI355X it is slower than the launch-per-product
-// path (BERT-base shape, 32 tokens: 0.65-0.71 vs 0.59 ms) -- a hand-off between workgroups costs more
-// than the kernel boundary it replaces.  VF_SQ_FUSED=1 (persistent) / VF_SQ_PHASES=1 (its phases as separate launches) in
-// the environment, or vf_debug_sq_mode(mode) at run time (returns the previous mode).
-static std::atomic<int> g_sq_mode{getenv("VF_SQ_FUSED") ? 1 : getenv("VF_SQ_PHASES") ? 2 : 0};
-// Diagnostics: a device buffer of [4 layers][grid][2] 64-bit words that receives every workgroup's phase begin / end clocks
-// (s_memrealtime, 100 MHz); nullptr switches the stamps off.  Captured graphs keep the pointer they were captured with.
-static std::atomic<unsigned long long*> g_sq_stamps{nullptr};
-extern "C" void vf_debug_sq_stamps(void* buf) { g_sq_stamps.store((unsigned long long*)buf); }
-#ifdef VF_EXPERIMENTS
-extern "C" int vf_debug_sq_mode(int mode) { return mode >= 0 && mode <= 2 ? g_sq_mode.exchange(mode) : g_sq_mode.load(); }
-extern "C" int vf_debug_experiments(void) { return 1; }
-#else
-extern "C" int vf_debug_sq_mode(int) { return -1; }      // the persistent one-query forward is not built
+// (the measured-and-rejected experiment kernels of rounds 1-3 were deleted in round 4; DESIGN.md section 7 keeps their numbers)
 extern "C" int vf_debug_experiments(void) { return 0; }
-#endif
 
 // ---- LayerNorm folded into the products (LnFold) ---------------------------------------------------------------------
 // W'[n][k] = fp16(W[n][k] * gamma[k]);  colsum[n] = sum_k W'[n][k] (of the ROUNDED values: what the MFMA multiplies);
@@ -5326,7 +3243,7 @@ static bool enc_fold_ok(const vf_encoder* e, int Mp) {
     const bool off = g_ln_fold.load(std::memory_order_relaxed) == 0;
     static const int env_kind = getenv("VF_GEMM_KIND") ? atoi(getenv("VF_GEMM_KIND")) : 0;
     const vf_encoder_config& c = e->cfg;
-    if (off || env_kind != 0 || g_ln_tail.load(std::memory_order_relaxed)) return false;
+    if (off || env_kind != 0) return false;
     if (Mp % PBM || c.hidden % PBN || c.ffn % PBN || c.hidden < 2 * PBK || !e->stats_a) return false;
     return (long long)(Mp / PBM) * (c.hidden / PBN) >= p8_min_wgs();
 }
@@ -5359,7 +3276,7 @@ static int enc_ensure_fold(vf_encoder* e, hipStream_t st) {
 template <int EPI>
 static hipError_t gemm8p_fold(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                               const LnFold& lf, hipStream_t st) {
-    hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, LnTail{}, lf);
+    hipLaunchKernelGGL(k_gemm8p_tn<EPI>, dim3((N / PBN) * (M / PBM)), dim3(PTHREADS), PLDS, st, A, W, bias, R, C, M, N, K, lf);
     return hipGetLastError();
 }
 
@@ -5375,45 +3292,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     const bool small = !no_splitk && Ms <= kSplitMaxRows && H % 64 == 0 && F % 64 == 0;
     static const bool no_skinny = getenv("VF_NO_SKINNY") != nullptr;  // A/B switch
     const bool skinny = !no_skinny && M <= 64 && H % 256 == 0 && F % 256 == 0;   // one short sequence: weight-streaming GEMMs
-    // one short query (or two): all layers in ONE persistent launch (k_sq_forward)
-    const int sq_mode = g_sq_mode.load(std::memory_order_relaxed);   // 0 off, 1 persistent, 2 one launch per phase (no grid barrier)
-    [[maybe_unused]] const bool sq_phases = sq_mode == 2;
-    const bool sq = skinny && sq_mode != 0 && e->sq_ok && !seq_off && (T == 32 || T == 64);
     if (!seq_off) hipLaunchKernelGGL(k_position_ids, dim3(B), dim3(64), 0, st, e->d_mask, B, T, c.roberta_pad_idx, e->d_pos);
     hipLaunchKernelGGL(k_embed_ln, dim3((M + 7) / 8), dim3(256), 0, st, e->d_ids, e->d_pos, has_tt ? e->d_tt : nullptr,
                        e->w16 + e->o_word, e->w16 + e->o_pos, e->w16 + e->o_type, e->w32 + e->f_emb_g, e->w32 + e->f_emb_b,
-                       c.ln_eps, M, H, e->x, sq ? e->sq_bar : nullptr);
-#ifdef VF_EXPERIMENTS
-    if (sq) {
-        SqParams p{};
-        p.w16 = e->w16 + e->o_layers; p.w32 = e->w32 + e->f_layers;
-        p.layer16 = (long long)e->layer16; p.layer32 = (long long)e->layer32;
-        p.H = H; p.F = F; p.heads = c.heads; p.layers = c.layers; p.B = B; p.T = T;
-        p.eps = c.ln_eps; p.q_folded = e->q_folded ? 1 : 0;
-        p.mask = e->d_mask; p.x = e->x; p.y = e->y; p.ctx = e->ctx; p.hbuf = e->hbuf;
-        p.stats = (float*)(e->sq_bar + 64); p.bar = e->sq_bar; p.timeout = e->sq_flag_d;
-        p.stamps = g_sq_stamps.load(std::memory_order_relaxed);
-        static const int nsleep = getenv("VF_SQ_SLEEP") ? atoi(getenv("VF_SQ_SLEEP")) : 1;
-        p.nsleep = nsleep;
-        const size_t lds = kSqHead + (size_t)M * (H + 8) * 2 + sizeof(float) * kSqRedSlots * 64 * 17;
-        const int nph = 4 * c.layers;
-        for (int ph = 0; ph < nph; ph = sq_phases ? ph + 1 : nph) {
-            const int pe = sq_phases ? ph + 1 : nph;
-            const dim3 grid(e->sq_grid), block(kSqThreads);
-            if (H >= 768) {      // a wave holds 24 k-steps of its QKV weight rows across the barrier
-                if (T == 64) hipLaunchKernelGGL((k_sq_forward<4, 4, 3>), grid, block, lds, st, p, ph, pe);
-                else if (B == 2) hipLaunchKernelGGL((k_sq_forward<2, 4, 3>), grid, block, lds, st, p, ph, pe);
-                else hipLaunchKernelGGL((k_sq_forward<2, 2, 3>), grid, block, lds, st, p, ph, pe);
-            } else {
-                if (T == 64) hipLaunchKernelGGL((k_sq_forward<4, 4, 1>), grid, block, lds, st, p, ph, pe);
-                else if (B == 2) hipLaunchKernelGGL((k_sq_forward<2, 4, 1>), grid, block, lds, st, p, ph, pe);
-                else hipLaunchKernelGGL((k_sq_forward<2, 2, 1>), grid, block, lds, st, p, ph, pe);
-            }
-        }
-        const float* fl = e->w32 + e->f_layers + (size_t)(c.layers - 1) * e->layer32;
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, fl + 7 * H + F, fl + 8 * H + F, c.ln_eps, M, H, e->x);
-    }
-#endif
+                       c.ln_eps, M, H, e->x);
     // V^T row stride: (T + pad) halves with (T + pad) / 2 == 2 (mod 64) -> conflict-free 8-byte reads
     // (rows must also be 16-byte aligned for the transposed staging writes -> multiple of 8 halves; a
     //  row stride of 4 (mod 64) dwords keeps the 8-byte reads of 32 lanes within a 2-way conflict)
@@ -5426,11 +3308,11 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     // write the RAW sums and their row sums, the next product reads the raw sum as its A operand through gamma-folded
     // weights, the next residual product normalises its residual element by element.  e->y holds y1 (attention sum),
     // e->x holds y2 (FFN sum) of the previous layer; the last layer writes y2 over y1 and one k_layernorm produces e->x.
-    const bool fold = !sq && !skinny && !small && enc_fold_ok(e, Mp);
+    const bool fold = !skinny && !small && enc_fold_ok(e, Mp);
     if (fold) { VFT_TRY(enc_ensure_fold(e, st)); g_ln_fold_forwards.fetch_add(1, std::memory_order_relaxed); }
     LnFold lf0{};
     lf0.n_parts = H / 256; lf0.Mp = e->cap_tokens; lf0.inv_h = 1.0f / (float)H; lf0.eps = c.ln_eps;
-    for (int l = 0; l < (sq ? 0 : c.layers); ++l) {
+    for (int l = 0; l < c.layers; ++l) {
         const half_t* w = e->w16 + e->o_layers + (size_t)l * e->layer16;
         const float* f = e->w32 + e->f_layers + (size_t)l * e->layer32;
         const half_t *Wqkv = w, *Wo = Wqkv + (size_t)3 * H * H, *W1 = Wo + (size_t)H * H, *W2 = W1 + (size_t)F * H;
@@ -5450,30 +3332,14 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         // src/utils/ragManager.py:50) cannot keep K and V^T of a head resident in LDS: they take the streaming kernel
         // (64-key tiles through LDS, online softmax), which has no length limit.
         if (att_stream || T > kEncResidentT) {
-#ifdef VF_EXPERIMENTS
-            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
-            if (stream_v1)
-                hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
-                                   sizeof(AttnStreamLds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
-                                   e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
-            else
-#endif
                 hipLaunchKernelGGL((k_attention_stream2<64, false>), dim3((T + 127) / 128, c.heads, B), dim3(256),
                                    sizeof(AttnStream2Lds<64>), st, e->qkv, e->d_mask, T, 3 * H, c.heads, c.heads,
                                    e->q_folded ? -1.f : 0.125f, e->ctx, H, seq_off);
-        } else if (e->q_folded) {
-            launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         } else {
-#ifdef VF_EXPERIMENTS
-            hipLaunchKernelGGL(k_attention, dim3(c.heads, B), dim3(ATHREADS), att_lds, st, e->qkv, e->d_mask, T, H, vt_ld,
-                               0.125f, 1.4426950408889634f, e->ctx);
-#else
             (void)att_lds;
-            return fail(VF_EUNSUPPORTED, "first-generation attention is not built (VF_EXPERIMENTS)");
-#endif
+            if (!e->q_folded) return fail(VF_EUNSUPPORTED, "the resident attention kernel needs the softmax scale folded into the query projection");
+            launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         }
-        bool fused_ln = false;          // the residual product carried its LayerNorm (k_gemm8p_tn<EPI_BIAS_RESIDUAL_LN>)
-        hipError_t ler = hipSuccess;
         if (fold) {
             LnFold lf = lf0;
             lf.stats_out = e->stats_a;
@@ -5494,12 +3360,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             continue;
         }
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
-        else if ((fused_ln = gemm_residual_ln(e, e->ctx, Wo, bo, e->x, e->y, g1, b1n, Mp, H, H, st, &ler))) VFT_HIP(ler);
         else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st, 0, &e->gws));
-        if (!fused_ln) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, M, F, H, st));
         else VFT_HIP(gemm<EPI_BIAS_GELU>(e->x, W1, b1, nullptr, e->hbuf, Mp, F, H, st, 0, &e->gws));
-        fused_ln = false;
         if (skinny) {
             VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, M, H, F, st, e->sk_part, e->sk_cnt));
         } else if (small && F >= 2048) {
@@ -5507,12 +3371,10 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             // forward); the K = hidden products are not (the split's extra dependent memory round trips cost more than
             // 12 short K-steps), nor anything from 256 tokens up (measured slower)
             VFT_HIP(gemm_splitk<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Ms, H, F, e->sk_part, e->sk_cnt, st));
-        } else if ((fused_ln = gemm_residual_ln(e, e->hbuf, W2, b2, e->x, e->y, g2, b2n, Mp, H, F, st, &ler))) {
-            VFT_HIP(ler);
         } else {
             VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->hbuf, W2, b2, e->x, e->y, Mp, H, F, st, 0, &e->gws));
         }
-        if (!fused_ln) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
     }
     int all_last = 0;
     if (c.pooling == 2) {
@@ -5528,15 +3390,6 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     return VF_OK;
 }
 
-// k_sq_forward's barrier gave up (a workgroup was not resident within its time limit): the output is not a forward's.
-// The persistent path is switched off for this handle; the caller gets an error and may simply call again.
-static int enc_check_sq(vf_encoder* e) {
-    if (!e->sq_flag_h || !*e->sq_flag_h) return VF_OK;
-    *e->sq_flag_h = 0u;
-    e->sq_ok = false;
-    enc_drop_graphs(e);
-    return fail(VF_EHIP, "k_sq_forward: grid barrier timed out; the persistent one-query path is now disabled for this handle");
-}
 
 static std::atomic<long long> g_packed_forwards{0};
 // Test hook: how many forwards took the packed (ragged-batch) path in this process.
@@ -5569,8 +3422,7 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     if (!no_graph && n <= 256 && e->cfg.pooling != 2) {   // (last-token pooling reads a flag back mid-forward: not capturable)
         if (!e->gstream) VFT_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
         hipStream_t gs = e->gstream;
-        const vf_encoder::GraphKey key{b, t, t_valid, type_ids != nullptr, e->cfg.pooling, e->cfg.normalize,
-                                       e->sq_ok ? g_sq_mode.load(std::memory_order_relaxed) : 0};
+        const vf_encoder::GraphKey key{b, t, t_valid, type_ids != nullptr, e->cfg.pooling, e->cfg.normalize};
         hipGraphExec_t exec = nullptr;
         for (auto& g : e->graphs) if (g.key == key) { exec = g.exec; break; }
         VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, gs));
@@ -5592,7 +3444,7 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
         VFT_HIP(hipGraphLaunch(exec, gs));
         VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, gs));
         VFT_HIP(hipStreamSynchronize(gs));
-        return enc_check_sq(e);
+        return VF_OK;
     }
     // Ragged batch (right-padded, CLS pooling or a classification head): the rows are PACKED -- every
     // sequence keeps ceil32(length) rows -- so the GEMMs, LayerNorms and attention only see the tokens that exist.  A row's
@@ -5652,7 +3504,7 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     if (rc != VF_OK) return rc;
     VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
     VFT_HIP(hipStreamSynchronize(nullptr));
-    return enc_check_sq(e);
+    return VF_OK;
 }
 
 extern "C" int vf_encoder_forward(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids,
@@ -5698,7 +3550,7 @@ extern "C" int vf_encoder_forward_hidden(vf_encoder* e, const int32_t* ids, cons
     hipLaunchKernelGGL(k_to_f32, dim3(1024), dim3(256), 0, nullptr, e->x, tot, e->d_hidden);
     VFT_HIP(hipMemcpyAsync(out_hidden, e->d_hidden, (size_t)tot * 4, hipMemcpyDeviceToHost, nullptr));
     VFT_HIP(hipStreamSynchronize(nullptr));
-    return enc_check_sq(e);
+    return VF_OK;
 }
 
 extern "C" int vf_encoder_info(vf_encoder* e, vf_encoder_config* out) {
@@ -5902,33 +3754,12 @@ static int dec_layers_device(vf_decoder* d, int b, int t, hipStream_t st, float*
         hipLaunchKernelGGL(k_qknorm_rope, dim3((M + 256 / (DH / 16) - 1) / (256 / (DH / 16)), 3), dim3(256), 0, st, d->qkv, M, t, QKV, c.heads, c.kv_heads, DH,
                            qn, kn, c.rms_eps, c.qk_norm, d->rope, pos);
         if (DH == 64) {
-#ifdef VF_EXPERIMENTS
-            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;
-            if (stream_v1)
-                hipLaunchKernelGGL((k_attention_stream<64, true>), agrid, dim3(256), sizeof(AttnStreamLds<64>), st, d->qkv, d->d_mask,
-                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
-            else
-#endif
                 hipLaunchKernelGGL((k_attention_stream2<64, true>), agrid, dim3(256), sizeof(AttnStream2Lds<64>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else if (DH == 128) {
-#ifdef VF_EXPERIMENTS
-            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: register-staged K / V tiles
-            if (stream_v1)
-                hipLaunchKernelGGL((k_attention_stream<128, true>), agrid, dim3(256), sizeof(AttnStreamLds<128>), st, d->qkv, d->d_mask,
-                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
-            else
-#endif
                 hipLaunchKernelGGL((k_attention_stream2<128, true>), agrid, dim3(256), sizeof(AttnStream2Lds<128>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         } else {
-#ifdef VF_EXPERIMENTS
-            static const bool stream_v1 = getenv("VF_ATT_STREAM_V1") != nullptr;   // A/B switch: the Q-in-LDS, register-staged kernel
-            if (stream_v1)
-                hipLaunchKernelGGL((k_attention_stream256<true>), agrid, dim3(256), sizeof(AttnStream256Lds), st, d->qkv, d->d_mask,
-                                   t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
-            else
-#endif
                 hipLaunchKernelGGL((k_attention_stream2<256, true>), agrid, dim3(256), sizeof(AttnStream2Lds<256>), st, d->qkv, d->d_mask,
                                    t, QKV, c.heads, c.kv_heads, scale, d->ctx, QD, seq_off);
         }
@@ -6691,27 +4522,12 @@ extern "C" int vf_debug_attention(const void* qkv, const int* mask, int B, int T
     if (kind != 3 && kind != 4 && T > kEncResidentT) return -2;
     hipStream_t st = (hipStream_t)stream;
     const int H = heads * ADH;
-#ifdef VF_EXPERIMENTS
-    if (kind == 1) {
-        int pad = 8;
-        while ((((T + pad) / 2) & 63) != 4) pad += 8;
-        const int vt_ld = T + pad;
-        const size_t att_lds = (size_t)T * AKLD * 2 + (size_t)ADH * vt_ld * 2 + (size_t)T * 4 + 64;
-        hipLaunchKernelGGL(k_attention, dim3(heads, B), dim3(ATHREADS), att_lds, st, (const half_t*)qkv, mask, T, H, vt_ld, 1.0f, 1.0f,
-                           (half_t*)ctx);
-#else
     if (kind == 1 || kind == 3) {
-        return -3;   // first-generation kernels: not built (VF_EXPERIMENTS)
-#endif
+        return -3;   // first-generation kernels: deleted in round 4
     } else if (kind == 2) {
         launch_attention2<0>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
     } else if (kind == 26) {
         launch_attention2<6>((const half_t*)qkv, mask, B, T, heads, (half_t*)ctx, st);
-#ifdef VF_EXPERIMENTS
-    } else if (kind == 3) {
-        hipLaunchKernelGGL((k_attention_stream<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStreamLds<64>), st,
-                           (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
-#endif
     } else if (kind == 4) {
         hipLaunchKernelGGL((k_attention_stream2<64, false>), dim3((T + 127) / 128, heads, B), dim3(256), sizeof(AttnStream2Lds<64>), st,
                            (const half_t*)qkv, mask, T, 3 * H, heads, heads, -1.f, (half_t*)ctx, H);
