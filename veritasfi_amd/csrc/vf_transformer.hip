@@ -1360,43 +1360,49 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
     }
     const unsigned long long a_m1_bytes = (unsigned long long)64 * K * 2, b_n1_bytes = (unsigned long long)32 * K * 2;
     const int nk = K / PBK;
-    int mt_c, nt_c;
-    int orig = blockIdx.x;
-    q_tile_of(orig, Mt, Nt, mt_c, nt_c);
-    bool has_next = orig + (int)gridDim.x < ntiles;
+    // ---- WORK ITEMS of this workgroup: its tiles b, b + G, ... (an item = a tile and a range of its K-tiles; today always all of them.
+    // Round 4 also built the remainder tiles of long-K products as K-slices inside this kernel -- partials through the handle's workspace,
+    // last arriver reduces in slice order -- correct and deterministic, and SLOWER in the forward than handing those products to the
+    // 8-phase kernel's split-K tail: 11.67 vs 11.48 ms at 768 wide, 36.4 vs 35.6 at 1024; profiles/r04_gemm9_tail_slices.log.  Removed.)
+    const int G_ = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int n_items = wg < ntiles ? (ntiles - wg + G_ - 1) / G_ : 0;
+    if (n_items == 0) return;                                   // (before any barrier)
+    auto item = [&](int idx, int& mt_, int& nt_, int& klo_, int& nk_) { q_tile_of(wg + idx * G_, Mt, Nt, mt_, nt_); klo_ = 0; nk_ = nk; };
+    int mt_c, nt_c, klo_c, nk_c;
+    item(0, mt_c, nt_c, klo_c, nk_c);
     int ktg = 0;   // K-tiles consumed by this workgroup so far: LDS buffer of local K-tile kt is (ktg + kt) & 1
     // ---- the STAGE CURSOR: half-tiles are staged strictly in sequence (A_m0, B_n0, B_n1, A_m1 of K-tile 0, then of K-tile 1, ...,
-    // running on into the workgroup's next tile), 1.75 K-tiles ahead of the MFMAs.  Its state lives in scalar registers and
+    // running on into the workgroup's next item), 1.75 K-tiles ahead of the MFMAs.  Its state lives in scalar registers and
     // moves by a few scalar adds per half-tile (the first version recomputed tile, K-tile and slot of every half-tile from its
     // index: ~45 scalar instructions per stage call, 180 in front of every K-tile's first barrier).
     unsigned long long st_a, st_w;          // byte addresses of the K-tile being staged: row 0 of the tile's A / W panel, its first k
-    int st_kt = 0, st_orig = orig;          // that K-tile's index in its tile; the dispatch index of the tile being staged
+    int st_kt = 0, st_nk = nk_c, st_item = 0;   // that K-tile's index in its item, the item's K-tiles, the item
     unsigned st_slot;                       // LDS byte address of that K-tile's buffer + this wave's 2 KB piece (toggles by 64 KB)
-    bool st_dump = false;                   // past the workgroup's last tile: the stage calls go on re-reading into the dump slot
+    bool st_dump = false;                   // past the workgroup's last item: the stage calls go on re-reading into the dump slot
     const unsigned lds_smem = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem);
     const unsigned lds0 = lds_smem + (unsigned)(16 * wid * 128);
-    {
-        const unsigned long long a0 = (unsigned long long)(A + (long long)mt_c * PBM * K), w0 = (unsigned long long)(W + (long long)nt_c * PBN * K);
+    auto panel = [&](int mt_, int nt_, int klo_) {
+        const unsigned long long a0 = (unsigned long long)A + ((unsigned long long)((long long)mt_ * PBM * K) + (unsigned long long)klo_ * PBK) * 2ull;
+        const unsigned long long w0 = (unsigned long long)W + ((unsigned long long)((long long)nt_ * PBN * K) + (unsigned long long)klo_ * PBK) * 2ull;
         st_a = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a0);
         st_w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w0);
-        st_slot = lds0;
-    }
-    auto stage_advance = [&]() {            // after A_m1: on to the next K-tile (of this tile, of the next one, or of the dump)
+    };
+    panel(mt_c, nt_c, klo_c);
+    st_slot = lds0;
+    auto stage_advance = [&]() {            // after A_m1: on to the next K-tile (of this item, of the next one, or of the dump)
         st_slot = lds0 + ((st_slot - lds0) ^ (4u * PSLOT));
         if (st_dump) return;
-        if (++st_kt < nk) { st_a += PBK * 2; st_w += PBK * 2; return; }
+        if (++st_kt < st_nk) { st_a += PBK * 2; st_w += PBK * 2; return; }
         st_kt = 0;
-        st_orig += (int)gridDim.x;
-        if (st_orig < ntiles) {
-            int mt_, nt_;
-            q_tile_of(st_orig, Mt, Nt, mt_, nt_);
-            st_a = (unsigned long long)A + (unsigned long long)((long long)mt_ * PBM * K) * 2ull;
-            st_w = (unsigned long long)W + (unsigned long long)((long long)nt_ * PBN * K) * 2ull;
+        if (++st_item < n_items) {
+            int mt_, nt_, klo_;
+            item(st_item, mt_, nt_, klo_, st_nk);
+            panel(mt_, nt_, klo_);
         } else {
             st_dump = true;                 // keep the last K-tile's addresses: valid memory, landing in the dump slot
         }
     };
-#define VF9_STAGE(S_, G_)                                                                                              \
+#define VF9_STAGE(S_)                                                                                                  \
     {                                                                                                                  \
         const unsigned dst_ = st_dump ? lds0 + 8u * PSLOT : st_slot + (unsigned)(S_) * PSLOT;                          \
         const unsigned long long b_ = (S_) == 0 ? st_a : (S_) == 3 ? st_a + a_m1_bytes : (S_) == 1 ? st_w : st_w + b_n1_bytes; \
@@ -1419,17 +1425,20 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
         DSTF[t][0] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c0);                     \
         DSTF[t][1] = *(const h8*)((SLOTBASE) + b_off + t * 2048 + c1);                     \
     }
+    // operands swapped (W fragment first): block (m-block MQ 4 + t, n-block NQ 2 + u) comes out TRANSPOSED -- lane (r15, kb) holds
+    // C[row 16 (MQ 4 + t) + r15][the four columns of n-block NQ 2 + u that MFMA rows 4 kb .. 4 kb + 3 stand for].  Consecutive MFMAs share
+    // the W fragment (the FIRST operand) over four A fragments; the other order (VF9_ORDER 0) measured level (profiles/r04_gemm9_k_sweep.log).
 #ifndef VF9_ORDER
 #define VF9_ORDER 1
 #endif
-#if VF9_ORDER == 0     /* consecutive MFMAs share the A fragment (second operand), the W fragment alternates */
+#if VF9_ORDER == 0
 #define VF9_QUAD_LOOPS _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int t = 0; t < 4; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u)
-#else                  /* consecutive MFMAs share the W fragment (FIRST operand) over four A fragments */
+#else
 #define VF9_QUAD_LOOPS _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int t = 0; t < 4; ++t)
 #endif
-#define VF9_QUAD(MQ, NQ, BF, ZERO_)   /* ZERO_ (literal): a tile's first K-tile starts from C = 0 at its first k-step: no accumulator is ever cleared */ \
+#define VF9_QUAD(MQ, NQ, BF)                                                               \
     VF9_QUAD_LOOPS                                                                         \
-                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], ((ZERO_) && ks == 0) ? f4v{0.f, 0.f, 0.f, 0.f} : acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
+                acc[(MQ) * 4 + t][(NQ) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[u][ks], Af[t][ks], acc[(MQ) * 4 + t][(NQ) * 2 + u], 0, 0, 0);
 #define VF9_MID()                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
@@ -1439,18 +1448,16 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
 #define VF9_TAIL()                                                                         \
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);
-    VF9_STAGE(0, 0) VF9_STAGE(1, 1) VF9_STAGE(2, 2) VF9_STAGE(3, 3) VF9_STAGE(0, 4) VF9_STAGE(1, 5) VF9_STAGE(2, 6)
+    VF9_STAGE(0) VF9_STAGE(1) VF9_STAGE(2) VF9_STAGE(3) VF9_STAGE(0) VF9_STAGE(1) VF9_STAGE(2)
     // DESYNCHRONISE the workgroups.  Tiles take the same time everywhere, so workgroups that start together reach every epilogue
-    // together: 256 x 128 KB of stores meet the memory system as one burst, the store acknowledgements come back at the HBM
-    // write rate (~8 us for 32 MB) and -- vmcnt being in order -- every wave's next stage waits behind them (measured: T(K) =
-    // 8 us + 1.5 us per K-tile with or without the LDS-free epilogue; profiles/r04_gemm9_k_sweep.log).  Spread over a tile's
-    // time, a third of the chip writes while two thirds compute and the write-back cache absorbs each tile.  The workgroups
-    // with the SMALLER tile count (blockIdx >= ntiles % grid) take their offsets for free: they end before the others anyway.
+    // together: 256 x 128 KB of stores meet the memory system as one burst.  Spread over a tile's time, a third of the chip writes
+    // while two thirds compute and the write-back cache absorbs each tile.  The workgroups with the SMALLER tile count
+    // (blockIdx >= ntiles % grid) take their offsets for free: they end before the others anyway (profiles/r04_gemm9_stagger.log).
     if (stagger_ticks > 0) {
-        const int G_ = (int)gridDim.x, rem = ntiles % G_, b = (int)blockIdx.x;
+        const int rem = ntiles % G_;
         int num = 0, den = 1;
-        if (rem != 0) { if (b >= rem) { num = ((b - rem) >> 3) + 1; den = ((G_ - rem + 7) >> 3) + 1; } }
-        else if (ntiles >= 2 * G_) { num = b >> 3; den = 2 * ((G_ + 7) >> 3); }       // exact rounds: half a tile's spread
+        if (rem != 0) { if (wg >= rem) { num = ((wg - rem) >> 3) + 1; den = ((G_ - rem + 7) >> 3) + 1; } }
+        else if (ntiles >= 2 * G_) { num = wg >> 3; den = 2 * ((G_ + 7) >> 3); }       // equal work: half a tile's spread
         const unsigned long long wait = (unsigned long long)stagger_ticks * (unsigned)num / (unsigned)den;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
@@ -1463,19 +1470,21 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
 #define VF9_STAMP(SLOT_)                                                                                              \
     if (dbg && wid == 0 && lane == 0 && it < k9StampTiles) stamps[it * k9Stamps + (SLOT_)] = __builtin_amdgcn_s_memrealtime();
     if (dbg && wid == 0) { for (int i = lane; i < k9StampTiles * k9Stamps; i += 64) stamps[i] = 0ull; }
-    // ---- the epilogue in TWO HALVES that ride INSIDE the MFMA blocks of the main loop.  Phase X of a K-tile touches only the
-    // accumulators of the wave's first 64 rows (acc[0..3]), phase Y only those of its second 64 (acc[4..7]).  After X of the LAST
-    // K-tile acc[0..3] are final: they are converted and stored between the 32 MFMAs of that K-tile's Y (which never touches
-    // them); acc[4..7] are final after that Y and leave between the MFMAs of the NEXT tile's first X.  Each micro-step clears the four
-    // registers it has converted (the MFMAs always accumulate in place: starting a tile from C = 0 instead made the allocator open new
-    // live ranges for the accumulators and spill), so no accumulator is copied.  History (profiles/r04_gemm9_*.log): the whole
-    // epilogue between two tiles made the two wave halves take turns at it under the one-barrier stagger (first K-tile of a tile 4.4
-    // us instead of 1.6, + 2.2 us epilogue: 5 of a tile's 25 us); the halves placed in front of their phase's barrier did the same
-    // to a lesser degree (every barrier interval with a half in it stretched to that half's length) -- only work issued in the
-    // shadow of the wave's OWN MFMAs is free.
+    // ---- the epilogue, straight from the accumulators, in two halves.  Phase X of a K-tile touches only the accumulators of the wave's
+    // first 64 rows (acc[0..3]), phase Y only those of its second 64 (acc[4..7]).  BOTH halves of an item's epilogue run in the NEXT
+    // item's first K-tile, each in front of the barrier of the phase that is about to overwrite its accumulators: acc[0..3] (final
+    // since X of the last K-tile) in front of X(0), acc[4..7] in front of Y(0); each half clears what it has stored (the MFMAs always
+    // accumulate in place).  Placements measured (first K-tile of a tile in the steady state, a normal K-tile 1.45 us;
+    // profiles/r04_gemm9_*.log): the whole epilogue between two tiles 4.4 us + 2.2 us -- the one-barrier stagger makes the wave halves take
+    // turns at it; each half right behind the MFMAs that finish it 4.9 us (it waits for them to drain through the pipe it shares
+    // with the other wave half); waves 0..3 behind their MFMAs, waves 4..7 in front of the barrier 5.6 us; this one 5.3 + 2.7 us with
+    // the steady K-tile at 1.32 us.  The cost is the stores themselves: a tile's 128 KB leave the CU at ~32 GB/s wherever they are
+    // issued.  Threading conversions and stores BETWEEN the 32 MFMAs of a phase would hide them and does not fit the register allocator:
+    // 128 accumulators + 64 fragment registers + the half in flight spill 60-120 registers around the block in every arrangement
+    // tried (peeled K-tiles, C = 0 starts, opaque zeros), and scratch accesses drain the DMA queue.
     // lane (r15, kb) of block mi holds row wr 128 + mi 16 + r15 and, for hf = 0, 1, the eight columns wc 64 + hf 32 + 8 kb .. + 7:
-    // acc[mi][2 hf][0..3], acc[mi][2 hf + 1][0..3].  Residual rows are loaded by VF9_EPI_LOAD_R at the TOP of the phase, before
-    // its stage DMAs (vmcnt is in order: loads issued after them would wait for them), and used a few hundred cycles later.
+    // acc[mi][2 hf][0..3], acc[mi][2 hf + 1][0..3].  Residual rows are loaded and consumed in front of the phase's stage DMAs (vmcnt is
+    // in order: loads issued behind them would wait for them).
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     h8 rr[4][2];
@@ -1517,107 +1526,28 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
                 }                                                                                                      \
                 *(u4v*)(cbase_ + (long long)t_ * 16 * N + hf_ * 32) = o_;                                              \
             }                                                                                                          \
-            _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) acc[mi_][b_] = f4v{0.f, 0.f, 0.f, 0.f}; \
+            _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) acc[mi_][b_] = f4v{0.f, 0.f, 0.f, 0.f};                   \
         }                                                                                                              \
     }
-    // The 32 MFMAs of a phase with the epilogue half threaded between them, in the order the hardware should issue it: after every
-    // second MFMA one micro-step (bias add + fp16 conversion of four accumulator registers: ~4 VALU instructions, issued in the
-    // shadow of the MFMA before them), after every fourth a 16-byte store.  sched_barrier(0) pins each group: left alone the
-    // scheduler hoists the conversions to the top of the block and spills the fragments.  (bias: 16 floats, read once per block.)
-    // MFMA order inside a quadrant: VF9_ORDER (k-step, then the W fragment u, then the four A fragments t).
-    u4v ob_;
-    f2v bvp_[4];
-    f4v bq0_, bq1_;
-    half_t* cb_ = C;
-    const float* bl_ = bias_lds;
-#define VF9_STEP(N_, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)                                                    \
-    {                                                                                                                  \
-        constexpr int r16_ = (N_) & 15, ks_ = r16_ >> 3, u_ = (r16_ >> 2) & 1, t_ = r16_ & 3;                           \
-        if ((N_) < 16) acc[(MQ_) * 4 + t_][(NQA_) * 2 + u_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BFA_[u_][ks_], Af[t_][ks_], acc[(MQ_) * 4 + t_][(NQA_) * 2 + u_], 0, 0, 0); \
-        else acc[(MQ_) * 4 + t_][(NQB_) * 2 + u_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BFB_[u_][ks_], Af[t_][ks_], acc[(MQ_) * 4 + t_][(NQB_) * 2 + u_], 0, 0, 0); \
-        if ((EON_) && (N_) == 8 && bias) { bq0_ = *(const f4v*)(bl_ + 32); bq1_ = *(const f4v*)(bl_ + 36); }   /* the second column half's bias, 8 MFMAs ahead */ \
-        if ((EON_) && (N_) == 15) {                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-            bvp_[0] = f2v{bq0_[0], bq0_[1]}; bvp_[1] = f2v{bq0_[2], bq0_[3]}; bvp_[2] = f2v{bq1_[0], bq1_[1]}; bvp_[3] = f2v{bq1_[2], bq1_[3]}; \
-        }                                                                                                              \
-        if ((EON_) && ((N_) & 1)) {       /* pieces in the order hf 0: t 0..3, then hf 1: t 0..3 */                    \
-            constexpr int j_ = (N_) >> 1, p_ = j_ >> 1, ehf_ = p_ >> 2, et_ = p_ & 3, eq_ = j_ & 1;                     \
-            const f4v a4_ = acc[4 * (MH_) + et_][2 * ehf_ + eq_];                                                      \
-            f2v v0_ = f2v{a4_[0], a4_[1]} + bvp_[2 * eq_], v1_ = f2v{a4_[2], a4_[3]} + bvp_[2 * eq_ + 1];               \
-            if (EPI == EPI_BIAS_GELU) { v0_ = gelu_erf2(v0_); v1_ = gelu_erf2(v1_); }                                  \
-            if (EPI == EPI_BIAS_QGELU) { v0_ = quick_gelu2(v0_); v1_ = quick_gelu2(v1_); }                             \
-            acc[4 * (MH_) + et_][2 * ehf_ + eq_] = f4v{0.f, 0.f, 0.f, 0.f};   /* ready for the next tile: the MFMAs always accumulate in place */ \
-            ob_[2 * eq_] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0_, h2v));                            \
-            ob_[2 * eq_ + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1_, h2v));                        \
-            if (eq_ == 1) *(u4v*)(cb_ + (long long)et_ * 16 * N + ehf_ * 32) = ob_;                                    \
-        }                                                                                                              \
-        if ((EON_) && ((N_) & 1)) __builtin_amdgcn_sched_barrier(0);                                                   \
-    }
-#define VF9_BLOCK(MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_, M0_, N0_, PAR_)                                       \
-    {                                                                                                                  \
-        if (EON_) {                                                                                                    \
-            bq0_ = f4v{0.f, 0.f, 0.f, 0.f}; bq1_ = bq0_;                                                               \
-            bl_ = bias_lds + (PAR_) * 256 + wc * 64 + 8 * kb;                                                          \
-            if (bias) { bq0_ = *(const f4v*)bl_; bq1_ = *(const f4v*)(bl_ + 4); }                                      \
-            cb_ = C + ((M0_) + wr * 128 + (4 * (MH_)) * 16 + r15) * N + (N0_) + wc * 64 + 8 * kb;                      \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-            bvp_[0] = f2v{bq0_[0], bq0_[1]}; bvp_[1] = f2v{bq0_[2], bq0_[3]}; bvp_[2] = f2v{bq1_[0], bq1_[1]}; bvp_[3] = f2v{bq1_[2], bq1_[3]}; \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-        }                                                                                                              \
-        VF9_STEP(0, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(1, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
-        VF9_STEP(2, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(3, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
-        VF9_STEP(4, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(5, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
-        VF9_STEP(6, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(7, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
-        VF9_STEP(8, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(9, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)     \
-        VF9_STEP(10, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(11, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(12, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(13, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(14, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(15, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(16, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(17, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(18, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(19, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(20, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(21, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(22, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(23, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(24, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(25, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(26, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(27, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(28, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(29, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-        VF9_STEP(30, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_) VF9_STEP(31, MQ_, BFA_, NQA_, BFB_, NQB_, ZERO_, EON_, MH_)   \
-    }
-    // one K-tile.  FIRST_: 0 = no, 1 = a tile's first K-tile (accumulators start from C = 0), 2 = the same with the PREVIOUS tile's
-    // second half leaving between phase X's MFMAs.  LAST_: this tile's first half leaves between phase Y's MFMAs.  All literals.
-    // Counted waits (vmcnt is in order and counts the epilogue's stores).  Queue around a tile boundary, oldest first:
-    // X(nk-1): 2 DMAs | Y(nk-1): 6 DMAs, 8 stores | X(0): 2 DMAs, 8 stores | Y(0): 6 DMAs | X(1): 2 DMAs ...
-    //   X(0) needs the DMAs of X(nk-1) landed  -> 6 + 8 may fly;   Y(0) those of Y(nk-1) -> 8 + 2 + 8 may fly;
-    //   X(1) those of X(0) -> 8 + 6 may fly (the first eight stores are older: they have had two phases);  Y(1): as ever.
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
-#ifndef VF9_EPI_SPLIT
-#define VF9_EPI_SPLIT 0   /* (unused by the current placement; the wave-half split measured slower: first K-tile 5.6 vs 4.9 us) */
-#endif
-#ifndef VF9_EPI_IN_X
-#define VF9_EPI_IN_X 0   /* 1: the second half's epilogue threaded through the MFMAs of the next tile's first phase (VF9_BLOCK's micro-steps).  Built and
-                            inspected in round 4: with 128 accumulators + 64 fragment registers live the allocator spills 60-120 registers around the block,
-                            in every arrangement tried (peeled K-tiles, C = 0 starts, opaque zeros); 0 = both halves in front of their phase's barrier */
-#endif
-    // One loop body for every K-tile (first is a wave-uniform run-time flag: peeling the first K-tile into a copy of its own let the
-    // compiler fold the cleared accumulators into C = 0 MFMAs with fresh destinations, and the allocator spilled).
-    // BOTH halves of a tile's epilogue run in the NEXT tile's first K-tile, each in front of the barrier of the phase that is about to
-    // overwrite its accumulators: acc[0..3] (final since X of the last K-tile) in front of X(0), acc[4..7] (final since Y of the last
-    // K-tile) in front of Y(0).  One phase earlier -- right behind the MFMAs that finish them -- a half first had to wait for those
-    // MFMAs to drain through the pipe it shares with the other wave half (first K-tile 4.9 us instead of 1.5; profiles/r04_gemm9_*.log).
-    long long m0p = 0, n0p = 0;   // the previous tile
+    // One loop body for every K-tile (first / second are wave-uniform run-time flags: peeling the first K-tile into a copy of its own let
+    // the compiler fold the cleared accumulators into C = 0 MFMAs with fresh destinations, and the allocator spilled).
+    long long m0p = 0, n0p = 0;   // the previous item's tile
     int it = 0;
     for (;; ++it) {
         const long long m0 = (long long)mt_c * PBM, n0 = (long long)nt_c * PBN;
         VF9_STAMP(0)
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nk_c; ++kt) {
             if (kt == 1) { VF9_STAMP(1) }
             if (kt == 2) { VF9_STAMP(2) }
             const char* base = smem + ((ktg + kt) & 1) * (4 * PSLOT);
             const bool first = kt == 0 && it > 0, second = kt == 1 && it > 0;
-            // Counted waits (vmcnt is in order and counts the epilogue's stores).  Queue around a tile boundary, oldest first:
-            // X(nk-1): 2 DMAs | Y(nk-1): 6 DMAs | X(0): 2 DMAs, 8 stores | Y(0): 6 DMAs, 8 stores | X(1): 2 DMAs | Y(1): 6 DMAs ...
-            //   X(0) needs the DMAs of X(nk-1): as ever (6);   Y(0) those of Y(nk-1) -> 2 + 8 may fly;   X(1) those of X(0) -> 8 + 6 + 8;
+            // Counted waits (vmcnt is in order and counts the epilogue's stores).  Queue around an item boundary, oldest first:
+            // X(last): 2 DMAs | Y(last): 6 DMAs | X(0): 2 DMAs, 8 stores | Y(0): 6 DMAs, 8 stores | X(1): 2 DMAs | Y(1): 6 DMAs ...
+            //   X(0) needs the DMAs of X(last): as ever (6);   Y(0) those of Y(last) -> 2 + 8 may fly;   X(1) those of X(0) -> 8 + 6 + 8;
             //   Y(1) those of Y(0) -> 8 + 2 (the first eight stores are older: three phases old);   X(2): as ever (the second eight: three phases).
             // (the residual form stores BEFORE it stages -- X(0): 8 stores, 2 DMAs | Y(0): 8 stores, 6 DMAs -- so X(1) may leave 8 + 6 in
             // flight and Y(1) is as ever)
@@ -1628,7 +1558,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
                 if (first) { VF9_EPI_LOAD_R(0, m0p, n0p) VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            VF9_STAGE(3, 0)
+            VF9_STAGE(3)
             if (kt == 0 && wid == 0 && bias) dma16u((unsigned long long)(bias + n0), (unsigned)lane * 16u, lds_smem + (unsigned)PLDS + (unsigned)(it & 1) * 1024u);
             if constexpr (EPI != EPI_BIAS_RESIDUAL) {
                 if (first) { VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }   // (before the fragment reads: their 64 registers are dead here)
@@ -1638,7 +1568,8 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
             VF9_READ_B(B1f, base + 2 * PSLOT)
             VF9_READ_A(base + 0 * PSLOT)
             VF9_MID()
-            VF9_BLOCK(0, B0f, 0, B1f, 1, 0, 0, 1, m0p, n0p, 0)
+            VF9_QUAD(0, 0, B0f)
+            VF9_QUAD(0, 1, B1f)
             VF9_TAIL()
             if (first || (second && EPI != EPI_BIAS_RESIDUAL)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1647,35 +1578,32 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
                 if (first) { VF9_EPI_LOAD_R(1, m0p, n0p) VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            VF9_STAGE(0, 0)
-            VF9_STAGE(1, 0)
-            VF9_STAGE(2, 0)
+            VF9_STAGE(0)
+            VF9_STAGE(1)
+            VF9_STAGE(2)
             if constexpr (EPI != EPI_BIAS_RESIDUAL) {
                 if (first) { VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }   // (the A fragments are dead here)
             }
             __builtin_amdgcn_sched_barrier(0);
             VF9_READ_A(base + 3 * PSLOT)
             VF9_MID()
-            VF9_BLOCK(1, B1f, 1, B0f, 0, 0, 0, 0, m0, n0, 0)
+            VF9_QUAD(1, 1, B1f)
+            VF9_QUAD(1, 0, B0f)
             VF9_TAIL()
         }
-        ktg += nk;
+        ktg += nk_c;
         VF9_STAMP(3)
         m0p = m0; n0p = n0;
-        if (!has_next) break;
-        orig += gridDim.x;
-        q_tile_of(orig, Mt, Nt, mt_c, nt_c);
-        has_next = orig + (int)gridDim.x < ntiles;
+        if (it + 1 >= n_items) break;
+        item(it + 1, mt_c, nt_c, klo_c, nk_c);
     }
-    // the last tile's epilogue
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+    // the last item's epilogue
     VF9_EPI_LOAD_R(0, m0p, n0p)
     VF9_EPI_HALF(0, m0p, n0p, it & 1)
-    // the last tile's second half
     VF9_EPI_LOAD_R(1, m0p, n0p)
     VF9_EPI_HALF(1, m0p, n0p, it & 1)
     VF9_STAMP(4)
-#undef VF9_BLOCK
-#undef VF9_STEP
 #undef VF9_EPI_HALF
 #undef VF9_EPI_LOAD_R
 #undef VF9_STAMP
@@ -1686,7 +1614,6 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
 #undef VF9_MID
 #undef VF9_TAIL
 #undef VF9_STAGE
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
     if (dbg && wid == 0) {                           // every store acknowledged: the workgroup's end; then the stamps leave LDS
         if (lane == 0) stamps[(k9StampTiles - 1) * k9Stamps + 5] = __builtin_amdgcn_s_memrealtime();
@@ -3095,29 +3022,24 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
     // 128 x 256 DMA kernel at M = 51200: 225 / 79 / 265 / 246 us vs 278 / 79 / 296 / 295 us (QKV / out / FFN-up / FFN-down
     // shapes of a 768-wide encoder; the vendor library: 210 / 66 / 234 / 217)
     const long long p8_min = p8_min_wgs();
-    // The PERSISTENT 8-phase form (k_gemm8q_tn, VF_GEMM_KIND=8) is an experiment, not the default.  Back to back on the same
-    // operands it wins everywhere (209 / 71 / 247 / 237 us on the four shapes, 1.02 - 1.11 x the vendor library; GELU / residual
-    // epilogues 331 / 79 + 247 vs 366 / 86 + 254 us: profiles/r02b_gemm_persistent.log), but INSIDE the forward, where the
-    // operands were written by the previous kernel and the first loads of a tile hit L2, the one-tile-per-workgroup form
-    // already runs at 328 / 161 / 187 us per layer and the persistent one at 328 / 162 / 184 (XLM-R-large shape: 498 / 258 / 289
-    // vs 508 / 270 / 291): what it hides -- load latency at the tile seams -- is not what the forward waits for, and its
-    // static tile schedule gives up the dispatcher's balancing.  The epilogue still runs on the waves that own the MFMAs.
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_RESIDUAL) {
         // round 4: the persistent two-phase kernel with the register-direct epilogue (k_gemm9_tn)
-        // Default for K < 4096 (VF_GEMM_9=0 switches it off).  In the 100-pair forward, per layer (profiles/r04_rerank_layer_8p_vs_gemm9.txt):
-        // 768 wide: QKV 167 vs 188 us, out projection 82 vs 87, FFN-up + GELU 235 vs 271, FFN-down (K = 3072) 231 vs 235; 1024 wide: 277 vs
-        // 281, 129 vs 127, 408 vs 408 -- and FFN-down (K = 4096, 800 tiles = 3.1 rounds) 391 vs 360: there the 8-phase kernel's split-K
-        // tail is worth more than the persistent pipeline, so long-K products stay with it.
+        // Default (VF_GEMM_9=0 switches it off) wherever the partial last round does not matter: K < 2048, or whole rounds.  In the 100-pair
+        // forward, per layer (profiles/r04_rerank_layer_8p_vs_gemm9.txt): 768 wide: QKV 167 vs 188 us, out projection 82 vs 87, FFN-up + GELU
+        // 235 vs 271; 1024 wide: 277 vs 281, 129 vs 127, 408 vs 408.  Long-K products with a remainder (FFN-down: K = 3072 / 4096, 600 / 800
+        // tiles) keep the 8-phase kernel, whose split-K tail is worth more there than the persistent pipeline (391 vs 360 us at K = 4096).
         static const int p9 = getenv("VF_GEMM_9") ? atoi(getenv("VF_GEMM_9")) : 1;
-        static const int p9_kmax = getenv("VF_GEMM_9_KMAX") ? atoi(getenv("VF_GEMM_9_KMAX")) : 4096;
         const int p9_now = g_gemm9.load(std::memory_order_relaxed) >= 0 ? g_gemm9.load(std::memory_order_relaxed) : p9;
-        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && K < p9_kmax && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
-            const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
-            // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
-            static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
-            const int ticks = tiles > ncu ? (int)((150ll * (K / PBK) + 200) * stg / 100) : 0;
-            hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, ticks, g_gemm9_dbg.load(std::memory_order_relaxed));
-            return hipGetLastError();
+        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+            const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7, nkt = K / PBK;
+            const int G = tiles < ncu ? tiles : ncu;
+            if (kind == 10 || K < 2048 || tiles % G == 0) {
+                // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
+                static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
+                const int ticks = tiles > ncu ? (int)((150ll * nkt + 200) * stg / 100) : 0;
+                hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(G), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, ticks, g_gemm9_dbg.load(std::memory_order_relaxed));
+                return hipGetLastError();
+            }
         }
     }
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
