@@ -1124,6 +1124,39 @@ def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
     assert st["exact_reruns"] <= max(1, nq // 16), st
 
 
+@pytest.mark.parametrize("n,d,nq,k", [
+    (90_001, 1024, 700, 10),       # three query tiles, ragged row count
+    (50_000, 768, 1024, 100),      # four tiles (one workgroup per CU), dp = 768: 12 K-tiles
+    (70_000, 1024, 256, 1000),     # large k
+    (300_000, 1024, 1500, 100),    # two passes (1024 + 476), several super-tiles per row group
+    (40_000, 256, 200, 5),         # 113 main rows per row group: less than one super-tile (clamped rows, NaN inverse norms)
+])
+def test_wide_scan_fp8_matrix_instruction_bit_exact(vf, oracle, n, d, nq, k):
+    """k_scan_wide8 (index option wide_mfma = 1): the e4m3 row bytes as the A operand of v_mfma_scale_f32_32x32x64_f8f6f4, the
+    query as hi + lo e4m3 codes, each query's own quantisation residual as its certificate bound.  Same ids and score bits as
+    the oracle, and as the fp16-instruction form on the same handle; repairs stay rare."""
+    from oracle import ref_numpy as R
+    q = np.random.default_rng(72).standard_normal((nq, d)).astype(np.float32)
+    codes = _e4m3_codes(n, d, 71)
+    rows16 = R.decode_e4m3(codes).astype(np.float16)
+    with vf.DenseIndex.from_e4m3(codes) as ix:
+        ix.set_option("wide_mfma", 1)
+        got_i, got_s = ix.search(q, k)
+        st = ix.stats()
+        ix.set_option("wide_mfma", 0)
+        f16_i, f16_s = ix.search(q, k)
+        st16 = ix.stats()
+    print("wide8 stats", (n, d, nq, k), st)
+    assert st["path"] == 1 and st["scan_kernel"] == 4 and st16["scan_kernel"] == 3 and st["overflowed"] == 0
+    assert st["wide_launches"] == (nq + 1023) // 1024 and st["wide_queries"] == nq
+    want_i, want_s = oracle.search(rows16, q, k)
+    bad = np.nonzero((got_i != want_i).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {nq} queries differ, first {bad[:5].tolist()}"
+    assert np.array_equal(_bits(got_s), _bits(want_s))
+    assert np.array_equal(f16_i, got_i) and np.array_equal(_bits(f16_s), _bits(got_s))
+    assert st["exact_reruns"] <= max(1, nq // 16), st
+
+
 def test_wide_scan_hostile_data(vf, oracle):
     """Duplicates and a score-sorted corpus under 200 queries: stage flushes, overflow to the global lists, repairs."""
     rng = np.random.default_rng(63)

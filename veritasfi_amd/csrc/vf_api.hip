@@ -92,6 +92,7 @@ struct Slot {
     int scan_kernel = 0;                       // main-scan kernel of the pending search: 1 k_scan, 2 k_scan2, 3 k_scan_wide
     DevBuf qn, qimg, s0, cnt, tau, hist, hist_coarse, cand, flags, counts;   // fused-path state
     DevBuf dbg, wgbase, tilecnt, sib;
+    DevBuf qimg8, epsq;                  // k_scan_wide8: hi / lo e4m3 query image, per-query certificate bounds
     int64_t wgbase_n = -1; int wgbase_grid = -1;
     DevBuf dense_s, cn_tmp, parts_ids, parts_sc, run_ids, run_sc, qsel; // exact-path scratch
     int* h_flags = nullptr;      // pinned, [max batches * 64]
@@ -141,7 +142,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1,
+            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = 0,
             aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
@@ -550,6 +551,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
     else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
+    else if (s == "wide_mfma") { if (!in_range(0, 1)) return fail(VF_EINVAL, "wide_mfma must be 0 (fp16 matrix instruction on converted rows) or 1 (the fp8 instruction on the e4m3 row bytes: k_scan_wide8)"); ix->wide_mfma = value; }
     else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
     else if (s == "aux_cus") {   // takes effect for slots created afterwards (set it before the first search)
         if (!in_range(-1, 128)) return fail(VF_EINVAL, "aux_cus must be -1 (auto) or in [0, 128]");
@@ -698,6 +700,15 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     const int RG = std::max(1, ix->n_cu / J);
     FusedPlan p = p0;
     if (p.kprime > 256) p.cap = 16384;   // k ~ 1000: ~k' (1 + ln(n / sample)) candidates per query
+    // k_scan_wide8 (the fp8 matrix instruction): e4m3 rows, K-tiles of 64, a row group's bytes within a 32-bit lane offset
+    const bool w8 = ix->wide_mfma == 1 && ix->dtype == VF_DTYPE_FP8_E4M3 && ix->dp % 64 == 0 &&
+                    (ix->n / RG + 2 * 256) * (int64_t)ix->dp < (int64_t)0xFFFFFFFFll;
+    if (w8) {
+        // the query's hi + lo split is good to ~2^-9 of the query's norm instead of fp16's 2^-11: the certificate needs the k-th score to
+        // clear the best row not re-scored by that much more, i.e. a deeper k' (and longer candidate lists)
+        if (ix->margin < 0) p.kprime = std::min((k + std::max(48, k / 2) + 31) / 32 * 32, 4096);
+        if (p.kprime > 256) p.cap = 32768;
+    }
     const int samp = J >= 2 ? 64 : 32;   // sample rows per row group = samp * 8: 32768 / 65536 rows in all
     const size_t slen = (size_t)RG * samp * 8;
     VF_TRY(s.qimg.ensure((size_t)ix->dp * qtot * 2));
@@ -716,6 +727,11 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
         s.wgbase_n = ix->n; s.wgbase_grid = -RG;
     }
     VF_HIP(launch_prep_queries(d_queries, nb, ix->d, ix->dp, qtot, qn_b, s.qimg.as<_Float16>(), st));
+    if (w8) {
+        VF_TRY(s.qimg8.ensure((size_t)ix->dp * qtot * 2));
+        VF_TRY(s.epsq.ensure((size_t)qtot * sizeof(float)));
+        VF_HIP(launch_prep_wide8(qn_b, nb, ix->d, ix->dp, qtot, (unsigned char*)s.qimg8.p, s.epsq.as<float>(), st));
+    }
     const bool f8 = ix->dtype == VF_DTYPE_FP8_E4M3;
     ScanArgs a{};
     a.rows = (const char*)ix->rows_scan; a.inv_scan = ix->inv_scan; a.qimg = s.qimg.as<_Float16>();
@@ -739,7 +755,12 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
         a.sib = s.sib.as<u32>(); a.sib_slack = (int)ix->wide_sync;
     }
     if (timed) VF_HIP(hipEventRecord(s.ev_t[0], st));
-    VF_HIP(launch_scan_wide(a, kModeMain, f8, st));
+    if (w8) {
+        ScanArgs a8 = a;
+        a8.qimg = (const _Float16*)s.qimg8.p;
+        VF_HIP(launch_scan_wide8(a8, st));
+    } else
+        VF_HIP(launch_scan_wide(a, kModeMain, f8, st));
     VF_HIP(hipEventRecord(s.ev_scan, st));
     if (timed) {
         VF_HIP(hipEventRecord(s.ev_t[1], st));
@@ -750,11 +771,13 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.tau_bin = a.tau_bin; f.rows_orig = ix->rows_orig;
     f.orig_dtype = ix->dtype; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
     f.d = ix->d; f.k = k; f.kprime = p.kprime; f.eps = p.eps; f.n_rows = ix->n; f.id_offset = ix->id_offset;
+    f.eps_q = w8 ? s.epsq.as<float>() : nullptr;   // (the sample pass scored with fp16 queries: its bound is the smaller one)
     f.out_ids = (long long*)d_ids; f.out_scores = d_scores;
     f.flags = s.d_flags + flag_off; f.cand_count_out = s.d_counts + flag_off;
     f.dbg = nullptr;
     if (ix->debug & 256) { VF_TRY(s.dbg.ensure((size_t)qtot * 8 * sizeof(u64))); f.dbg = s.dbg.as<u64>(); }
     VF_HIP(launch_final(f, nb, st));
+    s.scan_kernel = w8 ? 4 : 3;
     return VF_OK;
 }
 
@@ -798,7 +821,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             const int nb = std::min(kWideMaxQueries, nq - b0);
             VF_TRY(wide_pass(ix, s, p, d_queries + (size_t)b0 * ix->d, nb, k, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k,
                              b0, s.qn.as<float>() + (size_t)b0 * ix->d, s.timed && b0 == 0, st, slot_id));
-            ++s.wide_launches; s.wide_queries += nb; s.scan_kernel = 3;
+            ++s.wide_launches; s.wide_queries += nb;
         }
         if (s.timed) VF_HIP(hipEventRecord(s.ev_t[3], st));
         VF_HIP(hipEventRecord(s.ev_done, st));

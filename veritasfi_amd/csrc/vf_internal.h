@@ -81,6 +81,7 @@ struct FinalArgs {
     const float* norm;       // canonical norms [n]
     const float* qn;         // canonical normalised queries [nq][d] fp32
     int d; int k; int kprime; float eps;
+    const float* eps_q;      // optional [nq] per-query certificate bound (k_scan_wide8: the query's own quantisation residual); null = eps
     long long n_rows;        // rows in the shard (certificate is moot when all were re-scored)
     long long id_offset;
     long long* out_ids; float* out_scores;   // [nq][k]
@@ -114,6 +115,9 @@ size_t scan2_lds_bytes(int dp, int qn_tile, int stage_cap);
 int scan2_stage_cap(int dp, int qn_tile, int rows_are_fp8);
 hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s);
 size_t scan_wide_lds_bytes(int stage_cap);
+// k_scan_wide8: the wide main scan on the fp8 matrix instruction (e4m3 rows; a.qimg = the hi / lo code image of launch_prep_wide8)
+hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, unsigned char* img8, float* eps_q, hipStream_t s);
+hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s);
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
 hipError_t launch_final(FinalArgs a, int nq, hipStream_t s);
 hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,

@@ -1600,9 +1600,10 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
 // epilogue of ONE 32-row tile (rows t0 .. t0+31) against the 256 queries
 constexpr int kWideLaneList = 12;   // passing scores a lane notes per round (of its 128 per 32-row tile); + 4 mask words = 64 B per lane
 
-template <int MODE>
-__device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[kWideNT], float inv_lane, long long t0,
-                                              long long hi, long long s0_slot, int jt, int lane, char* ctl, uint2* lane_list, bool sync_tau) {
+template <int MODE, int NT = kWideNT>
+__device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[NT], float inv_lane, long long t0,
+                                              long long hi, long long s0_slot, int jt, int lane, char* ctl, uint2* lane_list, bool sync_tau,
+                                              int q0 = 0 /* first query (of the workgroup's 256) of this wave's NT tiles */) {
     const int r31 = lane & 31, h = lane >> 5;
     auto inv_of = [&](int reg) {
         const int r0 = (reg & 3) + 8 * (reg >> 2);
@@ -1614,8 +1615,8 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     if (MODE == kModeSample) {
         const long long s0_stride = (long long)a.rgroups * a.samp * kSampWaves;
 #pragma unroll
-        for (int nt = 0; nt < kWideNT; ++nt) {
-            const int q = qg0 + nt * kQueryTile + r31;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int q = qg0 + q0 + nt * kQueryTile + r31;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -1627,9 +1628,9 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     int* tau_lds = (int*)(ctl + 16);
     if (sync_tau) {   // one wave per super-tile folds the global thresholds into the workgroup's copy
 #pragma unroll
-        for (int nt = 0; nt < kWideNT; ++nt) {
-            const int tg = __hip_atomic_load(a.tau_bin + qg0 + nt * kQueryTile + r31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane < 32) atomicMax(tau_lds + nt * kQueryTile + lane, tg);
+        for (int nt = 0; nt < NT; ++nt) {
+            const int tg = __hip_atomic_load(a.tau_bin + qg0 + q0 + nt * kQueryTile + r31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 32) atomicMax(tau_lds + q0 + nt * kQueryTile + lane, tg);
         }
     }
     u32* stage_cnt = (u32*)ctl;
@@ -1644,10 +1645,10 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     u32* lane_mk = (u32*)(lane_sc + kWideLaneList);           // [4] which of the 128 scores passed (bit 16 (nt & 1) + reg of word nt >> 1)
     // the thresholds are read ONCE per tile: other waves raise them concurrently, and every round must see the same
     // set of passing scores (a score's ordinal in that set is what ties the rounds together)
-    float tb[kWideNT];
+    float tb[NT];
 #pragma unroll
-    for (int nt = 0; nt < kWideNT; ++nt) {
-        const int ql = nt * kQueryTile + r31;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ql = q0 + nt * kQueryTile + r31;
         const int t = tau_lds[ql];
         tb[nt] = (qg0 + ql) < a.nq ? (t <= 0 ? -INFINITY : (float)t) : INFINITY;
 #if defined(VF_WIDE_NOCAND)
@@ -1661,7 +1662,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         u32 cnt = 0u;
         u32 mk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int nt = 0; nt < kWideNT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const float sc = acc[nt][reg] * inv_of(reg);   // rows past the end carry a NaN inverse norm: never pass
@@ -1709,7 +1710,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
             if (take) {
                 const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
                 const float sc = lane_sc[idx - 1u - done];
-                const int ql = (2 * wq + (bpos >> 4)) * kQueryTile + r31, reg = bpos & 15;
+                const int ql = q0 + (2 * wq + (bpos >> 4)) * kQueryTile + r31, reg = bpos & 15;
                 const u32 row = (u32)(t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
                 const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
                 if (slot < (u32)a.stage_cap) {
@@ -1953,6 +1954,227 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
 #undef VF_CHUNK
 #undef VF_WRITE_B
 #undef VF_ISSUE_B
+}
+
+size_t scan_wide_lds_bytes(int stage_cap);
+// ------------------------------------------------------------------------------------------------
+// k_scan_wide8: the wide scan on the instruction BASELINE configs[4] names -- v_mfma_scale_f32_32x32x64_f8f6f4 -- for e4m3 rows.
+//
+// The row bytes ARE the A operand (no conversion); the query is split q = hi * 2^-8 + lo * 2^-12 + delta with hi, lo e4m3 codes
+// (k_prep_wide8), the two powers of two ride in the instruction's block-scale operand, and ||delta||_2 -- known exactly per query --
+// is that query's certificate bound (FinalArgs::eps_q) instead of the fp16 path's 2^-11.  Two MFMAs of 64 k per (row tile, query
+// tile, K-tile): the matrix time of the fp16 form, without its 32 conversions per chunk and with a quarter of its instructions.
+//
+// What round 4 learned on the transformer products (k_gemm9_tn) shapes the rest: BOTH operands reach LDS by DMA
+// (global_load_lds_dwordx4, no register hop, hand-counted waits, no vector-memory instruction the compiler knows about in the loop);
+// a wave owns 64 rows x 128 queries (2 x 4 accumulator tiles, 128 registers), so that a fragment read feeds two or four MFMAs:
+// 320 B of LDS reads per lane and K-tile against the old form's 512; a K-tile (64 elements) is 16 KB of rows + 2 x 16 KB of query
+// codes, two stages of 48 KB: the same 96 KB k_scan_wide spends on its three query buffers, so control block, candidate stage and
+// lane lists sit where they sat and the epilogue / flush / sibling pacing are k_scan_wide's own code.
+//   LDS slot (16 B) of (row r, piece p of its 64 bytes) = 4 r + (p ^ ((r >> 2) & 3)): a ds_read_b128 phase (16 rows, one piece)
+//   covers the 16 bank groups; DMA instruction I (1 KB) fills rows 16 I .. 16 I + 15, lane l fetching the piece its slot holds.
+//   The query image is laid out in exactly this form per (query tile, K-tile) by k_prep_wide8, so its DMA is a linear copy.
+// One barrier per K-tile: [my DMAs of tile t have landed] barrier [issue tile t + 1 into the other stage] 20 fragment reads, 16 MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef int i8v __attribute__((ext_vector_type(8)));
+constexpr int kW8Stage = 48 * 1024, kW8Threads = 512, kW8NT = 4;
+
+__device__ __forceinline__ void dma16s(unsigned long long ua, unsigned voff, unsigned lds_base) {   // scalar base + 32-bit lane offset
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ua), "s"(lds_base) : "memory");
+}
+
+// hi / lo e4m3 image of the normalised queries + each query's certificate bound.
+//   img8[((jt * NK + kt) * 2 + part) * 16384 + (4 ql + ((b >> 4) ^ ((ql >> 2) & 3))) * 16 + (b & 15)]   (part 0 = hi, 1 = lo;
+//   ql = query in its 256-tile jt, b = byte of K-tile kt): the LDS form of k_scan_wide8, copied verbatim.
+// The encode is the hardware's (v_cvt_pk_fp8_f32); delta is computed from the DECODED codes, so the bound holds whatever the
+// rounding did: |approx - q . c| <= ||delta||_2 for a unit row c (Cauchy-Schwarz).
+__global__ __launch_bounds__(256) void k_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, unsigned char* img8, float* eps_q) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int jt = slot >> 8, ql = slot & 255, NK = dp >> 6;
+    __shared__ float red[256];
+    float ss = 0.0f;
+    for (int j = tid; j < dp; j += 256) {
+        const float v = (slot < nq && j < d) ? qn[(long long)slot * d + j] : 0.0f;
+        const int hc = __builtin_amdgcn_cvt_pk_fp8_f32(v * 256.0f, 0.0f, 0, false) & 0xFF;
+        const float hv = __builtin_amdgcn_cvt_f32_fp8(hc, 0) * (1.0f / 256.0f);
+        const float r = v - hv;
+        const int lc = __builtin_amdgcn_cvt_pk_fp8_f32(r * 4096.0f, 0.0f, 0, false) & 0xFF;
+        const float lv = __builtin_amdgcn_cvt_f32_fp8(lc, 0) * (1.0f / 4096.0f);
+        const float dl = r - lv;
+        ss = __builtin_fmaf(dl, dl, ss);
+        const int kt = j >> 6, b = j & 63;
+        const long long base = ((long long)(jt * NK + kt) * 2) * 16384 + (4 * ql + ((b >> 4) ^ ((ql >> 2) & 3))) * 16 + (b & 15);
+        img8[base] = (unsigned char)hc;
+        img8[base + 16384] = (unsigned char)lc;
+    }
+    red[tid] = ss;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    // + the accumulation of 2 x dp products in the matrix unit and the canonical dot product's own rounding (generous: 8 d ulps of
+    // a unit-scale sum), + the subnormal floor of the codes (covered by delta itself), + slack for this sum's own rounding
+    if (tid == 0) eps_q[slot] = sqrtf(red[0]) * 1.002f + 8.0f * (float)dp * 5.9604645e-8f + 1e-6f;
+}
+
+hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, unsigned char* img8, float* eps_q, hipStream_t s) {
+    hipLaunchKernelGGL(k_prep_wide8, dim3(qtot), dim3(256), 0, s, qn, nq, d, dp, qtot, img8, eps_q);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;               // rows 64 wr .. + 63 of a super-tile, queries 128 wc .. + 127 of the tile
+    const int J = a.jtiles;
+    const int jt = ((int)blockIdx.x >> 3) % J;
+    const int rg = ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * J));
+    if (rg >= a.rgroups) return;
+    const long long Ra = a.n * rg / a.rgroups, Rb = a.n * (rg + 1) / a.rgroups;
+    const long long swg = (long long)a.samp * kSampWaves;
+    const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
+    const int nst = (int)((hi - lo + kWideRows - 1) / kWideRows);
+    const int NK = a.dp >> 6;
+    char* ctl = smem + 2 * kW8Stage;
+    {
+        uint4* z = (uint4*)ctl;
+        const int nz = kWideCtl / 16 + a.stage_cap;
+        for (int i = tid; i < nz; i += kW8Threads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (tid < kWideQ) ((int*)(ctl + 16))[tid] = a.tau_bin[jt * kWideQ + tid];
+    if (nst == 0) return;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
+    // ---- DMA duties of this wave per K-tile: rows 32 wid .. + 31 (two instructions), hi and lo codes of queries 32 wid .. + 31
+    int arow[2];
+    unsigned apiece[2], voffA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = 32 * wid + 16 * i + (lane >> 2);
+        apiece[i] = (unsigned)(((lane & 3) ^ ((arow[i] >> 2) & 3)) << 4);
+    }
+    const unsigned long long rows_base = (unsigned long long)(a.rows + lo * a.row_bytes);
+    const unsigned long long bimg = (unsigned long long)a.qimg + (unsigned long long)jt * NK * 32768ull;
+    const unsigned voffB = (unsigned)(2 * wid) * 1024u + (unsigned)lane * 16u;
+    const long long span = hi - lo;
+    auto set_rows = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long long r = (long long)st * kWideRows + arow[i];
+            r = r < span - 1 ? r : span - 1;                       // rows past the part's end re-read its last row (NaN inverse norm below)
+            voffA[i] = (unsigned)(r * a.row_bytes) + apiece[i];
+        }
+    };
+    auto issue = [&](int kt, int stage) {
+        const unsigned sb = lds0 + (unsigned)stage * kW8Stage + (unsigned)(2 * wid) * 1024u;
+        const unsigned long long ua = rows_base + (unsigned long long)kt * 64ull;
+        const unsigned long long ub = bimg + (unsigned long long)kt * 32768ull;
+        dma16s(ua, voffA[0], sb);
+        dma16s(ua, voffA[1], sb + 1024u);
+        dma16s(ub, voffB, sb + 16384u);
+        dma16s(ub + 1024ull, voffB, sb + 16384u + 1024u);
+        dma16s(ub + 16384ull, voffB, sb + 32768u);
+        dma16s(ub + 16384ull + 1024ull, voffB, sb + 32768u + 1024u);
+    };
+    // ---- fragment addresses of this lane (relative to a stage): row tiles m = 0, 1; query tiles nt = 0 .. 3; pieces 2 h, 2 h + 1
+    unsigned fa[2][2], fb[kW8NT][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = wr * 64 + m * 32 + r31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fa[m][j] = (unsigned)((4 * row + ((2 * h + j) ^ ((row >> 2) & 3))) << 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < kW8NT; ++nt) {
+        const int ql = wc * 128 + nt * 32 + r31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[nt][j] = 16384u + (unsigned)((4 * ql + ((2 * h + j) ^ ((ql >> 2) & 3))) << 4);
+    }
+    f16v acc[2][kW8NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nt = 0; nt < kW8NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+    bool sib_on = J > 1;
+    set_rows(0);
+    issue(0, 0);
+    int stage = 0;
+    float inv_lane[2] = {0.0f, 0.0f};
+    for (int st = 0; st < nst; ++st) {
+        const long long t0 = lo + (long long)st * kWideRows + wr * 64;
+        for (int kt = 0; kt < NK; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile (st, kt) have landed
+            __syncthreads();                                     // ... everyone's; and every wave is done reading the other stage
+            if (kt + 1 < NK) issue(kt + 1, stage ^ 1);
+            else if (st + 1 < nst) { set_rows(st + 1); issue(0, stage ^ 1); }
+            const char* sp = smem + stage * kW8Stage;
+            i8v af[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const uint4 x0 = *(const uint4*)(sp + fa[m][0]), x1 = *(const uint4*)(sp + fa[m][1]);
+                af[m] = i8v{(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+            }
+#pragma unroll
+            for (int nt = 0; nt < kW8NT; ++nt) {
+                const uint4 h0 = *(const uint4*)(sp + fb[nt][0]), h1 = *(const uint4*)(sp + fb[nt][1]);
+                const uint4 l0 = *(const uint4*)(sp + 16384 + fb[nt][0]), l1 = *(const uint4*)(sp + 16384 + fb[nt][1]);
+                const i8v bh = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
+                const i8v bl = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+                // (scale operands: E8M0 bytes, 2^(x - 127): rows as they are, hi codes x 2^-8, lo codes x 2^-12)
+                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bh, acc[0][nt], 0, 0, 0, 127, 0, 119);
+                acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bh, acc[1][nt], 0, 0, 0, 127, 0, 119);
+                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bl, acc[0][nt], 0, 0, 0, 127, 0, 115);
+                acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bl, acc[1][nt], 0, 0, 0, 127, 0, 115);
+            }
+            stage ^= 1;
+        }
+        // 1 / norm of this lane's rows; rows past the part's end get NaN: their scores compare false
+#pragma unroll
+        for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
+        int lane_e = lane, jt_e = jt;
+        char* ctl_e = ctl;
+        asm volatile("" : "+v"(lane_e), "+s"(jt_e));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            wide_epilogue<kModeMain, kW8NT>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
+                                            (uint2*)(ctl_e + kWideCtl + (size_t)a.stage_cap * 16 + (size_t)tid * ((kWideLaneList + 4) * 4)),
+                                            m == 0 && (st & 3) == wr, wc * 128);
+#pragma unroll
+            for (int nt = 0; nt < kW8NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+        }
+        if (a.sib && tid == 0 && sib_on) {   // sibling pacing: k_scan_wide's (a speed hint, bounded)
+            u32* pr = a.sib + rg * 4;
+            __hip_atomic_store(pr + jt, (u32)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 need = (u32)(st + 1) > (u32)a.sib_slack ? (u32)(st + 1) - (u32)a.sib_slack : 0u;
+            int spins = 0;
+            for (;;) {
+                u32 mn = 0xffffffffu;
+                for (int j = 0; j < J; ++j) {
+                    const u32 v = __hip_atomic_load(pr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mn = v < mn ? v : mn;
+                }
+                if (mn >= need) break;
+                if (++spins > 512) { sib_on = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        if (*(const u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wide_flush(a, ctl, jt, tid);
+}
+
+hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s) {
+    const int grid = 8 * a.jtiles * ((a.rgroups + 7) / 8);
+    hipLaunchKernelGGL(k_scan_wide8, dim3(grid), dim3(kW8Threads), scan_wide_lds_bytes(a.stage_cap), s, a);
+    return hipGetLastError();
 }
 
 size_t scan_wide_lds_bytes(int stage_cap) {
@@ -2433,7 +2655,7 @@ __global__ __launch_bounds__(kFinalThreads) void k_final(FinalArgs a) {
             if (a.k > m) flag = 1;
             else if (flag == 0) {
                 const float ck_k = unorderkey((u32)(ranked[a.k - 1] >> 32));
-                if (!(ck_k > approx_floor + a.eps)) flag = 1;
+                if (!(ck_k > approx_floor + (a.eps_q ? fmaxf(a.eps_q[q], a.eps) : a.eps))) flag = 1;
             }
         }
         // flags / counts live in host-mapped pinned memory: no device-to-host copy kernel needed
@@ -2478,6 +2700,7 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan_wide8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
