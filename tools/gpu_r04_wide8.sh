@@ -4,9 +4,10 @@ set -o pipefail
 mkdir -p gpurun_out
 L=gpurun_out/r04_wide8.log
 : > $L
-timeout -k 10 300 python -m pytest tests/test_gpu_retrieval.py -m gpu -q -p no:cacheprovider -x -k "fp8_matrix_instruction" >> $L 2>&1; rc=$?
+timeout -k 10 400 python -m pytest tests/test_gpu_retrieval.py -m gpu -q -p no:cacheprovider -x -k "fp8_matrix_instruction or wide_scan" >> $L 2>&1; rc=$?
 tail -3 $L
 [ $rc -ne 0 ] && tail -40 $L && exit $rc
+for rows in 1250000 10000000; do VF_LIB_PATH=$PWD/veritasfi_amd/lib/libvf_stamps.so timeout -k 10 300 python tools/stamps_wide8.py $rows 2>&1 | grep -v amdgpu.ids | tee -a $L; done
 for rows in 1250000 10000000; do
   C5="--rows $rows --dim 1024 --batch 1024 --k 1000 --corpus-dtype fp8 --no-cpu-baseline --no-rerank --steps 10 --warmup 2"
   for m in 0 1; do

@@ -758,6 +758,11 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     if (w8) {
         ScanArgs a8 = a;
         a8.qimg = (const _Float16*)s.qimg8.p;
+        if (ix->debug & 128) {   // per-wave phase times of k_scan_wide8 (vf_index_debug_read)
+            VF_TRY(s.dbg.ensure((size_t)8 * J * ((RG + 7) / 8) * 8 * 16 * sizeof(u64)));
+            VF_HIP(hipMemsetAsync(s.dbg.p, 0, s.dbg.bytes, st));
+            a8.dbg = s.dbg.as<u64>();
+        }
         VF_HIP(launch_scan_wide8(a8, st));
     } else
         VF_HIP(launch_scan_wide(a, kModeMain, f8, st));

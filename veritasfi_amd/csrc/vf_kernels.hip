@@ -1603,8 +1603,11 @@ constexpr int kWideLaneList = 12;   // passing scores a lane notes per round (of
 template <int MODE, int NT = kWideNT>
 __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[NT], float inv_lane, long long t0,
                                               long long hi, long long s0_slot, int jt, int lane, char* ctl, uint2* lane_list, bool sync_tau,
-                                              int q0 = 0 /* first query (of the workgroup's 256) of this wave's NT tiles */) {
+                                              int q0 = 0 /* first query (of the workgroup's 256) of this wave's NT tiles */,
+                                              unsigned long long* ph = nullptr /* debug: [4] ticks in thresholds + pass 1a, 1b, 2, publish */) {
     const int r31 = lane & 31, h = lane >> 5;
+    unsigned long long pc0 = ph ? wall_clock64() : 0ull;
+    auto ph_mark = [&](int i) { if (ph) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - pc0; pc0 = n_; } };
     auto inv_of = [&](int reg) {
         const int r0 = (reg & 3) + 8 * (reg >> 2);
         const float lo_half = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0));
@@ -1655,28 +1658,73 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         tb[nt] = INFINITY;   // timing experiments: the filter runs, nothing passes (results invalid)
 #endif
     }
+    // Pass 1a, branch-free over this lane's 16 NT scores: one bit per score -- did it pass? -- and nothing else.
+    // Round 4 measured the earlier form (a compare + s_and_saveexec + branch per score, the value noted inside): 5.9 us per
+    // 256-row super-tile and wave with NOTHING passing -- a dozen issue slots per score, mostly VALU -> SALU hazards
+    // (profiles/r04_wide8_phases.log).  Now two instructions per score:
+    //   e = acc * (-S / norm) + (tb - O - 2^-9)        one v_fma_f32  (bin_x(s) = S s + O, S a power of two)
+    //   mask = (mask << 1) | sign(e)                    one v_alignbit_b32
+    // e < 0  <=>  S acc / norm + O > tb - 2^-9: the scores the compare bin_x(acc / norm) >= tb passes, plus those within 2^-9 of a
+    // bin below the edge (the two roundings of the old form move x by < 2^-12 bins): a superset, which is all the certificate asks
+    // of the filter -- a candidate's bin is computed from its noted value as before.  Padded queries carry tb = +inf (e = +inf),
+    // rows past the end a NaN inverse norm (e = that NaN, sign clear): neither passes.  Bit (nt & 1) * 16 + reg of word nt >> 1, as
+    // pass 2 reads them: scores are taken in descending position order so that the first one shifted in ends up highest.
+    // (v_pk_fma_f32 on register pairs would halve the fma count, but hipcc 7.2 miscompiles the sign extraction of the pair's SECOND
+    //  element -- both shifts read element 0, also behind an opaque asm copy -- so the fma stays scalar: 2 instructions per score)
+    u32 mk[4] = {0u, 0u, 0u, 0u};
+    {
+        float ninv[16];   // -S / norm of the row behind accumulator register reg (two readlanes and a select each: once per call)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) ninv[reg] = inv_of(reg) * (-0.5f * kHistBins);
+#pragma unroll
+        for (int w = 0; w < NT / 2; ++w) {
+            u32 m = 0u;
+#pragma unroll
+            for (int hn = 1; hn >= 0; --hn) {
+                const float nc = tb[2 * w + hn] - 0.5f * kHistBins - 0.001953125f;
+#pragma unroll
+                for (int reg = 15; reg >= 0; --reg) {
+                    const float e = __builtin_fmaf(acc[2 * w + hn][reg], ninv[reg], nc);
+                    m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(u32, e), 31);
+                }
+            }
+            mk[w] = m;
+        }
+    }
+    const u32 cnt = (u32)(__popc(mk[0]) + __popc(mk[1]) + __popc(mk[2]) + __popc(mk[3]));
+    ph_mark(0);
+    if (__ballot(cnt != 0u) == 0ull) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) lane_mk[w] = mk[w];
+    u32 anyw[4] = {0u, 0u, 0u, 0u};   // which positions passed in ANY lane (scalar)
+#pragma unroll
+    for (int w = 0; w < NT / 2; ++w) anyw[w] = wave_or_u32(mk[w]);
     for (u32 done = 0u;; done += (u32)kWideLaneList) {
-        // Pass 1, straight-line over this lane's 128 scores: a passing score is NOTED -- its value in the lane's
-        // private LDS list, its position as a bit -- and nothing else happens here, so the 128 unrolled blocks stay
-        // three instructions each, need no per-block constants in registers and pin nothing across the MFMA loop.
-        u32 cnt = 0u;
-        u32 mk[4] = {0u, 0u, 0u, 0u};
+        // Pass 1b: the VALUES of this round's passing scores into the lane's private list, in position order.  A dynamic loop over
+        // the positions where SOME lane passed (the wave-wide OR of the masks, a scalar): the accumulator is picked by a jump on
+        // that scalar, so the cost follows the number of distinct positions, not the 16 NT of the tile.
+        {
+            u32 seen = 0u;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float sc = acc[nt][reg] * inv_of(reg);   // rows past the end carry a NaN inverse norm: never pass
-                if (bin_x(sc) >= tb[nt]) {
-                    const u32 o = cnt - done;
-                    if (o < (u32)kWideLaneList) lane_sc[o] = sc;
-                    mk[nt >> 1] |= 1u << ((nt & 1) * 16 + reg);
-                    ++cnt;
+            for (int nt = 0; nt < NT; ++nt) {   // (static tile, dynamic register: an indexed register read, no jump tree)
+                u32 bits = (u32)__builtin_amdgcn_readfirstlane((int)((anyw[nt >> 1] >> ((nt & 1) * 16)) & 0xFFFFu));
+                const u32 mine = mk[nt >> 1] >> ((nt & 1) * 16);
+                while (bits) {
+                    const int reg = __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    const float v = acc[nt][reg];
+                    const int r0 = (reg & 3) + 8 * (reg >> 2);
+                    const float iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0));
+                    const float iv4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0 + 4));
+                    if ((mine >> reg) & 1u) {
+                        const u32 o = seen - done;
+                        if (o < (u32)kWideLaneList) lane_sc[o] = v * (h ? iv4 : iv);
+                        ++seen;
+                    }
                 }
             }
         }
-        if (done == 0u && __ballot(cnt != 0u) == 0ull) return;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) lane_mk[w] = mk[w];
+        ph_mark(1);
         // Pass 2, ONE dynamic loop (the code exists once): every lane walks its set bits in the same order and the wave moves
         // in lockstep, "each lane's next noted score" per trip.  The wave claims the stage slots of ALL its noted scores of
         // this round with one LDS atomic and a trip hands them out by ballot rank (round 3: a per-candidate LDS atomic in a
@@ -1728,6 +1776,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         }
         if (__ballot(cnt > done + (u32)kWideLaneList) == 0ull) break;
     }
+    ph_mark(2);
     unsigned long long m = __ballot(need);
     while (m) {
         const int leader = __ffsll((long long)m) - 1;
@@ -1753,6 +1802,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
             }
         }
     }
+    ph_mark(3);
 }
 
 template <int MODE, int F8>
@@ -1977,6 +2027,10 @@ size_t scan_wide_lds_bytes(int stage_cap);
 // One barrier per K-tile: [my DMAs of tile t have landed] barrier [issue tile t + 1 into the other stage] 20 fragment reads, 16 MFMAs.
 // ------------------------------------------------------------------------------------------------
 typedef int i8v __attribute__((ext_vector_type(8)));
+#ifndef VF_W8_STAMPS
+#define VF_W8_STAMPS 0
+#endif
+constexpr bool kW8Stamps = VF_W8_STAMPS != 0;
 constexpr int kW8Stage = 48 * 1024, kW8Threads = 512, kW8NT = 4;
 
 __device__ __forceinline__ void dma16s(unsigned long long ua, unsigned voff, unsigned lds_base) {   // scalar base + 32-bit lane offset
@@ -2100,17 +2154,40 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
     bool sib_on = J > 1;
+    // debug bit 7: per wave [0] kernel time, [1] time waiting for its own DMAs at the K-tile boundary, [2] time in the K-tile barrier,
+    // [3] time in the epilogues (filter, candidates, sibling pacing, flush) -- ticks of the 100 MHz counter
+    // (compiled in by -DVF_W8_STAMPS=1 only -- tools/build_variant.sh stamps "-DVF_W8_STAMPS=1": the ten 64-bit counters cost the
+    //  shipped kernel 20 registers it does not have)
+    unsigned long long* dbg = (kW8Stamps && (a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * 8 + wid) * 16 : nullptr;
+    unsigned long long t_wait = 0, t_bar = 0, t_epi = 0, t_inv = 0, t_flt = 0, t_ph[4] = {0, 0, 0, 0};
+    const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
     set_rows(0);
     issue(0, 0);
-    int stage = 0;
+    int stage = 0;                       // stage of the tile about to be computed
     float inv_lane[2] = {0.0f, 0.0f};
+    // "Top" of tile (st_, kt_), whose operands went on their way one tile ago: this wave's DMAs have landed; barrier -- everyone's
+    // have, and every wave is done reading the other stage; the tile AFTER it goes on its way into that stage.
+    // The top of a super-tile's FIRST tile is taken BEFORE the previous super-tile's epilogue (below): the waves meet while they are
+    // still in step, and a wave that has little to note in its epilogue runs ahead into the next super-tile's first K-tile while its
+    // partner on the SIMD is still filtering -- matrix and vector work overlap instead of all eight waves waiting for the slowest
+    // epilogue (round 4 stamps, profiles/r04_wide8_phases.log: 3.8 of 20 ms in that barrier).
+    auto top = [&](int st_, int kt_) {
+        unsigned long long c0 = 0, c1 = 0;
+        if (dbg) c0 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg) c1 = wall_clock64();
+        __syncthreads();
+        if (dbg) { const unsigned long long c2 = wall_clock64(); t_wait += c1 - c0; t_bar += c2 - c1; }
+        // the candidate stage is flushed when half full -- tested where no wave is inside an epilogue (every thread reads the same count)
+        if (kt_ == 0 && st_ > 0 && *(const volatile u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
+        if (kt_ + 1 < NK) issue(kt_ + 1, stage ^ 1);
+        else if (st_ + 1 < nst) { set_rows(st_ + 1); issue(0, stage ^ 1); }
+    };
+    top(0, 0);
     for (int st = 0; st < nst; ++st) {
         const long long t0 = lo + (long long)st * kWideRows + wr * 64;
         for (int kt = 0; kt < NK; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile (st, kt) have landed
-            __syncthreads();                                     // ... everyone's; and every wave is done reading the other stage
-            if (kt + 1 < NK) issue(kt + 1, stage ^ 1);
-            else if (st + 1 < nst) { set_rows(st + 1); issue(0, stage ^ 1); }
+            if (kt > 0) top(st, kt);
             const char* sp = smem + stage * kW8Stage;
             i8v af[2];
 #pragma unroll
@@ -2131,23 +2208,38 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
                 acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bl, acc[1][nt], 0, 0, 0, 127, 0, 115);
             }
             stage ^= 1;
-        }
-        // 1 / norm of this lane's rows; rows past the part's end get NaN: their scores compare false
+            if (kt == NK - 2) {   // 1 / norm of this lane's rows, a K-tile ahead of its use; rows past the part's end get NaN: their scores compare false
 #pragma unroll
-        for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
+                for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
+            }
+        }
+        if (st + 1 < nst) top(st + 1, 0);
+        const unsigned long long e0 = dbg ? wall_clock64() : 0ull;
         int lane_e = lane, jt_e = jt;
         char* ctl_e = ctl;
         asm volatile("" : "+v"(lane_e), "+s"(jt_e));
+        unsigned long long e1 = 0;
+        if (dbg) { asm volatile("" :: "v"(inv_lane[0]), "v"(inv_lane[1])); e1 = wall_clock64(); t_inv += e1 - e0; }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+#if defined(VF_W8_NOEPI)   /* timing experiment (results invalid): 64 adds keep the accumulators alive */
+            float sm = inv_lane[m];
+#pragma unroll
+            for (int nt = 0; nt < kW8NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sm += acc[m][nt][e];
+            if (sm == 12345.678f) a.s0[0] = sm;
+#else
             wide_epilogue<kModeMain, kW8NT>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
                                             (uint2*)(ctl_e + kWideCtl + (size_t)a.stage_cap * 16 + (size_t)tid * ((kWideLaneList + 4) * 4)),
-                                            m == 0 && (st & 3) == wr, wc * 128);
+                                            m == 0 && (st & 3) == wr, wc * 128, dbg ? t_ph : nullptr);
+#endif
 #pragma unroll
             for (int nt = 0; nt < kW8NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
         }
+        if (dbg) t_flt += wall_clock64() - e1;
         if (a.sib && tid == 0 && sib_on) {   // sibling pacing: k_scan_wide's (a speed hint, bounded)
             u32* pr = a.sib + rg * 4;
             __hip_atomic_store(pr + jt, (u32)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2164,11 +2256,11 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        __syncthreads();
-        if (*(const u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
+        if (dbg) t_epi += wall_clock64() - e0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wide_flush(a, ctl, jt, tid);
+    if (dbg) { dbg[0] = wall_clock64() - t_begin; dbg[1] = t_wait; dbg[2] = t_bar; dbg[3] = t_epi; dbg[4] = t_inv; dbg[5] = t_flt; dbg[6] = t_ph[0]; dbg[7] = t_ph[1]; dbg[8] = t_ph[2]; dbg[9] = t_ph[3]; }
 }
 
 hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s) {
