@@ -2180,27 +2180,42 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         if (dbg) { const unsigned long long c2 = wall_clock64(); t_wait += c1 - c0; t_bar += c2 - c1; }
         // the candidate stage is flushed when half full -- tested where no wave is inside an epilogue (every thread reads the same count)
         if (kt_ == 0 && st_ > 0 && *(const volatile u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
+    };
+    auto issue_after = [&](int st_, int kt_) {   // the tile after (st_, kt_) goes on its way into the other stage
         if (kt_ + 1 < NK) issue(kt_ + 1, stage ^ 1);
         else if (st_ + 1 < nst) { set_rows(st_ + 1); issue(0, stage ^ 1); }
     };
     top(0, 0);
+    issue_after(0, 0);
     for (int st = 0; st < nst; ++st) {
         const long long t0 = lo + (long long)st * kWideRows + wr * 64;
         for (int kt = 0; kt < NK; ++kt) {
             if (kt > 0) top(st, kt);
+            // the first fragments are asked for BEFORE this wave's six DMA instructions are issued (~50 instructions with the M0
+            // hand-over): their LDS latency runs under that issue instead of after it
             const char* sp = smem + stage * kW8Stage;
-            i8v af[2];
+            i8v af[2], bh0, bl0;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const uint4 x0 = *(const uint4*)(sp + fa[m][0]), x1 = *(const uint4*)(sp + fa[m][1]);
                 af[m] = i8v{(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
             }
+            {
+                const uint4 h0 = *(const uint4*)(sp + fb[0][0]), h1 = *(const uint4*)(sp + fb[0][1]);
+                const uint4 l0 = *(const uint4*)(sp + 16384 + fb[0][0]), l1 = *(const uint4*)(sp + 16384 + fb[0][1]);
+                bh0 = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
+                bl0 = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+            }
+            if (kt > 0) issue_after(st, kt);
 #pragma unroll
             for (int nt = 0; nt < kW8NT; ++nt) {
-                const uint4 h0 = *(const uint4*)(sp + fb[nt][0]), h1 = *(const uint4*)(sp + fb[nt][1]);
-                const uint4 l0 = *(const uint4*)(sp + 16384 + fb[nt][0]), l1 = *(const uint4*)(sp + 16384 + fb[nt][1]);
-                const i8v bh = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
-                const i8v bl = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+                i8v bh = bh0, bl = bl0;
+                if (nt > 0) {
+                    const uint4 h0 = *(const uint4*)(sp + fb[nt][0]), h1 = *(const uint4*)(sp + fb[nt][1]);
+                    const uint4 l0 = *(const uint4*)(sp + 16384 + fb[nt][0]), l1 = *(const uint4*)(sp + 16384 + fb[nt][1]);
+                    bh = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
+                    bl = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+                }
                 // (scale operands: E8M0 bytes, 2^(x - 127): rows as they are, hi codes x 2^-8, lo codes x 2^-12)
                 acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bh, acc[0][nt], 0, 0, 0, 127, 0, 119);
                 acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bh, acc[1][nt], 0, 0, 0, 127, 0, 119);
@@ -2213,7 +2228,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
                 for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
             }
         }
-        if (st + 1 < nst) top(st + 1, 0);
+        if (st + 1 < nst) { top(st + 1, 0); issue_after(st + 1, 0); }
         const unsigned long long e0 = dbg ? wall_clock64() : 0ull;
         int lane_e = lane, jt_e = jt;
         char* ctl_e = ctl;
