@@ -739,7 +739,7 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     a.total_waves = RG * 8; a.samp = samp;
     a.s0 = s.s0.as<float>(); a.wg_base = s.wgbase.as<long long>(); a.cnt = s.cnt.as<u32>(); a.tau_bin = s.tau.as<int>();
     a.hist = s.hist.as<u32>(); a.hist_coarse = s.hist_coarse.as<u32>(); a.cand = s.cand.as<u64>(); a.cap = p.cap; a.kprime = p.kprime;
-    a.stage_cap = 1792; a.dbg = nullptr; a.debug = (int)ix->debug;   // 28 KB stage + 32 KB of per-lane notes: the LDS the three query buffers leave
+    a.stage_cap = 3584; a.dbg = nullptr; a.debug = (int)ix->debug;   // 56 KB of candidate stage: the LDS the 96 KB of operand buffers and the control block leave
     a.refresh_every = 1;   // a power of two on this path (block completion is tested with a mask)
     while (a.refresh_every * 2 <= (int)std::min<int64_t>(256, std::max<int64_t>(1, ix->refresh_every))) a.refresh_every *= 2;
     a.nq = nb; a.qn_total = qtot; a.jtiles = J; a.rgroups = RG;

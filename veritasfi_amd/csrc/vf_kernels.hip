@@ -1598,11 +1598,10 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
 }
 
 // epilogue of ONE 32-row tile (rows t0 .. t0+31) against the 256 queries
-constexpr int kWideLaneList = 12;   // passing scores a lane notes per round (of its 128 per 32-row tile); + 4 mask words = 64 B per lane
 
 template <int MODE, int NT = kWideNT>
 __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[NT], float inv_lane, long long t0,
-                                              long long hi, long long s0_slot, int jt, int lane, char* ctl, uint2* lane_list, bool sync_tau,
+                                              long long hi, long long s0_slot, int jt, int lane, char* ctl, bool sync_tau,
                                               int q0 = 0 /* first query (of the workgroup's 256) of this wave's NT tiles */,
                                               unsigned long long* ph = nullptr /* debug: [4] ticks in thresholds + pass 1a, 1b, 2, publish */) {
     const int r31 = lane & 31, h = lane >> 5;
@@ -1642,12 +1641,7 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     bool need = false;
     u32 myslot = 0u;
     int myq = 0;
-    // Rounds of (pass 1, pass 2); one round unless a lane has more than kWideLaneList passing scores (a loose seed's
-    // first tiles, hostile data): round r handles each lane's passing scores number L r .. L r + L - 1.
-    float* lane_sc = (float*)lane_list;                       // [kWideLaneList] passing scores of this round, in (nt, reg) order
-    u32* lane_mk = (u32*)(lane_sc + kWideLaneList);           // [4] which of the 128 scores passed (bit 16 (nt & 1) + reg of word nt >> 1)
-    // the thresholds are read ONCE per tile: other waves raise them concurrently, and every round must see the same
-    // set of passing scores (a score's ordinal in that set is what ties the rounds together)
+    // the thresholds are read ONCE per tile (other waves raise them concurrently; the masks and the claim below must agree)
     float tb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1694,87 +1688,53 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     const u32 cnt = (u32)(__popc(mk[0]) + __popc(mk[1]) + __popc(mk[2]) + __popc(mk[3]));
     ph_mark(0);
     if (__ballot(cnt != 0u) == 0ull) return;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) lane_mk[w] = mk[w];
     u32 anyw[4] = {0u, 0u, 0u, 0u};   // which positions passed in ANY lane (scalar)
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) anyw[w] = wave_or_u32(mk[w]);
-    for (u32 done = 0u;; done += (u32)kWideLaneList) {
-        // Pass 1b: the VALUES of this round's passing scores into the lane's private list, in position order.  A dynamic loop over
-        // the positions where SOME lane passed (the wave-wide OR of the masks, a scalar): the accumulator is picked by a jump on
-        // that scalar, so the cost follows the number of distinct positions, not the 16 NT of the tile.
-        {
-            u32 seen = 0u;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {   // (static tile, dynamic register: an indexed register read, no jump tree)
-                u32 bits = (u32)__builtin_amdgcn_readfirstlane((int)((anyw[nt >> 1] >> ((nt & 1) * 16)) & 0xFFFFu));
-                const u32 mine = mk[nt >> 1] >> ((nt & 1) * 16);
-                while (bits) {
-                    const int reg = __builtin_ctz(bits);
-                    bits &= bits - 1u;
-                    const float v = acc[nt][reg];
-                    const int r0 = (reg & 3) + 8 * (reg >> 2);
-                    const float iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0));
-                    const float iv4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0 + 4));
-                    if ((mine >> reg) & 1u) {
-                        const u32 o = seen - done;
-                        if (o < (u32)kWideLaneList) lane_sc[o] = v * (h ? iv4 : iv);
-                        ++seen;
-                    }
-                }
-            }
-        }
-        ph_mark(1);
-        // Pass 2, ONE dynamic loop (the code exists once): every lane walks its set bits in the same order and the wave moves
-        // in lockstep, "each lane's next noted score" per trip.  The wave claims the stage slots of ALL its noted scores of
-        // this round with one LDS atomic and a trip hands them out by ballot rank (round 3: a per-candidate LDS atomic in a
-        // divergent loop cost a third of this path at the 8-GPU shard size, profiles/r03_wide_ablation_1250k.log); the
-        // candidate that gets the last slot of a block of R publishes that block and refreshes one threshold (below).
-        const u32 mine = cnt > done ? (cnt - done < (u32)kWideLaneList ? cnt - done : (u32)kWideLaneList) : 0u;
-        const u32 total = wave_sum_u32(mine);
+    // Pass 2: ONE dynamic loop over the POSITIONS (query tile nt: static; accumulator register: a scalar, so the value is an indexed
+    // register read) where some lane passed.  The wave claims the stage slots of all its passing scores with one LDS atomic; a trip
+    // hands the lanes that pass at this position their slots by ballot rank and writes the entries.  No per-lane list, no rounds:
+    // the cost follows the number of distinct positions (round 4, profiles/r04_wide8_phases.log: noting the values in per-lane lists
+    // and walking them again was 2.7 of 20 ms at 10M rows, and 32 KB of LDS).  The candidate that gets the last slot of a block of R
+    // publishes that block and refreshes one threshold (below).
+    {
+        const u32 total = wave_sum_u32(cnt);
         u32 run = 0u;
         if (lane == 0) run = atomicAdd(stage_cnt, total);
         run = (u32)__builtin_amdgcn_readfirstlane((int)run);
-        u32 idx = 0u;
-        int w = 0;
-        u32 mw = lane_mk[0];
-        for (;;) {
-            // this lane's next noted score of THIS round (scores of other rounds are stepped over: o wraps for idx < done)
-            bool take = false;
-            int bpos = 0, wq = 0;
-            for (;;) {
-                while (mw == 0u && w < 3) { ++w; mw = lane_mk[w]; }
-                if (mw == 0u) break;
-                bpos = __builtin_ctz(mw);
-                mw &= mw - 1u;
-                wq = w;
-                const u32 o = idx - done;
-                ++idx;
-                if (o < (u32)kWideLaneList) { take = true; break; }
-                if (idx >= done + (u32)kWideLaneList) { mw = 0u; w = 3; break; }   // everything further belongs to later rounds
-            }
-            const unsigned long long bal = __ballot(take);
-            if (bal == 0ull) break;
-            if (take) {
-                const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                const float sc = lane_sc[idx - 1u - done];
-                const int ql = q0 + (2 * wq + (bpos >> 4)) * kQueryTile + r31, reg = bpos & 15;
-                const u32 row = (u32)(t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-                const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
-                if (slot < (u32)a.stage_cap) {
-                    stage_ent[slot] = make_uint4(row, key, (u32)ql | (bin << 8), 1u);
-                } else {   // stage full (the first tiles after a loose seed, or hostile data): straight to the global list
-                    const long long gq = qg0 + ql;
-                    const u32 gs = atomicAdd(a.cnt + gq * kCntStride, 1u);
-                    if (gs < (u32)a.cap) a.cand[gq * a.cap + gs] = ((u64)key << 32) | (u64)row;
-                    atomicAdd(a.hist + gq * kHistBins + bin, 1u);
-                    atomicAdd(a.hist_coarse + gq * 64 + (bin >> 5), 1u);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            u32 bits = (u32)__builtin_amdgcn_readfirstlane((int)((anyw[nt >> 1] >> ((nt & 1) * 16)) & 0xFFFFu));
+            const u32 mine = mk[nt >> 1] >> ((nt & 1) * 16);
+            const int ql = q0 + nt * kQueryTile + r31;
+            while (bits) {
+                const int reg = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                const float v = acc[nt][reg];
+                const int r0 = (reg & 3) + 8 * (reg >> 2);
+                const float iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0));
+                const float iv4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0 + 4));
+                const bool take = ((mine >> reg) & 1u) != 0u;
+                const unsigned long long bal = __ballot(take);
+                if (take) {
+                    const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                    const float sc = v * (h ? iv4 : iv);
+                    const u32 row = (u32)(t0 + r0 + 4 * h);
+                    const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
+                    if (slot < (u32)a.stage_cap) {
+                        stage_ent[slot] = make_uint4(row, key, (u32)ql | (bin << 8), 1u);
+                    } else {   // stage full (the first tiles after a loose seed, or hostile data): straight to the global list
+                        const long long gq = qg0 + ql;
+                        const u32 gs = atomicAdd(a.cnt + gq * kCntStride, 1u);
+                        if (gs < (u32)a.cap) a.cand[gq * a.cap + gs] = ((u64)key << 32) | (u64)row;
+                        atomicAdd(a.hist + gq * kHistBins + bin, 1u);
+                        atomicAdd(a.hist_coarse + gq * 64 + (bin >> 5), 1u);
+                    }
+                    if ((slot & Rm1) == Rm1) { need = true; myslot = slot; myq = ql; }
                 }
-                if ((slot & Rm1) == Rm1) { need = true; myslot = slot; myq = ql; }
+                run += (u32)__popcll(bal);
             }
-            run += (u32)__popcll(bal);
         }
-        if (__ballot(cnt > done + (u32)kWideLaneList) == 0ull) break;
     }
     ph_mark(2);
     unsigned long long m = __ballot(need);
@@ -1967,7 +1927,7 @@ __global__ __launch_bounds__(kWideThreads) void k_scan_wide(ScanArgs a) {
                 if (sm == 12345.678f) a.s0[0] = sm;
             } else
             wide_epilogue<MODE>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, (long long)rg * swg + (t0 + m * kRowTile - lo), jt_e,
-                                lane_e, ctl_e, (uint2*)(ctl_e + kWideCtl + (size_t)a.stage_cap * 16 + (size_t)tid * ((kWideLaneList + 4) * 4)),
+                                lane_e, ctl_e,
                                 m == 0 && (st & (kWideWaves - 1)) == wid);
 #pragma unroll
             for (int nt = 0; nt < kWideNT; ++nt)
@@ -2246,7 +2206,6 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
             if (sm == 12345.678f) a.s0[0] = sm;
 #else
             wide_epilogue<kModeMain, kW8NT>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
-                                            (uint2*)(ctl_e + kWideCtl + (size_t)a.stage_cap * 16 + (size_t)tid * ((kWideLaneList + 4) * 4)),
                                             m == 0 && (st & 3) == wr, wc * 128, dbg ? t_ph : nullptr);
 #endif
 #pragma unroll
@@ -2285,7 +2244,7 @@ hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s) {
 }
 
 size_t scan_wide_lds_bytes(int stage_cap) {
-    return (size_t)3 * kWideBuf + kWideCtl + (size_t)stage_cap * 16 + (stage_cap ? (size_t)kWideThreads * (kWideLaneList + 4) * 4 : 0);
+    return (size_t)3 * kWideBuf + kWideCtl + (size_t)stage_cap * 16;
 }
 
 hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s) {
