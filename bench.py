@@ -842,10 +842,10 @@ def main():
                     "flops_per_launch": flops, "queries_per_launch": qpass,
                     "peak_note": ("frac is against the dense fp16 peak (2.5 PF) so that the two kernels compare; frac_of_fp8_peak against the 5 PF "
                                   "of the instruction this kernel issues -- two MFMAs (hi + lo e4m3 query codes) per product, so the "
-                                  "useful rate is bounded by the fp16 figure; the e4m3 row bytes are the A operand as stored")
+                                  "useful rate is bounded by the fp16 figure; the e4m3 row bytes are the A operand as stored; --opt wide_mfma=0 runs the fp16 instruction instead")
                                  if w8 else
                                  ("dense fp16 MFMA (rows are converted to fp16 in registers; queries stay fp16: certificate bound 2^-11); "
-                                  "--opt wide_mfma=1 runs the fp8 instruction instead (k_scan_wide8)"),
+                                  "chosen by --opt wide_mfma=0; the default for e4m3 rows is the fp8 instruction (k_scan_wide8)"),
                     "algorithmic_bytes_per_launch": prof["scan_bytes_per_launch"],
                     "hbm_floor_ms": round(prof["scan_bytes_per_launch"] / HBM_PEAK_GBS / 1e6, 4),
                     "pipeline_ms_per_batch": round(prof["pipeline_ms_total"] / prof["scan_launches"], 4)}

@@ -1132,7 +1132,7 @@ def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
     (40_000, 256, 200, 5),         # 113 main rows per row group: less than one super-tile (clamped rows, NaN inverse norms)
 ])
 def test_wide_scan_fp8_matrix_instruction_bit_exact(vf, oracle, n, d, nq, k):
-    """k_scan_wide8 (index option wide_mfma = 1): the e4m3 row bytes as the A operand of v_mfma_scale_f32_32x32x64_f8f6f4, the
+    """k_scan_wide8 (the default for e4m3 rows; index option wide_mfma = 0 selects the fp16 instruction): the e4m3 row bytes as the A operand of v_mfma_scale_f32_32x32x64_f8f6f4, the
     query as hi + lo e4m3 codes, each query's own quantisation residual as its certificate bound.  Same ids and score bits as
     the oracle, and as the fp16-instruction form on the same handle; repairs stay rare."""
     from oracle import ref_numpy as R
@@ -1140,8 +1140,7 @@ def test_wide_scan_fp8_matrix_instruction_bit_exact(vf, oracle, n, d, nq, k):
     codes = _e4m3_codes(n, d, 71)
     rows16 = R.decode_e4m3(codes).astype(np.float16)
     with vf.DenseIndex.from_e4m3(codes) as ix:
-        ix.set_option("wide_mfma", 1)
-        got_i, got_s = ix.search(q, k)
+        got_i, got_s = ix.search(q, k)                      # the default for e4m3 rows
         st = ix.stats()
         ix.set_option("wide_mfma", 0)
         f16_i, f16_s = ix.search(q, k)

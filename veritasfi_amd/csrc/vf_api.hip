@@ -142,7 +142,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = 0,
+            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = -1,
             aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
@@ -551,7 +551,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
     else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
-    else if (s == "wide_mfma") { if (!in_range(0, 1)) return fail(VF_EINVAL, "wide_mfma must be 0 (fp16 matrix instruction on converted rows) or 1 (the fp8 instruction on the e4m3 row bytes: k_scan_wide8)"); ix->wide_mfma = value; }
+    else if (s == "wide_mfma") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "wide_mfma must be -1 (auto: the fp8 instruction for e4m3 rows), 0 (fp16 matrix instruction on converted rows) or 1 (the fp8 instruction on the e4m3 row bytes: k_scan_wide8)"); ix->wide_mfma = value; }
     else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
     else if (s == "aux_cus") {   // takes effect for slots created afterwards (set it before the first search)
         if (!in_range(-1, 128)) return fail(VF_EINVAL, "aux_cus must be -1 (auto) or in [0, 128]");
@@ -701,7 +701,7 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     FusedPlan p = p0;
     if (p.kprime > 256) p.cap = 16384;   // k ~ 1000: ~k' (1 + ln(n / sample)) candidates per query
     // k_scan_wide8 (the fp8 matrix instruction): e4m3 rows, K-tiles of 64, a row group's bytes within a 32-bit lane offset
-    const bool w8 = ix->wide_mfma == 1 && ix->dtype == VF_DTYPE_FP8_E4M3 && ix->dp % 64 == 0 &&
+    const bool w8 = ix->wide_mfma != 0 && ix->dtype == VF_DTYPE_FP8_E4M3 && ix->dp % 64 == 0 &&
                     (ix->n / RG + 2 * 256) * (int64_t)ix->dp < (int64_t)0xFFFFFFFFll;
     if (w8) {
         // the query's hi + lo split is good to ~2^-9 of the query's norm instead of fp16's 2^-11: the certificate needs the k-th score to
