@@ -2554,6 +2554,49 @@ __device__ __forceinline__ float rescore_pair(const void* rows, long long row, i
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
     const char* base = (const char*)rows + row * (long long)d * ESZ;
     const int nblk = d >> 4;
+    if constexpr (DT == VF_DTYPE_FP8_E4M3) {
+        if ((d & 15) == 0) {
+            // e4m3 rows: a 16-element block is 16 bytes.  Lane h loads block 2 p + h WHOLE (one 16-byte load instead of two lanes x
+            // 8 bytes: half the load instructions, twice the bytes in flight per lane -- the gather is latency-bound: round 4,
+            // profiles/r04_stamps_final_c5.log: 503 of 863 us of a k = 1000 workgroup at 10M rows) and the pair swaps halves by DPP:
+            // lane 0 keeps elements 0..7 of its block and takes elements 0..7 of the partner's, lane 1 the upper halves.  Blocks are
+            // consumed in ascending order, so every partial sum sees its elements in the oracle's order.
+            constexpr int kPair = 16;   // block pairs in flight per lane (256 bytes)
+            const int npair = (nblk + 1) >> 1;
+            for (int p0 = 0; p0 < npair; p0 += kPair) {
+                uint4 v[kPair];
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) {
+                    int b = 2 * (p0 + u) + h;
+                    b = b < nblk ? b : nblk - 1;
+                    v[u] = *(const uint4*)(base + (long long)b * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) {
+                    const u32 sx = h ? v[u].x : v[u].z, sy = h ? v[u].y : v[u].w;          // what the partner needs of my block
+                    const u32 rx = (u32)__shfl_xor((int)sx, 1), ry = (u32)__shfl_xor((int)sy, 1);
+                    const uint2 blk0 = h ? make_uint2(rx, ry) : make_uint2(v[u].x, v[u].y);      // my 8 elements of block 2 p
+                    const uint2 blk1 = h ? make_uint2(v[u].z, v[u].w) : make_uint2(rx, ry);      // ... of block 2 p + 1
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int bb = 2 * (p0 + u) + t;
+                        const bool live = bb < nblk;
+                        const int b = live ? bb : nblk - 1;
+                        float x[8];
+                        decode8<DT>(t ? blk1 : blk0, x);
+                        const float4 q0 = *(const float4*)(qs + b * 16 + 8 * h), q1 = *(const float4*)(qs + b * 16 + 8 * h + 4);
+                        const float qq[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float tt = __builtin_fmaf(qq[e], x[e] * inv, acc[e]);
+                            acc[e] = live ? tt : acc[e];
+                        }
+                    }
+                }
+            }
+            goto tail;
+        }
+    }
     if ((((long long)d * ESZ) & 15) == 0) {
         for (int b0 = 0; b0 < nblk; b0 += kBlk) {
             vec_t v[kBlk];
@@ -2585,6 +2628,7 @@ __device__ __forceinline__ float rescore_pair(const void* rows, long long row, i
                 acc[e] = __builtin_fmaf(qs[j], load_elem(rows, DT, row * (long long)d + j) * inv, acc[e]);
             }
     }
+tail:
     // tail block (d % 16 elements): element j = 16 nblk + 8 h + e exists while j < d
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -2735,7 +2779,10 @@ hipError_t launch_final(FinalArgs a, int nq, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     a.top_cap = (a.kprime + 1) & ~1;
     int sc = 1024;
-    while (sc < 3 * a.kprime && sc < 4096) sc <<= 1;   // survivors are typically 1.2-2 x k'
+    // survivors = k' + what shares the boundary fine bin (1 / 16 of a threshold bin: a handful of rows on smooth data; a list that
+    // does not fit is recomputed by the exact path).  Sized at 1.25 k' rounded up to a power of two: at k' = 1504 that is 2048 entries
+    // instead of 4096 -- 40 instead of 57 KB of LDS per workgroup, four workgroups per CU instead of two for a latency-bound gather
+    while (sc < a.kprime + a.kprime / 4 && sc < 4096) sc <<= 1;
     a.sel_cap = sc > a.top_cap ? sc : a.top_cap;
     const size_t lds = ((size_t)a.top_cap + a.sel_cap) * 8 + ((size_t)a.d + 4 + kHistBins + 4) * 4;
     hipLaunchKernelGGL(k_final, dim3(nq), dim3(kFinalThreads), lds, s, a);
