@@ -2036,6 +2036,193 @@ hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, u
     return hipGetLastError();
 }
 
+// ---- the K-tile bodies of k_scan_wide8 in asm with FIXED registers (generated by tools/gen_w8_asm.py; do not edit by hand) --------
+// Accumulators acc[m][nt] = v[64 m + 16 nt : +15]; five fragment slots of 16 registers S0 .. S4 = v[128 + 16 i : +15], each two
+// 8-register operands (A: row tiles m = 0 | 1; B: hi codes | lo codes).  A tile reads A -> S1 (even tile) / S0 (odd), B0 -> S2,
+// B1 -> S3, B2 -> the other A slot (the previous tile's A, dead once its held-back MFMAs have issued), B3 -> S4, and HOLDS BACK
+// the four MFMAs of query tile 3: they are issued first thing in the NEXT tile's body, interleaved with that tile's first reads,
+// so the matrix pipe has work while those reads are in flight (the fragment reads of tile t + 1 cannot start before the barrier
+// that certifies its operands).  The C++ source could not express this: with 128 accumulators the allocator spilled 530 bytes per
+// lane (reloads inside the MFMA sequence).  The compiler is told where everything lives through physical-register constraints.
+//   E0: first tile of a super-tile (nothing held back before it)   EM / OM: even / odd tile in the middle   OL: last tile (odd; runs its own tile 3)
+// Each body comes in two pieces: _A (the first held-back MFMAs and the first reads) is issued right behind the barrier, then the wave's
+// six DMA instructions for the next tile (C++ between the two asm statements: ~50 instructions that now run under those MFMAs), then _B.
+#define VF8_ASM_E0_A \
+    "ds_read_b128 v[144:147], %[pa0] offset:0\n\t" \
+    "ds_read_b128 v[148:151], %[pa1] offset:0\n\t" \
+    "ds_read_b128 v[152:155], %[pa0] offset:2048\n\t" \
+    "ds_read_b128 v[156:159], %[pa1] offset:2048\n\t" \
+    "ds_read_b128 v[160:163], %[pb0] offset:0\n\t" \
+    "ds_read_b128 v[164:167], %[pb1] offset:0\n\t" \
+    "ds_read_b128 v[168:171], %[pb0] offset:16384\n\t" \
+    "ds_read_b128 v[172:175], %[pb1] offset:16384\n\t"
+
+#define VF8_ASM_E0_B \
+    "ds_read_b128 v[176:179], %[pb0] offset:2048\n\t" \
+    "ds_read_b128 v[180:183], %[pb1] offset:2048\n\t" \
+    "ds_read_b128 v[184:187], %[pb0] offset:18432\n\t" \
+    "ds_read_b128 v[188:191], %[pb1] offset:18432\n\t" \
+    "ds_read_b128 v[128:131], %[pb0] offset:4096\n\t" \
+    "ds_read_b128 v[132:135], %[pb1] offset:4096\n\t" \
+    "ds_read_b128 v[136:139], %[pb0] offset:20480\n\t" \
+    "ds_read_b128 v[140:143], %[pb1] offset:20480\n\t" \
+    "ds_read_b128 v[192:195], %[pb0] offset:6144\n\t" \
+    "ds_read_b128 v[196:199], %[pb1] offset:6144\n\t" \
+    "ds_read_b128 v[200:203], %[pb0] offset:22528\n\t" \
+    "ds_read_b128 v[204:207], %[pb1] offset:22528\n\t" \
+    "s_waitcnt lgkmcnt(12)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[160:167], v[0:15], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[160:167], v[64:79], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[168:175], v[0:15], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[168:175], v[64:79], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(8)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[176:183], v[16:31], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[176:183], v[80:95], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[184:191], v[16:31], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[184:191], v[80:95], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[128:135], v[32:47], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[128:135], v[96:111], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[136:143], v[32:47], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[136:143], v[96:111], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+
+#define VF8_ASM_EM_A \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[128:135], v[192:199], v[48:63], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[144:147], %[pa0] offset:0\n\t" \
+    "ds_read_b128 v[148:151], %[pa1] offset:0\n\t" \
+    "ds_read_b128 v[152:155], %[pa0] offset:2048\n\t" \
+    "ds_read_b128 v[156:159], %[pa1] offset:2048\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[192:199], v[112:127], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[160:163], %[pb0] offset:0\n\t" \
+    "ds_read_b128 v[164:167], %[pb1] offset:0\n\t" \
+    "ds_read_b128 v[168:171], %[pb0] offset:16384\n\t" \
+    "ds_read_b128 v[172:175], %[pb1] offset:16384\n\t"
+
+#define VF8_ASM_EM_B \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[128:135], v[200:207], v[48:63], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[176:179], %[pb0] offset:2048\n\t" \
+    "ds_read_b128 v[180:183], %[pb1] offset:2048\n\t" \
+    "ds_read_b128 v[184:187], %[pb0] offset:18432\n\t" \
+    "ds_read_b128 v[188:191], %[pb1] offset:18432\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[128:131], %[pb0] offset:4096\n\t" \
+    "ds_read_b128 v[132:135], %[pb1] offset:4096\n\t" \
+    "ds_read_b128 v[136:139], %[pb0] offset:20480\n\t" \
+    "ds_read_b128 v[140:143], %[pb1] offset:20480\n\t" \
+    "ds_read_b128 v[192:195], %[pb0] offset:6144\n\t" \
+    "ds_read_b128 v[196:199], %[pb1] offset:6144\n\t" \
+    "ds_read_b128 v[200:203], %[pb0] offset:22528\n\t" \
+    "ds_read_b128 v[204:207], %[pb1] offset:22528\n\t" \
+    "s_waitcnt lgkmcnt(12)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[160:167], v[0:15], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[160:167], v[64:79], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[168:175], v[0:15], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[168:175], v[64:79], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(8)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[176:183], v[16:31], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[176:183], v[80:95], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[184:191], v[16:31], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[184:191], v[80:95], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[128:135], v[32:47], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[128:135], v[96:111], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[136:143], v[32:47], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[136:143], v[96:111], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+
+#define VF8_ASM_OM_A \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[144:151], v[192:199], v[48:63], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[128:131], %[pa0] offset:0\n\t" \
+    "ds_read_b128 v[132:135], %[pa1] offset:0\n\t" \
+    "ds_read_b128 v[136:139], %[pa0] offset:2048\n\t" \
+    "ds_read_b128 v[140:143], %[pa1] offset:2048\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[152:159], v[192:199], v[112:127], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[160:163], %[pb0] offset:0\n\t" \
+    "ds_read_b128 v[164:167], %[pb1] offset:0\n\t" \
+    "ds_read_b128 v[168:171], %[pb0] offset:16384\n\t" \
+    "ds_read_b128 v[172:175], %[pb1] offset:16384\n\t"
+
+#define VF8_ASM_OM_B \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[144:151], v[200:207], v[48:63], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[176:179], %[pb0] offset:2048\n\t" \
+    "ds_read_b128 v[180:183], %[pb1] offset:2048\n\t" \
+    "ds_read_b128 v[184:187], %[pb0] offset:18432\n\t" \
+    "ds_read_b128 v[188:191], %[pb1] offset:18432\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[152:159], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[144:147], %[pb0] offset:4096\n\t" \
+    "ds_read_b128 v[148:151], %[pb1] offset:4096\n\t" \
+    "ds_read_b128 v[152:155], %[pb0] offset:20480\n\t" \
+    "ds_read_b128 v[156:159], %[pb1] offset:20480\n\t" \
+    "ds_read_b128 v[192:195], %[pb0] offset:6144\n\t" \
+    "ds_read_b128 v[196:199], %[pb1] offset:6144\n\t" \
+    "ds_read_b128 v[200:203], %[pb0] offset:22528\n\t" \
+    "ds_read_b128 v[204:207], %[pb1] offset:22528\n\t" \
+    "s_waitcnt lgkmcnt(12)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[128:135], v[160:167], v[0:15], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[136:143], v[160:167], v[64:79], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[128:135], v[168:175], v[0:15], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[136:143], v[168:175], v[64:79], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(8)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[128:135], v[176:183], v[16:31], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[136:143], v[176:183], v[80:95], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[128:135], v[184:191], v[16:31], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[136:143], v[184:191], v[80:95], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[128:135], v[144:151], v[32:47], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[136:143], v[144:151], v[96:111], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[128:135], v[152:159], v[32:47], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[136:143], v[152:159], v[96:111], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+
+#define VF8_ASM_OL_A \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[144:151], v[192:199], v[48:63], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[128:131], %[pa0] offset:0\n\t" \
+    "ds_read_b128 v[132:135], %[pa1] offset:0\n\t" \
+    "ds_read_b128 v[136:139], %[pa0] offset:2048\n\t" \
+    "ds_read_b128 v[140:143], %[pa1] offset:2048\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[152:159], v[192:199], v[112:127], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[160:163], %[pb0] offset:0\n\t" \
+    "ds_read_b128 v[164:167], %[pb1] offset:0\n\t" \
+    "ds_read_b128 v[168:171], %[pb0] offset:16384\n\t" \
+    "ds_read_b128 v[172:175], %[pb1] offset:16384\n\t"
+
+#define VF8_ASM_OL_B \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[144:151], v[200:207], v[48:63], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[176:179], %[pb0] offset:2048\n\t" \
+    "ds_read_b128 v[180:183], %[pb1] offset:2048\n\t" \
+    "ds_read_b128 v[184:187], %[pb0] offset:18432\n\t" \
+    "ds_read_b128 v[188:191], %[pb1] offset:18432\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[152:159], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[144:147], %[pb0] offset:4096\n\t" \
+    "ds_read_b128 v[148:151], %[pb1] offset:4096\n\t" \
+    "ds_read_b128 v[152:155], %[pb0] offset:20480\n\t" \
+    "ds_read_b128 v[156:159], %[pb1] offset:20480\n\t" \
+    "ds_read_b128 v[192:195], %[pb0] offset:6144\n\t" \
+    "ds_read_b128 v[196:199], %[pb1] offset:6144\n\t" \
+    "ds_read_b128 v[200:203], %[pb0] offset:22528\n\t" \
+    "ds_read_b128 v[204:207], %[pb1] offset:22528\n\t" \
+    "s_waitcnt lgkmcnt(12)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[128:135], v[160:167], v[0:15], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[136:143], v[160:167], v[64:79], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[128:135], v[168:175], v[0:15], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[136:143], v[168:175], v[64:79], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(8)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[128:135], v[176:183], v[16:31], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[136:143], v[176:183], v[80:95], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[128:135], v[184:191], v[16:31], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[136:143], v[184:191], v[80:95], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[128:135], v[144:151], v[32:47], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[136:143], v[144:151], v[96:111], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[128:135], v[152:159], v[32:47], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[136:143], v[152:159], v[96:111], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[128:135], v[192:199], v[48:63], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[192:199], v[112:127], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[128:135], v[200:207], v[48:63], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t"
+
 __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2138,57 +2325,62 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         if (dbg) c1 = wall_clock64();
         __syncthreads();
         if (dbg) { const unsigned long long c2 = wall_clock64(); t_wait += c1 - c0; t_bar += c2 - c1; }
-        // the candidate stage is flushed when half full -- tested where no wave is inside an epilogue (every thread reads the same count)
-        if (kt_ == 0 && st_ > 0 && *(const volatile u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
     };
     auto issue_after = [&](int st_, int kt_) {   // the tile after (st_, kt_) goes on its way into the other stage
         if (kt_ + 1 < NK) issue(kt_ + 1, stage ^ 1);
         else if (st_ + 1 < nst) { set_rows(st_ + 1); issue(0, stage ^ 1); }
     };
+    // fragment addresses per stage (tile kt lives in stage kt & 1: NK is even) and the three block scales (E8M0: 2^(x - 127)):
+    // rows as they are, hi codes x 2^-8, lo codes x 2^-12
+    const unsigned pa0[2] = {lds0 + fa[0][0], lds0 + kW8Stage + fa[0][0]}, pa1[2] = {lds0 + fa[0][1], lds0 + kW8Stage + fa[0][1]};
+    const unsigned pb0[2] = {lds0 + fb[0][0], lds0 + kW8Stage + fb[0][0]}, pb1[2] = {lds0 + fb[0][1], lds0 + kW8Stage + fb[0][1]};
+    const int sc_a = 127, sc_h = 119, sc_l = 115;
+    i8v s0a, s0b, s1a, s1b, s2a, s2b, s3a, s3b, s4a, s4b;
+#define VF8_ACC_OPS "+{v[0:15]}"(acc[0][0]), "+{v[16:31]}"(acc[0][1]), "+{v[32:47]}"(acc[0][2]), "+{v[48:63]}"(acc[0][3]), \
+                    "+{v[64:79]}"(acc[1][0]), "+{v[80:95]}"(acc[1][1]), "+{v[96:111]}"(acc[1][2]), "+{v[112:127]}"(acc[1][3])
+#define VF8_IN_OPS(SG) [pa0] "v"(pa0[SG]), [pa1] "v"(pa1[SG]), [pb0] "v"(pb0[SG]), [pb1] "v"(pb1[SG]), [sa] "v"(sc_a), [sh] "v"(sc_h), [sl] "v"(sc_l)
+#define VF8_SLOTS_OUT "=&{v[128:135]}"(s0a), "=&{v[136:143]}"(s0b), "=&{v[144:151]}"(s1a), "=&{v[152:159]}"(s1b), "=&{v[160:167]}"(s2a),      \
+                      "=&{v[168:175]}"(s2b), "=&{v[176:183]}"(s3a), "=&{v[184:191]}"(s3b), "=&{v[192:199]}"(s4a), "=&{v[200:207]}"(s4b)
+#define VF8_SLOTS_IO "+{v[128:135]}"(s0a), "+{v[136:143]}"(s0b), "+{v[144:151]}"(s1a), "+{v[152:159]}"(s1b), "+{v[160:167]}"(s2a),            \
+                     "+{v[168:175]}"(s2b), "+{v[176:183]}"(s3a), "+{v[184:191]}"(s3b), "+{v[192:199]}"(s4a), "+{v[200:207]}"(s4b)
+    // tile 0 of a super-tile: its top (and the issue of tile 1) was taken before the previous epilogue
+#define VF8_TILE_FIRST()                                                                                                              \
+    do {                                                                                                                              \
+        asm volatile(VF8_ASM_E0_A : VF8_ACC_OPS, VF8_SLOTS_OUT : VF8_IN_OPS(0) : "memory");                                           \
+        asm volatile(VF8_ASM_E0_B : VF8_ACC_OPS, VF8_SLOTS_IO : VF8_IN_OPS(0) : "memory");                                            \
+        stage ^= 1;                                                                                                                   \
+    } while (0)
+#define VF8_TILE_NEXT(NAME, SG, KT)                                                                                                   \
+    do {                                                                                                                              \
+        top(st, (KT));                                                                                                                \
+        asm volatile(NAME##_A : VF8_ACC_OPS, VF8_SLOTS_IO : VF8_IN_OPS(SG) : "memory");                                               \
+        issue_after(st, (KT));                                                                                                        \
+        asm volatile(NAME##_B : VF8_ACC_OPS, VF8_SLOTS_IO : VF8_IN_OPS(SG) : "memory");                                               \
+        stage ^= 1;                                                                                                                   \
+    } while (0)
     top(0, 0);
     issue_after(0, 0);
     for (int st = 0; st < nst; ++st) {
         const long long t0 = lo + (long long)st * kWideRows + wr * 64;
-        for (int kt = 0; kt < NK; ++kt) {
-            if (kt > 0) top(st, kt);
-            // the first fragments are asked for BEFORE this wave's six DMA instructions are issued (~50 instructions with the M0
-            // hand-over): their LDS latency runs under that issue instead of after it
-            const char* sp = smem + stage * kW8Stage;
-            i8v af[2], bh0, bl0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const uint4 x0 = *(const uint4*)(sp + fa[m][0]), x1 = *(const uint4*)(sp + fa[m][1]);
-                af[m] = i8v{(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-            }
-            {
-                const uint4 h0 = *(const uint4*)(sp + fb[0][0]), h1 = *(const uint4*)(sp + fb[0][1]);
-                const uint4 l0 = *(const uint4*)(sp + 16384 + fb[0][0]), l1 = *(const uint4*)(sp + 16384 + fb[0][1]);
-                bh0 = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
-                bl0 = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
-            }
-            if (kt > 0) issue_after(st, kt);
-#pragma unroll
-            for (int nt = 0; nt < kW8NT; ++nt) {
-                i8v bh = bh0, bl = bl0;
-                if (nt > 0) {
-                    const uint4 h0 = *(const uint4*)(sp + fb[nt][0]), h1 = *(const uint4*)(sp + fb[nt][1]);
-                    const uint4 l0 = *(const uint4*)(sp + 16384 + fb[nt][0]), l1 = *(const uint4*)(sp + 16384 + fb[nt][1]);
-                    bh = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
-                    bl = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
-                }
-                // (scale operands: E8M0 bytes, 2^(x - 127): rows as they are, hi codes x 2^-8, lo codes x 2^-12)
-                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bh, acc[0][nt], 0, 0, 0, 127, 0, 119);
-                acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bh, acc[1][nt], 0, 0, 0, 127, 0, 119);
-                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bl, acc[0][nt], 0, 0, 0, 127, 0, 115);
-                acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bl, acc[1][nt], 0, 0, 0, 127, 0, 115);
-            }
-            stage ^= 1;
-            if (kt == NK - 2) {   // 1 / norm of this lane's rows, a K-tile ahead of its use; rows past the part's end get NaN: their scores compare false
-#pragma unroll
-                for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
-            }
+        VF8_TILE_FIRST();
+        VF8_TILE_NEXT(VF8_ASM_OM, 1, 1);
+        for (int kt = 2; kt < NK - 2; kt += 2) {
+            VF8_TILE_NEXT(VF8_ASM_EM, 0, kt);
+            VF8_TILE_NEXT(VF8_ASM_OM, 1, kt + 1);
         }
-        if (st + 1 < nst) { top(st + 1, 0); issue_after(st + 1, 0); }
+        VF8_TILE_NEXT(VF8_ASM_EM, 0, NK - 2);
+        {   // 1 / norm of this lane's rows, a K-tile ahead of its use; rows past the part's end get NaN: their scores never pass
+#pragma unroll
+            for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
+        }
+        VF8_TILE_NEXT(VF8_ASM_OL, 1, NK - 1);
+        if (st + 1 < nst) {
+            top(st + 1, 0);
+            // the candidate stage is flushed when half full -- tested behind this barrier, where no wave is inside an epilogue (every
+            // thread reads the same count)
+            if (*(const volatile u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
+            issue_after(st + 1, 0);
+        }
         const unsigned long long e0 = dbg ? wall_clock64() : 0ull;
         int lane_e = lane, jt_e = jt;
         char* ctl_e = ctl;
@@ -2236,6 +2428,13 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     wide_flush(a, ctl, jt, tid);
     if (dbg) { dbg[0] = wall_clock64() - t_begin; dbg[1] = t_wait; dbg[2] = t_bar; dbg[3] = t_epi; dbg[4] = t_inv; dbg[5] = t_flt; dbg[6] = t_ph[0]; dbg[7] = t_ph[1]; dbg[8] = t_ph[2]; dbg[9] = t_ph[3]; }
 }
+
+#undef VF8_TILE_NEXT
+#undef VF8_TILE_FIRST
+#undef VF8_SLOTS_IO
+#undef VF8_SLOTS_OUT
+#undef VF8_IN_OPS
+#undef VF8_ACC_OPS
 
 hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s) {
     const int grid = 8 * a.jtiles * ((a.rgroups + 7) / 8);
