@@ -2044,7 +2044,8 @@ hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, u
 // so the matrix pipe has work while those reads are in flight (the fragment reads of tile t + 1 cannot start before the barrier
 // that certifies its operands).  The C++ source could not express this: with 128 accumulators the allocator spilled 530 bytes per
 // lane (reloads inside the MFMA sequence).  The compiler is told where everything lives through physical-register constraints.
-//   E0: first tile of a super-tile (nothing held back before it)   EM / OM: even / odd tile in the middle   OL: last tile (odd; runs its own tile 3)
+//   E0: first tile of a super-tile (nothing held back before it; its MFMAs START the sums: C = 0, the accumulators are never cleared)
+//   O1: the second tile (the held-back four of tile 0 start theirs)   EM / OM: even / odd tile in the middle   OL: last tile (odd; runs its own tile 3)
 // Each body comes in two pieces: _A (the first held-back MFMAs and the first reads) is issued right behind the barrier, then the wave's
 // six DMA instructions for the next tile (C++ between the two asm statements: ~50 instructions that now run under those MFMAs), then _B.
 #define VF8_ASM_E0_A \
@@ -2071,20 +2072,64 @@ hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, u
     "ds_read_b128 v[200:203], %[pb0] offset:22528\n\t" \
     "ds_read_b128 v[204:207], %[pb1] offset:22528\n\t" \
     "s_waitcnt lgkmcnt(12)\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[160:167], v[0:15], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[160:167], v[64:79], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[160:167], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[160:167], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[144:151], v[168:175], v[0:15], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[152:159], v[168:175], v[64:79], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
     "s_waitcnt lgkmcnt(8)\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[176:183], v[16:31], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[176:183], v[80:95], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[176:183], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[176:183], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[144:151], v[184:191], v[16:31], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[152:159], v[184:191], v[80:95], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
     "s_waitcnt lgkmcnt(4)\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[128:135], v[32:47], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[128:135], v[96:111], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[128:135], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[128:135], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[144:151], v[136:143], v[32:47], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[152:159], v[136:143], v[96:111], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+
+#define VF8_ASM_O1_A \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[144:151], v[192:199], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[128:131], %[pa0] offset:0\n\t" \
+    "ds_read_b128 v[132:135], %[pa1] offset:0\n\t" \
+    "ds_read_b128 v[136:139], %[pa0] offset:2048\n\t" \
+    "ds_read_b128 v[140:143], %[pa1] offset:2048\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[152:159], v[192:199], 0, %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[160:163], %[pb0] offset:0\n\t" \
+    "ds_read_b128 v[164:167], %[pb1] offset:0\n\t" \
+    "ds_read_b128 v[168:171], %[pb0] offset:16384\n\t" \
+    "ds_read_b128 v[172:175], %[pb1] offset:16384\n\t"
+
+#define VF8_ASM_O1_B \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[144:151], v[200:207], v[48:63], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[176:179], %[pb0] offset:2048\n\t" \
+    "ds_read_b128 v[180:183], %[pb1] offset:2048\n\t" \
+    "ds_read_b128 v[184:187], %[pb0] offset:18432\n\t" \
+    "ds_read_b128 v[188:191], %[pb1] offset:18432\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[152:159], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "ds_read_b128 v[144:147], %[pb0] offset:4096\n\t" \
+    "ds_read_b128 v[148:151], %[pb1] offset:4096\n\t" \
+    "ds_read_b128 v[152:155], %[pb0] offset:20480\n\t" \
+    "ds_read_b128 v[156:159], %[pb1] offset:20480\n\t" \
+    "ds_read_b128 v[192:195], %[pb0] offset:6144\n\t" \
+    "ds_read_b128 v[196:199], %[pb1] offset:6144\n\t" \
+    "ds_read_b128 v[200:203], %[pb0] offset:22528\n\t" \
+    "ds_read_b128 v[204:207], %[pb1] offset:22528\n\t" \
+    "s_waitcnt lgkmcnt(12)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[128:135], v[160:167], v[0:15], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[136:143], v[160:167], v[64:79], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[0:15], v[128:135], v[168:175], v[0:15], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[64:79], v[136:143], v[168:175], v[64:79], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(8)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[128:135], v[176:183], v[16:31], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[136:143], v[176:183], v[80:95], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[16:31], v[128:135], v[184:191], v[16:31], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[80:95], v[136:143], v[184:191], v[80:95], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[128:135], v[144:151], v[32:47], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[136:143], v[144:151], v[96:111], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[32:47], v[128:135], v[152:159], v[32:47], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[136:143], v[152:159], v[96:111], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t"
 
 #define VF8_ASM_EM_A \
@@ -2363,7 +2408,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     for (int st = 0; st < nst; ++st) {
         const long long t0 = lo + (long long)st * kWideRows + wr * 64;
         VF8_TILE_FIRST();
-        VF8_TILE_NEXT(VF8_ASM_OM, 1, 1);
+        VF8_TILE_NEXT(VF8_ASM_O1, 1, 1);
         for (int kt = 2; kt < NK - 2; kt += 2) {
             VF8_TILE_NEXT(VF8_ASM_EM, 0, kt);
             VF8_TILE_NEXT(VF8_ASM_OM, 1, kt + 1);
@@ -2400,10 +2445,6 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
             wide_epilogue<kModeMain, kW8NT>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
                                             m == 0 && (st & 3) == wr, wc * 128, dbg ? t_ph : nullptr);
 #endif
-#pragma unroll
-            for (int nt = 0; nt < kW8NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
         }
         if (dbg) t_flt += wall_clock64() - e1;
         if (a.sib && tid == 0 && sib_on) {   // sibling pacing: k_scan_wide's (a speed hint, bounded)
