@@ -825,7 +825,7 @@ def main():
             tf = flops / (avg_ms * 1e-3) / 1e12
             wtraffic, wsrc = None, None
             try:
-                wfile = os.path.join("profiles", "pmc_traffic_scan_wide_c5_10Mx1024.json")
+                wfile = os.path.join("profiles", "pmc_traffic_scan_wide8_c5_10Mx1024.json" if stats.get("scan_kernel") == 4 else "pmc_traffic_scan_wide_c5_10Mx1024.json")
                 rec = json.load(open(os.path.join(ROOT, wfile)))
                 w = rec["workload"]
                 if not devs and args.corpus_dtype == "fp8" and (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (args.rows, args.dim, args.batch, args.k, world):
@@ -836,7 +836,7 @@ def main():
             w8 = stats.get("scan_kernel") == 4
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                     "frac_of_fp8_peak": round(tf / 5000.0, 4),
-                    "traffic": None if w8 else wtraffic, "traffic_source": None if w8 else wsrc,
+                    "traffic": wtraffic, "traffic_source": wsrc,
                     "kernel": "vf::k_scan_wide8 (v_mfma_scale_f32_32x32x64_f8f6f4)" if w8 else "vf::k_scan_wide<main> (v_mfma_f32_32x32x16_f16)",
                     "avg_launch_ms": round(avg_ms, 4),
                     "flops_per_launch": flops, "queries_per_launch": qpass,

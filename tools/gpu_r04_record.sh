@@ -15,6 +15,13 @@ tail -1 gpurun_out/r04_bench_rehearsal_1250k_exchange.log | cut -c1-400
 C5="--rows 10000000 --dim 1024 --batch 1024 --k 1000 --corpus-dtype fp8 --no-cpu-baseline --no-rerank"
 echo "== configs[4]"; timeout -k 10 400 python bench.py $C5 --steps 10 --warmup 2 > gpurun_out/r04_bench_c5.log 2>&1 || exit 1
 tail -1 gpurun_out/r04_bench_c5.log | cut -c1-400
+timeout -k 10 400 python bench.py $C5 --steps 10 --warmup 2 --opt wide_mfma=0 > gpurun_out/r04_bench_c5_f16mfma.log 2>&1 || exit 1
+tail -1 gpurun_out/r04_bench_c5_f16mfma.log | cut -c1-300
+timeout -k 10 400 python bench.py --rows 1250000 --dim 1024 --batch 1024 --k 1000 --corpus-dtype fp8 --no-cpu-baseline --no-rerank --steps 20 --warmup 3 > gpurun_out/r04_bench_c5_shard_1250k.log 2>&1 || exit 1
+tail -1 gpurun_out/r04_bench_c5_shard_1250k.log | cut -c1-300
+echo "== configs[4]: kernel stats + PMC"; bash tools/gpu_prof_bench.sh r04_c5 stats $C5 --steps 10 --warmup 2 || exit 1
+bash tools/gpu_prof_bench.sh r04_c5_fetch FETCH_SIZE $C5 --steps 6 --warmup 2 || exit 1
+bash tools/gpu_prof_bench.sh r04_c5_write WRITE_SIZE $C5 --steps 6 --warmup 2 || exit 1
 echo "== harness counterparts"
 timeout -k 10 300 python tools/continuous_retrieval.py > gpurun_out/r04_continuous_retrieval.log 2>&1; tail -3 gpurun_out/r04_continuous_retrieval.log
 timeout -k 10 300 python tools/rerank_stress.py > gpurun_out/r04_rerank_stress.log 2>&1; tail -3 gpurun_out/r04_rerank_stress.log

@@ -2434,17 +2434,8 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         if (dbg) { asm volatile("" :: "v"(inv_lane[0]), "v"(inv_lane[1])); e1 = wall_clock64(); t_inv += e1 - e0; }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-#if defined(VF_W8_NOEPI)   /* timing experiment (results invalid): 64 adds keep the accumulators alive */
-            float sm = inv_lane[m];
-#pragma unroll
-            for (int nt = 0; nt < kW8NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sm += acc[m][nt][e];
-            if (sm == 12345.678f) a.s0[0] = sm;
-#else
             wide_epilogue<kModeMain, kW8NT>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
                                             m == 0 && (st & 3) == wr, wc * 128, dbg ? t_ph : nullptr);
-#endif
         }
         if (dbg) t_flt += wall_clock64() - e1;
         if (a.sib && tid == 0 && sib_on) {   // sibling pacing: k_scan_wide's (a speed hint, bounded)
