@@ -349,6 +349,52 @@ def rerank_llm(args):
                     "(tokenizer stand-in, truncations, prompt), left padding, packed decoder forward, D2H of the logits"}
 
 
+def c5_leg(args, torch, vf, device):
+    """BASELINE configs[4] at full size on this GPU: 10M x 1024 e4m3 rows, 1024 queries per batch, top-1000 -- the wide scan on the
+    instruction the config names (k_scan_wide8: v_mfma_scale_f32_32x32x64_f8f6f4).  Same loop as the headline: batches pipelined
+    two deep on their own stream, inputs resident, HIP events around the scan launches (vf_index_profile)."""
+    rows, dim, nq, k, steps, warm = 10_000_000, 1024, 1024, 1000, 6, 2
+    corpus = make_shard(torch, 0, rows, dim, device, "fp8")
+    index = vf.DenseIndex(corpus)
+    try:
+        g = torch.Generator(device=device)
+        g.manual_seed(4321)
+        qpool = [torch.randn((nq, dim), generator=g, device=device, dtype=torch.float32) for _ in range(2)]
+        ids = [torch.empty((nq, k), dtype=torch.int64, device=device) for _ in range(2)]
+        sc = [torch.empty((nq, k), dtype=torch.float32, device=device) for _ in range(2)]
+        stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            def run(n):
+                for i in range(n + 1):
+                    if i < n:
+                        index.search_begin(i & 1, qpool[i & 1], k, ids[i & 1], sc[i & 1])
+                    if i >= 1:
+                        index.search_end((i - 1) & 1)
+            run(warm)
+            torch.cuda.synchronize()
+            index.set_option("profile", 1)
+            t0 = time.perf_counter()
+            run(steps)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        prof, st = index.profile(), index.stats()
+        index.set_option("profile", 0)
+        launch_ms = prof["scan_ms_total"] / max(1, prof["scan_launches"])
+        tf = 2.0 * nq * (prof["scan_bytes_per_launch"] // (dim + 4)) * dim / (launch_ms * 1e-3) / 1e12
+        return {"workload": f"{rows}x{dim} fp8-e4m3 corpus, batch-{nq} queries, exact cosine top-{k}, 1 GPU", "queries_per_s": round(steps * nq / el, 1),
+                "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": warm,
+                "roofline": {"bound": "mfma", "kernel": {4: "vf::k_scan_wide8 (v_mfma_scale_f32_32x32x64_f8f6f4)", 3: "vf::k_scan_wide<main> (v_mfma_f32_32x32x16_f16)"}.get(st.get("scan_kernel"), "?"),
+                             "avg_launch_ms": round(launch_ms, 3), "achieved": round(tf, 1), "unit": "TFLOP/s", "peak": 2500.0, "frac": round(tf / 2500.0, 4),
+                             "frac_of_fp8_peak": round(tf / 5000.0, 4),
+                             "peak_note": "two MFMAs (hi + lo e4m3 query codes) per product: the useful rate is bounded by the fp16 figure"},
+                "search_stats": {"candidates_per_query": round(st["candidates"] / max(1, st["n_queries"]), 1), "exact_reruns_last_batch": st["exact_reruns"],
+                                 "overflowed": st["overflowed"]},
+                "parity": "tests/test_gpu_retrieval.py::test_c5_10m_sharding_invariance_and_subset (this corpus, these queries: ids and score bits against the oracle)"}
+    finally:
+        index.close()
+        del corpus
+
+
 def c4_chain(args, torch, vf, corpus):
     """BASELINE configs[3], text leg, end to end for ONE query: embed_query (bge-base shape) -> exact top-100 over a
     5M x 768 corpus -> 100 (query, passage) pairs x 512 tokens through the cross-encoder (bge-reranker-base shape) ->
@@ -755,7 +801,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             host_entry = {"error": f"{type(e).__name__}: {e}"}
     # secondary legs: a failure here (environment, memory) must not take the main metric line down; it is reported in place
-    rr_ms, rr_info, emb_info, rr_large, lat_info, llm_info, c4_info = (None, None, None, None, None, None, None)
+    rr_ms, rr_info, emb_info, rr_large, lat_info, llm_info, c4_info, c5_info = (None, None, None, None, None, None, None, None)
     if (world > 1 or (exchange and dist.is_initialized())) and not devs and not args.no_rerank:   # (the one-rank rehearsal takes it too)
         # N > 1: the re-rank leg is the data-parallel form (all ranks take part); the single-GPU legs are reported by the N = 1 run
         try:
@@ -791,6 +837,11 @@ def main():
                 c4_info = c4_chain(args, torch, vf, corpus)
             except Exception as e:  # noqa: BLE001
                 c4_info = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not devs and args.corpus_dtype == "f16" and not args.no_c4 and (args.rows, args.dim) == (10_000_000, 768):
+            try:      # (the default line only: configs[4] at full size beside the headline)
+                c5_info = c5_leg(args, torch, vf, device)
+            except Exception as e:  # noqa: BLE001
+                c5_info = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -910,6 +961,7 @@ def main():
             "rerank_large": rr_large,
             "rerank_llm": llm_info,
             "c4": c4_info,
+            "c5": c5_info,
             "embed": emb_info,
             "request_latency": lat_info,
             "host_entry": host_entry,
