@@ -135,7 +135,11 @@ int vf_index_search_end(vf_index* idx, int32_t slot);
 int vf_index_info(vf_index* idx, int64_t* n, int32_t* d, int32_t* dtype, int32_t* device_id);
 int vf_index_stats(vf_index* idx, vf_search_stats* out);
 /* tuning knobs, by name ("force_path", "sample_rows", "margin", "cap", "waves" ...); tests use
- * force_path to exercise every path on the same data.  Unknown name -> VF_EINVAL. */
+ * force_path to exercise every path on the same data.  Unknown name -> VF_EINVAL.
+ * "wide_mfma": matrix instruction of the wide scan (batches of >= 129 queries) over e4m3 rows: -1 auto (= 1), 1 the fp8
+ *   instruction on the row bytes as stored (k_scan_wide8: the query goes in as a hi + lo pair of e4m3 codes and its exactly
+ *   known residual is the query's certificate bound), 0 the fp16 instruction on converted rows (k_scan_wide).  Results are
+ *   identical bit for bit; vf_search_stats.scan_kernel says which one ran. */
 int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
 /* Live kernel timing with HIP events on the stream the kernels run on (bench.py roofline):
  * after vf_index_set_option(idx, "profile", 1) every fused search records events around its main

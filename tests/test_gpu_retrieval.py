@@ -1156,6 +1156,33 @@ def test_wide_scan_fp8_matrix_instruction_bit_exact(vf, oracle, n, d, nq, k):
     assert st["exact_reruns"] <= max(1, nq // 16), st
 
 
+def test_wide_scan_fp8_matrix_instruction_hostile_data(vf, oracle):
+    """k_scan_wide8 under data its certificate cannot pass: 400 copies of a row close to query 0 (a tie group wider than
+    k' - k), a corpus sorted by score (every tile raises the thresholds: the stage overflows into the global lists), and
+    queries that are ALL the same vector (one query tile's 256 lists fill in step).  The per-query bound (the query's own
+    e4m3 hi + lo residual) must flag what it cannot certify and the exact path must repair it: ids and score bits equal
+    the oracle's in every case."""
+    import torch
+    from oracle import ref_numpy as R
+    rng = np.random.default_rng(73)
+    n, d, nq = 60_000, 512, 300
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    base = (rng.standard_normal((n, d)) * 0.5).astype(np.float32)
+    base[rng.choice(n, 400, replace=False)] = (q[0] * 0.5 + 0.02 * rng.standard_normal(d)).astype(np.float32)
+    codes = torch.from_numpy(base).to(torch.float8_e4m3fn).view(torch.uint8).numpy().copy()
+    rows16 = R.decode_e4m3(codes).astype(np.float16)
+    sims = oracle.cosine(q[1:2], rows16.astype(np.float32))[0]
+    order = np.argsort(sims, kind="stable")
+    for name, cd, r16, qq in (("duplicates", codes, rows16, q), ("sorted", codes[order], rows16[order], q),
+                              ("one query 300 times", codes, rows16, np.repeat(q[:1], nq, axis=0))):
+        with vf.DenseIndex.from_e4m3(np.ascontiguousarray(cd)) as ix:
+            ids, sc = ix.search(qq, 100)
+            st = ix.stats()
+        print("wide8 hostile stats", name, st)
+        assert st["path"] == 1 and st["scan_kernel"] == 4 and st["n_queries"] == nq
+        _assert_exact(oracle, r16, qq, 100, ids, sc)
+
+
 def test_wide_scan_hostile_data(vf, oracle):
     """Duplicates and a score-sorted corpus under 200 queries: stage flushes, overflow to the global lists, repairs."""
     rng = np.random.default_rng(63)
