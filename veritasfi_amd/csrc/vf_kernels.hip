@@ -1691,12 +1691,15 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
     u32 anyw[4] = {0u, 0u, 0u, 0u};   // which positions passed in ANY lane (scalar)
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) anyw[w] = wave_or_u32(mk[w]);
-    // Pass 2: ONE dynamic loop over the POSITIONS (query tile nt: static; accumulator register: a scalar, so the value is an indexed
-    // register read) where some lane passed.  The wave claims the stage slots of all its passing scores with one LDS atomic; a trip
-    // hands the lanes that pass at this position their slots by ballot rank and writes the entries.  No per-lane list, no rounds:
-    // the cost follows the number of distinct positions (round 4, profiles/r04_wide8_phases.log: noting the values in per-lane lists
-    // and walking them again was 2.7 of 20 ms at 10M rows, and 32 KB of LDS).  The candidate that gets the last slot of a block of R
-    // publishes that block and refreshes one threshold (below).
+    // Pass 2: the passing scores become stage entries, ALL LANES AT ONCE: per query tile with a passing score somewhere (scalar test
+    // on the wave-wide OR of the masks) every lane takes ITS lowest set bit, picks that accumulator register with a four-level
+    // select tree (15 v_cndmask: the register differs from lane to lane, so it cannot be an indexed read) and the row's inverse norm
+    // with one ds_bpermute; slots come from one LDS atomic per call, handed out by ballot rank.  A trip serves up to 64 candidates;
+    // a second trip on the same tile only if some lane has two passing scores in it.  Cost per call ~45 instructions per query tile
+    // whatever the candidate count -- the earlier loop over POSITIONS (value by indexed register read, one position per trip,
+    // ~60 instructions and their scalar <-> vector hand-overs each) paid per candidate: 0.28 us, 1.7 of 16.5 ms at 10M rows and a
+    // quarter of the launch at the 8-GPU shard, where candidates are eight times denser (profiles/r04_wide8_phases.log).
+    // The candidate that gets the last slot of a block of R publishes that block and refreshes one threshold (below).
     {
         const u32 total = wave_sum_u32(cnt);
         u32 run = 0u;
@@ -1704,22 +1707,32 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
         run = (u32)__builtin_amdgcn_readfirstlane((int)run);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            u32 bits = (u32)__builtin_amdgcn_readfirstlane((int)((anyw[nt >> 1] >> ((nt & 1) * 16)) & 0xFFFFu));
-            const u32 mine = mk[nt >> 1] >> ((nt & 1) * 16);
+            if ((u32)__builtin_amdgcn_readfirstlane((int)((anyw[nt >> 1] >> ((nt & 1) * 16)) & 0xFFFFu)) == 0u) continue;
+            u32 mine = (mk[nt >> 1] >> ((nt & 1) * 16)) & 0xFFFFu;
             const int ql = q0 + nt * kQueryTile + r31;
-            while (bits) {
-                const int reg = __builtin_ctz(bits);
-                bits &= bits - 1u;
-                const float v = acc[nt][reg];
-                const int r0 = (reg & 3) + 8 * (reg >> 2);
-                const float iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0));
-                const float iv4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_lane), r0 + 4));
-                const bool take = ((mine >> reg) & 1u) != 0u;
+            for (;;) {
+                const bool take = mine != 0u;
                 const unsigned long long bal = __ballot(take);
+                if (bal == 0ull) break;
+                const int reg = take ? __builtin_ctz(mine) : 0;
+                mine &= mine - 1u;
+                // (bitwise selects -- v_bfi_b32 with an all-ones / all-zeros lane mask per bit of reg: written as ?: on the vector's
+                //  elements hipcc turns the tree back into a dynamic extractelement and expands THAT as sixteen compare + select pairs, four times over)
+                const u32 m0 = 0u - ((u32)reg & 1u), m1 = 0u - (((u32)reg >> 1) & 1u), m2 = 0u - (((u32)reg >> 2) & 1u), m3 = 0u - (((u32)reg >> 3) & 1u);
+                u32 t8[8], t4[4], t2[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t8[i] = (m0 & __float_as_uint(acc[nt][2 * i + 1])) | (~m0 & __float_as_uint(acc[nt][2 * i]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t4[i] = (m1 & t8[2 * i + 1]) | (~m1 & t8[2 * i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) t2[i] = (m2 & t4[2 * i + 1]) | (~m2 & t4[2 * i]);
+                const float v = __uint_as_float((m3 & t2[1]) | (~m3 & t2[0]));
+                const int r0 = (reg & 3) + 8 * (reg >> 2) + 4 * h;                  // the row of that register: lane r0 holds its inverse norm
+                const float iv = __shfl(inv_lane, r0);
                 if (take) {
                     const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                    const float sc = v * (h ? iv4 : iv);
-                    const u32 row = (u32)(t0 + r0 + 4 * h);
+                    const float sc = v * iv;
+                    const u32 row = (u32)(t0 + r0);
                     const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
                     if (slot < (u32)a.stage_cap) {
                         stage_ent[slot] = make_uint4(row, key, (u32)ql | (bin << 8), 1u);
