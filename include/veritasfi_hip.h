@@ -56,7 +56,7 @@ typedef struct vf_search_stats {
     int64_t wide_queries;    /* queries those passes served (up to 1024 per pass) */
     int64_t aux_cus;         /* CUs the main scan left to the small kernels of the other slots (0 = no CU split) */
     int64_t scans_overlap;   /* 1 = main scans of consecutive slots were not ordered against each other */
-    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide, 4 k_scan_wide8 (fp8 matrix instruction) */
+    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide, 4 k_scan_wide8 (fp8 matrix instruction), 5 k_scan2 on the fp8 matrix instruction */
     int64_t reserved[4];
 } vf_search_stats;
 

@@ -695,12 +695,13 @@ def test_scan_kernels_agree_on_fp8_rows(vf, oracle, n, d, nq, k, want_kernel):
     ix = vf.DenseIndex.from_e4m3(codes)
     try:
         ix.set_option("force_path", 1)
-        for impl in (3, 2, 1):                              # 3 = k_scan2 also for e4m3 rows (measured slower there: not the default)
+        for impl in (4, 3, 2, 1):                           # 4 = k_scan2 on the fp8 matrix instruction, 3 = k_scan2 with converted rows
             ix.set_option("scan_impl", impl)
             i, s_ = ix.search(q, k)
             st = ix.stats()
             assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), impl
-            assert st["path"] == 1 and st["exact_reruns"] == 0 and st["scan_kernel"] == (want_kernel if impl == 3 else 1), st
+            want = {4: 5 if want_kernel == 2 else 1, 3: want_kernel}.get(impl, 1)
+            assert st["path"] == 1 and st["exact_reruns"] <= (nq // 16 if impl == 4 else 0) and st["scan_kernel"] == want, (impl, st)
     finally:
         ix.close()
 
