@@ -1131,6 +1131,8 @@ def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
     (70_000, 1024, 256, 1000),     # large k
     (300_000, 1024, 1500, 100),    # two passes (1024 + 476), several super-tiles per row group
     (40_000, 256, 200, 5),         # 113 main rows per row group: less than one super-tile (clamped rows, NaN inverse norms)
+    (80_000, 512, 300, 2000),      # k close to the fused path's limit (k' = 3008, 4096-entry survivor area)
+    (50_000, 2048, 150, 1),        # dp = 2048: 32 K-tiles per super-tile; k = 1
 ])
 def test_wide_scan_fp8_matrix_instruction_bit_exact(vf, oracle, n, d, nq, k):
     """k_scan_wide8 (the default for e4m3 rows; index option wide_mfma = 0 selects the fp16 instruction): the e4m3 row bytes as the A operand of v_mfma_scale_f32_32x32x64_f8f6f4, the
