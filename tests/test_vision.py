@@ -72,7 +72,9 @@ def test_vision_tower_matches_clip_fp32(vf, shape):
     cos = float(np.min(np.sum(got * want, 1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))))
     print("vision tower", shape, "max err / max|embed|", err, "min cosine", cos)
     assert err < 6e-3 and cos > 0.9999          # fp16 operands and residual stream, fp32 accumulation: measured 1-2e-3
-    assert np.array_equal(again, got[: again.shape[0]])
+    # a smaller batch may take other product kernels (the dispatch follows the tile count: round 4 moved mid-size products to the
+    # 256 x 256 persistent kernel), i.e. another summation order: same rows to fp16 rounding, not to the bit
+    assert float(np.abs(again - got[: again.shape[0]]).max()) / scale < 3e-3
 
 
 @pytest.mark.gpu
@@ -186,7 +188,9 @@ def test_text_tower_matches_clip_fp32(vf, shape):
     cos = float(np.min(np.sum(got * want, 1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))))
     print("text tower", shape, "max err / max|embed|", err, "masked", err_m, "min cosine", cos)
     assert err < 6e-3 and err_m < 6e-3 and cos > 0.9999      # the vision tower's tolerances (fp16 operands and residual stream)
-    assert np.array_equal(again, got[: again.shape[0]])
+    # a smaller batch may take other product kernels (the dispatch follows the tile count: round 4 moved mid-size products to the
+    # 256 x 256 persistent kernel), i.e. another summation order: same rows to fp16 rounding, not to the bit
+    assert float(np.abs(again - got[: again.shape[0]]).max()) / scale < 3e-3
 
 
 class _WordTokenizer:

@@ -2919,6 +2919,7 @@ static hipError_t gemm_splitk(const half_t* A, const half_t* W, const float* bia
 }
 
 static long long p8_min_wgs();   // tiles from which the 8-phase kernel is the default (defined with the LnFold helpers)
+static bool p8_min_forced();     // the test hook vf_debug_gemm_8p_min_wgs has set that number: the same gate then applies to k_gemm9_tn
 static std::atomic<int> g_loop2{getenv("VF_GEMM_8P_LOOP2") ? atoi(getenv("VF_GEMM_8P_LOOP2")) : 1};   // default: the two-phase loop (round 3: 2-7 % on the products, 0.7-2 % on the forward)
 extern "C" int vf_debug_gemm_8p_loop2(int on) { return on >= 0 ? g_loop2.exchange(on ? 1 : 0) : g_loop2.load(); }   // A/B: two-phase main loop of k_gemm8p_tn
 static std::atomic<unsigned long long*> g_gemm9_dbg{nullptr};
@@ -3030,10 +3031,20 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         // tiles) keep the 8-phase kernel, whose split-K tail is worth more there than the persistent pipeline (391 vs 360 us at K = 4096).
         static const int p9 = getenv("VF_GEMM_9") ? atoi(getenv("VF_GEMM_9")) : 1;
         const int p9_now = g_gemm9.load(std::memory_order_relaxed) >= 0 ? g_gemm9.load(std::memory_order_relaxed) : p9;
-        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+        // Mid-size products (the per-rank batches of a data-parallel re-rank: 13 / 25 / 50 pairs x 512 tokens = 78 ... 1200 tiles): every
+        // kernel forced on every shape of the layer (tools/gpu_r04_midsize.sh, profiles/r04_midsize_kernels.log) -- the 256 x 256
+        // persistent kernel wins from ~128 tiles on, partial round or not: 12 800 x 768 x 3072 59.6 us against 89.8 (128 x 256 DMA kernel)
+        // and 94.4 (128 x 128), 0.91 x the vendor library; 6 656 x 2304 x 768 27.6 against 34.8 / 41.4.  Below that (78 tiles: out
+        // projection and FFN-down of a 13-pair batch) the small-tile kernels are level or ahead (62.8 vs 56.1 us inside the forward).
+        // The old gate (1.5 rounds of tiles, shared with the 8-phase kernel) left 10-50 % on mid-size batches.
+        static const long long p9_min = getenv("VF_GEMM_9_MIN_WGS") ? atoll(getenv("VF_GEMM_9_MIN_WGS")) : 128;
+        const long long tiles_ll = (long long)(M / PBM) * (N / PBN);
+        const bool p9_size = p8_min_forced() ? tiles_ll >= p8_min : tiles_ll >= p9_min;
+        if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && p9_size))) {
             const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7, nkt = K / PBK;
             const int G = tiles < ncu ? tiles : ncu;
-            if (kind == 10 || K < 2048 || tiles % G == 0) {
+            // long-K products of MORE than one round with a remainder keep the 8-phase kernel (split-K tail)
+            if (kind == 10 || K < 2048 || tiles % G == 0 || tiles <= ncu) {
                 // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
                 static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
                 const int ticks = tiles > ncu ? (int)((150ll * nkt + 200) * stg / 100) : 0;
@@ -3042,7 +3053,8 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
             }
         }
     }
-    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && (long long)(M / PBM) * (N / PBN) >= p8_min))) {
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && ((long long)(M / PBM) * (N / PBN) >= p8_min ||
+                                                                               (K >= 2048 && (long long)(M / PBM) * (N / PBN) > (device_cus() & ~7) && !p8_min_forced()))))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
         // Round 3: the tiles of the partial last round are cut along K instead (LnFold::sk_*): S slices per tail tile so that
@@ -3151,6 +3163,7 @@ extern "C" int vf_debug_ln_fold(int on) { return on >= 0 ? g_ln_fold.exchange(on
 // model exercises that path; forwards that took the folded path so far.
 extern "C" long long vf_debug_gemm_8p_min_wgs(long long v) { return g_p8_min_override.exchange(v); }
 extern "C" long long vf_debug_ln_fold_forwards() { return g_ln_fold_forwards.load(std::memory_order_relaxed); }
+static bool p8_min_forced() { return g_p8_min_override.load(std::memory_order_relaxed) >= 0; }
 static long long p8_min_wgs() {
     static const long long env = getenv("VF_GEMM_8P_MIN_WGS") ? atoll(getenv("VF_GEMM_8P_MIN_WGS")) : 384;
     const long long o = g_p8_min_override.load(std::memory_order_relaxed);
