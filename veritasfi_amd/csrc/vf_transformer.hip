@@ -3043,8 +3043,10 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && p9_size))) {
             const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7, nkt = K / PBK;
             const int G = tiles < ncu ? tiles : ncu;
-            // long-K products of MORE than one round with a remainder keep the 8-phase kernel (split-K tail)
-            if (kind == 10 || K < 2048 || tiles % G == 0 || tiles <= ncu) {
+            // long-K products of MORE than two rounds with a remainder keep the 8-phase kernel (split-K tail): 800 tiles at K = 4096 360 vs
+            // 391 us, 600 at K = 3072 231 vs 235; up to two rounds the persistent kernel is level or ahead (400 tiles at K = 4096: 178 vs
+            // 188 us; 300 at K = 3072: 131 vs 126; profiles/r04_midsize_kernels.log, r04_midsize_large.log)
+            if (kind == 10 || K < 2048 || tiles % G == 0 || tiles <= 2 * ncu) {
                 // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
                 static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
                 const int ticks = tiles > ncu ? (int)((150ll * nkt + 200) * stg / 100) : 0;
@@ -3054,7 +3056,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         }
     }
     if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && ((long long)(M / PBM) * (N / PBN) >= p8_min ||
-                                                                               (K >= 2048 && (long long)(M / PBM) * (N / PBN) > (device_cus() & ~7) && !p8_min_forced()))))) {
+                                                                               (K >= 2048 && (long long)(M / PBM) * (N / PBN) > 2 * (device_cus() & ~7) && !p8_min_forced()))))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
         // Round 3: the tiles of the partial last round are cut along K instead (LnFold::sk_*): S slices per tail tile so that
