@@ -683,12 +683,13 @@ static int select_path(const vf_index* ix, int k) {
 }
 
 // ---- wide passes (k_scan_wide): up to 1024 queries share ONE read of the shard --------------------------------------
-constexpr int kWideMinQueries = 129;   // below this the 64-query HBM-bound passes are faster (2 of them at most)
+constexpr int kWideMinQueries = 129;   // e4m3 rows: below this the 64-query HBM-bound passes are faster (2 of them at most)
+constexpr int kWideMinQueries16 = 65;  // fp16 (and fp32 -> fp16 scan copy) rows: TWO 64-query passes cost two reads of the shard (5.2 ms at 10M x 768), one wide pass 4.2-4.3 ms (round 4, profiles/r04_wide_threshold.log)
 constexpr int kWideMaxQueries = 1024;  // 4 query tiles of 256 per pass: one workgroup per CU
 constexpr int kWideTile = 256;
 
 static bool wide_possible(const vf_index* ix, int nq) {
-    if (ix->wide_opt == 0 || nq < (ix->wide_opt > 1 ? (int)ix->wide_opt : kWideMinQueries)) return false;
+    if (ix->wide_opt == 0 || nq < (ix->wide_opt > 1 ? (int)ix->wide_opt : (ix->dtype == VF_DTYPE_FP8_E4M3 ? kWideMinQueries : kWideMinQueries16))) return false;
     // a register stage is 2 k-chunks of fp8 rows / 1 of fp16 rows and a tile alternates two stages
     return ix->dp % (ix->dtype == VF_DTYPE_FP8_E4M3 ? 256 : 128) == 0;
 }
