@@ -349,6 +349,19 @@ def rerank_llm(args):
                     "(tokenizer stand-in, truncations, prompt), left padding, packed decoder forward, D2H of the logits"}
 
 
+def _c5_traffic(scan_kernel, rows, dim, nq, k):
+    """HBM bytes per launch of the wide scan from the committed rocprofv3 --pmc passes of exactly this workload (not re-measured here)."""
+    name = "pmc_traffic_scan_wide8_c5_10Mx1024.json" if scan_kernel == 4 else "pmc_traffic_scan_wide_c5_10Mx1024.json"
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        w = rec["workload"]
+        if (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (rows, dim, nq, k, 1):
+            return {"traffic": round(rec["hbm_bytes_per_launch"]), "traffic_source": f"profiles/{name} (separate --pmc passes, committed)"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"traffic": None}
+
+
 def c5_leg(args, torch, vf, device):
     """BASELINE configs[4] at full size on this GPU: 10M x 1024 e4m3 rows, 1024 queries per batch, top-1000 -- the wide scan on the
     instruction the config names (k_scan_wide8: v_mfma_scale_f32_32x32x64_f8f6f4).  Same loop as the headline: batches pipelined
@@ -386,7 +399,9 @@ def c5_leg(args, torch, vf, device):
                 "roofline": {"bound": "mfma", "kernel": {4: "vf::k_scan_wide8 (v_mfma_scale_f32_32x32x64_f8f6f4)", 3: "vf::k_scan_wide<main> (v_mfma_f32_32x32x16_f16)"}.get(st.get("scan_kernel"), "?"),
                              "avg_launch_ms": round(launch_ms, 3), "achieved": round(tf, 1), "unit": "TFLOP/s", "peak": 2500.0, "frac": round(tf / 2500.0, 4),
                              "frac_of_fp8_peak": round(tf / 5000.0, 4),
-                             "peak_note": "two MFMAs (hi + lo e4m3 query codes) per product: the useful rate is bounded by the fp16 figure"},
+                             "peak_note": "two MFMAs (hi + lo e4m3 query codes) per product: the useful rate is bounded by the fp16 figure",
+                             "flops_per_launch": 2.0 * nq * (prof["scan_bytes_per_launch"] // (dim + 4)) * dim,
+                             "algorithmic_bytes_per_launch": prof["scan_bytes_per_launch"], **_c5_traffic(st.get("scan_kernel"), rows, dim, nq, k)},
                 "search_stats": {"candidates_per_query": round(st["candidates"] / max(1, st["n_queries"]), 1), "exact_reruns_last_batch": st["exact_reruns"],
                                  "overflowed": st["overflowed"]},
                 "parity": "tests/test_gpu_retrieval.py::test_c5_10m_sharding_invariance_and_subset (this corpus, these queries: ids and score bits against the oracle)"}
