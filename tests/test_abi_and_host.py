@@ -216,3 +216,13 @@ def test_embed_loop_to_corpus_file(tmp_path):
     with pytest.raises(RuntimeError):
         cf.embed_to_file(str(tmp_path / "f.vfc"), texts, Failing(), batch_size=100)
     assert not os.path.exists(str(tmp_path / "f.vfc")), "a failed embed loop must not leave a truncated corpus file"
+
+
+def test_generated_asm_block_of_the_wide_scan_is_in_sync():
+    """k_scan_wide8's K-tile bodies are generated (tools/gen_w8_asm.py); the source carries the generator's output verbatim."""
+    import subprocess
+    src = open(os.path.join(ROOT, "veritasfi_amd", "csrc", "vf_kernels.hip")).read()
+    a = src.index("#define VF8_ASM_E0_A \\")
+    b = src.index("__global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {")
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_w8_asm.py")], capture_output=True, text=True, check=True).stdout
+    assert src[a:b].strip() == gen.strip()

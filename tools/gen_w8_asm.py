@@ -1,4 +1,6 @@
-# generates the four asm K-tile bodies of k_scan_wide8 (fixed registers)
+#!/usr/bin/env python3
+"""Generates the asm K-tile bodies of k_scan_wide8 (fixed registers; veritasfi_amd/csrc/vf_kernels.hip carries the output verbatim
+between '#define VF8_ASM_E0_A' and the kernel; tests/test_abi_and_host.py checks that they agree).  usage: gen_w8_asm.py > block.inc"""
 ACC = {(m, nt): f"v[{64*m+16*nt}:{64*m+16*nt+15}]" for m in range(2) for nt in range(4)}
 def slot(i):
     b = 128 + 16 * i
