@@ -1086,6 +1086,8 @@ def test_single_process_sharded_handle(vf, oracle, tmp_path):
 # ---- wide scan (k_scan_wide): more than 128 queries share one read of the shard ---------------------------------------
 @pytest.mark.parametrize("n,d,nq,k,kind", [
     (60_000, 768, 130, 100, "f16"),      # one 256-query tile, padded
+    (60_000, 768, 96, 100, "f16"),       # fp16 rows take the wide pass from 65 queries on (one read of the shard instead of two)
+    (60_000, 1024, 96, 100, "fp8"),      # ... e4m3 rows only from 129: two narrow passes
     (90_001, 1024, 700, 10, "fp8"),      # three tiles, ragged row count
     (50_000, 768, 1024, 100, "fp8"),     # four tiles (one workgroup per CU), fp8 rows with dp = 768
     (120_000, 256, 1500, 50, "f16"),     # two passes (1024 + 476)
@@ -1119,6 +1121,7 @@ def test_wide_scan_bit_exact(vf, oracle, n, d, nq, k, kind):
     assert st["path"] == 1 and st["overflowed"] == 0
     # vf_search_stats says which kernel served the call (bench.py picks its roofline from it, not from the batch size)
     takes_wide = (d + 127) // 128 * 128 % (256 if kind == "fp8" else 128) == 0
+    takes_wide = takes_wide and nq >= (129 if kind == "fp8" else 65)
     assert st["wide_launches"] == ((nq + 1023) // 1024 if takes_wide else 0) and st["wide_queries"] == (nq if takes_wide else 0)
     assert st64["wide_launches"] == 0 and st64["wide_queries"] == 0
     want_i, want_s = oracle.search(rows16, q, k)
