@@ -705,9 +705,9 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     const bool w8 = ix->wide_mfma != 0 && ix->dtype == VF_DTYPE_FP8_E4M3 && ix->dp % 64 == 0 &&
                     (ix->n / RG + 2 * 256) * (int64_t)ix->dp < (int64_t)0xFFFFFFFFll;
     if (w8) {
-        // the query's hi + lo split is good to ~2^-9 of the query's norm instead of fp16's 2^-11: the certificate needs the k-th score to
-        // clear the best row not re-scored by that much more, i.e. a deeper k' (and longer candidate lists)
-        if (ix->margin < 0) p.kprime = std::min((k + std::max(48, k / 2) + 31) / 32 * 32, 4096);
+        // the query's hi + lo split leaves ||delta|| ~ 6e-4 of the query's norm (eps_q ~ 1.1e-3 at dp = 1024 against the fp16 path's
+        // 6.1e-4): the plan's k' = k + k / 4 still clears it on ordinary data (the k -> k' gap is ~2.4e-3); a deeper k' (k + k / 2) was the
+        // first setting and cost 14 % more candidates for nothing (profiles/r04_wide8_kprime.log)
         if (p.kprime > 256) p.cap = 32768;
     }
     const int samp = J >= 2 ? 64 : 32;   // sample rows per row group = samp * 8: 32768 / 65536 rows in all
@@ -834,13 +834,8 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         return VF_OK;
     }
     // e4m3 rows on the fp8 matrix instruction (k_scan2<NT, 2>, scan_impl = 4): the query goes in as hi + lo e4m3 codes and its own
-    // residual is its certificate bound (as in k_scan_wide8), so k' is deeper
+    // residual is its certificate bound (as in k_scan_wide8)
     const bool n8 = ix->dtype == VF_DTYPE_FP8_E4M3 && ix->scan_impl == 4 && !ix->steal_opt && scan2_stage_cap(ix->dp, qn_tile_for(std::min(nq, bl)), 1) >= 256;
-    if (n8 && ix->margin < 0) {
-        p.kprime = std::min((k + std::max(48, k / 2) + 31) / 32 * 32, 4096);
-        while (p.cap < 4 * p.kprime && p.cap < 16384) p.cap <<= 1;
-        while (p.cap < 2 * p.kprime) p.cap <<= 1;
-    }
     if (n8) {
         VF_TRY(s.qimg8.ensure((size_t)ix->dp * kMaxBatch * 2));
         VF_TRY(s.epsq.ensure((size_t)kMaxBatch * sizeof(float)));
