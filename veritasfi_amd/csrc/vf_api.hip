@@ -141,7 +141,7 @@ struct vf_index {
     std::mutex mu;
     Slot slots[kSlots];
     // options
-    int64_t force_path = -1, sample_rows = 16, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
+    int64_t force_path = -1, sample_rows = -1, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
             refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = -1,
             aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
@@ -543,7 +543,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     const std::string s(name);
     auto in_range = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
     if (s == "force_path") { if (!in_range(-1, 2)) return fail(VF_EINVAL, "force_path must be -1 (auto), 0, 1 or 2"); ix->force_path = value; }
-    else if (s == "sample_rows") { if (!in_range(1, 64)) return fail(VF_EINVAL, "sample_rows must be in [1, 64]"); ix->sample_rows = value; }
+    else if (s == "sample_rows") { if (!in_range(-1, 64) || value == 0) return fail(VF_EINVAL, "sample_rows must be -1 (auto) or in [1, 64]"); ix->sample_rows = value; }
     else if (s == "margin") { if (!in_range(-1, 2048)) return fail(VF_EINVAL, "margin must be -1 (auto) or in [0, 2048]"); ix->margin = value; }
     else if (s == "cap") { if (!in_range(0, 16384)) return fail(VF_EINVAL, "cap must be in [0, 16384]"); ix->cap_opt = value; }
     else if (s == "waves") { if (!in_range(0, 8 * 1024)) return fail(VF_EINVAL, "waves must be in [0, 8192]"); ix->waves_opt = value; }
@@ -661,7 +661,13 @@ static FusedPlan make_plan(const vf_index* ix, int k) {
     if (ix->waves_opt > 0) wgs = std::max<int64_t>(1, ix->waves_opt / (kScanThreads / 64));
     p.grid = (int)wgs;
     p.total_waves = p.grid * (kScanThreads / 64);
-    p.samp = (int)std::max<int64_t>(1, ix->sample_rows);
+    // sample rows per wave of the sample pass.  Auto: 16, but 4 for shards of up to 1.1M rows -- there a batch's own chain (k_final of
+    // the slot's previous batch -> host turn-around -> prep -> sample pass -> seed -> main scan; two slots in flight) is longer than
+    // two scans, so a shorter sample pass shortens the step although the looser seed admits 1.7 x the candidates: configs[1]
+    // (1M x 768) 0.304 -> 0.290 ms per batch; from 1.25M rows on the step is the scan's and nothing changes, at 10M the larger
+    // candidate lists cost 1.7 % (profiles/r04_sample_rows_sweep.log)
+    // (only while the sample still holds 16 k' rows: a top-2048 search seeds its threshold from the k'-th best sample score)
+    p.samp = ix->sample_rows > 0 ? (int)ix->sample_rows : ((ix->n <= 1100000 && 4ll * p.total_waves >= 16ll * p.kprime) ? 4 : 16);
     // |approx - canonical| bound (DESIGN.md "Exactness certificate").  fp16 has an 11-bit significand, so
     // round-to-nearest moves an element by at most 2^-11 of its magnitude: rounding the normalised query moves the
     // dot product by <= 2^-11 * sum|q_j c_j| <= 2^-11 (Cauchy-Schwarz, both vectors of unit norm); rounding an fp32
