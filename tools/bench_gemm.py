@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--kind", default="0", help="comma list: 0 auto, 5 DMA 128x256 (16x16x32 MFMA), 1 DMA 128x256 (32x32x16), "
                                                 "2 256x256, 3 128x128, 7 8-phase 256x256")
+    ap.add_argument("--data", default="random", help="random | zeros | ones (operand bits toggle less: the MFMA draws less power, the clock stays up)")
     ap.add_argument("--epi", type=int, default=0, help="0 bias, 1 bias + GELU, 2 bias + residual")
     a = ap.parse_args()
     kinds = [int(x) for x in str(a.kind).split(",")]
@@ -44,6 +45,10 @@ def main():
         g = torch.Generator(device=dev).manual_seed(1)
         A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
         W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()
+        if a.data == "zeros":
+            A.zero_(); W.zero_()
+        elif a.data == "ones":
+            A.fill_(1.0); W.fill_(1.0 / 64)
         bias = torch.randn(N, device=dev, generator=g)
         R = torch.randn(M, N, device=dev, generator=g).half()
         C = torch.empty(M, N, device=dev, dtype=torch.float16)

@@ -2631,425 +2631,6 @@ static hipError_t gws_ensure(GemmWs& g);
 static void gws_free(GemmWs& g);
 
 // ------------------------------------------------------------------------------------------------
-// k_gemm10_tn (round 4, after k_scan_wide8): the persistent 256 x 256 product on v_mfma_f32_32x32x16_f16 with the recipe that
-// brought the wide scan to the pure matrix rate -- both operands by LDS-DMA into two 64-KB stages, ONE barrier per K-tile, a wave
-// owns 64 rows x 128 columns (2 x 4 accumulator tiles = 128 registers), 24 fragment reads and 32 MFMAs of 32 cycles per K-tile
-// (k_gemm9_tn: 64 of 16 cycles, two barriers).  Micro-benchmarks of this round say what the old loop is NOT bound by: LDS-DMA alone
-// pulls 90 GB/s per CU from L2 with this very access pattern (tools/ubench/dma_feed.hip; the loop needs 44), the LDS index unit is
-// 21 % busy, both fp16 matrix instructions sustain ~2.0 PF register-only (tools/ubench/mfma_rate16.hip) -- and yet the pipe is
-// 55 % busy: the loss is in the schedule.
-//   LDS: row r of a tile = 128 bytes, slot (16 B) of piece p = 8 r + (p ^ ((r >> 1) & 7)) (k_scan2's swizzle: a ds_read_b128 phase
-//   of 16 rows and one piece covers the 16 bank groups); DMA instruction I fills rows 8 I .. 8 I + 7.
-//   Operands SWAPPED (D = W_frag x A_frag) and the W rows of every 32-row group PERMUTED in LDS -- LDS row i holds W row
-//   (i & 3) | ((i >> 3) & 3) << 2 | ((i >> 2) & 1) << 4 -- so that lane (c, h) ends up with output row c and the 16 CONSECUTIVE columns
-//   16 h .. 16 h + 15 of the 32-column tile in its 16 accumulator registers: two 16-byte stores straight from the registers.
-// ------------------------------------------------------------------------------------------------
-constexpr int XSTAGE = 65536, XLDS = 2 * XSTAGE + 2048;
-typedef int xi16v __attribute__((ext_vector_type(16)));
-typedef int xi8v __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void dma16x(unsigned long long ua, unsigned voff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(ua), "s"(lds_addr) : "memory");
-}
-
-// ---- the K-tile bodies in asm with FIXED registers (generated by tools/gen_gemm10_asm.py; do not edit by hand) -------------------
-//   F: K-tile 0 of a tile (nothing held back before it; its first k-step starts the sums with C = 0: accumulators are never cleared)
-//   E / O: even / odd K-tile in the middle (stage 0 / 1)      L: the tile's last K-tile (odd: NK is even; runs its own k-step 3)
-// Each body in two pieces: _A (the first held-back MFMAs, the reads of k-steps 0 and 1) right behind the barrier, then the wave's
-// eight DMA instructions for the next K-tile (C++ between the asm statements), then _B.
-#define VFX_ASM_F_A \
-    "ds_read_b128 v[128:131], %[pw0] offset:0\n\t" \
-    "ds_read_b128 v[132:135], %[pw0] offset:4096\n\t" \
-    "ds_read_b128 v[136:139], %[pw0] offset:8192\n\t" \
-    "ds_read_b128 v[140:143], %[pw0] offset:12288\n\t" \
-    "ds_read_b128 v[144:147], %[pa0] offset:0\n\t" \
-    "ds_read_b128 v[148:151], %[pa0] offset:4096\n\t" \
-    "ds_read_b128 v[152:155], %[pw1] offset:0\n\t" \
-    "ds_read_b128 v[156:159], %[pw1] offset:4096\n\t" \
-    "ds_read_b128 v[160:163], %[pw1] offset:8192\n\t" \
-    "ds_read_b128 v[164:167], %[pw1] offset:12288\n\t" \
-    "ds_read_b128 v[168:171], %[pa1] offset:0\n\t" \
-    "ds_read_b128 v[172:175], %[pa1] offset:4096\n\t"
-
-#define VFX_ASM_F_B \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[128:131], v[144:147], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[128:131], v[148:151], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[132:135], v[144:147], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[132:135], v[148:151], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[136:139], v[144:147], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[136:139], v[148:151], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[140:143], v[144:147], 0\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[140:143], v[148:151], 0\n\t" \
-    "ds_read_b128 v[176:179], %[pw2] offset:0\n\t" \
-    "ds_read_b128 v[180:183], %[pw2] offset:4096\n\t" \
-    "ds_read_b128 v[184:187], %[pw2] offset:8192\n\t" \
-    "ds_read_b128 v[188:191], %[pw2] offset:12288\n\t" \
-    "ds_read_b128 v[192:195], %[pa2] offset:0\n\t" \
-    "ds_read_b128 v[196:199], %[pa2] offset:4096\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[152:155], v[168:171], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[152:155], v[172:175], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[156:159], v[168:171], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[156:159], v[172:175], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[160:163], v[168:171], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[160:163], v[172:175], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[164:167], v[168:171], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[164:167], v[172:175], v[112:127]\n\t" \
-    "ds_read_b128 v[200:203], %[pw3] offset:0\n\t" \
-    "ds_read_b128 v[204:207], %[pw3] offset:4096\n\t" \
-    "ds_read_b128 v[208:211], %[pw3] offset:8192\n\t" \
-    "ds_read_b128 v[212:215], %[pw3] offset:12288\n\t" \
-    "ds_read_b128 v[216:219], %[pa3] offset:0\n\t" \
-    "ds_read_b128 v[220:223], %[pa3] offset:4096\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[176:179], v[192:195], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[176:179], v[196:199], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[180:183], v[192:195], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[180:183], v[196:199], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[184:187], v[192:195], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[184:187], v[196:199], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[188:191], v[192:195], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[188:191], v[196:199], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t"
-
-#define VFX_ASM_E_A \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[200:203], v[216:219], v[0:15]\n\t" \
-    "ds_read_b128 v[128:131], %[pw0] offset:0\n\t" \
-    "ds_read_b128 v[132:135], %[pw0] offset:4096\n\t" \
-    "ds_read_b128 v[136:139], %[pw0] offset:8192\n\t" \
-    "ds_read_b128 v[140:143], %[pw0] offset:12288\n\t" \
-    "ds_read_b128 v[144:147], %[pa0] offset:0\n\t" \
-    "ds_read_b128 v[148:151], %[pa0] offset:4096\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[200:203], v[220:223], v[16:31]\n\t" \
-    "ds_read_b128 v[152:155], %[pw1] offset:0\n\t" \
-    "ds_read_b128 v[156:159], %[pw1] offset:4096\n\t" \
-    "ds_read_b128 v[160:163], %[pw1] offset:8192\n\t" \
-    "ds_read_b128 v[164:167], %[pw1] offset:12288\n\t" \
-    "ds_read_b128 v[168:171], %[pa1] offset:0\n\t" \
-    "ds_read_b128 v[172:175], %[pa1] offset:4096\n\t"
-
-#define VFX_ASM_E_B \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[204:207], v[216:219], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[204:207], v[220:223], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[208:211], v[216:219], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[208:211], v[220:223], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[212:215], v[216:219], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[212:215], v[220:223], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[128:131], v[144:147], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[128:131], v[148:151], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[132:135], v[144:147], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[132:135], v[148:151], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[136:139], v[144:147], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[136:139], v[148:151], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[140:143], v[144:147], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[140:143], v[148:151], v[112:127]\n\t" \
-    "ds_read_b128 v[176:179], %[pw2] offset:0\n\t" \
-    "ds_read_b128 v[180:183], %[pw2] offset:4096\n\t" \
-    "ds_read_b128 v[184:187], %[pw2] offset:8192\n\t" \
-    "ds_read_b128 v[188:191], %[pw2] offset:12288\n\t" \
-    "ds_read_b128 v[192:195], %[pa2] offset:0\n\t" \
-    "ds_read_b128 v[196:199], %[pa2] offset:4096\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[152:155], v[168:171], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[152:155], v[172:175], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[156:159], v[168:171], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[156:159], v[172:175], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[160:163], v[168:171], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[160:163], v[172:175], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[164:167], v[168:171], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[164:167], v[172:175], v[112:127]\n\t" \
-    "ds_read_b128 v[200:203], %[pw3] offset:0\n\t" \
-    "ds_read_b128 v[204:207], %[pw3] offset:4096\n\t" \
-    "ds_read_b128 v[208:211], %[pw3] offset:8192\n\t" \
-    "ds_read_b128 v[212:215], %[pw3] offset:12288\n\t" \
-    "ds_read_b128 v[216:219], %[pa3] offset:0\n\t" \
-    "ds_read_b128 v[220:223], %[pa3] offset:4096\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[176:179], v[192:195], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[176:179], v[196:199], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[180:183], v[192:195], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[180:183], v[196:199], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[184:187], v[192:195], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[184:187], v[196:199], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[188:191], v[192:195], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[188:191], v[196:199], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t"
-
-#define VFX_ASM_O_A \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[200:203], v[216:219], v[0:15]\n\t" \
-    "ds_read_b128 v[128:131], %[pw0] offset:32768\n\t" \
-    "ds_read_b128 v[132:135], %[pw0] offset:36864\n\t" \
-    "ds_read_b128 v[136:139], %[pw0] offset:40960\n\t" \
-    "ds_read_b128 v[140:143], %[pw0] offset:45056\n\t" \
-    "ds_read_b128 v[144:147], %[pa0] offset:32768\n\t" \
-    "ds_read_b128 v[148:151], %[pa0] offset:36864\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[200:203], v[220:223], v[16:31]\n\t" \
-    "ds_read_b128 v[152:155], %[pw1] offset:32768\n\t" \
-    "ds_read_b128 v[156:159], %[pw1] offset:36864\n\t" \
-    "ds_read_b128 v[160:163], %[pw1] offset:40960\n\t" \
-    "ds_read_b128 v[164:167], %[pw1] offset:45056\n\t" \
-    "ds_read_b128 v[168:171], %[pa1] offset:32768\n\t" \
-    "ds_read_b128 v[172:175], %[pa1] offset:36864\n\t"
-
-#define VFX_ASM_O_B \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[204:207], v[216:219], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[204:207], v[220:223], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[208:211], v[216:219], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[208:211], v[220:223], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[212:215], v[216:219], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[212:215], v[220:223], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[128:131], v[144:147], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[128:131], v[148:151], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[132:135], v[144:147], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[132:135], v[148:151], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[136:139], v[144:147], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[136:139], v[148:151], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[140:143], v[144:147], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[140:143], v[148:151], v[112:127]\n\t" \
-    "ds_read_b128 v[176:179], %[pw2] offset:32768\n\t" \
-    "ds_read_b128 v[180:183], %[pw2] offset:36864\n\t" \
-    "ds_read_b128 v[184:187], %[pw2] offset:40960\n\t" \
-    "ds_read_b128 v[188:191], %[pw2] offset:45056\n\t" \
-    "ds_read_b128 v[192:195], %[pa2] offset:32768\n\t" \
-    "ds_read_b128 v[196:199], %[pa2] offset:36864\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[152:155], v[168:171], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[152:155], v[172:175], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[156:159], v[168:171], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[156:159], v[172:175], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[160:163], v[168:171], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[160:163], v[172:175], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[164:167], v[168:171], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[164:167], v[172:175], v[112:127]\n\t" \
-    "ds_read_b128 v[200:203], %[pw3] offset:32768\n\t" \
-    "ds_read_b128 v[204:207], %[pw3] offset:36864\n\t" \
-    "ds_read_b128 v[208:211], %[pw3] offset:40960\n\t" \
-    "ds_read_b128 v[212:215], %[pw3] offset:45056\n\t" \
-    "ds_read_b128 v[216:219], %[pa3] offset:32768\n\t" \
-    "ds_read_b128 v[220:223], %[pa3] offset:36864\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[176:179], v[192:195], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[176:179], v[196:199], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[180:183], v[192:195], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[180:183], v[196:199], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[184:187], v[192:195], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[184:187], v[196:199], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[188:191], v[192:195], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[188:191], v[196:199], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t"
-
-#define VFX_ASM_L_A \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[200:203], v[216:219], v[0:15]\n\t" \
-    "ds_read_b128 v[128:131], %[pw0] offset:32768\n\t" \
-    "ds_read_b128 v[132:135], %[pw0] offset:36864\n\t" \
-    "ds_read_b128 v[136:139], %[pw0] offset:40960\n\t" \
-    "ds_read_b128 v[140:143], %[pw0] offset:45056\n\t" \
-    "ds_read_b128 v[144:147], %[pa0] offset:32768\n\t" \
-    "ds_read_b128 v[148:151], %[pa0] offset:36864\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[200:203], v[220:223], v[16:31]\n\t" \
-    "ds_read_b128 v[152:155], %[pw1] offset:32768\n\t" \
-    "ds_read_b128 v[156:159], %[pw1] offset:36864\n\t" \
-    "ds_read_b128 v[160:163], %[pw1] offset:40960\n\t" \
-    "ds_read_b128 v[164:167], %[pw1] offset:45056\n\t" \
-    "ds_read_b128 v[168:171], %[pa1] offset:32768\n\t" \
-    "ds_read_b128 v[172:175], %[pa1] offset:36864\n\t"
-
-#define VFX_ASM_L_B \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[204:207], v[216:219], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[204:207], v[220:223], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[208:211], v[216:219], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[208:211], v[220:223], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[212:215], v[216:219], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[212:215], v[220:223], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[128:131], v[144:147], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[128:131], v[148:151], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[132:135], v[144:147], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[132:135], v[148:151], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[136:139], v[144:147], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[136:139], v[148:151], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[140:143], v[144:147], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[140:143], v[148:151], v[112:127]\n\t" \
-    "ds_read_b128 v[176:179], %[pw2] offset:32768\n\t" \
-    "ds_read_b128 v[180:183], %[pw2] offset:36864\n\t" \
-    "ds_read_b128 v[184:187], %[pw2] offset:40960\n\t" \
-    "ds_read_b128 v[188:191], %[pw2] offset:45056\n\t" \
-    "ds_read_b128 v[192:195], %[pa2] offset:32768\n\t" \
-    "ds_read_b128 v[196:199], %[pa2] offset:36864\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[152:155], v[168:171], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[152:155], v[172:175], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[156:159], v[168:171], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[156:159], v[172:175], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[160:163], v[168:171], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[160:163], v[172:175], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[164:167], v[168:171], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[164:167], v[172:175], v[112:127]\n\t" \
-    "ds_read_b128 v[200:203], %[pw3] offset:32768\n\t" \
-    "ds_read_b128 v[204:207], %[pw3] offset:36864\n\t" \
-    "ds_read_b128 v[208:211], %[pw3] offset:40960\n\t" \
-    "ds_read_b128 v[212:215], %[pw3] offset:45056\n\t" \
-    "ds_read_b128 v[216:219], %[pa3] offset:32768\n\t" \
-    "ds_read_b128 v[220:223], %[pa3] offset:36864\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[176:179], v[192:195], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[176:179], v[196:199], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[180:183], v[192:195], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[180:183], v[196:199], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[184:187], v[192:195], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[184:187], v[196:199], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[188:191], v[192:195], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[188:191], v[196:199], v[112:127]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[0:15], v[200:203], v[216:219], v[0:15]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[16:31], v[200:203], v[220:223], v[16:31]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[32:47], v[204:207], v[216:219], v[32:47]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[48:63], v[204:207], v[220:223], v[48:63]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[64:79], v[208:211], v[216:219], v[64:79]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[80:95], v[208:211], v[220:223], v[80:95]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[96:111], v[212:215], v[216:219], v[96:111]\n\t" \
-    "v_mfma_f32_32x32x16_f16 v[112:127], v[212:215], v[220:223], v[112:127]\n\t" \
-    "s_nop 15\n\t" \
-    "s_nop 15\n\t" \
-    "s_nop 15\n\t" \
-    "s_nop 15\n\t" \
-    "s_nop 15\n\t"
-
-
-template <int EPI>
-__global__ __launch_bounds__(PTHREADS) void k_gemm10_tn(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
-                                                        const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [A stage 0 | A stage 1 | W stage 0 | W stage 1] x 32 KB, bias
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5, wr = wid >> 1, wc = wid & 1;
-    const int Mt = M / PBM, Nt = N / PBN, ntiles = Mt * Nt, NK = K / PBK;   // NK even, >= 4 (the host checks)
-    const int G_ = (int)gridDim.x, wg = (int)blockIdx.x;
-    const int n_own = wg < ntiles ? (ntiles - wg + G_ - 1) / G_ : 0;
-    if (n_own == 0) return;
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-    // DMA duties per K-tile: rows 32 wid .. + 31 of the A tile and LDS rows 32 wid .. + 31 of the W tile (four instructions each)
-    unsigned voffA[4], voffW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wid * 32 + i * 8 + (lane >> 3);
-        const unsigned piece = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
-        const int li = row & 31, wrow = (row & ~31) + ((li & 3) | (((li >> 3) & 3) << 2) | (((li >> 2) & 1) << 4));
-        voffA[i] = (unsigned)row * (unsigned)K * 2u + piece;
-        voffW[i] = (unsigned)wrow * (unsigned)K * 2u + piece;
-    }
-    auto issue = [&](int mt, int nt, int kt, int stage) {
-        const unsigned long long ua = (unsigned long long)(A + (size_t)mt * PBM * K) + (unsigned long long)kt * 128ull;
-        const unsigned long long uw = (unsigned long long)(W + (size_t)nt * PBN * K) + (unsigned long long)kt * 128ull;
-        const unsigned sb = lds0 + (unsigned)stage * 32768u + (unsigned)wid * 4096u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dma16x(ua, voffA[i], sb + i * 1024u);
-            dma16x(uw, voffW[i], sb + 65536u + i * 1024u);
-        }
-    };
-    // fragment addresses: one register per (operand, k-step); the swizzle term of a row depends on c only
-    const unsigned sw = (unsigned)((c >> 1) & 7);
-    unsigned pa[4], pw[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned po = (unsigned)(((2 * ks + h) ^ sw) << 4);
-        pa[ks] = lds0 + (unsigned)((wr * 64 + c) * 128) + po;
-        pw[ks] = lds0 + 65536u + (unsigned)((wc * 128 + c) * 128) + po;
-    }
-    f16v acc[4][2];   // [ni][mi]: pinned to v[(2 ni + mi) 16 ..] by the asm statements
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.f;
-    xi16v f0w, f1w, f2w, f3w;
-    xi8v f0a, f1a, f2a, f3a;
-#define VFX_ACC "+{v[0:15]}"(acc[0][0]), "+{v[16:31]}"(acc[0][1]), "+{v[32:47]}"(acc[1][0]), "+{v[48:63]}"(acc[1][1]),              \
-                "+{v[64:79]}"(acc[2][0]), "+{v[80:95]}"(acc[2][1]), "+{v[96:111]}"(acc[3][0]), "+{v[112:127]}"(acc[3][1])
-#define VFX_SL_OUT "=&{v[128:143]}"(f0w), "=&{v[144:151]}"(f0a), "=&{v[152:167]}"(f1w), "=&{v[168:175]}"(f1a),                        \
-                   "=&{v[176:191]}"(f2w), "=&{v[192:199]}"(f2a), "=&{v[200:215]}"(f3w), "=&{v[216:223]}"(f3a)
-#define VFX_SL_IO "+{v[128:143]}"(f0w), "+{v[144:151]}"(f0a), "+{v[152:167]}"(f1w), "+{v[168:175]}"(f1a),                             \
-                  "+{v[176:191]}"(f2w), "+{v[192:199]}"(f2a), "+{v[200:215]}"(f3w), "+{v[216:223]}"(f3a)
-#define VFX_IN [pa0] "v"(pa[0]), [pa1] "v"(pa[1]), [pa2] "v"(pa[2]), [pa3] "v"(pa[3]), [pw0] "v"(pw[0]), [pw1] "v"(pw[1]), [pw2] "v"(pw[2]), [pw3] "v"(pw[3])
-#define VFX_TOP()                                                                                                                     \
-    do {                                                                                                                              \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's DMAs of the K-tile have landed (and its stores have left) */ \
-        __syncthreads();                                   /* ... everyone's; and every wave is done reading the other stage */       \
-    } while (0)
-#define VFX_TILE(NAME, OUTS, ISSUE)                                                                                                   \
-    do {                                                                                                                              \
-        VFX_TOP();                                                                                                                    \
-        asm volatile(NAME##_A : VFX_ACC, OUTS : VFX_IN : "memory");                                                                   \
-        ISSUE;                                                                                                                        \
-        asm volatile(NAME##_B : VFX_ACC, VFX_SL_IO : VFX_IN : "memory");                                                              \
-    } while (0)
-    int mt, nt;
-    q_tile_of(wg, Mt, Nt, mt, nt);
-    issue(mt, nt, 0, 0);
-    float* bias_l = (float*)(smem + 2 * XSTAGE);
-    for (int it = 0; it < n_own; ++it) {
-        int mt_n = mt, nt_n = nt;
-        if (it + 1 < n_own) q_tile_of(wg + (it + 1) * G_, Mt, Nt, mt_n, nt_n);
-        VFX_TILE(VFX_ASM_F, VFX_SL_OUT, issue(mt, nt, 1, 1));
-        VFX_TILE(VFX_ASM_O, VFX_SL_IO, issue(mt, nt, 2, 0));
-        for (int kt = 2; kt < NK - 2; kt += 2) {
-            VFX_TILE(VFX_ASM_E, VFX_SL_IO, issue(mt, nt, kt + 1, 1));
-            VFX_TILE(VFX_ASM_O, VFX_SL_IO, issue(mt, nt, kt + 2, 0));
-        }
-        VFX_TILE(VFX_ASM_E, VFX_SL_IO, issue(mt, nt, NK - 1, 1));
-        VFX_TILE(VFX_ASM_L, VFX_SL_IO, if (it + 1 < n_own) issue(mt_n, nt_n, 0, 0));
-        // ---- epilogue, straight from the registers: lane (c, h) of tile (ni, mi) holds row 64 wr + 32 mi + c, columns 128 wc + 32 ni + 16 h + r
-        if (bias) {   // the tile's 256 bias values through LDS (every wave needs 128 of them)
-            __syncthreads();
-            if (tid < 256) bias_l[tid] = bias[(size_t)nt * PBN + tid];
-            __syncthreads();
-        }
-        const long long row0 = (long long)mt * PBM + wr * 64 + c;
-        const int col0 = nt * PBN + wc * 128 + 16 * h;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            float bv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) bv[e] = bias ? bias_l[wc * 128 + ni * 32 + 16 * h + e] : 0.f;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const long long off = (row0 + mi * 32) * N + col0 + ni * 32;
-                h8 o0, o1;
-                h8 r0, r1;
-                if (EPI == EPI_BIAS_RESIDUAL) { r0 = *(const h8*)(R + off); r1 = *(const h8*)(R + off + 8); }
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    f2v v = {acc[ni][mi][e] + bv[e], acc[ni][mi][e + 1] + bv[e + 1]};
-                    if (EPI == EPI_BIAS_GELU) v = gelu_erf2(v);
-                    if (EPI == EPI_BIAS_QGELU) v = quick_gelu2(v);
-                    if (EPI == EPI_BIAS_RESIDUAL) {
-                        // fp16(acc + bias) first, then + R in fp32: the rounding points of the other product kernels
-                        const half_t t0 = (half_t)v[0], t1 = (half_t)v[1];
-                        v[0] = (float)t0 + (float)(e < 8 ? r0[e] : r1[e - 8]);
-                        v[1] = (float)t1 + (float)(e < 8 ? r0[e + 1] : r1[e - 7]);
-                    }
-                    if (e < 8) { o0[e] = (half_t)v[0]; o0[e + 1] = (half_t)v[1]; } else { o1[e - 8] = (half_t)v[0]; o1[e - 7] = (half_t)v[1]; }
-                }
-                *(h8*)(C + off) = o0;
-                *(h8*)(C + off + 8) = o1;
-            }
-        }
-        mt = mt_n; nt = nt_n;
-    }
-#undef VFX_TILE
-#undef VFX_TOP
-#undef VFX_IN
-#undef VFX_SL_IO
-#undef VFX_SL_OUT
-#undef VFX_ACC
-}
-
 // Opt every kernel into its dynamic LDS size (idempotent; cheap).
 // The library holds ONE kernel per operation and shape class.  The measured-and-rejected kernels of rounds 1-3 (k_gemm256_tn,
 // k_gemm_dma_tn with 32x32x16 MFMAs, the 128-wide DMA instance, the four-wave k_gemm4w_tn, the persistent k_gemm8q_tn, the all-layers
@@ -3069,10 +2650,6 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm10_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm10_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm10_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm10_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
@@ -3461,11 +3038,6 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         // and 94.4 (128 x 128), 0.91 x the vendor library; 6 656 x 2304 x 768 27.6 against 34.8 / 41.4.  Below that (78 tiles: out
         // projection and FFN-down of a 13-pair batch) the small-tile kernels are level or ahead (62.8 vs 56.1 us inside the forward).
         // The old gate (1.5 rounds of tiles, shared with the 8-phase kernel) left 10-50 % on mid-size batches.
-        if (kind == 11 && big_ok && K % (2 * PBK) == 0 && K >= 4 * PBK) {   // test hook: k_gemm10_tn
-            const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7;
-            hipLaunchKernelGGL(k_gemm10_tn<EPI>, dim3(tiles < ncu ? tiles : ncu), dim3(PTHREADS), XLDS, st, A, W, bias, R, C, M, N, K);
-            return hipGetLastError();
-        }
         static const long long p9_min = getenv("VF_GEMM_9_MIN_WGS") ? atoll(getenv("VF_GEMM_9_MIN_WGS")) : 128;
         const long long tiles_ll = (long long)(M / PBM) * (N / PBN);
         const bool p9_size = p8_min_forced() ? tiles_ll >= p8_min : tiles_ll >= p9_min;
@@ -4850,9 +4422,9 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     if (M % 128 || N % 128 || K % 64) return -2;
     if ((kind == 1 || kind == 5) && (M % DBM || N % DBN)) return -2;
     if (kind == 6 && (M % DBM || N % 128)) return -2;
-    if ((kind == 2 || kind == 7 || kind == 8 || kind == 10 || kind == 11) && (M % LBM || N % LBN)) return -2;
+    if ((kind == 2 || kind == 7 || kind == 8 || kind == 10) && (M % LBM || N % LBN)) return -2;
     if ((kind == 7 || kind == 8) && K < 128) return -2;
-    if ((kind == 10 || kind == 11) && (K < 256 || (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_QGELU && epi != EPI_BIAS_RESIDUAL))) return -2;
+    if (kind == 10 && (K < 256 || (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_QGELU && epi != EPI_BIAS_RESIDUAL))) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
     half_t* c = (half_t*)C;
