@@ -1209,3 +1209,26 @@ def test_wide_scan_hostile_data(vf, oracle):
             st = ix.stats()
         print("wide hostile stats", st)
         _assert_exact(oracle, corpus, q, 100, ids, sc)
+
+
+# ---- differential fuzz across the dispatch boundaries ------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_fuzz_across_dispatch_boundaries_bit_exact(vf, oracle):
+    """tools/fuzz_search.py for 45 s on a fixed seed: random rows / dim / queries / k / dtype / data shape / options drawn to sit on
+    the dispatch boundaries, every result compared bit for bit with the oracle (a 330-s run: profiles/r04_fuzz_seed1.log)."""
+    import importlib.util, time
+    spec = importlib.util.spec_from_file_location("fuzz_search", os.path.join(ROOT, "tools", "fuzz_search.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(20260404)
+    t0, n_cases, fails, kernels = time.time(), 0, [], set()
+    while time.time() - t0 < 45.0:
+        case = fz.draw_case(rng, 1e10)
+        ok, st, why = fz.run_case(vf, oracle, case)
+        n_cases += 1
+        kernels.add((st.get("path"), st.get("scan_kernel")))
+        if not ok:
+            fails.append((case, why, st))
+    print("fuzz:", n_cases, "cases; (path, scan kernel) seen:", sorted(kernels, key=str))
+    assert not fails, fails[:3]
+    assert n_cases >= 40 and len(kernels) >= 4

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Differential fuzz of vf_index_search against the CPU oracle: random (rows, dim, queries, k, dtype, data shape, options)
+drawn to sit ON the dispatch boundaries (dense path <= 16384 rows, narrow / wide pass at 65 / 129 queries, 64-multiples
+of dim for the fp8 instruction, k around the row count, sample rows 4 / 16), every result compared bit for bit
+(ids and score bits) with oracle.canonical.  Test infrastructure: the oracle is the checker, never the thing measured.
+
+    python tools/fuzz_search.py --seconds 240 --seed 1 [--max-work 2e10]
+
+Prints one line per case that FAILS (with the arguments to reproduce it) and a summary; exit code 1 on any failure."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def draw_case(rng, max_work):
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    dtype = pick(["f32", "f16", "f16", "fp8", "fp8"])
+    d = pick([1, 7, 16, 33, 64, 100, 128, 200, 256, 384, 512, 768, 768, 1000, 1024, 1024, 1536, 2048, int(rng.integers(1, 2049))])
+    nq = pick([1, 1, 2, 3, 8, 31, 63, 64, 65, 66, 100, 127, 128, 129, 130, 200, 256, 257, 300, int(rng.integers(1, 400))])
+    n_edges = [1, 2, 15, 255, 256, 257, 1000, 16383, 16384, 16385, 16640, 20000, 32768, 40000, 65536, 70001, 131072, 200000, 300000]
+    n = pick(n_edges + [int(np.exp(rng.uniform(0, np.log(400000))))] * 6)
+    while float(n) * nq * d > max_work and n > 17000:
+        n = max(17000, n // 2)
+    while float(n) * nq * d > max_work and nq > 1:
+        nq = max(1, nq // 2)
+    k = pick([1, 2, 10, 100, 100, 128, 500, 1000, 1000, 2048, n, n + 3, max(1, n - 1), int(rng.integers(1, 2049))])
+    k = max(1, min(k, 2048))
+    data = pick(["normal", "normal", "dupes", "clusters", "scaled", "zeros", "sorted", "lowrank"])
+    opts = {}
+    if rng.random() < 0.3:
+        opts["scan_impl"] = pick([1, 2, 3, 4])
+    if rng.random() < 0.2:
+        opts["wide_mfma"] = pick([0, 1])
+    if rng.random() < 0.2:
+        opts["sample_rows"] = pick([1, 4, 16, 64])
+    return dict(dtype=dtype, d=int(d), nq=int(nq), n=int(n), k=int(k), data=data, opts=opts, seed=int(rng.integers(1 << 31)))
+
+
+def make_data(case):
+    rng = np.random.default_rng(case["seed"])
+    n, d, nq, data = case["n"], case["d"], case["nq"], case["data"]
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    c = rng.standard_normal((n, d)).astype(np.float32)
+    if data == "dupes" and n >= 4:          # exact duplicate rows: ties broken by id
+        src = rng.integers(0, n, max(1, n // 3))
+        dst = rng.integers(0, n, src.size)
+        c[dst] = c[src]
+    elif data == "clusters":                # many rows near a few queries: dense candidate lists, stage flushes
+        m = max(1, min(n, 600))
+        who = rng.integers(0, nq, m)
+        c[rng.choice(n, m, replace=False)] = q[who] + 0.05 * rng.standard_normal((m, d)).astype(np.float32)
+    elif data == "scaled":                  # rows of very different norms (cosine must not care)
+        c *= np.exp(rng.uniform(-6, 6, (n, 1))).astype(np.float32)
+    elif data == "zeros":                   # zero rows and a zero query: score 0 by convention
+        c[rng.integers(0, n, max(1, n // 50))] = 0.0
+        q[rng.integers(0, nq)] = 0.0
+    elif data == "lowrank":                 # everything in a 3-dimensional subspace: near-ties everywhere
+        r = min(3, d)
+        basis = rng.standard_normal((r, d)).astype(np.float32)
+        c = (rng.standard_normal((n, r)).astype(np.float32) @ basis).astype(np.float32)
+    if case["dtype"] == "fp8":
+        import torch
+        from oracle import ref_numpy as R
+        s = 0.5 if data != "scaled" else 1.0
+        x = torch.from_numpy(np.clip(c * s, -400, 400))
+        codes = x.to(torch.float8_e4m3fn).view(torch.uint8).numpy().copy()
+        rows = R.decode_e4m3(codes).astype(np.float16)     # exact: the decoded values ARE the corpus
+        return codes, rows, q
+    if case["dtype"] == "f16":
+        c = np.clip(c, -60000, 60000).astype(np.float16)
+    return None, c, q
+
+
+def run_case(vf, oracle, case):
+    codes, rows, q = make_data(case)
+    if case["data"] == "sorted":            # score-sorted corpus (ascending for query 0): thresholds rise all the way through
+        sims = oracle.cosine(q[:1], rows.astype(np.float32))[0]
+        order = np.argsort(sims, kind="stable")
+        rows = np.ascontiguousarray(rows[order])
+        if codes is not None:
+            codes = np.ascontiguousarray(codes[order])
+    ix = vf.DenseIndex.from_e4m3(codes) if codes is not None else vf.DenseIndex(rows)
+    try:
+        for key, val in case["opts"].items():
+            try:
+                ix.set_option(key, val)
+            except RuntimeError:
+                pass                        # an option the shape does not admit: the default stays
+        ids, sc = ix.search(q, case["k"])
+        st = ix.stats()
+    finally:
+        ix.close()
+    oi, os_ = oracle.search(rows, q, case["k"])
+    ok = np.array_equal(oi, ids) and np.array_equal(os_.view(np.uint32), sc.view(np.uint32))
+    why = None
+    if not ok:
+        badq = np.nonzero((oi != ids).any(axis=1) | (os_.view(np.uint32) != sc.view(np.uint32)).any(axis=1))[0]
+        why = {"queries": badq[:6].tolist(), "n_bad": int(badq.size)}
+        b = int(badq[0])
+        j = int(np.nonzero((oi[b] != ids[b]) | (os_[b].view(np.uint32) != sc[b].view(np.uint32)))[0][0])
+        why["first"] = {"rank": j, "got": [int(ids[b, j]), float(sc[b, j])], "want": [int(oi[b, j]), float(os_[b, j])]}
+    return ok, st, why
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-work", type=float, default=2e10, help="cap on rows x queries x dim per case (the oracle's cost)")
+    ap.add_argument("--case", default=None, help="JSON of one case to re-run")
+    a = ap.parse_args()
+    import veritasfi_amd as vf
+    from veritasfi_amd import _ffi
+    _ffi.lib()
+    from oracle import canonical
+    canonical.build()
+    if a.case:
+        case = json.loads(a.case)
+        ok, st, why = run_case(vf, canonical, case)
+        print("OK" if ok else "FAIL", json.dumps(case), st, why)
+        return 0 if ok else 1
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    n_cases = n_fail = 0
+    paths = {}
+    while time.time() - t0 < a.seconds:
+        case = draw_case(rng, a.max_work)
+        try:
+            ok, st, why = run_case(vf, canonical, case)
+        except Exception as e:   # noqa: BLE001 -- a fuzz driver reports everything
+            ok, st, why = False, {}, {"exception": repr(e)}
+        n_cases += 1
+        key = (st.get("path"), st.get("scan_kernel"), case["dtype"])
+        paths[key] = paths.get(key, 0) + 1
+        if st.get("exact_reruns"):
+            paths[("exact_reruns",)] = paths.get(("exact_reruns",), 0) + 1
+        if not ok:
+            n_fail += 1
+            print("FAIL", json.dumps(case), why, st, flush=True)
+        if n_cases % 25 == 0:
+            print(f"... {n_cases} cases, {n_fail} failures, {time.time() - t0:.0f} s", flush=True)
+    print(json.dumps({"cases": n_cases, "failures": n_fail, "seconds": round(time.time() - t0, 1), "seed": a.seed,
+                      "by_path_kernel_dtype": {str(k): v for k, v in sorted(paths.items(), key=str)}}))
+    return 1 if n_fail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
