@@ -337,11 +337,13 @@ def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):
     (25600, 768, 320, 1, 2),       # 5 K-tiles: slices of 2 and 3 K-tiles, GELU epilogue
     (6656, 768, 3072, 2, 3),       # less than one round (13 x 512 tokens, 78 tiles): EVERY tile is cut, in 3; the sliced grid is padded to 80 tiles
     (3328, 1024, 1024, 0, 4),      # 52 tiles (padded to 56), cut in 4
+    (6656, 1024, 4096, 2, 2),      # 104 tiles, K = 4096: the shape the dispatch cuts whole BY DEFAULT (FFN-down of 13 x 512 tokens, 1024 wide)
 ])
 def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, want_S):
-    """The tiles of the 8-phase kernel's partial last round are cut along K (one workgroup per slice, fp32 partials handed
-    over through write-through stores, the last arrival adds them in slice order): against torch fp32, against the same
-    product without the split, and twice -- the result must not depend on which slice arrives last."""
+    """The tiles of the 8-phase kernel's partial last round are cut along K (one workgroup per slice; every slice hands the 16-row
+    blocks it does not own over as fp32 partials through write-through stores, waits for the others and finishes ITS blocks, adding
+    the partials in slice order): against torch fp32, against the same product without the split, and twice -- the result must
+    not depend on the order in which the slices arrive.  A long-K product of less than half a round takes this form by default."""
     import ctypes
     import torch
     from veritasfi_amd import _ffi
@@ -361,10 +363,10 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
     bias = torch.randn(N, device=dev, generator=g) * 0.1
     R = (torch.randn(M, N, device=dev, generator=g)).half()
 
-    def run():
+    def run(kind=7):
         C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
         rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), R.data_ptr(), C.data_ptr(), M, N, K, epi,
-                             torch.cuda.current_stream().cuda_stream, 7)
+                             torch.cuda.current_stream().cuda_stream, kind)
         assert rc == 0
         torch.cuda.synchronize()
         return C
@@ -381,10 +383,16 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
         c0 = run()
     finally:
         L.vf_debug_splitk_tail(was)
-    # every cut tile is summed by exactly one workgroup per launch; the slices of a tile share an XCD (dispatch indices
+    counted = (stats[0], stats[1])
+    if K >= 4096 and 2 * ((tiles + 7) // 8 * 8) <= cus:     # the dispatch's own choice for this shape is the same cut
+        L.vf_debug_splitk_stats(stats, -1)
+        c_auto = run(0)
+        assert L.vf_debug_splitk_stats(stats, -1) == 1 and stats[0] + stats[1] == ntail
+        assert torch.equal(c_auto, c1)
+    # every cut tile is counted once per launch; the slices of a tile share an XCD (dispatch indices
     # congruent modulo 8), so the read-back normally goes through that XCD's L2 -- either way the result is the same
-    print("split-K read-backs through L2 / from memory:", stats[0], stats[1])
-    assert stats[0] + stats[1] == 2 * ntail
+    print("split-K read-backs through L2 / from memory:", counted[0], counted[1])
+    assert counted[0] + counted[1] == 2 * ntail
     assert torch.equal(c1, c2), "the split-K tail is not deterministic"
     ref = A[-2048:].float() @ W.float().T + bias          # the tail tiles are the LAST dispatch indices: their rows are checked ...
     if epi == 1:

@@ -797,11 +797,13 @@ struct LnFold {
     // Split-K TAIL (independent of the fold; rides in this struct so that every launch site passes one extra argument): the
     // tiles of the partial last round -- dispatch indices >= sk_nfull -- are cut into sk_S slices along K, one workgroup each
     // (600 tiles on 256 CUs are 2.34 rounds of work in 3; with the 88 tail tiles cut in two the third round is 176 half-length
-    // workgroups).  A slice leaves its fp32 accumulators in sk_ws (write-through) and counts itself in sk_cnt[tile]; the last
-    // arrival adds the others' IN SLICE ORDER (deterministic), runs the epilogue and resets the counter.
+    // workgroups).  Co-operative finish (round 4): a slice leaves the 16-row blocks it does NOT own in sk_ws (write-through), counts
+    // itself in sk_cnt[tile], waits for the other slices and adds their partials of ITS blocks IN SLICE ORDER (deterministic), runs
+    // the epilogue on its rows; the last slice to finish reading resets the counters.  (Until round 4 the last arrival read all S
+    // partials back and finished the whole tile alone: 3 % slower on a 600-tile product, 10 % on a product cut whole.)
     // The slices of one tile sit at dispatch indices that are congruent modulo 8 -- one XCD under the round-robin placement
     // -- and every slice notes the XCD it really ran on (HW_REG_XCC_ID): when they all match the reader's, the partials are
-    // still in THAT L2 (the write-through stores went through it) and the read-back uses L1-bypassing loads that hit it;
+    // still in THAT L2 (the write-through stores went through it) and the read-backs use L1-bypassing loads that hit it;
     // otherwise it falls back to memory-side (sc1) loads.  Placement decides the speed, never the result.
     float* sk_ws;            // [tail tiles][sk_S][256 x 256] fp32
     unsigned* sk_cnt;        // [tail tiles][2]: arrivals, XCD mask; zero between launches
@@ -873,6 +875,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
     int mt_idx, nt_idx;
     int sk_tile = -1, sk_slice = 0;
+    int sk_lo = 0, sk_hi = 8;   // 16-row blocks (of both 128-row halves) whose rows THIS workgroup finishes and stores: all, or a co-operative slice's share
     {   // XCD-contiguous, n-major groups of 4 m-tiles
         const int Mt = M / PBM, Nt = N / PBN, nwg = Mt * Nt;
         int orig = blockIdx.x;
@@ -1063,64 +1066,118 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
     __syncthreads();
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
-        if (sk_tile >= 0) {   // split-K tail: leave the partial, count, and only the last arrival goes on to the epilogue
+        if (sk_tile >= 0) {
+            // Split-K, co-operative form (round 4).  The last-arrival form below makes ONE workgroup read S x 256 KB back (one CU pulls
+            // 50-60 GB/s: ~9 us per slice) while the others have already left.  Here every slice FINISHES its own share of the tile:
+            // slice s owns the 16-row blocks mi in [8 s / S, 8 (s + 1) / S) of both 128-row halves, leaves only the blocks it does not
+            // own in sk_ws ((S - 1) / S of a partial), waits until all S slices have done so, adds the others' partials of ITS blocks
+            // in slice order (its own term comes from the registers, at its place in the order: the sum is bit for bit the
+            // last-arrival form's) and runs the epilogue on its rows only.  Written and read bytes per slice: (S - 1) / S x 256 KB each.
+            // The wait cannot deadlock: the sliced workgroups are the LAST of the grid and at most one round of the CUs (the host
+            // checks), one workgroup fits a CU, and every workgroup ahead of them finishes without waiting for anybody.
             const sq_rsrc_t rw = sq_rsrc(lf.sk_ws);
-            const int S = lf.sk_S;
-            const int my = ((sk_tile * S + sk_slice) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
-            if (!(lf.sk_dbg & 1)) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have reached memory ...
-            __syncthreads();
+            const int S = lf.sk_S, me = sk_slice;
+            sk_lo = 8 * me / S; sk_hi = 8 * (me + 1) / S;
+            const int my = ((sk_tile * S + me) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
             unsigned* flag = (unsigned*)(smem + 8 * PSLOT);
-            if (tid == 0) {
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                xcc &= 15u;
-                const unsigned seen = __hip_atomic_fetch_or(lf.sk_cnt + 2 * sk_tile + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                flag[1] = (seen | (1u << xcc)) == (1u << xcc) ? 1u : 0u;   // (the returned value orders the two atomics)
-                flag[0] = __hip_atomic_fetch_add(lf.sk_cnt + 2 * sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
-            }
-            __syncthreads();
-            if (flag[0] != (unsigned)(S - 1)) return;
-            const bool same_xcd = flag[1] != 0u;   // the last arrival saw every slice's XCD: all its own
-            if (tid == 0) {                        // ready for the next launch
-                __hip_atomic_store(lf.sk_cnt + 2 * sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(lf.sk_cnt + 2 * sk_tile + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(lf.sk_stat + (same_xcd ? 0 : 1), 1u);
-            }
-            // slice order, whoever arrived last (its own partial is read back like the others): the sum does not depend on timing
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4v{0.f, 0.f, 0.f, 0.f};
-            for (int sl = 0; sl < ((lf.sk_dbg & 2) ? 0 : S); ++sl) {
-                const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
-                if (same_xcd) {   // sc0: past this CU's L1, into the L2 the slices' stores went through
+            auto coop = [&](auto LO, auto HI) {
+                constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+                if (!(lf.sk_dbg & 1)) {
 #pragma unroll
                     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) {
-                            const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 1));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[mi][ni][e] += v[e];
-                        }
-                } else {          // sc1: memory side
-#pragma unroll
-                    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) {
-                            const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[mi][ni][e] += v[e];
-                        }
+                        for (int ni = 0; ni < 4; ++ni)
+                            if (mi < lo || mi >= hi)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have reached memory ...
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    xcc &= 15u;
+                    (void)__hip_atomic_fetch_or(lf.sk_cnt + 2 * sk_tile + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_add(lf.sk_cnt + 2 * sk_tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+                    while (__hip_atomic_load(lf.sk_cnt + 2 * sk_tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) __builtin_amdgcn_s_sleep(4);
+                    const unsigned mask = __hip_atomic_load(lf.sk_cnt + 2 * sk_tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[1] = mask == (1u << xcc) ? 1u : 0u;   // every slice ran on this XCD: the partials are in ITS L2
+                }
+                __syncthreads();
+                const bool same_xcd = flag[1] != 0u;
+                // two blocks at a time (64 more registers beside the 128 accumulators; the whole share at once spilled)
+                auto reduce2 = [&](auto B0, auto NB) {
+                    constexpr int b0 = decltype(B0)::value, nb = decltype(NB)::value;
+                    f4v t[nb][4];
+#pragma unroll
+                    for (int m = 0; m < nb; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) t[m][ni] = f4v{0.f, 0.f, 0.f, 0.f};
+                    auto add_slice = [&](int sl) {
+                        const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
+                        f4v v[nb][4];
+                        if (same_xcd) {   // sc0: past this CU's L1, into the L2 the slices' stores went through
+#pragma unroll
+                            for (int m = 0; m < nb; ++m)
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni)
+                                    v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 1));
+                        } else {          // sc1: memory side
+#pragma unroll
+                            for (int m = 0; m < nb; ++m)
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni)
+                                    v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+                        }
+#pragma unroll
+                        for (int m = 0; m < nb; ++m)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) t[m][ni][e] += v[m][ni][e];
+                    };
+                    if (!(lf.sk_dbg & 2))
+                        for (int sl = 0; sl < me; ++sl) add_slice(sl);
+#pragma unroll
+                    for (int m = 0; m < nb; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[m][ni][e] += acc[b0 + m][ni][e];
+                    if (!(lf.sk_dbg & 2))
+                        for (int sl = me + 1; sl < S; ++sl) add_slice(sl);
+#pragma unroll
+                    for (int m = 0; m < nb; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[b0 + m][ni] = t[m][ni];
+                };
+                using std::integral_constant;
+                reduce2(integral_constant<int, lo>{}, integral_constant<int, (hi - lo >= 2 ? 2 : 1)>{});
+                if constexpr (hi - lo == 3) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 1>{});
+                if constexpr (hi - lo == 4) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 2>{});
+                // every slice counts a second time when it has read what it needs; the last of those leaves the counters at zero
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const unsigned done = __hip_atomic_fetch_add(lf.sk_cnt + 2 * sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (done == (unsigned)(2 * S - 1)) {
+                        __hip_atomic_store(lf.sk_cnt + 2 * sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(lf.sk_cnt + 2 * sk_tile + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (me == 0) atomicAdd(lf.sk_stat + (same_xcd ? 0 : 1), 1u);
+                }
+            };
+            using std::integral_constant;
+            switch (sk_lo * 16 + sk_hi) {   // the eight (first block, end) pairs of S = 2, 3, 4
+                case 0 * 16 + 4: coop(integral_constant<int, 0>{}, integral_constant<int, 4>{}); break;
+                case 4 * 16 + 8: coop(integral_constant<int, 4>{}, integral_constant<int, 8>{}); break;
+                case 0 * 16 + 2: coop(integral_constant<int, 0>{}, integral_constant<int, 2>{}); break;
+                case 2 * 16 + 5: coop(integral_constant<int, 2>{}, integral_constant<int, 5>{}); break;
+                case 5 * 16 + 8: coop(integral_constant<int, 5>{}, integral_constant<int, 8>{}); break;
+                case 2 * 16 + 4: coop(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+                case 4 * 16 + 6: coop(integral_constant<int, 4>{}, integral_constant<int, 6>{}); break;
+                case 6 * 16 + 8: coop(integral_constant<int, 6>{}, integral_constant<int, 8>{}); break;
+                default: __builtin_trap();   // the host only launches S in {2, 3, 4}
             }
-            __syncthreads();
         }
     }
     if (EPI == EPI_RESIDUAL_F32) {
@@ -1253,32 +1310,46 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gr[e] = lf.gR[n0 + cc0 * 8 + e]; br[e] = lf.bR[n0 + cc0 * 8 + e]; }
     }
+    // pass i covers rows 16 i .. 16 i + 15 = block mi = i & 7 of half i >> 3.  A co-operative split-K slice stores its own blocks only:
+    // its passes over the others repeat an owned block (every load stays unconditional, so all sixteen are in flight together) and
+    // their stores go out of the buffer's bounds, where the hardware drops them -- no branch in either form of the loop (with a
+    // branch around each store the compiler issued one pass's loads after the previous pass's store: + 2 % on a 600-tile product)
+    auto store_tile = [&](auto SPLIT) {
+        constexpr bool split = decltype(SPLIT)::value;
+        const sq_rsrc_t rc = sq_rsrc(C + m0 * N + n0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = tid + PTHREADS * i, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
-        h8 o = *(const h8*)(Es + row * PBN + cc * 8);
-        const long long off = (m0 + row) * N + n0 + cc * 8;
-        if (RES16) {
-            const h8 r = *(const h8*)(R + off);
-            if constexpr (EPI == EPI_LNRES_STATS) {
-                const float2 st = rowst[row];
+        for (int i = 0; i < 16; ++i) {
+            bool own = true;
+            int ie = i;
+            if constexpr (split) { own = (i & 7) >= sk_lo && (i & 7) < sk_hi; ie = own ? i : ((i & 8) | sk_lo); }
+            const int c = tid + PTHREADS * ie, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
+            h8 o = *(const h8*)(Es + row * PBN + cc * 8);
+            const long long off = (m0 + row) * N + n0 + cc * 8;
+            if (RES16) {
+                const h8 r = *(const h8*)(R + off);
+                if constexpr (EPI == EPI_LNRES_STATS) {
+                    const float2 st = rowst[row];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (((float)r[e] - st.x) * st.y * gr[e] + br[e]));
-            } else {
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (((float)r[e] - st.x) * st.y * gr[e] + br[e]));
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+                }
             }
-        }
-        if constexpr (STATS) {   // row sums of the ROUNDED output: the 32 lanes of a half-wave hold one row's 32 chunks
-            float sm = 0.f, sq = 0.f;
+            if constexpr (STATS) {   // row sums of the ROUNDED output: the 32 lanes of a half-wave hold one row's 32 chunks
+                float sm = 0.f, sq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float y = (float)o[e]; sm += y; sq += y * y; }
+                for (int e = 0; e < 8; ++e) { const float y = (float)o[e]; sm += y; sq += y * y; }
 #pragma unroll
-            for (int d_ = 16; d_; d_ >>= 1) { sm += __shfl_xor(sm, d_, 32); sq += __shfl_xor(sq, d_, 32); }
-            if (cc == 0) *(float2*)(lf.stats_out + ((long long)nt_idx * lf.Mp + m0 + row) * 2) = make_float2(sm, sq);
+                for (int d_ = 16; d_; d_ >>= 1) { sm += __shfl_xor(sm, d_, 32); sq += __shfl_xor(sq, d_, 32); }
+                if (cc == 0) *(float2*)(lf.stats_out + ((long long)nt_idx * lf.Mp + m0 + row) * 2) = make_float2(sm, sq);
+            }
+            if constexpr (split) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, o), rc, own ? (int)((row * N + cc * 8) * 2) : 0x7ffffff0, 0, 0);
+            else *(h8*)(C + off) = o;
         }
-        *(h8*)(C + off) = o;
-    }
+    };
+    if (sk_tile >= 0) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
 }
 
 
@@ -3056,7 +3127,21 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
             }
         }
     }
-    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || (kind == 0 && ((long long)(M / PBM) * (N / PBN) >= p8_min ||
+    // Less than HALF a round of 256 x 256 tiles with a very long K (FFN-down of a 13-pair batch at 1024 wide: 104 tiles, K = 4096): the
+    // 8-phase kernel with EVERY tile cut along K (2-4 slices, co-operative finish) -- 6656 x 1024 x 4096 67-68 us against 78-80 (128 x 128
+    // tiles) and 80 (persistent kernel, 104 workgroups); the 13-pair forward 6.36 -> 6.17 ms.  At K = 3072 (78 tiles, 768 wide) the cut wins
+    // 3 % in isolation (55-56 us against 56-58) and LOSES 4 % inside the forward (2.52 against 2.42 ms: 40 MB of partials through a cold
+    // L2), so the gate is K >= 4096 (profiles/r04_skcoop.log, r04_skcoop_forward.log)
+    bool sub_split = false;
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
+        const long long t_ll = big_ok ? (long long)(M / PBM) * (N / PBN) : 0;
+        const int cus = device_cus();
+        const long long pad_ll = (t_ll + 7) & ~7ll;
+        const long long s_ll = pad_ll > 0 ? std::min<long long>(std::min<long long>(cus / pad_ll, K / PBK / 2), 4) : 0;   // the slice count chosen below
+        sub_split = kind == 0 && !p8_min_forced() && big_ok && K % PBK == 0 && K >= 4096 && t_ll > 0 && s_ll >= 2 &&
+                    splitk_tail_on() && gws && gws->ws && t_ll <= kSkMaxTiles && (size_t)t_ll * s_ll * PBM * PBN * sizeof(float) <= gws->bytes;
+    }
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || sub_split || (kind == 0 && ((long long)(M / PBM) * (N / PBN) >= p8_min ||
                                                                                (K >= 2048 && (long long)(M / PBM) * (N / PBN) > 2 * (device_cus() & ~7) && !p8_min_forced()))))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
@@ -3075,7 +3160,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
             // forward SLOWER (12.53 vs 12.26 ms); the general form stays reachable through vf_debug_splitk_tail(2).
             const int mode = g_splitk_tail.load(std::memory_order_relaxed);
             int S = ntail > 0 ? std::min(std::min(cus / pad, nk / 2), 4) : 0;
-            if (mode == 1) S = (nk >= 32 && S >= 2 && tiles > cus) ? 2 : 0;
+            if (mode == 1 && !sub_split) S = (nk >= 32 && S >= 2 && tiles > cus) ? 2 : 0;
             if (S >= 2 && splitk_tail_on() && gws && gws->ws && ntail <= kSkMaxTiles && (size_t)ntail * S * PBM * PBN * sizeof(float) <= gws->bytes) {
                 lf.sk_ws = gws->ws; lf.sk_cnt = gws->cnt; lf.sk_nfull = tiles - ntail; lf.sk_S = S; lf.sk_ntail = ntail;
                 lf.sk_stat = gws->cnt + 2 * (size_t)kSkMaxTiles; lf.sk_dbg = g_sk_dbg.load(std::memory_order_relaxed);
