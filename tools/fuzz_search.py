@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzz of vf_index_search against the CPU oracle: random (rows, dim, queries, k, dtype, data shape, options)
 drawn to sit ON the dispatch boundaries (dense path <= 16384 rows, narrow / wide pass at 65 / 129 queries, 64-multiples
-of dim for the fp8 instruction, k around the row count, sample rows 4 / 16), every result compared bit for bit
-(ids and score bits) with oracle.canonical.  Test infrastructure: the oracle is the checker, never the thing measured.
+of dim for the fp8 instruction, k around the row count, sample rows 4 / 16), one handle or a handle over 2-5 row blocks
+(all on device 0: the merge and the id offsets), every result compared bit for bit (ids and score bits) with
+oracle.canonical.  Test infrastructure: the oracle is the checker, never the thing measured.
 
     python tools/fuzz_search.py --seconds 240 --seed 1 [--max-work 2e10]
 
@@ -34,7 +35,8 @@ def draw_case(rng, max_work):
         opts["wide_mfma"] = pick([0, 1])
     if rng.random() < 0.2:
         opts["sample_rows"] = pick([1, 4, 16, 64])
-    return dict(dtype=dtype, d=int(d), nq=int(nq), n=int(n), k=int(k), data=data, opts=opts, seed=int(rng.integers(1 << 31)))
+    shards = int(pick([1, 1, 1, 2, 3, 5])) if n >= 8 else 1      # > 1: one handle over that many row blocks, all on device 0
+    return dict(dtype=dtype, d=int(d), nq=int(nq), n=int(n), k=int(k), data=data, opts=opts, shards=shards, seed=int(rng.integers(1 << 31)))
 
 
 def make_data(case):
@@ -80,7 +82,8 @@ def run_case(vf, oracle, case):
         rows = np.ascontiguousarray(rows[order])
         if codes is not None:
             codes = np.ascontiguousarray(codes[order])
-    ix = vf.DenseIndex.from_e4m3(codes) if codes is not None else vf.DenseIndex(rows)
+    dev_ids = [0] * case.get("shards", 1) if case.get("shards", 1) > 1 else None
+    ix = vf.DenseIndex.from_e4m3(codes, device_ids=dev_ids) if codes is not None else vf.DenseIndex(rows, device_ids=dev_ids)
     try:
         for key, val in case["opts"].items():
             try:
@@ -132,6 +135,8 @@ def main():
             ok, st, why = False, {}, {"exception": repr(e)}
         n_cases += 1
         key = (st.get("path"), st.get("scan_kernel"), case["dtype"])
+        if case.get("shards", 1) > 1:
+            paths[("sharded handle",)] = paths.get(("sharded handle",), 0) + 1
         paths[key] = paths.get(key, 0) + 1
         if st.get("exact_reruns"):
             paths[("exact_reruns",)] = paths.get(("exact_reruns",), 0) + 1
