@@ -384,6 +384,16 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
     finally:
         L.vf_debug_splitk_tail(was)
     counted = (stats[0], stats[1])
+    # wait bound zero: every slice but the last hands its whole partial over and leaves, the last arrival finishes the tile through
+    # the take-over code (what a slice does after waiting 300 us for partners that cannot get a CU) -- same bits
+    L.vf_debug_splitk_tail(2)
+    try:
+        L.vf_debug_splitk_stats(stats, 16)
+        c3 = run()
+    finally:
+        L.vf_debug_splitk_stats(stats, 0)
+        L.vf_debug_splitk_tail(was)
+    assert torch.equal(c3, c1), "the take-over path of the split-K finish differs"
     if K >= 4096 and 2 * ((tiles + 7) // 8 * 8) <= cus:     # the dispatch's own choice for this shape is the same cut
         L.vf_debug_splitk_stats(stats, -1)
         c_auto = run(0)
@@ -404,6 +414,40 @@ def test_gemm_splitk_tail_matches_torch_and_is_deterministic(vf, M, N, K, epi, w
     d01 = float((c1.float() - c0.float()).abs().max())     # ... and the whole output against the unsplit launch
     print("split-K tail", (M, N, K, epi), "max err vs torch", err, "vs the unsplit launch", d01)
     assert err < 2e-2 and d01 < 1.6e-2      # fp16 output of O(10) values: one ulp is 7.8e-3
+
+
+def test_two_handles_run_split_products_concurrently(vf):
+    """Two encoder handles on two threads, each forward containing a product that is cut whole along K (13 x 512 tokens, 1024 wide:
+    FFN-down = 104 tiles x 2 slices whose slices wait for one another): concurrent launches could each hold the CUs the other's
+    missing slices need -- the bounded wait hands over and the results equal the sequential ones bit for bit."""
+    import threading
+    sys_path_tools = os.path.join(_ROOT, "tools")
+    if sys_path_tools not in sys.path:
+        sys.path.insert(0, sys_path_tools)
+    from bench_rerank import random_encoder
+    encs = []
+    for seed in (0, 1):
+        enc, _cfg = random_encoder("xlmr-large", head=1, seed=seed, vocab=2000)
+        encs.append(enc)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(5, 2000, size=(13, 512)).astype(np.int32)
+    mask = np.ones_like(ids)
+    want = [e.forward(ids, mask).copy() for e in encs]
+    got = [[None] * 6, [None] * 6]
+    def work(k):
+        for it in range(6):
+            got[k][it] = encs[k].forward(ids, mask).copy()
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths: t.start()
+    for t in ths: t.join(timeout=120)
+    alive = [t.is_alive() for t in ths]
+    for e in encs:
+        if not any(alive):
+            e.close()
+    assert not any(alive), "concurrent split-K forwards did not finish"
+    for k in range(2):
+        for it in range(6):
+            assert np.array_equal(got[k][it].view(np.uint32), want[k].view(np.uint32))
 
 
 @pytest.mark.parametrize("kind", [3, 5, 7, 10])

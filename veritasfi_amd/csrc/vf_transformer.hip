@@ -875,7 +875,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
     int mt_idx, nt_idx;
     int sk_tile = -1, sk_slice = 0;
-    int sk_lo = 0, sk_hi = 8;   // 16-row blocks (of both 128-row halves) whose rows THIS workgroup finishes and stores: all, or a co-operative slice's share
+    unsigned sk_own = 0xffu;    // bit mi: THIS workgroup finishes and stores the 16-row blocks mi of both 128-row halves (all, or a split-K slice's share)
     {   // XCD-contiguous, n-major groups of 4 m-tiles
         const int Mt = M / PBM, Nt = N / PBN, nwg = Mt * Nt;
         int orig = blockIdx.x;
@@ -1067,20 +1067,65 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     __syncthreads();
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
         if (sk_tile >= 0) {
-            // Split-K, co-operative form (round 4).  The last-arrival form below makes ONE workgroup read S x 256 KB back (one CU pulls
-            // 50-60 GB/s: ~9 us per slice) while the others have already left.  Here every slice FINISHES its own share of the tile:
-            // slice s owns the 16-row blocks mi in [8 s / S, 8 (s + 1) / S) of both 128-row halves, leaves only the blocks it does not
-            // own in sk_ws ((S - 1) / S of a partial), waits until all S slices have done so, adds the others' partials of ITS blocks
-            // in slice order (its own term comes from the registers, at its place in the order: the sum is bit for bit the
-            // last-arrival form's) and runs the epilogue on its rows only.  Written and read bytes per slice: (S - 1) / S x 256 KB each.
-            // The wait cannot deadlock: the sliced workgroups are the LAST of the grid and at most one round of the CUs (the host
-            // checks), one workgroup fits a CU, and every workgroup ahead of them finishes without waiting for anybody.
+            // Split-K, co-operative finish (round 4).  Until then the LAST slice to arrive read all S partials back (one CU pulls 50-60
+            // GB/s: ~9 us per 256 KB) and finished the tile alone.  Now slice s owns the 16-row blocks mi in [8 s / S, 8 (s + 1) / S) of
+            // both 128-row halves: it leaves only the blocks it does not own in sk_ws ((S - 1) / S of a partial), counts itself, waits
+            // until all S slices have done so, adds the others' partials of ITS blocks in slice order (its own term comes from the
+            // registers, at its place in the order: bit for bit the old sum) and runs the epilogue on its rows only.
+            // The wait is BOUNDED.  Slices of one launch alone cannot block one another (they are the last workgroups of the grid, at
+            // most one round of the CUs, one per CU, and nothing ahead of them waits) -- but two such launches on different streams,
+            // or in two processes sharing the GPU, could each hold the CUs the other's missing slices need.  So a slice that has
+            // waited kSkWaitTicks (300 us; partners normally arrive within one tile's time) hands ITS blocks over as well, marks
+            // itself in the tile's state word and leaves its CU; the slice that arrives LAST sees the marks in the value its own
+            // arrival returns and finishes those blocks too.  One 32-bit word per tile orders everything: bits 0-7 arrivals, 8-15
+            // "has handed over" per slice, 16-23 finished; a slice whose mark lands after the last arrival learns that from the
+            // returned value and carries on itself (the word is then harmlessly marked).  vf_debug_splitk_stats(.., 16) sets the bound
+            // to zero: every slice but the last hands over at once -- the old last-arrival scheme, through the take-over code (tests).
+            constexpr unsigned long long kSkWaitTicks = 30000ull;   // of the 100 MHz real-time counter
             const sq_rsrc_t rw = sq_rsrc(lf.sk_ws);
             const int S = lf.sk_S, me = sk_slice;
-            sk_lo = 8 * me / S; sk_hi = 8 * (me + 1) / S;
+            const int lo_me = 8 * me / S, hi_me = 8 * (me + 1) / S;
+            sk_own = ((1u << hi_me) - 1u) & ~((1u << lo_me) - 1u);
             const int my = ((sk_tile * S + me) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
+            unsigned* const w0 = lf.sk_cnt + 2 * sk_tile;               // the state word; w0[1]: slices per XCD, 3 bits each
             unsigned* flag = (unsigned*)(smem + 8 * PSLOT);
-            auto coop = [&](auto LO, auto HI) {
+            auto finished = [&](bool same_xcd) {   // tid 0: this slice needs nothing from the workspace any more
+                const unsigned v = __hip_atomic_fetch_add(w0, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((v >> 16) & 0xffu) == (unsigned)(S - 1)) {   // the last to finish leaves the words at zero for the next launch
+                    __hip_atomic_store(w0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w0 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(lf.sk_stat + (same_xcd ? 0 : 1), 1u);
+                }
+            };
+            // one block (16 rows of either half) summed in slice order: any slice's share, one block at a time (take-over only)
+            auto take_block = [&](auto MI, bool same_xcd) {
+                constexpr int mi = decltype(MI)::value;
+                f4v t[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) t[ni] = f4v{0.f, 0.f, 0.f, 0.f};
+                for (int sl = 0; sl < S; ++sl) {
+                    if (sl == me) {
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[ni][e] += acc[mi][ni][e];
+                    } else {
+                        const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
+                        f4v v[4];
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            v[ni] = same_xcd ? __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 1))
+                                             : __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[ni][e] += v[ni][e];
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = t[ni];
+            };
+            auto coop = [&](auto LO, auto HI) -> bool {   // true: the share has been handed over, the workgroup leaves
                 constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
                 if (!(lf.sk_dbg & 1)) {
 #pragma unroll
@@ -1095,12 +1140,45 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
                 if (tid == 0) {
                     unsigned xcc;
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                    xcc &= 15u;
-                    (void)__hip_atomic_fetch_or(lf.sk_cnt + 2 * sk_tile + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    (void)__hip_atomic_fetch_add(lf.sk_cnt + 2 * sk_tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
-                    while (__hip_atomic_load(lf.sk_cnt + 2 * sk_tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) __builtin_amdgcn_s_sleep(4);
-                    const unsigned mask = __hip_atomic_load(lf.sk_cnt + 2 * sk_tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[1] = mask == (1u << xcc) ? 1u : 0u;   // every slice ran on this XCD: the partials are in ITS L2
+                    xcc &= 7u;
+                    (void)__hip_atomic_fetch_add(w0 + 1, 1u << (3 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned a = __hip_atomic_fetch_add(w0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+                    const bool last = (a & 0xffu) == (unsigned)(S - 1);
+                    unsigned give_up = 0u;
+                    if (!last) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), bound = (lf.sk_dbg & 16) ? 0ull : kSkWaitTicks;
+                        for (;;) {
+                            if ((__hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) >= (unsigned)S) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t0 >= bound) { give_up = 1u; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
+                    flag[0] = give_up;
+                    flag[2] = last ? ((a >> 8) & 0xffu) : 0u;   // the last arrival: whose blocks are left for it
+                    flag[3] = xcc;
+                }
+                __syncthreads();
+                if (flag[0]) {   // waited long enough: my own blocks go to the workspace too, then the mark
+                    if (!(lf.sk_dbg & 1)) {
+#pragma unroll
+                        for (int mi = lo; mi < hi; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) {
+                        const unsigned b = __hip_atomic_fetch_or(w0, 1u << (8 + me), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = (b & 0xffu) >= (unsigned)S ? 0u : 1u;   // everybody is here after all: nobody will finish my blocks for me
+                        if (flag[0]) finished(false);
+                    }
+                    __syncthreads();
+                    if (flag[0]) return true;
+                }
+                if (tid == 0) {   // all S slices have arrived: the per-XCD counts are complete
+                    const unsigned per_xcd = __hip_atomic_load(w0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[1] = ((per_xcd >> (3 * flag[3])) & 7u) == (unsigned)S ? 1u : 0u;   // every slice ran on this XCD: the partials are in ITS L2
                 }
                 __syncthreads();
                 const bool same_xcd = flag[1] != 0u;
@@ -1154,30 +1232,42 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
                 reduce2(integral_constant<int, lo>{}, integral_constant<int, (hi - lo >= 2 ? 2 : 1)>{});
                 if constexpr (hi - lo == 3) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 1>{});
                 if constexpr (hi - lo == 4) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 2>{});
-                // every slice counts a second time when it has read what it needs; the last of those leaves the counters at zero
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    const unsigned done = __hip_atomic_fetch_add(lf.sk_cnt + 2 * sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (done == (unsigned)(2 * S - 1)) {
-                        __hip_atomic_store(lf.sk_cnt + 2 * sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(lf.sk_cnt + 2 * sk_tile + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (me == 0) atomicAdd(lf.sk_stat + (same_xcd ? 0 : 1), 1u);
-                }
+                return false;
             };
             using std::integral_constant;
-            switch (sk_lo * 16 + sk_hi) {   // the eight (first block, end) pairs of S = 2, 3, 4
-                case 0 * 16 + 4: coop(integral_constant<int, 0>{}, integral_constant<int, 4>{}); break;
-                case 4 * 16 + 8: coop(integral_constant<int, 4>{}, integral_constant<int, 8>{}); break;
-                case 0 * 16 + 2: coop(integral_constant<int, 0>{}, integral_constant<int, 2>{}); break;
-                case 2 * 16 + 5: coop(integral_constant<int, 2>{}, integral_constant<int, 5>{}); break;
-                case 5 * 16 + 8: coop(integral_constant<int, 5>{}, integral_constant<int, 8>{}); break;
-                case 2 * 16 + 4: coop(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
-                case 4 * 16 + 6: coop(integral_constant<int, 4>{}, integral_constant<int, 6>{}); break;
-                case 6 * 16 + 8: coop(integral_constant<int, 6>{}, integral_constant<int, 8>{}); break;
+            bool leave = false;
+            switch (lo_me * 16 + hi_me) {   // the eight (first block, end) pairs of S = 2, 3, 4
+                case 0 * 16 + 4: leave = coop(integral_constant<int, 0>{}, integral_constant<int, 4>{}); break;
+                case 4 * 16 + 8: leave = coop(integral_constant<int, 4>{}, integral_constant<int, 8>{}); break;
+                case 0 * 16 + 2: leave = coop(integral_constant<int, 0>{}, integral_constant<int, 2>{}); break;
+                case 2 * 16 + 5: leave = coop(integral_constant<int, 2>{}, integral_constant<int, 5>{}); break;
+                case 5 * 16 + 8: leave = coop(integral_constant<int, 5>{}, integral_constant<int, 8>{}); break;
+                case 2 * 16 + 4: leave = coop(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+                case 4 * 16 + 6: leave = coop(integral_constant<int, 4>{}, integral_constant<int, 6>{}); break;
+                case 6 * 16 + 8: leave = coop(integral_constant<int, 6>{}, integral_constant<int, 8>{}); break;
                 default: __builtin_trap();   // the host only launches S in {2, 3, 4}
             }
+            if (leave) return;
+            const bool same_xcd = flag[1] != 0u;
+            const unsigned gone = flag[2];
+            if (gone) {   // the last arrival finishes the blocks of the slices that have left (their whole partial is in the workspace)
+                unsigned take = 0u;
+                for (int x = 0; x < S; ++x)
+                    if ((gone >> x) & 1u) take |= ((1u << (8 * (x + 1) / S)) - 1u) & ~((1u << (8 * x / S)) - 1u);
+                take &= ~sk_own;
+                if (take & 1u) take_block(integral_constant<int, 0>{}, same_xcd);
+                if (take & 2u) take_block(integral_constant<int, 1>{}, same_xcd);
+                if (take & 4u) take_block(integral_constant<int, 2>{}, same_xcd);
+                if (take & 8u) take_block(integral_constant<int, 3>{}, same_xcd);
+                if (take & 16u) take_block(integral_constant<int, 4>{}, same_xcd);
+                if (take & 32u) take_block(integral_constant<int, 5>{}, same_xcd);
+                if (take & 64u) take_block(integral_constant<int, 6>{}, same_xcd);
+                if (take & 128u) take_block(integral_constant<int, 7>{}, same_xcd);
+                sk_own |= take;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) finished(same_xcd);
         }
     }
     if (EPI == EPI_RESIDUAL_F32) {
@@ -1321,7 +1411,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
         for (int i = 0; i < 16; ++i) {
             bool own = true;
             int ie = i;
-            if constexpr (split) { own = (i & 7) >= sk_lo && (i & 7) < sk_hi; ie = own ? i : ((i & 8) | sk_lo); }
+            if constexpr (split) { own = (sk_own >> (i & 7)) & 1u; ie = own ? i : ((i & 8) | __builtin_ctz(sk_own)); }
             const int c = tid + PTHREADS * ie, row = c >> 5, cc = c & 31;  // 32 chunks of 8 halves per 256-wide row
             h8 o = *(const h8*)(Es + row * PBN + cc * 8);
             const long long off = (m0 + row) * N + n0 + cc * 8;
