@@ -139,7 +139,12 @@ int vf_index_stats(vf_index* idx, vf_search_stats* out);
  * "wide_mfma": matrix instruction of the wide scan (batches of >= 129 queries) over e4m3 rows: -1 auto (= 1), 1 the fp8
  *   instruction on the row bytes as stored (k_scan_wide8: the query goes in as a hi + lo pair of e4m3 codes and its exactly
  *   known residual is the query's certificate bound), 0 the fp16 instruction on converted rows (k_scan_wide).  Results are
- *   identical bit for bit; vf_search_stats.scan_kernel says which one ran. */
+ *   identical bit for bit; vf_search_stats.scan_kernel says which one ran.
+ * "sample_rows": rows per wave the sample pass scores to seed the thresholds: -1 auto (4 for shards of up to 1.1M rows while the
+ *   sample still holds 16 k' rows, else 16), or 1..64.  A speed setting: a looser seed admits more candidates, results do not change.
+ * "scan_impl": the narrow scan's kernel: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA loads) for fp16 rows (default),
+ *   3 k_scan2 wherever it fits (e4m3 rows converted in registers), 4 k_scan2 with e4m3 rows on the fp8 matrix instruction.  Same
+ *   results from each. */
 int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
 /* Live kernel timing with HIP events on the stream the kernels run on (bench.py roofline):
  * after vf_index_set_option(idx, "profile", 1) every fused search records events around its main
