@@ -306,6 +306,7 @@ def rerank_p50(args, shape=None):
     tf = flops(cfg, args.rerank_pairs, args.rerank_tokens) / p50 / 1e9
     return p50, {"model_shape": shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens,
                  "tflops": round(tf, 1), "bound": "mfma", "peak_tflops": 2500.0, "frac": round(tf / 2500.0, 4),
+                 "power_limited": _power_note(tf),
                  "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of logits",
                  "what": "median of 12 HipEncoder.forward calls on pre-tokenised ids (tokenisation is not timed)",
                  "ragged": {"lengths": f"uniform {max(1, args.rerank_tokens // 4)}..{args.rerank_tokens}",
@@ -344,9 +345,22 @@ def rerank_llm(args):
     return {"model_shape": "gemma-2b (bge-reranker-v2-gemma's architecture: 18 layers, hidden 2048, MQA head dim 256, GeGLU 16384)",
             "pairs": len(pairs), "max_length": 1024, "tokens_per_pair": {"min": int(lens.min()), "mean": round(float(lens.mean()), 1), "max": int(lens.max())},
             "p50_ms": round(p50, 2), "tflops": round(tf, 1), "bound": "mfma", "peak_tflops": 2500.0, "frac": round(tf / 2500.0, 4),
+            "power_limited": _power_note(tf),
             "finite": bool(np.isfinite(scores).all()), "weights": "seeded random (no checkpoints offline)",
             "what": "median of 4 HipLLMReranker.compute_score(pairs, batch_size=8) calls: host-side input construction "
                     "(tokenizer stand-in, truncations, prompt), left padding, packed decoder forward, D2H of the logits"}
+
+
+# What fp16 products sustain on this part on activation-like operands: the socket sits at its power limit and the clock gives way
+# (profiles/r04_power_clock_under_products.log: 1.37 kW / 2.0 GHz, this repo's kernel and the vendor library alike at 1.05 PF); a product
+# loop with every wait removed (fragment reads + MFMAs only) reaches 1.21 PF on random operands, 1.57 PF on zeros
+# (profiles/r04_gemm_power_operands.log).  Reported BESIDE frac (which stays against the nominal dense peak), never instead of it.
+POWER_LIMITED = {"tflops": 1210.0, "what": "a 256 x 256 fp16 product loop with every wait removed, random operands, measured on this part "
+                                           "(profiles/r04_gemm_power_operands.log; the vendor library sustains 1050 on the same operands)"}
+
+
+def _power_note(tf):
+    return {"ceiling_tflops": POWER_LIMITED["tflops"], "frac_of_ceiling": round(tf / POWER_LIMITED["tflops"], 4), "what": POWER_LIMITED["what"]}
 
 
 def _c5_traffic(scan_kernel, rows, dim, nq, k):
