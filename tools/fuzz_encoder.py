@@ -15,6 +15,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="real widths (768 / 12 heads / 3072 and 1024 / 16 heads / 4096, 2 layers), batches of up to 100 "
+                                                       "x 512 tokens: the forwards then run the LARGE product kernels and their dispatch gates; the HF "
+                                                       "side runs in torch fp32 on the GPU")
     a = ap.parse_args()
     import veritasfi_amd as vf
     spec = importlib.util.spec_from_file_location("tge", os.path.join(ROOT, "tests", "test_gpu_encoder.py"))
@@ -25,6 +28,13 @@ def main():
         "bert-embedder-2heads": (tge._hf_bert(128, 2, 2, 256, seed=3), 0, 8e-4),
         "xlmr-reranker": (tge._hf_xlmr_cls(256, 3, 4, 512), 1, 2.5e-3),
     }
+    dev = "cpu"
+    if a.big:
+        dev = "cuda"
+        models = {
+            "bert-embedder-768": (tge._hf_bert(768, 2, 12, 3072).to(dev), 0, 8e-4),
+            "xlmr-reranker-1024": (tge._hf_xlmr_cls(1024, 2, 16, 4096).to(dev), 1, 2.5e-3),
+        }
     encs = {k: vf.HipEncoder.from_hf(m[0]) for k, m in models.items()}
     rng = np.random.default_rng(a.seed)
     pick = lambda xs: xs[int(rng.integers(len(xs)))]
@@ -36,6 +46,8 @@ def main():
             kind = pick(list(models))
             m, pad_id, tol = models[kind]
             b = pick([1, 1, 2, 3, 7, 8, 13, 16, 24, 25, 32, 33, 48, int(rng.integers(1, 49))])
+            if a.big:
+                b = pick([1, 7, 13, 16, 25, 26, 32, 50, 51, 64, 100, int(rng.integers(1, 101))])
             t = pick([1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 300, 384, 511, 512, int(rng.integers(1, 513))])
             dist = pick(["full", "tiny", "one_long", "random", "random", "mult32", "off32"])
             if dist == "full":
@@ -56,12 +68,14 @@ def main():
             ids[mask == 0] = pad_id
             with torch.no_grad():
                 if kind.startswith("bert"):
-                    ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state[:, 0]
-                    ref = torch.nn.functional.normalize(ref, dim=-1).numpy()
+                    ref = m(input_ids=torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev)).last_hidden_state[:, 0]
+                    ref = torch.nn.functional.normalize(ref, dim=-1).cpu().numpy()
                 else:
-                    ref = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits[:, 0].numpy()
+                    ref = m(input_ids=torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev)).logits[:, 0].cpu().numpy()
             got = encs[kind].forward(ids.astype(np.int32), mask.astype(np.int32))
             err = float(np.abs(np.asarray(got).reshape(ref.shape) - ref).max()) if np.isfinite(got).all() else float("inf")
+            if not kind.startswith("bert"):
+                err /= max(1.0, float(np.abs(ref).max()))          # logits: relative to their scale, as the tests do
             worst[kind] = max(worst.get(kind, 0.0), err / tol)
             n += 1
             if not err < tol:
