@@ -56,7 +56,7 @@ typedef struct vf_search_stats {
     int64_t wide_queries;    /* queries those passes served (up to 1024 per pass) */
     int64_t aux_cus;         /* CUs the main scan left to the small kernels of the other slots (0 = no CU split) */
     int64_t scans_overlap;   /* 1 = main scans of consecutive slots were not ordered against each other */
-    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide, 4 k_scan_wide8 (fp8 matrix instruction), 5 k_scan2 on the fp8 matrix instruction */
+    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide, 4 k_scan_wide8 (fp8 matrix instruction) */
     int64_t reserved[4];
 } vf_search_stats;
 
@@ -143,8 +143,7 @@ int vf_index_stats(vf_index* idx, vf_search_stats* out);
  * "sample_rows": rows per wave the sample pass scores to seed the thresholds: -1 auto (4 for shards of up to 1.1M rows while the
  *   sample still holds 16 k' rows, else 16), or 1..64.  A speed setting: a looser seed admits more candidates, results do not change.
  * "scan_impl": the narrow scan's kernel: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA loads) for fp16 rows (default),
- *   3 k_scan2 wherever it fits (e4m3 rows converted in registers), 4 k_scan2 with e4m3 rows on the fp8 matrix instruction.  Same
- *   results from each. */
+ *   3 k_scan2 wherever it fits (e4m3 rows converted in registers).  Same results from each. */
 int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
 /* Live kernel timing with HIP events on the stream the kernels run on (bench.py roofline):
  * after vf_index_set_option(idx, "profile", 1) every fused search records events around its main

@@ -560,7 +560,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
         ix->aux_cus = value;
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
-    else if (s == "scan_impl") { if (!in_range(1, 4)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (k_scan2 for fp16 rows), 3 (k_scan2 wherever it fits, e4m3 rows converted) or 4 (k_scan2, e4m3 rows on the fp8 matrix instruction)"); ix->scan_impl = value; }
+    else if (s == "scan_impl") { if (!in_range(1, 3)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (k_scan2 for fp16 rows) or 3 (k_scan2 wherever it fits, e4m3 rows converted)"); ix->scan_impl = value; }
     else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") {
@@ -839,13 +839,6 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         VF_HIP(hipEventRecord(s.ev_done, st));
         return VF_OK;
     }
-    // e4m3 rows on the fp8 matrix instruction (k_scan2<NT, 2>, scan_impl = 4): the query goes in as hi + lo e4m3 codes and its own
-    // residual is its certificate bound (as in k_scan_wide8)
-    const bool n8 = ix->dtype == VF_DTYPE_FP8_E4M3 && ix->scan_impl == 4 && !ix->steal_opt && scan2_stage_cap(ix->dp, qn_tile_for(std::min(nq, bl)), 1) >= 256;
-    if (n8) {
-        VF_TRY(s.qimg8.ensure((size_t)ix->dp * kMaxBatch * 2));
-        VF_TRY(s.epsq.ensure((size_t)kMaxBatch * sizeof(float)));
-    }
     VF_TRY(s.s0.ensure((size_t)kMaxBatch * p.total_waves * p.samp * sizeof(float)));
     VF_TRY(s.cnt.ensure((size_t)kMaxBatch * kCntStride * sizeof(u32)));
     VF_TRY(s.tau.ensure(kMaxBatch * sizeof(int)));
@@ -867,7 +860,6 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         const int qt = qn_tile_for(nb);
         float* qn_b = s.qn.as<float>() + (size_t)b0 * ix->d;
         VF_HIP(launch_prep_queries(d_queries + (size_t)b0 * ix->d, nb, ix->d, ix->dp, qt, qn_b, s.qimg.as<_Float16>(), st));
-        if (n8) VF_HIP(launch_prep_scan8(qn_b, nb, ix->d, ix->dp, qt, (unsigned char*)s.qimg8.p, s.epsq.as<float>(), st));
         ScanArgs a{};
         a.rows = (const char*)ix->rows_scan; a.inv_scan = ix->inv_scan; a.qimg = s.qimg.as<_Float16>();
         a.n = ix->n; a.dp = ix->dp; a.row_bytes = (long long)ix->dp * (ix->dtype == VF_DTYPE_FP8_E4M3 ? 1 : 2); a.total_waves = p.total_waves; a.samp = p.samp;
@@ -918,13 +910,12 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // k_scan2 serves fp16 rows by default; e4m3 rows only on request (scan_impl = 3): per byte they carry twice the MFMA and
         // LDS work plus the conversions, and with ONE wave per SIMD nothing hides it -- measured 0.53 against k_scan's 0.66 of
         // peak at 10M x 768 fp8 (profiles/r03_f8_sweep.log)
-        const int cap2 = ((ix->scan_impl == 3 || n8 || ((ix->scan_impl == 2 || ix->scan_impl == 4) && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
+        const int cap2 = ((ix->scan_impl == 3 || (ix->scan_impl == 2 && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
         if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
             ScanArgs a2 = a;
             a2.stage_cap = cap2;
-            if (n8) a2.qimg = (const _Float16*)s.qimg8.p;
-            VF_HIP(launch_scan2(a2, qt, p.grid, n8 ? 2 : f8, sst));
-            s.scan_kernel = n8 ? 5 : 2;
+            VF_HIP(launch_scan2(a2, qt, p.grid, f8, sst));
+            s.scan_kernel = 2;
         } else {
             VF_HIP(launch_scan(a, kModeMain, qt, p.grid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, sst));
             s.scan_kernel = 1;
@@ -941,7 +932,6 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         f.cnt = a.cnt; f.cand = a.cand; f.cap = p.cap; f.tau_bin = a.tau_bin; f.rows_orig = ix->rows_orig;
         f.orig_dtype = ix->dtype; f.orig_row_elems = ix->d; f.norm = ix->norm; f.qn = qn_b;
         f.d = ix->d; f.k = k; f.kprime = p.kprime; f.eps = p.eps; f.n_rows = ix->n; f.id_offset = ix->id_offset;
-        f.eps_q = (n8 && s.scan_kernel == 5) ? s.epsq.as<float>() : nullptr;
         f.out_ids = (long long*)(d_ids + (size_t)b0 * k); f.out_scores = d_scores + (size_t)b0 * k;
         f.flags = s.d_flags + b0; f.cand_count_out = s.d_counts + b0;
         f.dbg = nullptr;

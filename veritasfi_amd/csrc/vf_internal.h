@@ -119,7 +119,6 @@ size_t scan_wide_lds_bytes(int stage_cap);
 hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, unsigned char* img8, float* eps_q, hipStream_t s);
 hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s);
 // k_scan2<NT, 2>: the narrow main scan on the fp8 matrix instruction (launch_scan2 with rows_are_fp8 = 2; a.qimg = this image)
-hipError_t launch_prep_scan8(const float* qn, int nq, int d, int dp, int qn_tile, unsigned char* img8, float* eps_q, hipStream_t s);
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
 hipError_t launch_final(FinalArgs a, int nq, hipStream_t s);
 hipError_t launch_merge_topk(const long long* ids_parts, const float* score_parts, int nparts, int nq,

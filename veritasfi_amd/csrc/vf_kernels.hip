@@ -1355,29 +1355,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                 // flight; everything older has landed
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 const char* ab = a_lane + buf * kSegBytes;
-                if constexpr (F8 == 2) {
-                    // e4m3 rows on the fp8 matrix instruction (round 4; k_scan_wide8's operands at batch 64): the 32 bytes lane
-                    // (r, h) reads of chunk c -- pieces 4 c + 2 h, + 1 of its row -- ARE the A operand of
-                    // v_mfma_scale_f32_32x32x64_f8f6f4; the query image holds hi and lo e4m3 codes (q = hi 2^-8 + lo 2^-12 + delta,
-                    // k_prep_scan8): [chunk of 64][hi | lo][piece 0..3][QN][16 B].  Two MFMAs per (chunk, query tile): the matrix
-                    // time of the converted form without its conversions and with half its fragment reads.
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const uint4 w0 = *(const uint4*)(ab + (((4 * c + 2 * h) ^ asw) << 4));
-                        const uint4 w1 = *(const uint4*)(ab + (((4 * c + 2 * h + 1) ^ asw) << 4));
-                        const i8v af = i8v{(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
-                        const char* bb = img + (long long)(sg * 2 + c) * (8 * QN * 16) + (2 * h) * (QN * 16) + r31 * 16;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const uint4 h0 = *(const uint4*)(bb + nt * (kQueryTile * 16)), h1 = *(const uint4*)(bb + QN * 16 + nt * (kQueryTile * 16));
-                            const uint4 l0 = *(const uint4*)(bb + 4 * QN * 16 + nt * (kQueryTile * 16)), l1 = *(const uint4*)(bb + 5 * QN * 16 + nt * (kQueryTile * 16));
-                            const i8v bh = i8v{(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
-                            const i8v bl = i8v{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
-                            acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af, bh, acc[nt], 0, 0, 0, 127, 0, 119);
-                            acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af, bl, acc[nt], 0, 0, 0, 127, 0, 115);
-                        }
-                    }
-                } else if constexpr (F8 == 0) {
+                if constexpr (F8 == 0) {
                     const char* bb = lds_lane + (long long)sg * (8 * QN * 16);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -2066,34 +2044,6 @@ __global__ __launch_bounds__(256) void k_prep_wide8(const float* qn, int nq, int
     if (tid == 0) eps_q[slot] = sqrtf(red[0]) * 1.002f + 8.0f * (float)dp * 5.9604645e-8f + 1e-6f;
 }
 
-// the same split for the NARROW scan on the fp8 instruction (k_scan2<NT, 2>): image [chunk of 64][hi | lo][piece 0..3][QN][16 B]
-__global__ __launch_bounds__(256) void k_prep_scan8(const float* qn, int nq, int d, int dp, int QN, unsigned char* img8, float* eps_q) {
-    const int slot = blockIdx.x, tid = threadIdx.x;
-    __shared__ float red[256];
-    float ss = 0.0f;
-    for (int j = tid; j < dp; j += 256) {
-        const float v = (slot < nq && j < d) ? qn[(long long)slot * d + j] : 0.0f;
-        const int hc = __builtin_amdgcn_cvt_pk_fp8_f32(v * 256.0f, 0.0f, 0, false) & 0xFF;
-        const float r = v - __builtin_amdgcn_cvt_f32_fp8(hc, 0) * (1.0f / 256.0f);
-        const int lc = __builtin_amdgcn_cvt_pk_fp8_f32(r * 4096.0f, 0.0f, 0, false) & 0xFF;
-        const float dl = r - __builtin_amdgcn_cvt_f32_fp8(lc, 0) * (1.0f / 4096.0f);
-        ss = __builtin_fmaf(dl, dl, ss);
-        const int C = j >> 6, b = j & 63;
-        const long long base = (((long long)C * 2) * 4 + (b >> 4)) * ((long long)QN * 16) + (long long)slot * 16 + (b & 15);
-        img8[base] = (unsigned char)hc;
-        img8[base + 4ll * QN * 16] = (unsigned char)lc;
-    }
-    red[tid] = ss;
-    __syncthreads();
-    for (int o = 128; o; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) eps_q[slot] = sqrtf(red[0]) * 1.002f + 8.0f * (float)dp * 5.9604645e-8f + 1e-6f;
-}
-
-hipError_t launch_prep_scan8(const float* qn, int nq, int d, int dp, int qn_tile, unsigned char* img8, float* eps_q, hipStream_t s) {
-    hipLaunchKernelGGL(k_prep_scan8, dim3(qn_tile), dim3(256), 0, s, qn, nq, d, dp, qn_tile, img8, eps_q);
-    return hipGetLastError();
-}
-
 hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, unsigned char* img8, float* eps_q, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_wide8, dim3(qtot), dim3(256), 0, s, qn, nq, d, dp, qtot, img8, eps_q);
     return hipGetLastError();
@@ -2607,12 +2557,10 @@ hipError_t launch_scan(const ScanArgs& a, int mode, int qn_tile, int grid, int w
 hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_fp8, hipStream_t s) {
     const size_t lds = scan2_lds_bytes(a.dp, qn_tile, a.stage_cap);
     if (qn_tile == kQueryTile) {
-        if (rows_are_fp8 == 2) hipLaunchKernelGGL((k_scan2<1, 2>), dim3(grid), dim3(kScan2Threads), lds, s, a);
-        else if (rows_are_fp8) hipLaunchKernelGGL((k_scan2<1, 1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+        if (rows_are_fp8) hipLaunchKernelGGL((k_scan2<1, 1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
         else hipLaunchKernelGGL((k_scan2<1, 0>), dim3(grid), dim3(kScan2Threads), lds, s, a);
     } else {
-        if (rows_are_fp8 == 2) hipLaunchKernelGGL((k_scan2<2, 2>), dim3(grid), dim3(kScan2Threads), lds, s, a);
-        else if (rows_are_fp8) hipLaunchKernelGGL((k_scan2<2, 1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
+        if (rows_are_fp8) hipLaunchKernelGGL((k_scan2<2, 1>), dim3(grid), dim3(kScan2Threads), lds, s, a);
         else hipLaunchKernelGGL((k_scan2<2, 0>), dim3(grid), dim3(kScan2Threads), lds, s, a);
     }
     return hipGetLastError();
@@ -3105,8 +3053,6 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
