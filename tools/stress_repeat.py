@@ -16,6 +16,7 @@ CASES = [
     ("narrow fp16 rows, 3 queries, clustered data", dict(dtype="f16", d=1024, nq=3, n=200000, k=1000, data="clusters", seed=12), {}),
     ("wide fp8 rows, 200 queries (k_scan_wide8)", dict(dtype="fp8", d=1024, nq=200, n=60000, k=1000, data="normal", seed=13), {}),
     ("wide fp8 rows, 300 queries, duplicates (k_scan_wide8)", dict(dtype="fp8", d=768, nq=300, n=40000, k=100, data="dupes", seed=14), {}),
+    ("wide fp8 rows, 1024 queries, k = 1000: the configs[4] call shape (k_scan_wide8)", dict(dtype="fp8", d=1024, nq=1024, n=150000, k=1000, data="normal", seed=17), {}),
     ("wide fp8 rows on the fp16 instruction (k_scan_wide)", dict(dtype="fp8", d=1024, nq=200, n=60000, k=1000, data="normal", seed=13), {"wide_mfma": 0}),
     ("wide fp16 rows, 96 queries (k_scan_wide)", dict(dtype="f16", d=768, nq=96, n=80000, k=100, data="normal", seed=15), {}),
     ("sharded handle, 3 row blocks, fp16", dict(dtype="f16", d=768, nq=64, n=150000, k=100, data="normal", seed=16, shards=3), {}),
