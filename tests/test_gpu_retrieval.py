@@ -1226,7 +1226,7 @@ def test_fuzz_across_dispatch_boundaries_bit_exact(vf, oracle):
     t0, n_cases, fails, kernels = time.time(), 0, [], set()
     while time.time() - t0 < 45.0:
         case = fz.draw_case(rng, 1e10)
-        ok, st, why = fz.run_case(vf, oracle, case)
+        ok, st, why = fz.run_case(vf, oracle, case, repeat=2)
         n_cases += 1
         kernels.add((st.get("path"), st.get("scan_kernel")))
         if not ok:

@@ -74,7 +74,7 @@ def make_data(case):
     return None, c, q
 
 
-def run_case(vf, oracle, case):
+def run_case(vf, oracle, case, repeat=1):
     codes, rows, q = make_data(case)
     if case["data"] == "sorted":            # score-sorted corpus (ascending for query 0): thresholds rise all the way through
         sims = oracle.cosine(q[:1], rows.astype(np.float32))[0]
@@ -90,16 +90,18 @@ def run_case(vf, oracle, case):
                 ix.set_option(key, val)
             except RuntimeError:
                 pass                        # an option the shape does not admit: the default stays
-        ids, sc = ix.search(q, case["k"])
+        runs = [ix.search(q, case["k"]) for _ in range(max(1, repeat))]   # repeated runs of one case: timing-dependent faults
         st = ix.stats()
     finally:
         ix.close()
     oi, os_ = oracle.search(rows, q, case["k"])
-    ok = np.array_equal(oi, ids) and np.array_equal(os_.view(np.uint32), sc.view(np.uint32))
+    bad_runs = [r for r, (i_, s_) in enumerate(runs) if not (np.array_equal(oi, i_) and np.array_equal(os_.view(np.uint32), s_.view(np.uint32)))]
+    ok = not bad_runs
+    ids, sc = runs[bad_runs[0]] if bad_runs else runs[0]
     why = None
     if not ok:
         badq = np.nonzero((oi != ids).any(axis=1) | (os_.view(np.uint32) != sc.view(np.uint32)).any(axis=1))[0]
-        why = {"queries": badq[:6].tolist(), "n_bad": int(badq.size)}
+        why = {"queries": badq[:6].tolist(), "n_bad": int(badq.size), "bad_runs": bad_runs, "of_runs": len(runs)}
         b = int(badq[0])
         j = int(np.nonzero((oi[b] != ids[b]) | (os_[b].view(np.uint32) != sc[b].view(np.uint32)))[0][0])
         why["first"] = {"rank": j, "got": [int(ids[b, j]), float(sc[b, j])], "want": [int(oi[b, j]), float(os_[b, j])]}
@@ -112,6 +114,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-work", type=float, default=2e10, help="cap on rows x queries x dim per case (the oracle's cost)")
     ap.add_argument("--case", default=None, help="JSON of one case to re-run")
+    ap.add_argument("--repeat", type=int, default=1, help="searches per case on the same index (all compared with the oracle)")
     a = ap.parse_args()
     import veritasfi_amd as vf
     from veritasfi_amd import _ffi
@@ -120,7 +123,7 @@ def main():
     canonical.build()
     if a.case:
         case = json.loads(a.case)
-        ok, st, why = run_case(vf, canonical, case)
+        ok, st, why = run_case(vf, canonical, case, a.repeat)
         print("OK" if ok else "FAIL", json.dumps(case), st, why)
         return 0 if ok else 1
     rng = np.random.default_rng(a.seed)
@@ -130,7 +133,7 @@ def main():
     while time.time() - t0 < a.seconds:
         case = draw_case(rng, a.max_work)
         try:
-            ok, st, why = run_case(vf, canonical, case)
+            ok, st, why = run_case(vf, canonical, case, a.repeat)
         except Exception as e:   # noqa: BLE001 -- a fuzz driver reports everything
             ok, st, why = False, {}, {"exception": repr(e)}
         n_cases += 1
