@@ -73,6 +73,10 @@ def main():
                 else:
                     ref = m(input_ids=torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev)).logits[:, 0].cpu().numpy()
             got = encs[kind].forward(ids.astype(np.int32), mask.astype(np.int32))
+            again = encs[kind].forward(ids.astype(np.int32), mask.astype(np.int32))      # the same call twice: bit for bit the same
+            if not np.array_equal(np.asarray(got).view(np.uint32), np.asarray(again).view(np.uint32)):
+                fails += 1
+                print("FAIL (not repeatable)", json.dumps({"kind": kind, "b": b, "t": t, "dist": dist, "lens": lens.tolist()[:50]}), flush=True)
             err = float(np.abs(np.asarray(got).reshape(ref.shape) - ref).max()) if np.isfinite(got).all() else float("inf")
             if not kind.startswith("bert"):
                 err /= max(1.0, float(np.abs(ref).max()))          # logits: relative to their scale, as the tests do
