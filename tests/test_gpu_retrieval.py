@@ -422,6 +422,17 @@ def test_errors_are_reported_not_fatal(vf):
     with vf.DenseIndex(np.ones((4, 16), np.float32)) as ix:
         with pytest.raises(ValueError):
             ix.search(np.ones((1, 8), np.float32), 1)
+    # a corpus of up to 16384 rows is built without the fused scan's operands: forcing the fused path on it is refused (round 4: the
+    # option fuzz found this running the scan on null operands -- a GPU memory fault), for a plain and for a sharded handle
+    rows = np.random.default_rng(3).standard_normal((14078, 16)).astype(np.float16)
+    q = np.ones((2, 16), np.float32)
+    for kw in ({}, {"device_ids": [0, 0]}):
+        with vf.DenseIndex(rows, **kw) as ix:
+            ix.set_option("force_path", 1)
+            with pytest.raises(RuntimeError, match="forced fused path"):
+                ix.search(q, 5)
+            ix.set_option("force_path", -1)
+            assert ix.search(q, 5)[0].shape == (2, 5)
 
 
 # ---- BASELINE configs[1] at full size: 1M x 768 fp16, B = 64, k = 100 ----------------------------

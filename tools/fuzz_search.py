@@ -35,6 +35,12 @@ def draw_case(rng, max_work):
         opts["wide_mfma"] = pick([0, 1])
     if rng.random() < 0.2:
         opts["sample_rows"] = pick([1, 4, 16, 64])
+    if rng.random() < 0.35:      # the other tuning knobs: every one of them is a speed setting, none may change a result
+        knobs = {"force_path": [0, 1, 2], "margin": [0, 1, 8, 64, 2048], "cap": [0, 256, 1024, 16384], "waves": [0, 64, 1024, 8192],
+                 "scan_g": [0, 1, 2, 3, 4], "refresh_every": [1, 4, 128, 256], "steal": [0, 1], "wide": [0, 1, 16, 65, 200],
+                 "wide_sync": [-1, 0, 2, 8], "aux_cus": [0, 32, 64], "sample_grid": [0, 8, 64, 1024], "overlap_scans": [0, 1]}
+        for name in rng.choice(sorted(knobs), size=int(rng.integers(1, 4)), replace=False):
+            opts[str(name)] = int(pick(knobs[str(name)]))
     shards = int(pick([1, 1, 1, 2, 3, 5])) if n >= 8 else 1      # > 1: one handle over that many row blocks, all on device 0
     return dict(dtype=dtype, d=int(d), nq=int(nq), n=int(n), k=int(k), data=data, opts=opts, shards=shards, seed=int(rng.integers(1 << 31)))
 
@@ -90,7 +96,14 @@ def run_case(vf, oracle, case, repeat=1):
                 ix.set_option(key, val)
             except RuntimeError:
                 pass                        # an option the shape does not admit: the default stays
-        runs = [ix.search(q, case["k"]) for _ in range(max(1, repeat))]   # repeated runs of one case: timing-dependent faults
+        try:
+            first = ix.search(q, case["k"])
+        except RuntimeError as e:            # a forced fused path the index cannot take is REFUSED (an error, not a crash): drop the knob
+            if "forced fused path" not in str(e):
+                raise
+            ix.set_option("force_path", -1)
+            first = ix.search(q, case["k"])
+        runs = [first] + [ix.search(q, case["k"]) for _ in range(max(1, repeat) - 1)]   # repeated runs of one case: timing-dependent faults
         st = ix.stats()
     finally:
         ix.close()

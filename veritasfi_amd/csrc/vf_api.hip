@@ -636,6 +636,9 @@ static int qn_tile_for(int nq_batch) { return nq_batch <= kQueryTile ? kQueryTil
 
 static bool fused_possible(const vf_index* ix, int k) {
     if (ix->n <= 1024 || k > kMaxKFused || k <= 0) return false;
+    // corpora of up to kSmallN rows are built WITHOUT the scan copy and its inverse norms (they never take the fused path on their
+    // own): forcing path 1 on one must be refused, not run on null operands (round 4: found by the option fuzz -- a memory fault)
+    if (!ix->rows_scan || !ix->inv_scan) return false;
     if (scan_lds_bytes(ix->dp, kQueryTile) > 160 * 1024) return false;
     return true;
 }
