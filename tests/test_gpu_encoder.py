@@ -277,7 +277,23 @@ def test_encoder_errors(vf):
         e.forward(np.zeros((1, 600), np.int64), np.ones((1, 600), np.int64))
     with pytest.raises(ValueError):                                  # beyond the 8192-token limit of the encoder path
         e.forward(np.zeros((1, 8200), np.int64), np.ones((1, 8200), np.int64))
+    # a token id outside the embedding table (another model's tokenizer, -1 as padding) is an error, not an out-of-bounds read on the GPU
+    ok_ids = np.full((2, 32), 7, np.int64)
+    for bad_id in (cfg["vocab"], -1, 1 << 30):
+        bad_ids = ok_ids.copy(); bad_ids[1, 5] = bad_id
+        with pytest.raises(RuntimeError, match="outside the vocabulary"):
+            e.forward(bad_ids, np.ones_like(ok_ids))
+    with pytest.raises(RuntimeError, match="token type id"):
+        e.forward(ok_ids, np.ones_like(ok_ids), np.full_like(ok_ids, cfg["type_vocab"]))
+    assert np.isfinite(e.forward(ok_ids, np.ones_like(ok_ids))).all()
     e.close()
+    dm = _hf_qwen3(128, 1, 2, 2, 64, 256, vocab=300)
+    dec = vf.HipDecoder.from_hf(dm, pooling=2, normalize=False)
+    bad_ids = np.full((1, 32), 5, np.int64); bad_ids[0, 31] = 300
+    with pytest.raises(RuntimeError, match="outside the vocabulary"):
+        dec.forward(bad_ids, np.ones_like(bad_ids))
+    assert np.isfinite(dec.forward(np.full((1, 32), 5, np.int64), np.ones((1, 32), np.int64))).all()
+    dec.close()
 
 
 def test_pipeline_embed_retrieve_rerank_rank_chunk(vf):

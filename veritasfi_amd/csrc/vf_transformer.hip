@@ -3508,6 +3508,15 @@ static std::atomic<long long> g_packed_forwards{0};
 // Test hook: how many forwards took the packed (ragged-batch) path in this process.
 extern "C" long long vf_debug_packed_forwards() { return g_packed_forwards.load(std::memory_order_relaxed); }
 
+// Token ids index the embedding table on the device: an id outside [0, vocab) (a tokenizer that does not belong to the model, a -1
+// used as padding) would be an out-of-bounds read there -- a GPU memory fault, not an exception.  Checked here, on the host copy
+// the caller hands over (b * t compares: ~15 us for 100 x 512 tokens); padded positions are looked up too, so they count.
+static long long first_id_out_of_range(const int32_t* ids, size_t n, int32_t hi) {
+    for (size_t i = 0; i < n; ++i)
+        if ((uint32_t)ids[i] >= (uint32_t)hi) return (long long)i;
+    return -1;
+}
+
 static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, const int32_t* type_ids, int32_t b,
                         int32_t t, int32_t t_valid, int32_t pooling, int32_t normalize, float* out) {
     if (!e) return fail(VF_EINVAL, "vf_encoder_forward: null handle");
@@ -3518,6 +3527,12 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_encoder_forward: t_valid must be in [1, t]");
     if (t > e->cfg.max_pos - (e->cfg.roberta_pad_idx >= 0 ? e->cfg.roberta_pad_idx + 1 : 0))
         return fail(VF_EINVAL, "vf_encoder_forward: t exceeds the position table");
+    {
+        const long long bad = first_id_out_of_range(ids, (size_t)b * t, e->cfg.vocab);
+        if (bad >= 0) return fail(VF_EINVAL, "vf_encoder_forward: token id " + std::to_string(ids[bad]) + " at [" + std::to_string(bad / t) + ", " + std::to_string(bad % t) + "] is outside the vocabulary [0, " + std::to_string(e->cfg.vocab) + ")");
+        const long long badt = type_ids ? first_id_out_of_range(type_ids, (size_t)b * t, e->cfg.type_vocab) : -1;
+        if (badt >= 0) return fail(VF_EINVAL, "vf_encoder_forward: token type id " + std::to_string(type_ids[badt]) + " is outside [0, " + std::to_string(e->cfg.type_vocab) + ")");
+    }
     std::lock_guard<std::mutex> g(e->mu);
     // per-call pooling / normalisation: swapped in under the handle's lock, restored on every exit path
     struct Restore {
@@ -3649,6 +3664,12 @@ extern "C" int vf_encoder_forward_hidden(vf_encoder* e, const int32_t* ids, cons
     if (t == 0 || t % 32 != 0 || t > kEncMaxT) return fail(VF_EINVAL, "vf_encoder_forward_hidden: t must be a multiple of 32 in [32, 8192]");
     if (t > e->cfg.max_pos - (e->cfg.roberta_pad_idx >= 0 ? e->cfg.roberta_pad_idx + 1 : 0))
         return fail(VF_EINVAL, "vf_encoder_forward_hidden: t exceeds the position table");
+    {
+        const long long bad = first_id_out_of_range(ids, (size_t)b * t, e->cfg.vocab);
+        if (bad >= 0) return fail(VF_EINVAL, "vf_encoder_forward_hidden: token id " + std::to_string(ids[bad]) + " is outside the vocabulary [0, " + std::to_string(e->cfg.vocab) + ")");
+        const long long badt = type_ids ? first_id_out_of_range(type_ids, (size_t)b * t, e->cfg.type_vocab) : -1;
+        if (badt >= 0) return fail(VF_EINVAL, "vf_encoder_forward_hidden: token type id " + std::to_string(type_ids[badt]) + " is outside [0, " + std::to_string(e->cfg.type_vocab) + ")");
+    }
     std::lock_guard<std::mutex> g(e->mu);
     VFT_HIP(hipSetDevice(e->device));
     int rc = enc_ensure_ws(e, b, t);
@@ -3900,6 +3921,10 @@ static int dec_check_call(vf_decoder* d, const int32_t* ids, const int32_t* mask
     if (b > 0 && (!ids || !mask || !out)) return fail(VF_EINVAL, std::string(who) + ": null buffer");
     if (b > 0 && (t == 0 || t % 32 != 0 || t > kDecMaxT))
         return fail(VF_EINVAL, std::string(who) + ": t must be a multiple of 32 in [32, 4096] (pad with mask 0)");
+    if (b > 0) {
+        const long long bad = first_id_out_of_range(ids, (size_t)b * t, d->cfg.vocab);
+        if (bad >= 0) return fail(VF_EINVAL, std::string(who) + ": token id " + std::to_string(ids[bad]) + " at [" + std::to_string(bad / t) + ", " + std::to_string(bad % t) + "] is outside the vocabulary [0, " + std::to_string(d->cfg.vocab) + ")");
+    }
     return VF_OK;
 }
 
