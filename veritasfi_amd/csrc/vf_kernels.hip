@@ -1393,6 +1393,14 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                 // operands -- so that all THREE ring buffers are in flight while the epilogue below runs (with the issue in
                 // front of the compute, as first written, a tile whose epilogue takes the candidate path left the queue dry:
                 // a wave has no partner on its SIMD to cover for it)
+                // The refill overwrites the LDS this segment's fragments were READ from: those ds_reads must have RETURNED, not merely
+                // issued.  The matrix instructions above wait for them -- as long as the compiler keeps them above this point; it is
+                // free not to (they touch registers only, the asm below is a memory barrier to memory operations only): in round 4's
+                // fp8-instruction variant of this loop it sank all four MFMAs and their lgkmcnt waits BELOW the refill, and a DMA that
+                // found its line in L2 beat the reads it should have followed -- one wrong score in ~10^4, a lost row in 12 of 40 runs
+                // (found by the fuzz; that variant is gone).  In the shipped variants the wait is already lgkmcnt(0) here, so this costs
+                // nothing; it turns an accident of scheduling into a guarantee.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const int s3 = sg + kRing;
                 if (s3 < S) issue_seg(src_cur, s3, buf);
                 else {
