@@ -226,3 +226,19 @@ def test_generated_asm_block_of_the_wide_scan_is_in_sync():
     b = src.index("__global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {")
     gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_w8_asm.py")], capture_output=True, text=True, check=True).stdout
     assert src[a:b].strip() == gen.strip()
+
+
+def test_wide_scan_asm_bodies_drain_their_lds_reads():
+    """Every K-tile body of k_scan_wide8 ends its second piece with s_waitcnt lgkmcnt(0) behind its last ds_read: the stage it read is
+    handed to the NEXT tile's LDS-DMA after the following barrier, so the reads must have returned by then (the hazard class that
+    tools/lint_lds_dma.py looks for in compiled code; in hand-written asm nothing else would put the wait there)."""
+    import re
+    src = open(os.path.join(ROOT, "veritasfi_amd", "csrc", "vf_kernels.hip")).read()
+    a = src.index("#define VF8_ASM_E0_A \\")
+    b = src.index("__global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {")
+    bodies = re.findall(r"#define (VF8_ASM_\w+_B) \\\n((?:.*\\\n)*.*\n)", src[a:b])
+    assert len(bodies) == 5
+    for name, body in bodies:
+        ins = re.findall(r'"([^"\\]+)\\n\\t"', body)
+        last_read = max(i for i, x in enumerate(ins) if x.startswith("ds_read"))
+        assert any("lgkmcnt(0)" in x for x in ins[last_read + 1:]), name
