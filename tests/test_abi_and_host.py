@@ -242,3 +242,18 @@ def test_wide_scan_asm_bodies_drain_their_lds_reads():
         ins = re.findall(r'"([^"\\]+)\\n\\t"', body)
         last_read = max(i for i, x in enumerate(ins) if x.startswith("ds_read"))
         assert any("lgkmcnt(0)" in x for x in ins[last_read + 1:]), name
+
+
+def test_isa_lint_no_lds_reads_outstanding_where_lds_is_handed_to_a_dma():
+    """tools/lint_lds_dma.py on the compiled kernels (hipcc cross-compiles here; about a minute): in no kernel -- the two that read
+    across the hand-over point by design aside -- can a ds_read still be outstanding where an LDS-DMA is issued or a barrier gives the
+    bytes back.  The source cannot promise that on its own: the compiler may move the consuming matrix instructions, and the waits in
+    front of them, below a refill (round 4: it did, in a kernel variant that then lost rows intermittently)."""
+    import importlib.util
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("lint_lds_dma", os.path.join(ROOT, "tools", "lint_lds_dma.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    assert lint.main() == 0

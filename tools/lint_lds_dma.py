@@ -11,7 +11,7 @@ Expected: zero everywhere, except the two kernels whose design reads across the 
   k_gemm8p_tn   issues a phase's fragment reads, takes the phase barrier, waits lgkmcnt(0) first thing behind it; the slot is refilled
                 a further barrier later.
     python tools/lint_lds_dma.py        (exit code 1 if any other kernel shows a non-zero count)"""
-import os, re, subprocess, sys, tempfile
+import os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "veritasfi_amd", "csrc")
 ALLOW = ("k_scan_wide8", "k_gemm8p_tn")
@@ -22,7 +22,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for src in ("vf_kernels.hip", "vf_transformer.hip"):
             out = os.path.join(tmp, src + ".s")
-            subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-w", "--cuda-device-only",
+            subprocess.check_call([shutil.which("hipcc") or "/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-w", "--cuda-device-only",
                                    "-S", "-o", out, os.path.join(CSRC, src)], cwd=CSRC)
             s = open(out).read()
             for m in re.finditer(r"^(_Z[^:\n]*):\s*; @", s, re.M):
