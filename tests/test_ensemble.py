@@ -161,3 +161,80 @@ def test_constructor_defaults_and_empty_cases():
 
 # The GPU end-to-end case compares with the REAL reference's output: tests/test_control_flow_golden.py
 # (test_g5_gpu_ensemble_matches_reference_invoke).
+
+
+def test_stage_hooks_carry_the_reference_names():
+    """veritasfi_amd.set_profiler(p): EnsembleRetriever.invoke brackets "retrieve" and one stage per branch and reports the
+    "retrieved_chunks" metric -- the names /root/reference/src/utils/ensembleRetriever.py:50,63,135,138,185,188,229,231 use -- and
+    rank_chunk brackets "rerank" (vllmChatService.py:31) with its two device legs inside; without a profiler nothing is recorded, a
+    skipped stage is left to the host, a stage that raises is still ended."""
+    from datetime import datetime
+    import veritasfi_amd as vf
+    from veritasfi_amd import stages
+    from veritasfi_amd.rank import rank_chunk
+    import veritasfi_amd.rank as rank_mod
+
+    class Rec:
+        def __init__(self): self.log, self.metrics = [], {}
+        def start(self, name): self.log.append(("start", name))
+        def end(self, name): self.log.append(("end", name))
+        def add_metric(self, name, value): self.metrics.setdefault(name, []).append(value)
+
+    from veritasfi_amd.ensemble import EnsembleRetriever
+    chroma, ts, emb, bm, queries, metas, titles = _world(2, n=40, n_titles=4)
+    er = EnsembleRetriever("unused_dir", chroma, ts, 3, emb, faiss_ts_k=2, bm25_k=2, bm25_retriever=bm, retriever_cls=CosineRetriever)
+    assert vf.get_profiler() is None
+    base = er.invoke("q0", [])
+    rec = Rec()
+    prev = vf.set_profiler(rec)
+    try:
+        assert prev is None
+        out = er.invoke("q0", [])
+        assert out == base
+        names = [n for kind, n in rec.log if kind == "start"]
+        assert names == ["retrieve", "retrieve_faiss", "retrieve_faiss_ts", "retrieve_bm25"]
+        assert rec.log[0] == ("start", "retrieve") and rec.log[-1] == ("end", "retrieve")
+        assert rec.metrics["retrieved_chunks"] == [len(out)]
+        # rank_chunk: the device legs replaced by host stand-ins (this is a CPU test of the brackets, not of the arithmetic)
+        class RR:
+            def compute_score(self, pairs, batch_size=8): return [float(len(p[1])) for p in pairs]
+        chunks = [{"page_content": "x" * (i + 1), "bundle_id": i, "metadata": {"date_published": "2024-01-0%d" % (i + 1)}} for i in range(4)]
+        saved = (rank_mod.fuse_and_rank, rank_mod.compute_similarity_mtx)
+        rank_mod.fuse_and_rank = lambda a, b, dev=0: (None, list(np.argsort(-(np.asarray(a) + np.asarray(b)), kind="stable")))
+        rank_mod.compute_similarity_mtx = lambda emb, texts, dev=0, as_torch=True, **kw: np.eye(len(texts), dtype=np.float32)
+        try:
+            rec.log.clear()
+            got = rank_chunk(chunks, "q", datetime(2024, 1, 5), RR(), None, chunk_topk=2)
+            assert got == [2, 3]
+            assert rec.log == [("start", "rerank"), ("start", "rerank_score"), ("end", "rerank_score"), ("start", "rerank_similarity"),
+                               ("end", "rerank_similarity"), ("end", "rerank")]
+            vf.set_profiler(rec, skip=("rerank",))            # the host's own decorator keeps "rerank"
+            rec.log.clear()
+            rank_chunk(chunks, "q", datetime(2024, 1, 5), RR(), None, chunk_topk=2)
+            assert ("start", "rerank") not in rec.log and ("start", "rerank_score") in rec.log
+            class Boom:
+                def compute_score(self, pairs, batch_size=8): raise RuntimeError("device lost")
+            vf.set_profiler(rec)
+            rec.log.clear()
+            with pytest.raises(RuntimeError):
+                rank_chunk(chunks, "q", datetime(2024, 1, 5), Boom(), None, chunk_topk=2)
+            assert rec.log[-2:] == [("end", "rerank_score"), ("end", "rerank")]
+        finally:
+            rank_mod.fuse_and_rank, rank_mod.compute_similarity_mtx = saved
+        with pytest.raises(TypeError):
+            vf.set_profiler(object())
+    finally:
+        vf.set_profiler(None)
+    rec.log.clear()
+    er.invoke("q0", [])
+    assert rec.log == []
+    # the recorder that ships: per-thread timers, the reference's profile_data shape
+    t = vf.StageTimer()
+    vf.set_profiler(t)
+    try:
+        er.invoke("q0", [])
+        er.invoke("q0", [])
+    finally:
+        vf.set_profiler(None)
+    assert t.profile_data["retrieve"]["calls"] == 2 and len(t.profile_data["retrieve_faiss"]["execution_times"]) == 2
+    assert t.metrics["retrieved_chunks"] == [len(base)] * 2 and t.summary()["retrieve"]["p50_ms"] >= t.summary()["retrieve_faiss"]["p50_ms"]

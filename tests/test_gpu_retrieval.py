@@ -382,9 +382,16 @@ def test_cosine_matrix_of_index_rows_by_id(vf, oracle):
         assert np.array_equal(_bits(a), _bits(b))
         with pytest.raises(ValueError):
             vf.compute_similarity_mtx(FakeEmb(), ["1", "2"], index=ix, row_ids=[1])
-    with vf.DenseIndex(c32[:4000], device_ids=[0, 0]) as grp:          # rows on several devices: refused, not guessed
-        with pytest.raises(RuntimeError, match="sharded"):
-            grp.cosine_matrix_rows([1, 2])
+    # a sharded handle (round 5): every shard normalises its own rows, the blocks meet on the home device in the caller's order --
+    # the same bits as the one-device matrix; ids that straddle the shard bounds, a shard that owns none of them, duplicates
+    with vf.DenseIndex(c32[:4001], device_ids=[0, 0, 0]) as grp:       # blocks [0, 1334), [1334, 2668), [2668, 4001)
+        pick = np.array([4000, 0, 1333, 1334, 2667, 2668, 17, 17, 3999, 1335], np.int64)
+        want = oracle.cosine(c32[pick], c32[pick])
+        assert np.array_equal(_bits(grp.cosine_matrix_rows(pick)), _bits(want))
+        only_last = np.array([2700, 3000, 2668], np.int64)
+        assert np.array_equal(_bits(grp.cosine_matrix_rows(only_last)), _bits(oracle.cosine(c32[only_last], c32[only_last])))
+        with pytest.raises(RuntimeError, match="outside the index"):
+            grp.cosine_matrix_rows([1, 4001])
 
 
 def test_drop_in_classes(vf, oracle):
@@ -1094,6 +1101,115 @@ def test_single_process_sharded_handle(vf, oracle, tmp_path):
             a.close(); b.close()
     with pytest.raises(RuntimeError):
         vf.DenseIndex(c[:10], device_ids=[0, 99])
+
+
+def test_sharded_handle_without_peer_access_takes_the_staged_exchange(vf, oracle):
+    """Multi-GPU readiness on a one-GPU box: vf_debug_force_no_peer makes every shard of a handle built afterwards unreachable by
+    peer copy, so queries and packed results travel home -> pinned host -> shard and back (streams of the owning device on either
+    side, events across) -- the path a refused hipDeviceEnablePeerAccess falls to on a real node.  Same bits as the oracle through
+    the host entry, the device entry and two batches in flight; the rows-by-id similarity matrix and rank_chunk(similarity_index=)
+    work on the sharded handle (peer and staged) as on one device."""
+    import ctypes
+    from datetime import datetime
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_force_no_peer.argtypes = [ctypes.c_int32]
+    c, q = _data(71, 50_003, 256, 33, np.float16)
+    k = 20
+    want_i, want_s = oracle.search(c, q, k)
+    prev = L.vf_debug_force_no_peer(1)
+    try:
+        ix = vf.DenseIndex(c, device_ids=[0, 0, 0])
+    finally:
+        L.vf_debug_force_no_peer(prev)
+    with ix:
+        assert ix.peer_access() == [False, False, False]
+        for _ in range(3):                                           # the pinned buffers are reused from call to call
+            i, s = ix.search(q, k)
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s), _bits(want_s))
+        qd = torch.from_numpy(q).cuda()
+        outs = []
+        for step in range(6):
+            slot = step % 2
+            if step >= 2:
+                ix.search_end(slot)
+            outs.append(ix.search_begin(slot, qd, k))
+        ix.search_end(0); ix.search_end(1)
+        torch.cuda.synchronize()
+        for a, b in outs:
+            assert np.array_equal(a.cpu().numpy(), want_i) and np.array_equal(_bits(b.cpu().numpy()), _bits(want_s))
+        pick = np.array([50_002, 0, 16_667, 16_668, 33_335, 33_336, 5, 5], np.int64)
+        cf = c.astype(np.float32)
+        assert np.array_equal(_bits(ix.cosine_matrix_rows(pick)), _bits(oracle.cosine(cf[pick], cf[pick])))
+    with vf.DenseIndex(c, device_ids=[0, 0]) as peer:                # a handle built after the hook was switched off is untouched
+        assert peer.peer_access() == [True, True]
+
+    # rank_chunk with the similarity matrix from the corpus rows, on one device and behind a sharded handle: the same selection
+    rng = np.random.default_rng(72)
+    table = rng.standard_normal((3000, 96)).astype(np.float32)
+    table[1501] = table[10] + 1e-3 * rng.standard_normal(96).astype(np.float32)   # a near-duplicate across the shard bound
+
+    class Emb:
+        def embed_documents(self, texts): return [table[int(t)].tolist() for t in texts]
+
+    class RR:
+        def compute_score(self, pairs, batch_size=8): return [float((int(p[1]) * 7919) % 101) / 50.0 for p in pairs]
+
+    rows = [10, 1501, 2999, 1499, 1500, 7, 2000, 42]
+    chunks = [{"page_content": str(r), "bundle_id": b, "row_id": r, "metadata": {"date_published": "2024-03-%02d" % (b + 1)}}
+              for b, r in enumerate(rows)]
+    when = datetime(2024, 3, 9)
+    base = vf.rank_chunk(chunks, "q", when, RR(), Emb(), chunk_topk=5)
+    with vf.DenseIndex(table) as one, vf.DenseIndex(table, device_ids=[0, 0]) as two:
+        got_one = vf.rank_chunk(chunks, "q", when, RR(), Emb(), chunk_topk=5, similarity_index=one)
+        got_two = vf.rank_chunk(chunks, "q", when, RR(), Emb(), chunk_topk=5, similarity_index=two)
+    assert got_one == base and got_two == base and len(base) >= 3 and not ({0, 1} <= set(base))   # the 0.9 rule dropped one of the twins
+
+
+def test_small_dense_entry_points_reuse_their_workspace(vf, oracle):
+    """vf_cosine_scores / _matrix / _matrix_rows / vf_fuse_rank lease one arena from a pool instead of 3 - 8 hipMalloc / hipFree pairs
+    per call (they sit on the serve chain: rank_chunk makes two of them per request): after a warm-up call of each shape the
+    allocation counter stands still, also with four request threads at once, and the results stay the oracle's."""
+    import ctypes
+    import threading
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_small_allocs.restype = ctypes.c_longlong
+    rng = np.random.default_rng(73)
+    x = rng.standard_normal((100, 768)).astype(np.float32)
+    y = rng.standard_normal((7, 768)).astype(np.float32)
+    want_m, want_s = oracle.cosine(x, x), oracle.cosine(y, x)
+    a, b = rng.standard_normal(100).astype(np.float32), rng.random(100).astype(np.float32)
+
+    def one_request():
+        assert np.array_equal(_bits(vf.cosine_matrix(x)), _bits(want_m))
+        assert np.array_equal(_bits(vf.cosine_scores(y, x)), _bits(want_s))
+        sc, order = vf.fuse_rank(a, b)
+        assert np.array_equal(sc, a + b) and sorted(order.tolist()) == list(range(100))
+
+    one_request()
+    n0 = L.vf_debug_small_allocs()
+    for _ in range(20):
+        one_request()
+    assert L.vf_debug_small_allocs() == n0, "a steady-state call allocated device memory"
+    errs = []
+    def worker():
+        try:
+            for _ in range(10):
+                one_request()
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    # concurrent callers each hold an arena of their own; one that pops a smaller arena than its call needs grows it once per size
+    # class (three call shapes here): bounded by callers x shapes, and then steady again
+    assert L.vf_debug_small_allocs() <= n0 + 12
+    n1 = L.vf_debug_small_allocs()
+    for _ in range(5):
+        one_request()
+    assert L.vf_debug_small_allocs() == n1
 
 
 # ---- wide scan (k_scan_wide): more than 128 queries share one read of the shard ---------------------------------------

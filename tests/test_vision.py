@@ -227,6 +227,12 @@ def test_clip_text_embeddings_surface_and_errors(vf):
     assert I[0, 0] == 2 and I[1, 0] == 7 and np.all(D[:, 0] > 0.999)
     with pytest.raises(ValueError):
         enc.forward(np.zeros((2, 78), np.int64))                    # beyond max_pos
+    for bad in (-1, 1000, 1 << 20):                                 # an id outside the token table is refused by name, not clamped
+        ids = np.ones((2, 8), np.int64)
+        ids[1, 3] = bad
+        with pytest.raises(ValueError, match="outside the vocabulary"):
+            enc.forward(ids)
+    assert np.isfinite(enc.forward(np.ones((2, 8), np.int64))).all()   # the handle survives the refusals
     enc.close()
     with pytest.raises(RuntimeError):
         enc.forward(np.zeros((1, 8), np.int64))

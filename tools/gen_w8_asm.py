@@ -32,7 +32,9 @@ def body(even, has_prev, is_last, first=False, second=False):   # first / second
     L += ["s_waitcnt lgkmcnt(12)"] + mm(0, cur, 2, first) + ["s_waitcnt lgkmcnt(8)"] + mm(1, cur, 3, first) + ["s_waitcnt lgkmcnt(4)"] + mm(2, cur, prv, first)
     L += ["s_waitcnt lgkmcnt(0)"]
     if is_last:
-        L += mm(3, cur, 4)
+        # compiler-generated VALU code reads the accumulators right behind this body, and LLVM's hazard recognizer does not look
+        # inside inline asm: the 16-pass matrix result -> VALU read wait states are spelled out (they cost 24 cycles per super-tile)
+        L += mm(3, cur, 4) + ["s_nop 15", "s_nop 7"]
     return L
 def cstr(lines):
     return "\n".join(f'        "{l}\\n\\t"' for l in lines)

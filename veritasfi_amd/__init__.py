@@ -16,6 +16,8 @@ Drop-in names (same signatures as the reference):
 * ``EnsembleRetriever``                  -- ``src/utils/ensembleRetriever.py:19-232`` (candidate gathering around the search)
 * ``ShardedRetriever``                   -- row-sharded multi-GPU search
 * ``ShardedScorer``                      -- data-parallel re-rank / embed: a replica per rank + one all-gather of the scores
+* ``set_profiler``                       -- routes the reference's stage names ("retrieve", "retrieve_faiss", "retrieve_faiss_ts",
+                                            "rerank"; ``src/utils/profiler.py``) out of the drop-in classes (off by default)
 """
 from .index import (DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device,  # noqa: F401
                     merge_topk_packed_device, packed_part_bytes, packed_result_buffer)
@@ -29,5 +31,6 @@ from .rank import rank_chunk  # noqa: F401
 from .vision import (HipClipTextEmbeddings, HipClipTextEncoder, HipImageEmbeddings, HipVisionEncoder, pack_hf_clip_text,  # noqa: F401
                      pack_hf_clip_vision)
 from .ensemble import EnsembleRetriever  # noqa: F401
+from .stages import StageTimer, get_profiler, set_profiler  # noqa: F401
 
 __version__ = "0.1.0"

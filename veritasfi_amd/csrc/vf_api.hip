@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -81,6 +82,20 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+struct HostBuf {   // pinned host staging
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return VF_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(VF_ENOMEM, std::string("hipHostMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
+        bytes = need;
+        return VF_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
 struct Slot {
     hipStream_t stream = nullptr;        // everything but the main scan (any CU)
     hipStream_t scan_stream = nullptr;   // the main k_scan launches: CU-masked to the scan partition when the split is on, else == stream
@@ -116,6 +131,17 @@ struct GroupSlot {
     std::vector<DevBuf> dq, blob;        // [G] queries / packed result [ids | scores] on shard g's device
     DevBuf all;                          // home device: G packed parts, the merge kernel's input
     hipEvent_t ev_in = nullptr;          // home device: the caller's stream at _begin time
+    // Host-staged exchange for shards WITHOUT peer access to the home device (hipDeviceEnablePeerAccess refused, or the test hook
+    // vf_debug_force_no_peer): queries home -> pinned host -> shard, packed result shard -> pinned host -> home.  Every copy is issued
+    // on a stream of the device that owns the DEVICE side of it; events carry the order across devices.  Created on first use.
+    hipStream_t hq_stream = nullptr;     // home device: the query copy to the host (once per search, shared by the staged shards)
+    hipEvent_t ev_hq = nullptr;          // home device: the queries are in `hq`
+    HostBuf hq;                          // pinned: the batch's queries
+    std::vector<hipStream_t> hfeed;      // [G] home device: shard g's result, host -> `all`
+    std::vector<hipEvent_t> ev_hb;       // [G] shard device: shard g's result is in hb[g]
+    std::vector<hipEvent_t> ev_home;     // [G] home device: ... and has landed in `all` (what the merge waits for instead of ev[g])
+    std::vector<HostBuf> hb;             // [G] pinned: shard g's packed result
+    std::vector<char> staged_last;       // [G] the last search of this slot took the staged way for shard g (ev_home[g] is recorded)
     bool pending = false;
     int nq = 0, k = 0;
     int64_t* d_ids = nullptr; float* d_scores = nullptr;
@@ -142,7 +168,7 @@ struct vf_index {
     Slot slots[kSlots];
     // options
     int64_t force_path = -1, sample_rows = -1, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
-            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = -1,
+            refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = -1, wide8_waves = 8, wide8_stage = 0,
             aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
@@ -267,9 +293,16 @@ static void destroy_index(vf_index* ix) {
                 if (g < gs.blob.size()) gs.blob[g].release();
                 if (g < gs.feed.size() && gs.feed[g]) (void)hipStreamDestroy(gs.feed[g]);
                 if (g < gs.ev.size() && gs.ev[g]) (void)hipEventDestroy(gs.ev[g]);
+                if (g < gs.ev_hb.size() && gs.ev_hb[g]) (void)hipEventDestroy(gs.ev_hb[g]);
+                if (g < gs.hb.size()) gs.hb[g].release();
             }
             (void)hipSetDevice(ix->device);
             gs.all.release();
+            gs.hq.release();
+            for (hipStream_t st : gs.hfeed) if (st) (void)hipStreamDestroy(st);
+            for (hipEvent_t ev : gs.ev_home) if (ev) (void)hipEventDestroy(ev);
+            if (gs.hq_stream) (void)hipStreamDestroy(gs.hq_stream);
+            if (gs.ev_hq) (void)hipEventDestroy(gs.ev_hq);
             if (gs.ev_in) (void)hipEventDestroy(gs.ev_in);
         }
         for (vf_index* sh : ix->shards) destroy_index(sh);
@@ -551,6 +584,8 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
     else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
+    else if (s == "wide8_stage") { if (!in_range(0, 3584)) return fail(VF_EINVAL, "wide8_stage must be 0 (auto) or 64..3584 candidate-stage entries"); ix->wide8_stage = value; }
+    else if (s == "wide8_waves") { if (value != 4 && value != 8) return fail(VF_EINVAL, "wide8_waves must be 4 (two 256-thread workgroups per CU, 128-query tiles: the default) or 8 (one 512-thread workgroup, 256-query tiles)"); ix->wide8_waves = value; }
     else if (s == "wide_mfma") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "wide_mfma must be -1 (auto: the fp8 instruction for e4m3 rows), 0 (fp16 matrix instruction on converted rows) or 1 (the fp8 instruction on the e4m3 row bytes: k_scan_wide8)"); ix->wide_mfma = value; }
     else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
     else if (s == "aux_cus") {   // takes effect for slots created afterwards (set it before the first search)
@@ -759,21 +794,25 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     VF_HIP(launch_sel0(a, qtot, st));
     for (int o = 0; o < kSlots; ++o)
         if (o != slot_id && ix->slots[o].ev_scan) VF_HIP(hipStreamWaitEvent(st, ix->slots[o].ev_scan, 0));
-    if (J > 1 && ix->wide_sync >= 0) {   // sibling progress words of the main pass (see k_scan_wide)
-        VF_TRY(s.sib.ensure((size_t)RG * 4 * sizeof(u32)));
-        VF_HIP(hipMemsetAsync(s.sib.p, 0, (size_t)RG * 4 * sizeof(u32), st));
+    const int w8_waves = ix->wide8_waves == 4 ? 4 : 8;
+    const int J8 = w8 && w8_waves == 4 ? (nb + 127) / 128 : J;   // query tiles of the main pass: 128 wide for the two-workgroups-per-CU form
+    if (J8 > 1 && ix->wide_sync >= 0) {   // sibling progress words of the main pass (see k_scan_wide; eight per row group)
+        VF_TRY(s.sib.ensure((size_t)RG * 8 * sizeof(u32)));
+        VF_HIP(hipMemsetAsync(s.sib.p, 0, (size_t)RG * 8 * sizeof(u32), st));
         a.sib = s.sib.as<u32>(); a.sib_slack = (int)ix->wide_sync;
     }
     if (timed) VF_HIP(hipEventRecord(s.ev_t[0], st));
     if (w8) {
         ScanArgs a8 = a;
         a8.qimg = (const _Float16*)s.qimg8.p;
+        a8.jtiles = J8;
+        a8.stage_cap = ix->wide8_stage > 0 ? (int)std::min<int64_t>(ix->wide8_stage, scan_wide8_stage_cap(w8_waves)) : scan_wide8_stage_cap(w8_waves);
         if (ix->debug & 128) {   // per-wave phase times of k_scan_wide8 (vf_index_debug_read)
-            VF_TRY(s.dbg.ensure((size_t)8 * J * ((RG + 7) / 8) * 8 * 16 * sizeof(u64)));
+            VF_TRY(s.dbg.ensure((size_t)8 * J8 * ((RG + 7) / 8) * w8_waves * 16 * sizeof(u64)));
             VF_HIP(hipMemsetAsync(s.dbg.p, 0, s.dbg.bytes, st));
             a8.dbg = s.dbg.as<u64>();
         }
-        VF_HIP(launch_scan_wide8(a8, st));
+        VF_HIP(launch_scan_wide8(a8, w8_waves, st));
     } else
         VF_HIP(launch_scan_wide(a, kModeMain, f8, st));
     VF_HIP(hipEventRecord(s.ev_scan, st));
@@ -1032,6 +1071,26 @@ static int group_ensure_slot(vf_index* ix, GroupSlot& gs) {
     }
     VF_HIP(hipSetDevice(ix->device));
     VF_HIP(hipEventCreateWithFlags(&gs.ev_in, hipEventDisableTiming));
+    gs.hfeed.assign(G, nullptr); gs.ev_hb.assign(G, nullptr); gs.ev_home.assign(G, nullptr); gs.hb.resize(G); gs.staged_last.assign(G, 0);
+    return VF_OK;
+}
+
+static bool shard_is_staged(const vf_index* ix, size_t g) { return g < ix->peer_ok.size() && !ix->peer_ok[g]; }
+
+// streams / events of the host-staged exchange for shard g (first use)
+static int group_ensure_staged(vf_index* ix, GroupSlot& gs, size_t g) {
+    if (!gs.hq_stream) {
+        VF_HIP(hipSetDevice(ix->device));
+        VF_HIP(hipStreamCreateWithFlags(&gs.hq_stream, hipStreamNonBlocking));
+        VF_HIP(hipEventCreateWithFlags(&gs.ev_hq, hipEventDisableTiming));
+    }
+    if (!gs.hfeed[g]) {
+        VF_HIP(hipSetDevice(ix->device));
+        VF_HIP(hipStreamCreateWithFlags(&gs.hfeed[g], hipStreamNonBlocking));
+        VF_HIP(hipEventCreateWithFlags(&gs.ev_home[g], hipEventDisableTiming));
+        VF_HIP(hipSetDevice(ix->shards[g]->device));
+        VF_HIP(hipEventCreateWithFlags(&gs.ev_hb[g], hipEventDisableTiming));
+    }
     return VF_OK;
 }
 
@@ -1051,14 +1110,30 @@ static int group_begin(vf_index* ix, int slot_id, const float* d_queries, int nq
     VF_HIP(hipEventRecord(gs.ev_in, user));
     size_t started = 0;
     int rc = VF_OK;
+    bool host_copy_issued = false;
     for (size_t g = 0; g < G && rc == VF_OK; ++g) {
         vf_index* sh = ix->shards[g];
-        hipError_t e = hipSetDevice(sh->device);
-        if (e == hipSuccess) e = hipStreamWaitEvent(gs.feed[g], gs.ev_in, 0);
+        const bool staged = shard_is_staged(ix, g);
+        hipError_t e = hipSuccess;
+        if (staged) {   // home -> pinned host (once per search, on a home-device stream) -> shard g (on its feed stream)
+            if ((rc = group_ensure_staged(ix, gs, g)) != VF_OK) break;
+            if (!host_copy_issued) {
+                if ((rc = gs.hq.ensure(qbytes)) != VF_OK) break;
+                e = hipSetDevice(ix->device);
+                if (e == hipSuccess) e = hipStreamWaitEvent(gs.hq_stream, gs.ev_in, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(gs.hq.p, d_queries, qbytes, hipMemcpyDeviceToHost, gs.hq_stream);
+                if (e == hipSuccess) e = hipEventRecord(gs.ev_hq, gs.hq_stream);
+                if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("sharded search: staged query copy (home -> host): ") + hipGetErrorString(e)); break; }
+                host_copy_issued = true;
+            }
+        }
+        e = hipSetDevice(sh->device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(gs.feed[g], staged ? gs.ev_hq : gs.ev_in, 0);
         if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("sharded search: ") + hipGetErrorString(e)); break; }
         if ((rc = gs.dq[g].ensure(qbytes)) != VF_OK || (rc = gs.blob[g].ensure(part)) != VF_OK) break;
-        e = hipMemcpyPeerAsync(gs.dq[g].p, sh->device, d_queries, ix->device, qbytes, gs.feed[g]);
-        if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("sharded search: query peer copy: ") + hipGetErrorString(e)); break; }
+        if (staged) e = hipMemcpyAsync(gs.dq[g].p, gs.hq.p, qbytes, hipMemcpyHostToDevice, gs.feed[g]);
+        else e = hipMemcpyPeerAsync(gs.dq[g].p, sh->device, d_queries, ix->device, qbytes, gs.feed[g]);
+        if (e != hipSuccess) { rc = fail(VF_EHIP, std::string("sharded search: query ") + (staged ? "staged" : "peer") + " copy: " + hipGetErrorString(e)); break; }
         std::lock_guard<std::mutex> lk(sh->mu);
         rc = begin_impl(sh, slot_id, gs.dq[g].as<float>(), nq, k, (int64_t*)gs.blob[g].p,
                         (float*)((char*)gs.blob[g].p + (size_t)nq * k * 8), gs.feed[g]);
@@ -1105,17 +1180,31 @@ static int group_end(vf_index* ix, int slot_id) {
                 tot.scan_kernel = std::max(tot.scan_kernel, st.scan_kernel);
             }
         }
-        if (r == VF_OK) {
+        if (r == VF_OK && !shard_is_staged(ix, g)) {
             hipError_t e = hipMemcpyPeerAsync((char*)gs.all.p + g * part, ix->device, gs.blob[g].p, sh->device, part, gs.feed[g]);
             if (e == hipSuccess) e = hipEventRecord(gs.ev[g], gs.feed[g]);
             if (e != hipSuccess) r = fail(VF_EHIP, std::string("sharded search: result peer copy: ") + hipGetErrorString(e));
+            gs.staged_last[g] = 0;
+        } else if (r == VF_OK) {   // shard -> pinned host on the shard's stream, host -> `all` on a home-device stream
+            r = gs.hb[g].ensure(part);
+            hipError_t e = hipSuccess;
+            // hb[g] is free again once the PREVIOUS search's host -> home copy out of it has run
+            if (r == VF_OK && gs.staged_last[g]) e = hipStreamWaitEvent(gs.feed[g], gs.ev_home[g], 0);
+            if (r == VF_OK && e == hipSuccess) e = hipMemcpyAsync(gs.hb[g].p, gs.blob[g].p, part, hipMemcpyDeviceToHost, gs.feed[g]);
+            if (r == VF_OK && e == hipSuccess) e = hipEventRecord(gs.ev_hb[g], gs.feed[g]);
+            if (r == VF_OK && e == hipSuccess) e = hipSetDevice(ix->device);
+            if (r == VF_OK && e == hipSuccess) e = hipStreamWaitEvent(gs.hfeed[g], gs.ev_hb[g], 0);
+            if (r == VF_OK && e == hipSuccess) e = hipMemcpyAsync((char*)gs.all.p + g * part, gs.hb[g].p, part, hipMemcpyHostToDevice, gs.hfeed[g]);
+            if (r == VF_OK && e == hipSuccess) e = hipEventRecord(gs.ev_home[g], gs.hfeed[g]);
+            if (r == VF_OK && e != hipSuccess) r = fail(VF_EHIP, std::string("sharded search: staged result copy: ") + hipGetErrorString(e));
+            if (r == VF_OK) gs.staged_last[g] = 1;
         }
         if (r != VF_OK && rc == VF_OK) rc = r;
     }
     if (rc != VF_OK) return rc;
     VF_HIP(hipSetDevice(ix->device));
     VF_HIP(scan_configure());
-    for (size_t g = 0; g < G; ++g) VF_HIP(hipStreamWaitEvent(gs.user, gs.ev[g], 0));
+    for (size_t g = 0; g < G; ++g) VF_HIP(hipStreamWaitEvent(gs.user, shard_is_staged(ix, g) ? gs.ev_home[g] : gs.ev[g], 0));
     // parts are in ascending id-range order (shard order), which the merge's tie rule relies on
     VF_HIP(launch_merge_topk_packed(gs.all.p, (int)G, gs.nq, gs.k, (long long*)gs.d_ids, gs.d_scores, gs.user));
     ix->stats = tot;
@@ -1196,6 +1285,12 @@ extern "C" int vf_index_search(vf_index* ix, const float* queries, int32_t nq, i
     return VF_OK;
 }
 
+static std::atomic<bool> g_force_no_peer{false};
+// Test hook (not in the public header): handles grouped from now on treat EVERY shard as unreachable by peer copy.
+extern "C" int vf_debug_force_no_peer(int32_t on) {
+    return g_force_no_peer.exchange(on != 0) ? 1 : 0;
+}
+
 // Take ownership of per-device indexes (built with id_offset = first row of their block, in ascending block order)
 // and present them as one index.  home = shards[0]'s device.
 static int make_group(vf_index** out, std::vector<vf_index*>& shards) {
@@ -1218,7 +1313,11 @@ static int make_group(vf_index** out, std::vector<vf_index*>& shards) {
         return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
     };
     grp->peer_ok.assign(shards.size(), 1);
+    const bool forced = g_force_no_peer.load(std::memory_order_relaxed);
     for (size_t g = 0; g < shards.size(); ++g) {
+        // test hook: every shard -- the ones on the home device too -- takes the host-staged exchange, so that the path a refused
+        // peer link falls to runs on a one-GPU box (device_ids = [0, 0]); nothing is enabled or disabled on the devices
+        if (forced) { grp->peer_ok[g] = 0; continue; }
         if (shards[g]->device == grp->device) continue;
         const bool a = enable(grp->device, shards[g]->device), b = enable(shards[g]->device, grp->device);
         grp->peer_ok[g] = a && b ? 1 : 0;
@@ -1324,7 +1423,63 @@ extern "C" int vf_index_peer_access(vf_index* ix, int32_t* ok, int32_t cap, int3
 
 // ------------------------------------------------------------------------------------------------
 // small dense cosine (compute_similarity_mtx / cosine_similarity restatements)
+//
+// These entry points sit on the serve chain (rank_chunk calls two of them per request) and used to pay 3 - 8 hipMalloc / hipFree
+// pairs per call.  They now lease ONE arena from a small process-wide pool: a call pops an arena of its device (or makes one),
+// carves its buffers out of it and pushes it back -- concurrent request threads each hold their own, none waits for another, and
+// nothing hangs on thread-exit destructors.  Arenas above 64 MB and arenas beyond eight go back to the driver on release.
 // ------------------------------------------------------------------------------------------------
+namespace {
+struct Arena { int device = -1; DevBuf buf; };
+std::mutex g_arena_mu;
+std::vector<Arena*> g_arena_free;
+std::atomic<long long> g_arena_allocs{0};            // hipMalloc calls made for arenas (test hook: vf_debug_small_allocs)
+constexpr size_t kArenaKeepBytes = (size_t)64 << 20, kArenaKeepCount = 8;
+
+struct Lease {
+    Arena* a = nullptr;
+    size_t used = 0;
+    // the caller has made `device` current
+    int acquire(int device, size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(g_arena_mu);
+            int best = -1;
+            for (int i = 0; i < (int)g_arena_free.size(); ++i)
+                if (g_arena_free[i]->device == device && (best < 0 || g_arena_free[i]->buf.bytes > g_arena_free[best]->buf.bytes)) best = i;
+            if (best >= 0) { a = g_arena_free[best]; g_arena_free.erase(g_arena_free.begin() + best); }
+        }
+        if (!a) { a = new (std::nothrow) Arena(); if (!a) return fail(VF_ENOMEM, "small-op arena: host allocation failed"); a->device = device; }
+        if (bytes > a->buf.bytes) g_arena_allocs.fetch_add(1, std::memory_order_relaxed);
+        const int rc = a->buf.ensure(bytes);
+        if (rc != VF_OK) { a->buf.release(); delete a; a = nullptr; }
+        return rc;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    template <class T> T* take(size_t count) {
+        T* p = (T*)((char*)a->buf.p + used);
+        used += padded(count * sizeof(T));
+        return p;
+    }
+    ~Lease() {
+        if (!a) return;
+        std::unique_lock<std::mutex> lk(g_arena_mu);
+        if (a->buf.bytes <= kArenaKeepBytes && g_arena_free.size() < kArenaKeepCount) { g_arena_free.push_back(a); return; }
+        lk.unlock();
+        a->buf.release();
+        delete a;
+    }
+};
+}  // namespace
+
+// Test hook (not in the public header): resident workgroups per CU of k_scan_wide8<waves> with `stage_cap` candidate-stage entries
+extern "C" int vf_debug_wide8_occupancy(int32_t waves, int32_t stage_cap) {
+    if (scan_configure() != hipSuccess) return -1;
+    return scan_wide8_occupancy(waves, stage_cap > 0 ? stage_cap : scan_wide8_stage_cap(waves));
+}
+
+// Test hook (not in the public header): arena allocations so far -- steady-state calls of the small entry points make none.
+extern "C" long long vf_debug_small_allocs(void) { return g_arena_allocs.load(std::memory_order_relaxed); }
+
 extern "C" int vf_cosine_scores(const float* a, int32_t na, const float* b, int64_t nb, int32_t d, float* out,
                                 int32_t device_id) {
     DeviceGuard restore_callers_device;
@@ -1332,66 +1487,124 @@ extern "C" int vf_cosine_scores(const float* a, int32_t na, const float* b, int6
     if (na == 0 || nb == 0) return VF_OK;
     if (!a || !b || !out) return fail(VF_EINVAL, "vf_cosine_scores: null buffer");
     VF_HIP(hipSetDevice(device_id));
-    DevBuf da, db, an, bn, na_norm, nb_norm, tmp, dout;
-    int rc = VF_OK;
-    auto done = [&](int code) {
-        DevBuf* bufs[] = {&da, &db, &an, &bn, &na_norm, &nb_norm, &tmp, &dout};
-        for (DevBuf* x : bufs) x->release();
-        return code;
-    };
-#define VF_CS(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return done(fail(VF_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
-#define VF_CT(expr) do { rc = (expr); if (rc != VF_OK) return done(rc); } while (0)
-    VF_CT(da.ensure((size_t)na * d * 4)); VF_CT(db.ensure((size_t)nb * d * 4));
-    VF_CT(an.ensure((size_t)na * d * 4)); VF_CT(bn.ensure((size_t)nb * d * 4));
-    VF_CT(na_norm.ensure((size_t)na * 4)); VF_CT(nb_norm.ensure((size_t)nb * 4));
-    VF_CT(tmp.ensure((size_t)std::max<int64_t>(na, nb) * 4)); VF_CT(dout.ensure((size_t)na * nb * 4));
-    VF_CS(hipMemcpy(da.p, a, (size_t)na * d * 4, hipMemcpyHostToDevice));
-    VF_CS(hipMemcpy(db.p, b, (size_t)nb * d * 4, hipMemcpyHostToDevice));
-    VF_CS(launch_prep_rows(da.p, 0, na, d, d, nullptr, na_norm.as<float>(), tmp.as<float>(), nullptr));
-    VF_CS(launch_prep_rows(db.p, 0, nb, d, d, nullptr, nb_norm.as<float>(), tmp.as<float>(), nullptr));
-    VF_CS(launch_normalize_rows(da.p, 0, 0, na, d, na_norm.as<float>(), an.as<float>(), nullptr));
-    VF_CS(launch_normalize_rows(db.p, 0, 0, nb, d, nb_norm.as<float>(), bn.as<float>(), nullptr));
-    VF_CS(launch_dense_dot16(an.as<float>(), na, bn.as<float>(), nb, d, dout.as<float>(), nb, nullptr));
-    VF_CS(hipMemcpy(out, dout.p, (size_t)na * nb * 4, hipMemcpyDeviceToHost));
-#undef VF_CS
-#undef VF_CT
-    return done(VF_OK);
+    const bool same = a == b && (int64_t)na == nb;       // vf_cosine_matrix: one operand, prepared once
+    const size_t ea = (size_t)na * d, eb = same ? 0 : (size_t)nb * d;
+    Lease ws;
+    VF_TRY(ws.acquire(device_id, 2 * Lease::padded(ea * 4) + 2 * Lease::padded(eb * 4) + Lease::padded((size_t)na * 4) + Lease::padded((size_t)nb * 4) +
+                                     Lease::padded((size_t)std::max<int64_t>(na, nb) * 4) + Lease::padded((size_t)na * nb * 4)));
+    float* da = ws.take<float>(ea); float* an = ws.take<float>(ea);
+    float* db = same ? da : ws.take<float>(eb); float* bn = same ? an : ws.take<float>(eb);
+    float* norm_a = ws.take<float>(na); float* norm_b = same ? norm_a : ws.take<float>(nb);
+    float* tmp = ws.take<float>(std::max<int64_t>(na, nb)); float* dout = ws.take<float>((size_t)na * nb);
+    VF_HIP(hipMemcpy(da, a, ea * 4, hipMemcpyHostToDevice));
+    if (!same) VF_HIP(hipMemcpy(db, b, eb * 4, hipMemcpyHostToDevice));
+    VF_HIP(launch_prep_rows(da, 0, na, d, d, nullptr, norm_a, tmp, nullptr));
+    if (!same) VF_HIP(launch_prep_rows(db, 0, nb, d, d, nullptr, norm_b, tmp, nullptr));
+    VF_HIP(launch_normalize_rows(da, 0, 0, na, d, norm_a, an, nullptr));
+    if (!same) VF_HIP(launch_normalize_rows(db, 0, 0, nb, d, norm_b, bn, nullptr));
+    VF_HIP(launch_dense_dot16(an, na, bn, nb, d, dout, nb, nullptr));
+    VF_HIP(hipMemcpy(out, dout, (size_t)na * nb * 4, hipMemcpyDeviceToHost));
+    return VF_OK;
 }
 
 extern "C" int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out, int32_t device_id) {
     return vf_cosine_scores(x, n, x, n, d, out, device_id);
 }
 
+// rows `sel` (local row numbers) of ONE device's index, canonically normalised, into xn [count][d] on that device (null stream)
+static int gather_normalised(vf_index* sh, Lease& ws, const std::vector<long long>& sel, float* xn) {
+    long long* dsel = ws.take<long long>(sel.size());
+    VF_HIP(hipMemcpy(dsel, sel.data(), sel.size() * 8, hipMemcpyHostToDevice));
+    VF_HIP(launch_normalize_rows_gather(sh->rows_orig, sh->dtype, dsel, (int)sel.size(), sh->d, sh->norm, xn, nullptr));
+    return VF_OK;
+}
+
 // Cosine matrix of rows ALREADY in the index, picked by id (round 4): compute_similarity_mtx re-embeds the n retrieved chunk
 // texts (src/utils/ensembleRetriever.py:265-281: n encoder forwards upstream, one batched forward here -- 19 ms for 100 chunks
 // of 512 tokens); when the chunks came out of this index and the embedder treats documents and queries alike, their
 // embeddings are rows of the HBM-resident corpus: gather + canonical normalise (the index's own norms) + dot16.
+// A SHARDED handle (round 5): every shard normalises its own rows on its own device (the norms are per row, so the values are the
+// single-device ones bit for bit), the blocks travel to the home device -- peer copy, or through the host where the link is
+// missing -- and are put back into the caller's order there by the same gather kernel (norm 1: x * (float)(1.0 / 1.0) = x).
 extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n, float* out) {
     DeviceGuard restore_callers_device;
     if (!ix) return fail(VF_EINVAL, "vf_cosine_matrix_rows: null handle");
     if (n < 0) return fail(VF_EINVAL, "vf_cosine_matrix_rows: negative n");
     if (n == 0) return VF_OK;
     if (!ids || !out) return fail(VF_EINVAL, "vf_cosine_matrix_rows: null buffer");
-    if (!ix->shards.empty()) return fail(VF_EUNSUPPORTED, "vf_cosine_matrix_rows: the rows of a sharded handle live on several devices");
     if (n > 4096) return fail(VF_EINVAL, "vf_cosine_matrix_rows: n must be <= 4096");
-    std::vector<long long> sel((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const int64_t r = ids[i] - ix->id_offset;
-        if (r < 0 || r >= ix->n) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
-        sel[(size_t)i] = r;
-    }
+    const size_t nd = (size_t)n * ix->d;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->shards.empty()) {
+        std::vector<long long> sel((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const int64_t r = ids[i] - ix->id_offset;
+            if (r < 0 || r >= ix->n) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
+            sel[(size_t)i] = r;
+        }
+        VF_HIP(hipSetDevice(ix->device));
+        Lease ws;
+        VF_TRY(ws.acquire(ix->device, Lease::padded((size_t)n * 8) + Lease::padded(nd * 4) + Lease::padded((size_t)n * n * 4)));
+        float* xn = ws.take<float>(nd); float* dout = ws.take<float>((size_t)n * n);
+        VF_TRY(gather_normalised(ix, ws, sel, xn));
+        VF_HIP(launch_dense_dot16(xn, n, xn, n, ix->d, dout, n, nullptr));
+        VF_HIP(hipMemcpy(out, dout, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+        return VF_OK;
+    }
+    const size_t G = ix->shards.size();
+    std::vector<std::vector<long long>> sel(G);
+    std::vector<int> owner((size_t)n), rank_in((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        size_t g = 0;
+        while (g < G && !(ids[i] >= ix->shards[g]->id_offset && ids[i] < ix->shards[g]->id_offset + ix->shards[g]->n)) ++g;
+        if (g == G) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
+        owner[(size_t)i] = (int)g; rank_in[(size_t)i] = (int)sel[g].size();
+        sel[g].push_back(ids[i] - ix->shards[g]->id_offset);
+    }
+    std::vector<long long> start(G + 1, 0), where((size_t)n);   // block of shard g in the concatenation; position i's row in it
+    for (size_t g = 0; g < G; ++g) start[g + 1] = start[g] + (long long)sel[g].size();
+    for (int i = 0; i < n; ++i) where[(size_t)i] = start[(size_t)owner[(size_t)i]] + rank_in[(size_t)i];
     VF_HIP(hipSetDevice(ix->device));
-    DevBuf dsel, xn, dout;
-    auto done = [&](int code) { dsel.release(); xn.release(); dout.release(); return code; };
-    int rc;
-    if ((rc = dsel.ensure((size_t)n * 8)) || (rc = xn.ensure((size_t)n * ix->d * 4)) || (rc = dout.ensure((size_t)n * n * 4))) return done(rc);
-    hipError_t e = hipMemcpy(dsel.p, sel.data(), (size_t)n * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_normalize_rows_gather(ix->rows_orig, ix->dtype, dsel.as<long long>(), n, ix->d, ix->norm, xn.as<float>(), nullptr);
-    if (e == hipSuccess) e = launch_dense_dot16(xn.as<float>(), n, xn.as<float>(), n, ix->d, dout.as<float>(), n, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n * n * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return done(fail(VF_EHIP, std::string("vf_cosine_matrix_rows: ") + hipGetErrorString(e)));
-    return done(VF_OK);
+    Lease home;
+    VF_TRY(home.acquire(ix->device, 2 * Lease::padded(nd * 4) + Lease::padded((size_t)n * 4) + Lease::padded((size_t)n * 8) + Lease::padded((size_t)n * n * 4)));
+    float* cat = home.take<float>(nd); float* xn = home.take<float>(nd); float* ones = home.take<float>(n);
+    long long* dwhere = home.take<long long>(n); float* dout = home.take<float>((size_t)n * n);
+    std::vector<float> stage;
+    for (size_t g = 0; g < G; ++g) {
+        if (sel[g].empty()) continue;
+        vf_index* sh = ix->shards[g];
+        const size_t cnt = sel[g].size(), bytes = cnt * ix->d * 4;
+        float* dst = cat + (size_t)start[g] * ix->d;
+        VF_HIP(hipSetDevice(sh->device));
+        if (sh->device == ix->device && !shard_is_staged(ix, g)) {        // already at home: normalise straight into its block
+            Lease ws;
+            VF_TRY(ws.acquire(sh->device, Lease::padded(cnt * 8)));
+            VF_TRY(gather_normalised(sh, ws, sel[g], dst));
+            VF_HIP(hipStreamSynchronize(nullptr));
+            continue;
+        }
+        Lease ws;
+        VF_TRY(ws.acquire(sh->device, Lease::padded(cnt * 8) + Lease::padded(bytes)));
+        float* part = ws.take<float>(cnt * ix->d);
+        VF_TRY(gather_normalised(sh, ws, sel[g], part));
+        VF_HIP(hipStreamSynchronize(nullptr));
+        if (!shard_is_staged(ix, g)) {
+            VF_HIP(hipMemcpyPeer(dst, ix->device, part, sh->device, bytes));
+        } else {                                                          // no peer link: through the host
+            stage.resize(cnt * ix->d);
+            VF_HIP(hipMemcpy(stage.data(), part, bytes, hipMemcpyDeviceToHost));
+            VF_HIP(hipSetDevice(ix->device));
+            VF_HIP(hipMemcpy(dst, stage.data(), bytes, hipMemcpyHostToDevice));
+        }
+    }
+    VF_HIP(hipSetDevice(ix->device));
+    const std::vector<float> one((size_t)n, 1.0f);
+    VF_HIP(hipMemcpy(ones, one.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    VF_HIP(hipMemcpy(dwhere, where.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    VF_HIP(launch_normalize_rows_gather(cat, VF_DTYPE_F32, dwhere, n, ix->d, ones, xn, nullptr));
+    VF_HIP(launch_dense_dot16(xn, n, xn, n, ix->d, dout, n, nullptr));
+    VF_HIP(hipMemcpy(out, dout, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+    return VF_OK;
 }
 
 extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts, int32_t nparts, int32_t nq,
@@ -1428,17 +1641,15 @@ extern "C" int vf_fuse_rank(const float* rerank_scores, const float* time_scores
     if (n == 0) return VF_OK;
     if (!rerank_scores || !time_scores || !out_scores || !out_order) return fail(VF_EINVAL, "vf_fuse_rank: null buffer");
     VF_HIP(hipSetDevice(device_id));
-    DevBuf a, b, o, ord;
-    auto done = [&](int code) { a.release(); b.release(); o.release(); ord.release(); return code; };
-    int rc;
-    if ((rc = a.ensure(n * 4)) || (rc = b.ensure(n * 4)) || (rc = o.ensure(n * 4)) || (rc = ord.ensure(n * 8))) return done(rc);
-    hipError_t e = hipMemcpy(a.p, rerank_scores, n * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(b.p, time_scores, n * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_fuse_rank(a.as<float>(), b.as<float>(), n, o.as<float>(), ord.as<long long>(), nullptr);
-    if (e == hipSuccess) e = hipMemcpy(out_scores, o.p, n * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out_order, ord.p, n * 8, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return done(fail(VF_EHIP, std::string("vf_fuse_rank: ") + hipGetErrorString(e)));
-    return done(VF_OK);
+    Lease ws;
+    VF_TRY(ws.acquire(device_id, 3 * Lease::padded((size_t)n * 4) + Lease::padded((size_t)n * 8)));
+    float* a = ws.take<float>(n); float* b = ws.take<float>(n); float* o = ws.take<float>(n); long long* ord = ws.take<long long>(n);
+    VF_HIP(hipMemcpy(a, rerank_scores, (size_t)n * 4, hipMemcpyHostToDevice));
+    VF_HIP(hipMemcpy(b, time_scores, (size_t)n * 4, hipMemcpyHostToDevice));
+    VF_HIP(launch_fuse_rank(a, b, n, o, ord, nullptr));
+    VF_HIP(hipMemcpy(out_scores, o, (size_t)n * 4, hipMemcpyDeviceToHost));
+    VF_HIP(hipMemcpy(out_order, ord, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return VF_OK;
 }
 
 // Test hook (not in the public header): the fused scan's HARDWARE e4m3 -> fp16 conversion applied to `count` codes,

@@ -117,7 +117,9 @@ hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipSt
 size_t scan_wide_lds_bytes(int stage_cap);
 // k_scan_wide8: the wide main scan on the fp8 matrix instruction (e4m3 rows; a.qimg = the hi / lo code image of launch_prep_wide8)
 hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, unsigned char* img8, float* eps_q, hipStream_t s);
-hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s);
+hipError_t launch_scan_wide8(const ScanArgs& a, int waves /* 8: 256-query tiles, one workgroup per CU; 4: 128-query tiles, two per CU */, hipStream_t s);
+int scan_wide8_stage_cap(int waves);
+int scan_wide8_occupancy(int waves, int stage_cap);
 // k_scan2<NT, 2>: the narrow main scan on the fp8 matrix instruction (launch_scan2 with rows_are_fp8 = 2; a.qimg = this image)
 hipError_t launch_sel0(const ScanArgs& a, int qn_tile, hipStream_t s);
 hipError_t launch_final(FinalArgs a, int nq, hipStream_t s);

@@ -1563,7 +1563,9 @@ __device__ __forceinline__ void wide_compute(f16v (&acc)[kWideM][kWideNT], const
 
 // WG-wide: move the staged candidates to the per-query global lists (see k_scan's final flush), publish the entries
 // the block-wise publisher has not reached yet, and empty the stage for reuse.  Called by every thread.
+template <int Q = kWideQ, int THREADS = kWideThreads>
 __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt, int tid) {
+    constexpr int kWideQ = Q, kWideThreads = THREADS, kWideCtl = 16 + 3 * Q * 4;   // (shadow the file-level constants: the body is unchanged)
     u32* stage_cnt = (u32*)ctl;
     u32* qcnt = (u32*)(ctl + 16 + kWideQ * 4);
     u32* qbase = qcnt + kWideQ;
@@ -1608,11 +1610,12 @@ __device__ __forceinline__ void wide_flush(const ScanArgs& a, char* ctl, int jt,
 
 // epilogue of ONE 32-row tile (rows t0 .. t0+31) against the 256 queries
 
-template <int MODE, int NT = kWideNT>
+template <int MODE, int NT = kWideNT, int Q = kWideQ>
 __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&acc)[NT], float inv_lane, long long t0,
                                               long long hi, long long s0_slot, int jt, int lane, char* ctl, bool sync_tau,
-                                              int q0 = 0 /* first query (of the workgroup's 256) of this wave's NT tiles */,
+                                              int q0 = 0 /* first query (of the workgroup's Q) of this wave's NT tiles */,
                                               unsigned long long* ph = nullptr /* debug: [4] ticks in thresholds + pass 1a, 1b, 2, publish */) {
+    constexpr int kWideQ = Q, kWideCtl = 16 + 3 * Q * 4;   // (shadow the file-level constants: the body is unchanged)
     const int r31 = lane & 31, h = lane >> 5;
     unsigned long long pc0 = ph ? wall_clock64() : 0ull;
     auto ph_mark = [&](int i) { if (ph) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - pc0; pc0 = n_; } };
@@ -1743,7 +1746,11 @@ __device__ __forceinline__ void wide_epilogue(const ScanArgs& a, const f16v (&ac
                     const float sc = v * iv;
                     const u32 row = (u32)(t0 + r0);
                     const u32 bin = (u32)bin_of_x(bin_x(sc)), key = orderkey(sc);
-                    if (slot < (u32)a.stage_cap) {
+                    // rows past the part's end are kept out by their NaN inverse norm (sign clear in pass 1a) -- but IEEE leaves the
+                    // sign of a propagated NaN open, so the row bound is tested here as well: its claimed slot stays empty (w == 0:
+                    // skipped by the flush and the publisher), nothing out of range can reach k_final's gather
+                    if (t0 + r0 >= hi) {
+                    } else if (slot < (u32)a.stage_cap) {
                         stage_ent[slot] = make_uint4(row, key, (u32)ql | (bin << 8), 1u);
                     } else {   // stage full (the first tiles after a loose seed, or hostile data): straight to the global list
                         const long long gq = qg0 + ql;
@@ -2012,12 +2019,42 @@ size_t scan_wide_lds_bytes(int stage_cap);
 #define VF_W8_STAMPS 0
 #endif
 constexpr bool kW8Stamps = VF_W8_STAMPS != 0;
-constexpr int kW8Stage = 48 * 1024, kW8Threads = 512, kW8NT = 4;
+constexpr int kW8Stage = 48 * 1024, kW8NT = 4;
 
 __device__ __forceinline__ void dma16s(unsigned long long ua, unsigned voff, unsigned lds_base) {   // scalar base + 32-bit lane offset
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(ua), "s"(lds_base) : "memory");
+}
+
+// The wave's DMA instructions of one K-tile in TWO asm statements instead of one per instruction (each of which saved and restored
+// M0 and had its 64-bit base and LDS address computed by the compiler: ~12 instructions per DMA, 100 per K-tile in the 4-wave form).
+// Rows: instruction i fetches the rows 16 i below instruction 0's -- the step goes into a scratch lane offset (an address register
+// is read when the instruction issues: it may be overwritten right behind it); LDS destination + 1 KB each.
+template <int N>
+__device__ __forceinline__ void dma_rows(unsigned long long ua, unsigned voff0, unsigned lds_base, unsigned row_step) {
+    unsigned keep, vt;
+    if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_add_u32 %1, %5, %2\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(vt) : "v"(voff0), "s"(ua), "s"(lds_base), "s"(row_step) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_add_u32 %1, %5, %2\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tv_add_u32 %1, %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tv_add_u32 %1, %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(vt) : "v"(voff0), "s"(ua), "s"(lds_base), "s"(row_step) : "memory");
+}
+// Query codes: 2 KB of hi codes, then the lo codes 16 KB further on in the image and in LDS.  The second instruction of each pair
+// goes through the instruction's immediate offset, which the hardware adds to the global address AND to the LDS address
+// (LDS address = M0 base + instruction offset + 16 x lane): + 1 KB on both sides, M0 untouched.
+__device__ __forceinline__ void dma_codes(unsigned long long ub, unsigned voff, unsigned lds_base) {
+    unsigned keep, vt;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_add_u32 %1, 0x4000, %2\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                 "s_add_u32 m0, m0, 0x4000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&v"(vt) : "v"(voff), "s"(ub), "s"(lds_base) : "memory");
 }
 
 // hi / lo e4m3 image of the normalised queries + each query's certificate bound.
@@ -2287,14 +2324,33 @@ hipError_t launch_prep_wide8(const float* qn, int nq, int d, int dp, int qtot, u
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[128:135], v[192:199], v[48:63], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[192:199], v[112:127], %[sa], %[sh] op_sel_hi:[0,0,0]\n\t" \
     "v_mfma_scale_f32_32x32x64_f8f6f4 v[48:63], v[128:135], v[200:207], v[48:63], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
-    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t"
+    "v_mfma_scale_f32_32x32x64_f8f6f4 v[112:127], v[136:143], v[200:207], v[112:127], %[sa], %[sl] op_sel_hi:[0,0,0]\n\t" \
+    "s_nop 15\n\t" \
+    "s_nop 7\n\t"
 
-__global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
+// WAVES = 8: one workgroup of 512 threads per CU, tile 256 rows x 256 queries (wave (wr, wc) = 64 rows x 128 queries), two stages of
+//   48 KB [rows 16 K | hi codes 16 K | lo codes 16 K]; a.jtiles = 256-query tiles.
+// WAVES = 4 (round 5): TWO workgroups of 256 threads per CU, tile 256 rows x 128 queries (wave wr = 64 rows x the 128 queries: the same
+//   wave tile, the same asm bodies), a.jtiles counts 128-query tiles.  The two workgroups of a CU are independent barrier domains, so
+//   the hardware de-phases them: one's epilogue (VALU) and K-tile boundaries (barrier, DMA wait, first fragment reads) run under the
+//   other's matrix instructions -- with ONE 8-wave workgroup all eight waves meet at every boundary and reach the epilogue together
+//   (3.4 + ~3 ms of a 16.5-ms launch at 10M rows with the matrix pipes idle).  Two stages of 32 KB, laid out so
+//   that the asm bodies' "lo codes = hi codes + 16384" still holds:
+//     [rows s0 16 K | hi s0 8 K | hi s1 8 K | lo s0 8 K | lo s1 8 K | rows s1 16 K] = 64 KB, + control block + candidate stage <= 80 KB.
+//   Price: a row's bytes reach LDS once per 128 instead of once per 256 queries (L2 -> LDS traffic per product + 33 %).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_scan_wide8(ScanArgs a) {
+    static_assert(WAVES == 8 || WAVES == 4, "k_scan_wide8: 8 waves (256 x 256 tile) or 4 waves (256 x 128 tile, two workgroups per CU)");
+    constexpr int kW8Threads = 64 * WAVES, Q = WAVES == 8 ? 256 : 128, kCtl = 16 + 3 * Q * 4, kDmaRows = 256 / WAVES / 16;
+    // LDS byte offsets of the two stages' row / hi-code areas (the lo codes sit 16384 above the hi codes in both layouts)
+    constexpr unsigned kRowsAt0 = 0u, kRowsAt1 = WAVES == 8 ? (unsigned)kW8Stage : 49152u;
+    constexpr unsigned kHiAt0 = 16384u, kHiAt1 = WAVES == 8 ? (unsigned)kW8Stage + 16384u : 24576u;
+    constexpr int kOperandBytes = WAVES == 8 ? 2 * kW8Stage : 65536;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r31 = lane & 31, h = lane >> 5;
-    const int wr = wid >> 1, wc = wid & 1;               // rows 64 wr .. + 63 of a super-tile, queries 128 wc .. + 127 of the tile
+    const int wr = WAVES == 8 ? wid >> 1 : wid, wc = WAVES == 8 ? wid & 1 : 0;   // rows 64 wr .. + 63 of a super-tile, queries 128 wc .. + 127 of the tile
     const int J = a.jtiles;
     const int jt = ((int)blockIdx.x >> 3) % J;
     const int rg = ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * J));
@@ -2304,46 +2360,54 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
     const int nst = (int)((hi - lo + kWideRows - 1) / kWideRows);
     const int NK = a.dp >> 6;
-    char* ctl = smem + 2 * kW8Stage;
+    char* ctl = smem + kOperandBytes;
     {
         uint4* z = (uint4*)ctl;
-        const int nz = kWideCtl / 16 + a.stage_cap;
+        const int nz = kCtl / 16 + a.stage_cap;
         for (int i = tid; i < nz; i += kW8Threads) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
-    if (tid < kWideQ) ((int*)(ctl + 16))[tid] = a.tau_bin[jt * kWideQ + tid];
+    if (tid < Q) ((int*)(ctl + 16))[tid] = a.tau_bin[jt * Q + tid];
     if (nst == 0) return;
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
-    // ---- DMA duties of this wave per K-tile: rows 32 wid .. + 31 (two instructions), hi and lo codes of queries 32 wid .. + 31
-    int arow[2];
-    unsigned apiece[2], voffA[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        arow[i] = 32 * wid + 16 * i + (lane >> 2);
-        apiece[i] = (unsigned)(((lane & 3) ^ ((arow[i] >> 2) & 3)) << 4);
-    }
+    // ---- DMA duties of this wave per K-tile: rows (256 / WAVES) wid .. (kDmaRows instructions of 16 rows), hi and lo codes of queries
+    //      32 wid .. + 31 (two instructions each).  The query image holds 256-query tiles (k_prep_wide8): a 128-query tile is one half
+    //      of one -- a query's 64 bytes stay together under the swizzle, so the half is a contiguous 8 KB of each part.
+    // Register budget: the asm bodies own v[0:207]; what the compiler keeps across the K loop must fit the other 48.  So ONE lane
+    // offset serves all of the wave's row instructions (instruction i fetches the rows 16 i further down: + 16 i rows on the SCALAR
+    // base) -- except in a super-tile that crosses the part's end, where every row is clamped on its own (recomputed per K-tile in
+    // that one super-tile) -- and the fragment addresses below exist once and are toggled between the stages.
+    const unsigned apiece = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);   // (row >> 2) & 3 of row 16 x + (lane >> 2)
     const unsigned long long rows_base = (unsigned long long)(a.rows + lo * a.row_bytes);
-    const unsigned long long bimg = (unsigned long long)a.qimg + (unsigned long long)jt * NK * 32768ull;
+    const unsigned long long bimg = (unsigned long long)a.qimg + (WAVES == 8 ? (unsigned long long)jt * NK * 32768ull
+                                                                           : (unsigned long long)(jt >> 1) * NK * 32768ull + (unsigned long long)(jt & 1) * 8192ull);
     const unsigned voffB = (unsigned)(2 * wid) * 1024u + (unsigned)lane * 16u;
     const long long span = hi - lo;
+    const unsigned row_bytes32 = (unsigned)a.row_bytes;             // (a row group's bytes fit a 32-bit lane offset: checked by the host)
+    unsigned voffA0 = 0u, row_first = 0u;
+    bool tail_tile = false;
     auto set_rows = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            long long r = (long long)st * kWideRows + arow[i];
-            r = r < span - 1 ? r : span - 1;                       // rows past the part's end re-read its last row (NaN inverse norm below)
-            voffA[i] = (unsigned)(r * a.row_bytes) + apiece[i];
-        }
+        row_first = (unsigned)st * kWideRows + (unsigned)(16 * kDmaRows * wid);
+        tail_tile = (long long)st * kWideRows + kWideRows > span;
+        const unsigned r = row_first + (unsigned)(lane >> 2), last = (unsigned)(span - 1);
+        voffA0 = (r < last ? r : last) * row_bytes32 + apiece;      // rows past the part's end re-read its last row (NaN inverse norm below)
     };
     auto issue = [&](int kt, int stage) {
-        const unsigned sb = lds0 + (unsigned)stage * kW8Stage + (unsigned)(2 * wid) * 1024u;
+        const unsigned sa = lds0 + (stage ? kRowsAt1 : kRowsAt0) + (unsigned)(kDmaRows * wid) * 1024u;
+        const unsigned sh = lds0 + (stage ? kHiAt1 : kHiAt0) + (unsigned)(2 * wid) * 1024u;
         const unsigned long long ua = rows_base + (unsigned long long)kt * 64ull;
         const unsigned long long ub = bimg + (unsigned long long)kt * 32768ull;
-        dma16s(ua, voffA[0], sb);
-        dma16s(ua, voffA[1], sb + 1024u);
-        dma16s(ub, voffB, sb + 16384u);
-        dma16s(ub + 1024ull, voffB, sb + 16384u + 1024u);
-        dma16s(ub + 16384ull, voffB, sb + 32768u);
-        dma16s(ub + 16384ull + 1024ull, voffB, sb + 32768u + 1024u);
+        if (!tail_tile) {
+            dma_rows<kDmaRows>(ua, voffA0, sa, 16u * row_bytes32);
+        } else {
+            const unsigned last = (unsigned)(span - 1);
+#pragma unroll
+            for (int i = 0; i < kDmaRows; ++i) {
+                const unsigned r = row_first + (unsigned)(16 * i) + (unsigned)(lane >> 2);
+                dma16s(ua, (r < last ? r : last) * row_bytes32 + apiece, sa + 1024u * i);
+            }
+        }
+        dma_codes(ub, voffB, sh);
     };
     // ---- fragment addresses of this lane (relative to a stage): row tiles m = 0, 1; query tiles nt = 0 .. 3; pieces 2 h, 2 h + 1
     unsigned fa[2][2], fb[kW8NT][2];
@@ -2357,7 +2421,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     for (int nt = 0; nt < kW8NT; ++nt) {
         const int ql = wc * 128 + nt * 32 + r31;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[nt][j] = 16384u + (unsigned)((4 * ql + ((2 * h + j) ^ ((ql >> 2) & 3))) << 4);
+        for (int j = 0; j < 2; ++j) fb[nt][j] = (unsigned)((4 * ql + ((2 * h + j) ^ ((ql >> 2) & 3))) << 4);   // relative to the stage's hi-code area
     }
     f16v acc[2][kW8NT];
 #pragma unroll
@@ -2371,7 +2435,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     // [3] time in the epilogues (filter, candidates, sibling pacing, flush) -- ticks of the 100 MHz counter
     // (compiled in by -DVF_W8_STAMPS=1 only -- tools/build_variant.sh stamps "-DVF_W8_STAMPS=1": the ten 64-bit counters cost the
     //  shipped kernel 20 registers it does not have)
-    unsigned long long* dbg = (kW8Stamps && (a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * 8 + wid) * 16 : nullptr;
+    unsigned long long* dbg = (kW8Stamps && (a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * WAVES + wid) * 16 : nullptr;
     unsigned long long t_wait = 0, t_bar = 0, t_epi = 0, t_inv = 0, t_flt = 0, t_ph[4] = {0, 0, 0, 0};
     const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
     set_rows(0);
@@ -2398,13 +2462,21 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     };
     // fragment addresses per stage (tile kt lives in stage kt & 1: NK is even) and the three block scales (E8M0: 2^(x - 127)):
     // rows as they are, hi codes x 2^-8, lo codes x 2^-12
-    const unsigned pa0[2] = {lds0 + fa[0][0], lds0 + kW8Stage + fa[0][0]}, pa1[2] = {lds0 + fa[0][1], lds0 + kW8Stage + fa[0][1]};
-    const unsigned pb0[2] = {lds0 + fb[0][0], lds0 + kW8Stage + fb[0][0]}, pb1[2] = {lds0 + fb[0][1], lds0 + kW8Stage + fb[0][1]};
+    // (one copy, stepped to the other stage behind every tile -- VF8_STEP; the opaque asm keeps the compiler from recognising the two
+    //  values of each and holding both across the loop, which is what the array form [2] amounted to: 8 registers instead of 4)
+    unsigned pa0 = lds0 + kRowsAt0 + fa[0][0], pa1 = lds0 + kRowsAt0 + fa[0][1], pb0 = lds0 + kHiAt0 + fb[0][0], pb1 = lds0 + kHiAt0 + fb[0][1];
+    constexpr unsigned kStepA = kRowsAt1 - kRowsAt0, kStepB = kHiAt1 - kHiAt0;
     const int sc_a = 127, sc_h = 119, sc_l = 115;
     i8v s0a, s0b, s1a, s1b, s2a, s2b, s3a, s3b, s4a, s4b;
 #define VF8_ACC_OPS "+{v[0:15]}"(acc[0][0]), "+{v[16:31]}"(acc[0][1]), "+{v[32:47]}"(acc[0][2]), "+{v[48:63]}"(acc[0][3]), \
                     "+{v[64:79]}"(acc[1][0]), "+{v[80:95]}"(acc[1][1]), "+{v[96:111]}"(acc[1][2]), "+{v[112:127]}"(acc[1][3])
-#define VF8_IN_OPS(SG) [pa0] "v"(pa0[SG]), [pa1] "v"(pa1[SG]), [pb0] "v"(pb0[SG]), [pb1] "v"(pb1[SG]), [sa] "v"(sc_a), [sh] "v"(sc_h), [sl] "v"(sc_l)
+#define VF8_IN_OPS(SG) [pa0] "v"(pa0), [pa1] "v"(pa1), [pb0] "v"(pb0), [pb1] "v"(pb1), [sa] "v"(sc_a), [sh] "v"(sc_h), [sl] "v"(sc_l)
+#define VF8_STEP(SG)                                                                                                                  \
+    do {                                                                                                                              \
+        if (SG) { pa0 -= kStepA; pa1 -= kStepA; pb0 -= kStepB; pb1 -= kStepB; }                                                       \
+        else { pa0 += kStepA; pa1 += kStepA; pb0 += kStepB; pb1 += kStepB; }                                                          \
+        asm volatile("" : "+v"(pa0), "+v"(pa1), "+v"(pb0), "+v"(pb1));                                                                \
+    } while (0)
 #define VF8_SLOTS_OUT "=&{v[128:135]}"(s0a), "=&{v[136:143]}"(s0b), "=&{v[144:151]}"(s1a), "=&{v[152:159]}"(s1b), "=&{v[160:167]}"(s2a),      \
                       "=&{v[168:175]}"(s2b), "=&{v[176:183]}"(s3a), "=&{v[184:191]}"(s3b), "=&{v[192:199]}"(s4a), "=&{v[200:207]}"(s4b)
 #define VF8_SLOTS_IO "+{v[128:135]}"(s0a), "+{v[136:143]}"(s0b), "+{v[144:151]}"(s1a), "+{v[152:159]}"(s1b), "+{v[160:167]}"(s2a),            \
@@ -2414,6 +2486,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
     do {                                                                                                                              \
         asm volatile(VF8_ASM_E0_A : VF8_ACC_OPS, VF8_SLOTS_OUT : VF8_IN_OPS(0) : "memory");                                           \
         asm volatile(VF8_ASM_E0_B : VF8_ACC_OPS, VF8_SLOTS_IO : VF8_IN_OPS(0) : "memory");                                            \
+        VF8_STEP(0);                                                                                                                  \
         stage ^= 1;                                                                                                                   \
     } while (0)
 #define VF8_TILE_NEXT(NAME, SG, KT)                                                                                                   \
@@ -2422,6 +2495,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         asm volatile(NAME##_A : VF8_ACC_OPS, VF8_SLOTS_IO : VF8_IN_OPS(SG) : "memory");                                               \
         issue_after(st, (KT));                                                                                                        \
         asm volatile(NAME##_B : VF8_ACC_OPS, VF8_SLOTS_IO : VF8_IN_OPS(SG) : "memory");                                               \
+        VF8_STEP(SG);                                                                                                                 \
         stage ^= 1;                                                                                                                   \
     } while (0)
     top(0, 0);
@@ -2436,15 +2510,32 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         }
         VF8_TILE_NEXT(VF8_ASM_EM, 0, NK - 2);
         {   // 1 / norm of this lane's rows, a K-tile ahead of its use; rows past the part's end get NaN: their scores never pass
+            // (scalar base + 32-bit lane index: as 64-bit per-lane row numbers the compiler kept (long long)r31 in a register pair across
+            //  the K loop -- in scratch, that is, reloaded here behind the next tile's DMAs)
+            const long long rem = hi - t0;
+            const int remi = rem > 2 * kRowTile ? 2 * kRowTile : (int)rem;
+            const float* ivp = a.inv_scan + t0;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) inv_lane[m] = (t0 + m * kRowTile + r31 < hi) ? a.inv_scan[t0 + m * kRowTile + r31] : __builtin_nanf("");
+            for (int m = 0; m < 2; ++m) inv_lane[m] = (m * kRowTile + r31 < remi) ? ivp[m * kRowTile + r31] : __builtin_nanf("");
         }
         VF8_TILE_NEXT(VF8_ASM_OL, 1, NK - 1);
         if (st + 1 < nst) {
+            // The candidate stage is flushed when half full.  The decision must be ONE value for the whole workgroup (wide_flush has
+            // barriers inside): thread 0 copies the count into a spare control word BEFORE the barrier -- every epilogue of super-tile
+            // st - 1 ended before the barrier of this super-tile's second K-tile and none of super-tile st starts before the barrier
+            // below, so the count is at rest -- and everyone tests the copy behind it.  (Reading stage_cnt itself behind the barrier
+            // raced with the epilogue of a wave that had run ahead: two waves could see values on either side of the limit.)
+            if (tid == 0) ((volatile u32*)ctl)[1] = *(const volatile u32*)ctl;
             top(st + 1, 0);
-            // the candidate stage is flushed when half full -- tested behind this barrier, where no wave is inside an epilogue (every
-            // thread reads the same count)
-            if (*(const volatile u32*)ctl >= (u32)(a.stage_cap >> 1)) wide_flush(a, ctl, jt, tid);
+            if (((const volatile u32*)ctl)[1] >= (u32)(a.stage_cap >> 1)) {
+                // (opaque copies: with the plain ids LICM computes the flush's per-thread addresses -- qcnt + tid, qbase + tid, the
+                //  stage entry, the global counter of query tid -- once in front of the super-tile loop, and with 48 registers to
+                //  its name the allocator parks them in scratch: 7 registers, reloaded in every epilogue BEHIND the next tile's
+                //  DMAs, i.e. with a vmcnt(0) that waits for them.  The flush runs once in a dozen super-tiles: it can add.)
+                int tid_f = tid, jt_f = jt;
+                asm volatile("" : "+v"(tid_f), "+s"(jt_f));
+                wide_flush<Q, kW8Threads>(a, ctl, jt_f, tid_f);
+            }
             issue_after(st + 1, 0);
         }
         const unsigned long long e0 = dbg ? wall_clock64() : 0ull;
@@ -2455,12 +2546,12 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         if (dbg) { asm volatile("" :: "v"(inv_lane[0]), "v"(inv_lane[1])); e1 = wall_clock64(); t_inv += e1 - e0; }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            wide_epilogue<kModeMain, kW8NT>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
+            wide_epilogue<kModeMain, kW8NT, Q>(a, acc[m], inv_lane[m], t0 + m * kRowTile, hi, 0, jt_e, lane_e, ctl_e,
                                             m == 0 && (st & 3) == wr, wc * 128, dbg ? t_ph : nullptr);
         }
         if (dbg) t_flt += wall_clock64() - e1;
         if (a.sib && tid == 0 && sib_on) {   // sibling pacing: k_scan_wide's (a speed hint, bounded)
-            u32* pr = a.sib + rg * 4;
+            u32* pr = a.sib + rg * 8;   // (eight progress words per row group: up to eight 128-query siblings)
             __hip_atomic_store(pr + jt, (u32)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 need = (u32)(st + 1) > (u32)a.sib_slack ? (u32)(st + 1) - (u32)a.sib_slack : 0u;
             int spins = 0;
@@ -2478,7 +2569,7 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
         if (dbg) t_epi += wall_clock64() - e0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wide_flush(a, ctl, jt, tid);
+    wide_flush<Q, kW8Threads>(a, ctl, jt, tid);
     if (dbg) { dbg[0] = wall_clock64() - t_begin; dbg[1] = t_wait; dbg[2] = t_bar; dbg[3] = t_epi; dbg[4] = t_inv; dbg[5] = t_flt; dbg[6] = t_ph[0]; dbg[7] = t_ph[1]; dbg[8] = t_ph[2]; dbg[9] = t_ph[3]; }
 }
 
@@ -2487,11 +2578,28 @@ __global__ __launch_bounds__(kW8Threads) void k_scan_wide8(ScanArgs a) {
 #undef VF8_SLOTS_IO
 #undef VF8_SLOTS_OUT
 #undef VF8_IN_OPS
+#undef VF8_STEP
 #undef VF8_ACC_OPS
 
-hipError_t launch_scan_wide8(const ScanArgs& a, hipStream_t s) {
+// waves = 8: a.jtiles 256-query tiles, one 512-thread workgroup per CU; waves = 4: a.jtiles 128-query tiles, two 256-thread workgroups per CU
+size_t scan_wide8_lds_bytes(int waves, int stage_cap) {
+    return waves == 8 ? scan_wide_lds_bytes(stage_cap) : (size_t)65536 + (16 + 3 * 128 * 4) + (size_t)stage_cap * 16;
+}
+int scan_wide8_stage_cap(int waves) { return waves == 8 ? 3584 : 896; }   // what the operand stages and the control block leave of 160 / 80 KB
+
+// resident workgroups per CU of the wide8 kernel with that many candidate-stage entries (hipOccupancyMaxActiveBlocksPerMultiprocessor)
+int scan_wide8_occupancy(int waves, int stage_cap) {
+    int n = -1;
+    const size_t lds = scan_wide8_lds_bytes(waves, stage_cap);
+    hipError_t e = waves == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_wide8<4>, 256, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_wide8<8>, 512, lds);
+    return e == hipSuccess ? n : -(int)e;
+}
+
+hipError_t launch_scan_wide8(const ScanArgs& a, int waves, hipStream_t s) {
     const int grid = 8 * a.jtiles * ((a.rgroups + 7) / 8);
-    hipLaunchKernelGGL(k_scan_wide8, dim3(grid), dim3(kW8Threads), scan_wide_lds_bytes(a.stage_cap), s, a);
+    if (waves == 4) hipLaunchKernelGGL(k_scan_wide8<4>, dim3(grid), dim3(256), scan_wide8_lds_bytes(4, a.stage_cap), s, a);
+    else hipLaunchKernelGGL(k_scan_wide8<8>, dim3(grid), dim3(512), scan_wide8_lds_bytes(8, a.stage_cap), s, a);
     return hipGetLastError();
 }
 
@@ -3065,7 +3173,8 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeSample, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan_wide8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

@@ -4565,6 +4565,10 @@ extern "C" int vf_clip_text_forward(vf_clip_text* v, const int32_t* ids, const i
     if (!ids || !out) return fail(VF_EINVAL, "vf_clip_text_forward: null buffer");
     const vf_clip_text_config& c = v->cfg;
     if (t == 0 || t > c.max_pos) return fail(VF_EINVAL, "vf_clip_text_forward: t must be in [1, max_pos]");
+    {   // refused on the host like the encoder's and the decoder's ids: the pooled position below is computed from these very values
+        const long long bad = first_id_out_of_range(ids, (size_t)b * t, c.vocab);
+        if (bad >= 0) return fail(VF_EINVAL, "vf_clip_text_forward: token id " + std::to_string(ids[bad]) + " at [" + std::to_string(bad / t) + ", " + std::to_string(bad % t) + "] is outside the vocabulary [0, " + std::to_string(c.vocab) + ")");
+    }
     std::vector<int> eos((size_t)b), ones;
     for (int i = 0; i < b; ++i) {
         const int32_t* r = ids + (size_t)i * t;

@@ -20,6 +20,7 @@ from __future__ import annotations
 import importlib
 from typing import Dict, List
 
+from . import stages
 from .faiss_retriever import FaissRetriever
 from .similarity import compute_similarity, compute_similarity_mtx
 
@@ -128,45 +129,68 @@ class EnsembleRetriever:
 
     # -- the reference's entry point ------------------------------------------------------------------
     def invoke(self, input: str, hyde_chunks: List[str]) -> List[Dict]:
+        """Stage brackets as upstream (``"retrieve"`` around the call, one per branch, the ``retrieved_chunks`` metric): no-ops
+        unless ``veritasfi_amd.set_profiler`` was given the host's profiler (stages.py)."""
+        with stages.stage("retrieve"):
+            out = self._invoke(input, hyde_chunks)
+        stages.metric("retrieved_chunks", len(out))
+        return out
+
+    def _invoke(self, input: str, hyde_chunks: List[str]) -> List[Dict]:
         seen: set = set()
         out: list = []
         bundle_cnt = 0
         if self.faiss_k > 0:
-            inputs = [input] + list(hyde_chunks)
-            ids_list, scores_list = self.faiss_retriever.invoke(inputs, SEARCH_DEPTH)
-            for ids, scores in zip(ids_list, scores_list):
-                ids = [int(i) for i in ids]
-                score_map = dict(zip(ids, scores))
-                for row, score in zip(ids[:self.faiss_k], scores[:self.faiss_k]):
-                    if row < 0 or row in seen:   # -1 pads a corpus smaller than the search depth
-                        continue
-                    seen.add(row)
-                    md = self.chunk_metadata[row]
-                    rows = self._bundle_of(row, seen)
-                    if score > EXPAND_SCORE and self.enable_expand:
-                        self._expand(rows, md, score_map, seen)
-                    self._emit(out, "FAISS", score, rows, bundle_cnt)
-                    bundle_cnt += 1
+            with stages.stage("retrieve_faiss"):
+                bundle_cnt = self._faiss_branch(input, hyde_chunks, seen, out, bundle_cnt)
         if self.faiss_ts_k > 0:
-            t_ids, t_scores = self.title_summary_faiss_retriever.invoke([input], self.faiss_ts_k)
-            for t, score in zip(t_ids[0], t_scores[0]):
-                if t < 0:
-                    continue
-                for row in self._title_rows.get(self.title_summaries[int(t)], ()):
-                    if row in seen:
-                        continue
-                    seen.add(row)
-                    self._emit(out, "Title Summary", score, self._bundle_of(row, seen), bundle_cnt)
-                    bundle_cnt += 1
+            with stages.stage("retrieve_faiss_ts"):
+                bundle_cnt = self._title_branch(input, seen, out, bundle_cnt)
         if self.bm25_k > 0:
-            b_ids, b_scores = self.bm25_retriever.invoke(input, self.num_chunk)
-            for row, score in zip(b_ids[:self.bm25_k], b_scores[:self.bm25_k]):
+            with stages.stage("retrieve_bm25"):
+                bundle_cnt = self._bm25_branch(input, seen, out, bundle_cnt)
+        return out
+
+    def _faiss_branch(self, input, hyde_chunks, seen, out, bundle_cnt):
+        inputs = [input] + list(hyde_chunks)
+        ids_list, scores_list = self.faiss_retriever.invoke(inputs, SEARCH_DEPTH)
+        for ids, scores in zip(ids_list, scores_list):
+            ids = [int(i) for i in ids]
+            score_map = dict(zip(ids, scores))
+            for row, score in zip(ids[:self.faiss_k], scores[:self.faiss_k]):
+                if row < 0 or row in seen:   # -1 pads a corpus smaller than the search depth
+                    continue
+                seen.add(row)
+                md = self.chunk_metadata[row]
+                rows = self._bundle_of(row, seen)
+                if score > EXPAND_SCORE and self.enable_expand:
+                    self._expand(rows, md, score_map, seen)
+                self._emit(out, "FAISS", score, rows, bundle_cnt)
+                bundle_cnt += 1
+        return bundle_cnt
+
+    def _title_branch(self, input, seen, out, bundle_cnt):
+        t_ids, t_scores = self.title_summary_faiss_retriever.invoke([input], self.faiss_ts_k)
+        for t, score in zip(t_ids[0], t_scores[0]):
+            if t < 0:
+                continue
+            for row in self._title_rows.get(self.title_summaries[int(t)], ()):
                 if row in seen:
                     continue
                 seen.add(row)
-                self._emit(out, "BM25", score, self._bundle_of(row, seen), bundle_cnt)
+                self._emit(out, "Title Summary", score, self._bundle_of(row, seen), bundle_cnt)
                 bundle_cnt += 1
-        return out
+        return bundle_cnt
+
+    def _bm25_branch(self, input, seen, out, bundle_cnt):
+        b_ids, b_scores = self.bm25_retriever.invoke(input, self.num_chunk)
+        for row, score in zip(b_ids[:self.bm25_k], b_scores[:self.bm25_k]):
+            if row in seen:
+                continue
+            seen.add(row)
+            self._emit(out, "BM25", score, self._bundle_of(row, seen), bundle_cnt)
+            bundle_cnt += 1
+        return bundle_cnt
 
     # ensembleRetriever.py:235-281
     def compute_similarity(self, chunks, selected_indices, candidate_index):

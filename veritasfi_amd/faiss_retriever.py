@@ -31,15 +31,12 @@ class FaissRetriever:
         logger.info(f"Building HIP dense index with {len(embeddings)} vectors of dimension {dimension}")
 
     def invoke(self, querys: list, k: int):
-        # reference :33-38: one embed_query per string, fp32, normalise, search, return (I, D)
-        # (an embedder that offers a batched embed_queries -- ours does -- gets one forward instead of
-        #  len(querys); any other embedder is called exactly as the reference calls it)
-        if hasattr(self.embeddings, "embed_queries"):
-            query_vec_list = self.embeddings.embed_queries(list(querys))
-        else:
-            query_vec_list = [self.embeddings.embed_query(q) for q in querys]
-        query_vector = np.array(query_vec_list).astype("float32")
-        if query_vector.ndim == 1:
-            query_vector = query_vector.reshape(len(querys), -1)
-        indices, distances = self.index.search(query_vector, k)
-        return indices, distances
+        """(I, D) = ids and cosine scores, best first, shape [len(querys), k]; -1 / -FLT_MAX pad a corpus with fewer than k rows
+        (reference :28-38: embed each string, fp32, L2-normalise, IndexFlatIP.search).  An embedder with a batched
+        ``embed_queries`` -- ours has one -- gets ONE forward for all strings; any other is called per string, as upstream does."""
+        texts = list(querys)
+        embed_many = getattr(self.embeddings, "embed_queries", None)
+        vectors = embed_many(texts) if embed_many is not None else [self.embeddings.embed_query(t) for t in texts]
+        q = np.asarray(vectors, dtype=np.float32).reshape(len(texts), -1)
+        ids, scores = self.index.search(q, k)      # normalisation happens on the device (k_prep_queries), canonical order
+        return ids, scores

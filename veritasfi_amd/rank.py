@@ -20,6 +20,7 @@ from datetime import datetime
 
 import numpy as np
 
+from . import stages
 from .similarity import compute_similarity_mtx, fuse_and_rank
 
 
@@ -28,35 +29,46 @@ def rank_chunk(chunks, question: str, query_time: datetime, reranker, embedding_
                row_id_key: str = "row_id"):
     """chunks: list of dicts with 'page_content', 'bundle_id', 'metadata'['date_published' = 'YYYY-MM-DD'].
     similarity_index (opt-in, see compute_similarity_mtx): the DenseIndex the chunks were retrieved from, each chunk carrying its
-    row as chunk[row_id_key] -- the similarity matrix then comes from the corpus rows in HBM instead of re-embedding n texts."""
-    bundle_map = {}
-    for idx, chunk in enumerate(chunks):
-        bundle_map.setdefault(chunk["bundle_id"], []).append(idx)
-    pairs = [[question, chunk["page_content"]] for chunk in chunks]
-    chunk_content_list = [chunk["page_content"] for chunk in chunks]
-    time_scores = []
-    for chunk in chunks:  # :443-447  max(0, 1 - |query date - chunk date| / 365)
-        score = abs((query_time - datetime.strptime(chunk["metadata"]["date_published"], "%Y-%m-%d")).days)
-        time_scores.append(max(0, 1 - score / 365))
+    row as chunk[row_id_key] -- the similarity matrix then comes from the corpus rows in HBM instead of re-embedding n texts.
+    Stage brackets (stages.py; no-ops unless a profiler was set): "rerank" around the call -- the name upstream gives the function
+    that wraps this method (vllmChatService.py:31) -- and "rerank_score" / "rerank_similarity" around its two device legs."""
+    with stages.stage("rerank"):
+        return _rank_chunk(chunks, question, query_time, reranker, embedding_fn, chunk_topk, similar_threshhold, reranker_lock,
+                           device_id, similarity_index, row_id_key)
+
+
+def _rank_chunk(chunks, question, query_time, reranker, embedding_fn, chunk_topk, similar_threshhold, reranker_lock, device_id,
+                similarity_index, row_id_key):
     if not chunks:
         return []
-    with (reranker_lock if reranker_lock is not None else contextlib.nullcontext()):  # :450
-        reranker_scores = reranker.compute_score(pairs, batch_size=8)
-    _, ranked_indices = fuse_and_rank(reranker_scores, time_scores, device_id)       # :454-457
-    if similarity_index is not None:
-        similar_mtx = compute_similarity_mtx(embedding_fn, chunk_content_list, device_id, as_torch=False, index=similarity_index,
-                                             row_ids=[chunk[row_id_key] for chunk in chunks])
-    else:
-        similar_mtx = compute_similarity_mtx(embedding_fn, chunk_content_list, device_id, as_torch=False)  # :462
-    selected_indices = []
-    current_size = 0
-    for idx in ranked_indices:                                                        # :464-481
-        bundle_id = chunks[idx]["bundle_id"]
-        bundle = bundle_map[bundle_id]
-        if bundle_id in selected_indices or current_size + len(bundle) > chunk_topk:
+    members = {}                                   # bundle id -> positions of its chunks
+    for pos, chunk in enumerate(chunks):
+        members.setdefault(chunk["bundle_id"], []).append(pos)
+    texts = [chunk["page_content"] for chunk in chunks]
+    # :443-447  max(0, 1 - |query date - chunk date| / 365)
+    recency = [max(0, 1 - abs((query_time - datetime.strptime(chunk["metadata"]["date_published"], "%Y-%m-%d")).days) / 365)
+               for chunk in chunks]
+    with stages.stage("rerank_score"):
+        with (reranker_lock if reranker_lock is not None else contextlib.nullcontext()):          # :450
+            relevance = reranker.compute_score([[question, text] for text in texts], batch_size=8)
+    _, order = fuse_and_rank(relevance, recency, device_id)                                       # :454-457
+    with stages.stage("rerank_similarity"):
+        if similarity_index is not None:
+            sim = compute_similarity_mtx(embedding_fn, texts, device_id, as_torch=False, index=similarity_index,
+                                         row_ids=[chunk[row_id_key] for chunk in chunks])
+        else:
+            sim = compute_similarity_mtx(embedding_fn, texts, device_id, as_torch=False)          # :462
+    # :464-481 greedy pick, best fused score first: a bundle is taken whole if it is new, still fits chunk_topk, and its chunk is not
+    # a near-duplicate (> threshold) of what was taken -- where "what was taken" is the list of BUNDLE ids used as COLUMN numbers of
+    # the chunk-by-chunk matrix (the upstream quirk, :476; a bundle id >= n raises IndexError there and here)
+    taken, size = [], 0
+    for pos in order:
+        bid = chunks[pos]["bundle_id"]
+        n_members = len(members[bid])
+        if bid in taken or size + n_members > chunk_topk:
             continue
-        if selected_indices and np.any(similar_mtx[idx, selected_indices] > similar_threshhold):
+        if taken and np.any(sim[pos, taken] > similar_threshhold):
             continue
-        selected_indices.append(bundle_id)
-        current_size += len(bundle)
-    return selected_indices[::-1]
+        taken.append(bid)
+        size += n_members
+    return taken[::-1]                             # :483 reverse selection order
