@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-rerank", action="store_true", help="skip every transformer leg (re-rank, embed, latency, llm, c4)")
     ap.add_argument("--no-llm", action="store_true", help="skip the gemma-2b-shape LLM re-ranker leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] end-to-end chain")
+    ap.add_argument("--no-shard-legs", action="store_true", help="skip the configs[1] (c2) and 8-GPU-shard (shard8) legs of the default line")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed run push one bucket through the exchange path and compare the merged result "
                          "with per-batch searches (one rank) / with the CPU oracle run per shard (several ranks: on by default)")
@@ -301,10 +302,30 @@ def rerank_p50(args, shape=None):
         t0 = time.perf_counter()
         enc.forward(rids, rmask)
         tr.append((time.perf_counter() - t0) * 1e3)
+    # what ONE rank of the 8-GPU (and 4-GPU) data-parallel split scores: ceil(100 / 8) = 13 (25) pairs -- ShardedScorer hands every rank
+    # a contiguous block of the pairs (vllmManager.py:450-452 is the call being split); a perfect 1/8 of the 100-pair time is the ideal
+    dp_share = []
+    for share in (13, 25):
+        if share >= args.rerank_pairs:
+            continue
+        enc.forward(ids[:share], mask[:share])
+        tsh = []
+        for _ in range(16):
+            t0 = time.perf_counter()
+            enc.forward(ids[:share], mask[:share])
+            tsh.append((time.perf_counter() - t0) * 1e3)
+        p = float(np.median(tsh))
+        tfs = flops(cfg, share, args.rerank_tokens) / p / 1e9
+        dp_share.append({"pairs": share, "of_gpus": -(-args.rerank_pairs // share), "p50_ms": round(p, 3), "tflops": round(tfs, 1),
+                         "frac": round(tfs / 2500.0, 4)})
     enc.close()
     p50 = float(np.median(ts))
+    for d_ in dp_share:
+        d_["ideal_ms"] = round(p50 * d_["pairs"] / args.rerank_pairs, 3)
+        d_["dp_efficiency"] = round(d_["ideal_ms"] / d_["p50_ms"], 3)
     tf = flops(cfg, args.rerank_pairs, args.rerank_tokens) / p50 / 1e9
-    return p50, {"model_shape": shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens,
+    return p50, {"model_shape": shape, "pairs": args.rerank_pairs, "tokens": args.rerank_tokens, "dp_share": dp_share[0] if dp_share else None,
+                 "dp_shares": dp_share,
                  "tflops": round(tf, 1), "bound": "mfma", "peak_tflops": 2500.0, "frac": round(tf / 2500.0, 4),
                  "power_limited": _power_note(tf),
                  "weights": "seeded random (no checkpoints offline)", "includes": "H2D of token ids + D2H of logits",
@@ -380,7 +401,7 @@ def c5_leg(args, torch, vf, device):
     """BASELINE configs[4] at full size on this GPU: 10M x 1024 e4m3 rows, 1024 queries per batch, top-1000 -- the wide scan on the
     instruction the config names (k_scan_wide8: v_mfma_scale_f32_32x32x64_f8f6f4).  Same loop as the headline: batches pipelined
     two deep on their own stream, inputs resident, HIP events around the scan launches (vf_index_profile)."""
-    rows, dim, nq, k, steps, warm = 10_000_000, 1024, 1024, 1000, 6, 2
+    rows, dim, nq, k, steps, warm = 10_000_000, 1024, 1024, 1000, 24, 3
     corpus = make_shard(torch, 0, rows, dim, device, "fp8")
     index = vf.DenseIndex(corpus)
     try:
@@ -422,6 +443,125 @@ def c5_leg(args, torch, vf, device):
     finally:
         index.close()
         del corpus
+
+
+def _shard_traffic(tag):
+    """HBM bytes per launch of the main scan at a shard size, from the committed rocprofv3 --pmc passes (not re-measured here)."""
+    name = f"pmc_traffic_scan2_{tag}.json"
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return {"traffic": round(rec["hbm_bytes_per_launch"]), "traffic_source": f"profiles/{name} (separate --pmc passes, committed)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
+def small_shard_leg(args, torch, vf, device, corpus, rows, tag, with_exchange, steps=200, warm=20):
+    """The headline loop on the first `rows` rows of the same corpus (make_shard builds it in 125000-row chunks seeded by chunk number,
+    so the prefix IS make_shard(0, rows)): configs[1] (1M x 768, one GPU: `c2`) and what ONE rank of configs[2] does per step on its
+    1.25M-row shard (`shard8`: the packed per-shard top-k of 4 batches through an RCCL all-gather -- world 1 here, the driver's
+    8-GPU run measures the real one -- and the merge kernel, inside the timed loop).  Batches pipelined two deep, inputs resident."""
+    import numpy as np
+    import torch.distributed as dist
+    nq, k, dim = args.batch, args.k, int(corpus.shape[1])
+    E = 4 if with_exchange else 1
+    own_pg = False
+    if with_exchange and not dist.is_initialized():
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        own_pg = True
+    index = vf.DenseIndex(corpus[:rows])
+    try:
+        g = torch.Generator(device=device)
+        g.manual_seed(4321)
+        qpool = [torch.randn((nq, dim), generator=g, device=device, dtype=torch.float32) for _ in range(4)]
+        buckets = [vf.packed_result_buffer(E * nq, k, device) for _ in range(2 if E > 1 else 3)]
+        if with_exchange:
+            g_blob = torch.empty(vf.packed_part_bytes(E * nq, k), dtype=torch.uint8, device=device)
+            m_ids = torch.empty((E * nq, k), dtype=torch.int64, device=device)
+            m_sc = torch.empty((E * nq, k), dtype=torch.float32, device=device)
+        merged = [None]
+
+        def views(i):
+            blob, ids, sc = buckets[(i // E) % len(buckets)]
+            e = i % E
+            return ids[e * nq:(e + 1) * nq], sc[e * nq:(e + 1) * nq]
+
+        def finish(slot, i, last):
+            index.search_end(slot)
+            if with_exchange and (i % E == E - 1 or last):
+                dist.all_gather_into_tensor(g_blob, buckets[(i // E) % len(buckets)][0])
+                merged[0] = vf.merge_topk_packed_device(g_blob, 1, E * nq, k, m_ids, m_sc)
+
+        def run(n):
+            pending = []
+            for i in range(n):
+                if len(pending) == 2:
+                    finish(*pending.pop(0), False)
+                oi, osc = views(i)
+                index.search_begin(i % 2, qpool[i % 4], k, oi, osc)
+                pending.append((i % 2, i))
+            while pending:
+                finish(*pending.pop(0), len(pending) == 1)
+
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            run(warm)
+            torch.cuda.synchronize()
+            index.set_option("profile", 1)
+            t0 = time.perf_counter()
+            run(steps)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            prof, st = index.profile(), index.stats()
+            iso = None
+            if st.get("scans_overlap"):      # the isolated kernel: the same workload with the scans ordered by events
+                index.set_option("overlap_scans", 0)
+                run(10)
+                torch.cuda.synchronize()
+                index.set_option("profile", 1)
+                run(60)
+                torch.cuda.synchronize()
+                iso = index.profile()
+                index.set_option("overlap_scans", -1)
+            index.set_option("profile", 0)
+            verified = None
+            if with_exchange:                # one full bucket: the exchanged + merged result equals the direct one, bit for bit
+                run(E)
+                torch.cuda.synchronize()
+                mi, ms = merged[0]
+                verified = all(torch.equal(index.search_device(qpool[e % 4], k)[0], mi[e * nq:(e + 1) * nq]) and
+                               torch.equal(index.search_device(qpool[e % 4], k)[1], ms[e * nq:(e + 1) * nq]) for e in range(E))
+        torch.cuda.current_stream(device).wait_stream(side)
+        n_l = max(1, prof["scan_launches"])
+        interval = prof["span_ms"] / n_l if (st.get("scans_overlap") and prof.get("span_ms")) else prof["scan_ms_total"] / n_l
+        gbs = prof["scan_bytes_per_launch"] / (interval * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": {2: "vf::k_scan2<2> (whole-line LDS-DMA corpus loads)", 1: "vf::k_scan<main> (register loads)"}.get(st.get("scan_kernel"), "?"),
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(interval, 4),
+                "launches_timed": n_l, "algorithmic_bytes_per_launch": prof["scan_bytes_per_launch"],
+                "measured_in": ("launch interval = makespan of the timed launches (HIP events on the scan streams) / launches: consecutive scans overlap "
+                                f"on this shard size (CU split {st.get('aux_cus', 0)})") if st.get("scans_overlap") else "HIP-event bracket per launch, timed region",
+                **_shard_traffic(tag)}
+        if iso is not None and iso["scan_launches"] > 0:
+            ims = iso["scan_ms_total"] / iso["scan_launches"]
+            roof["isolated_launch"] = {"avg_launch_ms": round(ims, 4), "achieved": round(iso["scan_bytes_per_launch"] / (ims * 1e-3) / 1e9, 1),
+                                       "frac": round(iso["scan_bytes_per_launch"] / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": iso["scan_launches"]}
+        out = {"workload": f"{rows}x{dim} fp16 corpus, batch-{nq} queries, exact cosine top-{k}, 1 GPU" +
+                           (f"; every {E} batches one RCCL all-gather of the packed per-shard top-k (world 1) + the merge kernel, inside the timed loop" if with_exchange else ""),
+               "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warm, "roofline": roof,
+               "search_stats": {"candidates_per_query": round(st["candidates"] / max(1, st["n_queries"]), 1), "exact_reruns_last_batch": st["exact_reruns"],
+                                "aux_cus": st.get("aux_cus", 0), "scans_overlap": st.get("scans_overlap", 0)}}
+        if with_exchange:
+            out["exchange"] = {"batches_per_exchange": E, "bytes_per_rank": vf.packed_part_bytes(E * nq, k), "backend": dist.get_backend(),
+                               "world": dist.get_world_size(), "merged_equals_direct": verified}
+        return out
+    finally:
+        index.close()
+        if own_pg:
+            dist.destroy_process_group()
 
 
 def c4_chain(args, torch, vf, corpus):
@@ -523,7 +663,16 @@ def c4_chain(args, torch, vf, corpus):
                   "frac": round(flops_per_image(v_cfg) * 64 / p50 / 2.5e15, 4), "out_dim": int(out.shape[1]), "pcie_inclusive": True}
     except Exception as e:  # noqa: BLE001
         figure = {"error": f"{type(e).__name__}: {e}"}
-    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20, "figure_encoder": figure, "mixed_modality": mixed,
+    # Row kinds of the config's one index (veritasfi_amd.mixed.MixedModalIndex's split of a 5M-chunk filing corpus: 80 % narrative text,
+    # 15 % tables, 5 % figures).  TABLE ROWS ARE TABLE-AS-TEXT: the serialised table goes through the text embedder (HipEmbeddings), exactly
+    # as /root/reference/src/load_data.py:120-128 embeds every chunk with add_texts; "table-transformer" (BASELINE configs[3]) is a DETR
+    # detector that finds tables upstream of ingest and has no pooled output to index (README).
+    n_fig, n_tab = n // 20, (n * 3) // 20
+    row_kinds = {"text_rows": n - n_fig - n_tab, "table_rows": n_tab, "figure_rows": n_fig,
+                 "table_rows_encoder": "HipEmbeddings (table-as-text through the text embedder: the reference's own ingest path)",
+                 "figure_rows_encoder": "HipImageEmbeddings (CLIP vision tower -> 768-d)"}
+    return {"rows": n, "dim": int(corpus.shape[1]), "k": 100, "pairs": 100, "keep": 20, "table_rows": n_tab, "row_kinds": row_kinds,
+            "figure_encoder": figure, "mixed_modality": mixed,
             "p50_ms": {k: round(float(np.median(v)), 3) for k, v in stages.items()},
             "what": "configs[3] text leg: embed_query (bert-base shape, ~20 tokens) -> vf_index_search top-100 (host entry) -> "
                     "HipReranker.compute_score over 100 pairs of ~512 tokens (xlmr-base shape) -> rank_chunk (re-embeds the 100 "
@@ -871,6 +1020,19 @@ def main():
                 c5_info = c5_leg(args, torch, vf, device)
             except Exception as e:  # noqa: BLE001
                 c5_info = {"error": f"{type(e).__name__}: {e}"}
+    # configs[1] and one rank's share of configs[2] on the same corpus (the default line only; no transformer needed)
+    c2_info, shard8_info = None, None
+    if rank == 0 and world == 1 and not devs and corpus is not None and args.corpus_dtype == "f16" and not args.no_shard_legs and \
+            (args.rows, args.dim, args.batch, args.k) == (10_000_000, 768, 64, 100) and not dist.is_initialized():
+        for name_, rows_, tag_, exch_ in (("c2", 1_000_000, "1000k", False), ("shard8", 1_250_000, "1250k", True)):
+            try:
+                info_ = small_shard_leg(args, torch, vf, device, corpus, rows_, tag_, exch_)
+            except Exception as e:  # noqa: BLE001
+                info_ = {"error": f"{type(e).__name__}: {e}"}
+            if name_ == "c2":
+                c2_info = info_
+            else:
+                shard8_info = info_
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -989,6 +1151,8 @@ def main():
             "rerank": rr_info,
             "rerank_large": rr_large,
             "rerank_llm": llm_info,
+            "c2": c2_info,
+            "shard8": shard8_info,
             "c4": c4_info,
             "c5": c5_info,
             "embed": emb_info,

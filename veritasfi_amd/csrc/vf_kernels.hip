@@ -2570,6 +2570,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_scan_wide8(S
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wide_flush<Q, kW8Threads>(a, ctl, jt, tid);
+    if (dbg) {   // where and when this wave ran: absolute start (100 MHz), HW_ID (CU / SE / SIMD / wave slot) and XCC_ID registers
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+        dbg[10] = t_begin; dbg[11] = ((unsigned long long)xcc_id << 32) | hw_id;
+    }
     if (dbg) { dbg[0] = wall_clock64() - t_begin; dbg[1] = t_wait; dbg[2] = t_bar; dbg[3] = t_epi; dbg[4] = t_inv; dbg[5] = t_flt; dbg[6] = t_ph[0]; dbg[7] = t_ph[1]; dbg[8] = t_ph[2]; dbg[9] = t_ph[3]; }
 }
 
@@ -2598,7 +2603,8 @@ int scan_wide8_occupancy(int waves, int stage_cap) {
 
 hipError_t launch_scan_wide8(const ScanArgs& a, int waves, hipStream_t s) {
     const int grid = 8 * a.jtiles * ((a.rgroups + 7) / 8);
-    if (waves == 4) hipLaunchKernelGGL(k_scan_wide8<4>, dim3(grid), dim3(256), scan_wide8_lds_bytes(4, a.stage_cap), s, a);
+    static const size_t pad4 = [] { const char* e = getenv("VF_W8_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // experiment: extra LDS per 4-wave workgroup (forces one per CU)
+    if (waves == 4) hipLaunchKernelGGL(k_scan_wide8<4>, dim3(grid), dim3(256), scan_wide8_lds_bytes(4, a.stage_cap) + pad4, s, a);
     else hipLaunchKernelGGL(k_scan_wide8<8>, dim3(grid), dim3(512), scan_wide8_lds_bytes(8, a.stage_cap), s, a);
     return hipGetLastError();
 }
@@ -3174,7 +3180,7 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
