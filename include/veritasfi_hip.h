@@ -207,7 +207,9 @@ typedef struct vf_encoder vf_encoder;
 typedef struct vf_encoder_config {
     int32_t vocab, hidden, layers, heads, ffn, max_pos, type_vocab;
     int32_t roberta_pad_idx; /* -1: BERT positions 0..t-1; >= 0: cumsum(mask)*mask + pad_idx (RoBERTa / XLM-R) */
-    int32_t pooling;         /* 0 CLS, 1 unmasked mean (continuous_retrieval.py:148), 2 last token (step3_mul.py:181-188) */
+    int32_t pooling;         /* 0 CLS, 1 unmasked mean (continuous_retrieval.py:148), 2 last token (step3_mul.py:181-188),
+                              * 3 masked mean (sentence-transformers pooling_mode_mean_tokens: src/utils/ragManager.py:50's
+                              * HuggingFaceEmbeddings on a model whose 1_Pooling/config.json selects it) */
     int32_t normalize;       /* 1: L2-normalise the pooled vector (bge models) */
     int32_t head;            /* 0: embeddings [b, hidden]; 1: RobertaClassificationHead -> one logit per sequence */
     float ln_eps;

@@ -16,6 +16,9 @@ Drop-in names (same signatures as the reference):
 * ``EnsembleRetriever``                  -- ``src/utils/ensembleRetriever.py:19-232`` (candidate gathering around the search)
 * ``ShardedRetriever``                   -- row-sharded multi-GPU search
 * ``ShardedScorer``                      -- data-parallel re-rank / embed: a replica per rank + one all-gather of the scores
+* ``HuggingFaceEmbeddings(model_name=...)`` / ``FlagLLMReranker(name, ...)`` / ``from_config(cfg)``
+                                         -- the reference's two constructor calls (``ragManager.py:50``, ``vllmChatService.py:90``) and
+                                            its YAML keys (``config/example.yaml``), returning the HIP-backed objects (pretrained.py)
 * ``set_profiler``                       -- routes the reference's stage names ("retrieve", "retrieve_faiss", "retrieve_faiss_ts",
                                             "rerank"; ``src/utils/profiler.py``) out of the drop-in classes (off by default)
 """
@@ -32,5 +35,7 @@ from .vision import (HipClipTextEmbeddings, HipClipTextEncoder, HipImageEmbeddin
                      pack_hf_clip_vision)
 from .ensemble import EnsembleRetriever  # noqa: F401
 from .stages import StageTimer, get_profiler, set_profiler  # noqa: F401
+from .pretrained import (FlagLLMReranker, FlagReranker, HuggingFaceEmbeddings, ReplicaSet, from_config, load_embeddings,  # noqa: F401
+                         load_reranker, read_sentence_transformers_layout)
 
 __version__ = "0.1.0"

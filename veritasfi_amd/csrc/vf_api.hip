@@ -407,8 +407,16 @@ static int read_vfc_header(int fd, const char* path, VfcHeader* h, size_t* esz) 
     *esz = h->dtype == VF_DTYPE_F32 ? 4 : (h->dtype == VF_DTYPE_F16 ? 2 : 1);
     struct stat st;
     if (fstat(fd, &st) != 0) return fail(VF_EINVAL, std::string("cannot stat corpus file: ") + path);
-    const unsigned long long need = 64ull + (unsigned long long)h->n * h->d * *esz + ((h->flags & 1u) ? h->n * 8ull : 0ull);
+    // n * d * element size (+ the id table) against the file's size, WITHOUT wrapping: a header with n = 2^61 and d = 16 would
+    // otherwise multiply to a small number, pass this check and hand a huge row count to the loader (round 5: found by the header
+    // fuzz of tools/host_sanitize_check.cc; unsigned wrap-around is not an error any sanitizer reports)
+    unsigned long long payload = 0, ids = 0, need = 0;
+    if (__builtin_mul_overflow((unsigned long long)h->n, (unsigned long long)h->d * (unsigned long long)*esz, &payload) ||
+        __builtin_mul_overflow((unsigned long long)h->n, (h->flags & 1u) ? 8ull : 0ull, &ids) ||
+        __builtin_add_overflow(payload, ids, &need) || __builtin_add_overflow(need, 64ull, &need))
+        return fail(VF_EINVAL, std::string("corpus file header is corrupt (n x d overflows): ") + path);
     if ((unsigned long long)st.st_size < need) return fail(VF_EINVAL, std::string("corpus file is truncated: ") + path);
+    if (h->n >= 0x7fffffffffffffffull / 2) return fail(VF_EINVAL, std::string("corpus file header is corrupt: ") + path);
     return VF_OK;
 }
 

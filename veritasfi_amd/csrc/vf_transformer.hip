@@ -822,6 +822,220 @@ struct GemmWs {
 };
 constexpr int kSkMaxTiles = 256;
 
+// geometry of the 256 x 256 x 64 kernels (k_gemm8p_tn, k_gemm9_tn): 512 threads, eight 16-KB half-tile slots + a dump slot
+constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLDS = 2 * 4 * PSLOT + PSLOT;
+// ------------------------------------------------------------------------------------------------
+// The co-operative split-K finish, shared by the 8-phase kernel's tail tiles and the persistent kernel's whole-product cut (round 5):
+// `acc` holds this slice's partial sums of the tile in the kernel's own register layout (both kernels: acc[mi][ni], 16-row block mi of
+// the wave's 128 rows), `flag` is 16 bytes of LDS nobody else is using, every thread of the workgroup calls it behind a barrier with
+// no vector-memory access of its own pending.  Returns true when the workgroup has handed its share over and must leave; otherwise
+// sk_own names the blocks it has to finish (bias, activation, residual, store).
+struct SkCtx { float* ws; unsigned* cnt; unsigned* stat; int S; int dbg; };
+
+__device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk, int sk_tile, int me, unsigned& sk_own, unsigned* flag, int tid) {
+    // Split-K, co-operative finish (round 4).  Until then the LAST slice to arrive read all S partials back (one CU pulls 50-60
+    // GB/s: ~9 us per 256 KB) and finished the tile alone.  Now slice s owns the 16-row blocks mi in [8 s / S, 8 (s + 1) / S) of
+    // both 128-row halves: it leaves only the blocks it does not own in sk_ws ((S - 1) / S of a partial), counts itself, waits
+    // until all S slices have done so, adds the others' partials of ITS blocks in slice order (its own term comes from the
+    // registers, at its place in the order: bit for bit the old sum) and runs the epilogue on its rows only.
+    // The wait is BOUNDED.  Slices of one launch alone cannot block one another (they are the last workgroups of the grid, at
+    // most one round of the CUs, one per CU, and nothing ahead of them waits) -- but two such launches on different streams,
+    // or in two processes sharing the GPU, could each hold the CUs the other's missing slices need.  So a slice that has
+    // waited kSkWaitTicks (300 us; partners normally arrive within one tile's time) hands ITS blocks over as well, marks
+    // itself in the tile's state word and leaves its CU; the slice that arrives LAST sees the marks in the value its own
+    // arrival returns and finishes those blocks too.  One 32-bit word per tile orders everything: bits 0-7 arrivals, 8-15
+    // "has handed over" per slice, 16-23 finished; a slice whose mark lands after the last arrival learns that from the
+    // returned value and carries on itself (the word is then harmlessly marked).  vf_debug_splitk_stats(.., 16) sets the bound
+    // to zero: every slice but the last hands over at once -- the old last-arrival scheme, through the take-over code (tests).
+    constexpr unsigned long long kSkWaitTicks = 30000ull;   // of the 100 MHz real-time counter
+    const sq_rsrc_t rw = sq_rsrc(sk.ws);
+    const int S = sk.S;
+    const int lo_me = 8 * me / S, hi_me = 8 * (me + 1) / S;
+    sk_own = ((1u << hi_me) - 1u) & ~((1u << lo_me) - 1u);
+    const int my = ((sk_tile * S + me) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
+    unsigned* const w0 = sk.cnt + 2 * sk_tile;               // the state word; w0[1]: slices per XCD, 3 bits each
+    auto finished = [&](bool same_xcd) {   // tid 0: this slice needs nothing from the workspace any more
+        const unsigned v = __hip_atomic_fetch_add(w0, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((v >> 16) & 0xffu) == (unsigned)(S - 1)) {   // the last to finish leaves the words at zero for the next launch
+            __hip_atomic_store(w0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w0 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(sk.stat + (same_xcd ? 0 : 1), 1u);
+        }
+    };
+    // one block (16 rows of either half) summed in slice order: any slice's share, one block at a time (take-over only)
+    auto take_block = [&](auto MI, bool same_xcd) {
+        constexpr int mi = decltype(MI)::value;
+        f4v t[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) t[ni] = f4v{0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < S; ++sl) {
+            if (sl == me) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[ni][e] += acc[mi][ni][e];
+            } else {
+                const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
+                f4v v[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    v[ni] = same_xcd ? __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 1))
+                                     : __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[ni][e] += v[ni][e];
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = t[ni];
+    };
+    auto coop = [&](auto LO, auto HI) -> bool {   // true: the share has been handed over, the workgroup leaves
+        constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+        if (!(sk.dbg & 1)) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    if (mi < lo || mi >= hi)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have reached memory ...
+        __syncthreads();
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            (void)__hip_atomic_fetch_add(w0 + 1, 1u << (3 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned a = __hip_atomic_fetch_add(w0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+            const bool last = (a & 0xffu) == (unsigned)(S - 1);
+            unsigned give_up = 0u;
+            if (!last) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), bound = (sk.dbg & 16) ? 0ull : kSkWaitTicks;
+                for (;;) {
+                    if ((__hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) >= (unsigned)S) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 >= bound) { give_up = 1u; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            flag[0] = give_up;
+            flag[2] = last ? ((a >> 8) & 0xffu) : 0u;   // the last arrival: whose blocks are left for it
+            flag[3] = xcc;
+        }
+        __syncthreads();
+        if (flag[0]) {   // waited long enough: my own blocks go to the workspace too, then the mark
+            if (!(sk.dbg & 1)) {
+#pragma unroll
+                for (int mi = lo; mi < hi; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned b = __hip_atomic_fetch_or(w0, 1u << (8 + me), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                flag[0] = (b & 0xffu) >= (unsigned)S ? 0u : 1u;   // everybody is here after all: nobody will finish my blocks for me
+                if (flag[0]) finished(false);
+            }
+            __syncthreads();
+            if (flag[0]) return true;
+        }
+        if (tid == 0) {   // all S slices have arrived: the per-XCD counts are complete
+            const unsigned per_xcd = __hip_atomic_load(w0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[1] = ((per_xcd >> (3 * flag[3])) & 7u) == (unsigned)S ? 1u : 0u;   // every slice ran on this XCD: the partials are in ITS L2
+        }
+        __syncthreads();
+        const bool same_xcd = flag[1] != 0u;
+        // two blocks at a time (64 more registers beside the 128 accumulators; the whole share at once spilled)
+        auto reduce2 = [&](auto B0, auto NB) {
+            constexpr int b0 = decltype(B0)::value, nb = decltype(NB)::value;
+            f4v t[nb][4];
+#pragma unroll
+            for (int m = 0; m < nb; ++m)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) t[m][ni] = f4v{0.f, 0.f, 0.f, 0.f};
+            auto add_slice = [&](int sl) {
+                const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
+                f4v v[nb][4];
+                if (same_xcd) {   // sc0: past this CU's L1, into the L2 the slices' stores went through
+#pragma unroll
+                    for (int m = 0; m < nb; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 1));
+                } else {          // sc1: memory side
+#pragma unroll
+                    for (int m = 0; m < nb; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+                }
+#pragma unroll
+                for (int m = 0; m < nb; ++m)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[m][ni][e] += v[m][ni][e];
+            };
+            if (!(sk.dbg & 2))
+                for (int sl = 0; sl < me; ++sl) add_slice(sl);
+#pragma unroll
+            for (int m = 0; m < nb; ++m)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[m][ni][e] += acc[b0 + m][ni][e];
+            if (!(sk.dbg & 2))
+                for (int sl = me + 1; sl < S; ++sl) add_slice(sl);
+#pragma unroll
+            for (int m = 0; m < nb; ++m)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[b0 + m][ni] = t[m][ni];
+        };
+        using std::integral_constant;
+        reduce2(integral_constant<int, lo>{}, integral_constant<int, (hi - lo >= 2 ? 2 : 1)>{});
+        if constexpr (hi - lo == 3) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 1>{});
+        if constexpr (hi - lo == 4) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 2>{});
+        return false;
+    };
+    using std::integral_constant;
+    bool leave = false;
+    switch (lo_me * 16 + hi_me) {   // the eight (first block, end) pairs of S = 2, 3, 4
+        case 0 * 16 + 4: leave = coop(integral_constant<int, 0>{}, integral_constant<int, 4>{}); break;
+        case 4 * 16 + 8: leave = coop(integral_constant<int, 4>{}, integral_constant<int, 8>{}); break;
+        case 0 * 16 + 2: leave = coop(integral_constant<int, 0>{}, integral_constant<int, 2>{}); break;
+        case 2 * 16 + 5: leave = coop(integral_constant<int, 2>{}, integral_constant<int, 5>{}); break;
+        case 5 * 16 + 8: leave = coop(integral_constant<int, 5>{}, integral_constant<int, 8>{}); break;
+        case 2 * 16 + 4: leave = coop(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+        case 4 * 16 + 6: leave = coop(integral_constant<int, 4>{}, integral_constant<int, 6>{}); break;
+        case 6 * 16 + 8: leave = coop(integral_constant<int, 6>{}, integral_constant<int, 8>{}); break;
+        default: __builtin_trap();   // the host only launches S in {2, 3, 4}
+    }
+    if (leave) return true;
+    const bool same_xcd = flag[1] != 0u;
+    const unsigned gone = flag[2];
+    if (gone) {   // the last arrival finishes the blocks of the slices that have left (their whole partial is in the workspace)
+        unsigned take = 0u;
+        for (int x = 0; x < S; ++x)
+            if ((gone >> x) & 1u) take |= ((1u << (8 * (x + 1) / S)) - 1u) & ~((1u << (8 * x / S)) - 1u);
+        take &= ~sk_own;
+        if (take & 1u) take_block(integral_constant<int, 0>{}, same_xcd);
+        if (take & 2u) take_block(integral_constant<int, 1>{}, same_xcd);
+        if (take & 4u) take_block(integral_constant<int, 2>{}, same_xcd);
+        if (take & 8u) take_block(integral_constant<int, 3>{}, same_xcd);
+        if (take & 16u) take_block(integral_constant<int, 4>{}, same_xcd);
+        if (take & 32u) take_block(integral_constant<int, 5>{}, same_xcd);
+        if (take & 64u) take_block(integral_constant<int, 6>{}, same_xcd);
+        if (take & 128u) take_block(integral_constant<int, 7>{}, same_xcd);
+        sk_own |= take;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) finished(same_xcd);
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_gemm8p_tn: 256 x 256 x 64 tiles, 8 waves (2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles,
 // 128 accumulator VGPRs), ONE workgroup per CU, LDS-DMA staging with a counted vmcnt and raw barriers --
@@ -852,7 +1066,6 @@ constexpr int kSkMaxTiles = 256;
 //  is what the LayerNorm-fold instances run.
 //  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128.
 // ------------------------------------------------------------------------------------------------
-constexpr int PBM = 256, PBN = 256, PBK = 64, PTHREADS = 512, PSLOT = 16384, PLDS = 2 * 4 * PSLOT + PSLOT;
 
 template <int EPI>
 __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
@@ -1067,207 +1280,8 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm8p_tn(const half_t* __restrict
     __syncthreads();
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
         if (sk_tile >= 0) {
-            // Split-K, co-operative finish (round 4).  Until then the LAST slice to arrive read all S partials back (one CU pulls 50-60
-            // GB/s: ~9 us per 256 KB) and finished the tile alone.  Now slice s owns the 16-row blocks mi in [8 s / S, 8 (s + 1) / S) of
-            // both 128-row halves: it leaves only the blocks it does not own in sk_ws ((S - 1) / S of a partial), counts itself, waits
-            // until all S slices have done so, adds the others' partials of ITS blocks in slice order (its own term comes from the
-            // registers, at its place in the order: bit for bit the old sum) and runs the epilogue on its rows only.
-            // The wait is BOUNDED.  Slices of one launch alone cannot block one another (they are the last workgroups of the grid, at
-            // most one round of the CUs, one per CU, and nothing ahead of them waits) -- but two such launches on different streams,
-            // or in two processes sharing the GPU, could each hold the CUs the other's missing slices need.  So a slice that has
-            // waited kSkWaitTicks (300 us; partners normally arrive within one tile's time) hands ITS blocks over as well, marks
-            // itself in the tile's state word and leaves its CU; the slice that arrives LAST sees the marks in the value its own
-            // arrival returns and finishes those blocks too.  One 32-bit word per tile orders everything: bits 0-7 arrivals, 8-15
-            // "has handed over" per slice, 16-23 finished; a slice whose mark lands after the last arrival learns that from the
-            // returned value and carries on itself (the word is then harmlessly marked).  vf_debug_splitk_stats(.., 16) sets the bound
-            // to zero: every slice but the last hands over at once -- the old last-arrival scheme, through the take-over code (tests).
-            constexpr unsigned long long kSkWaitTicks = 30000ull;   // of the 100 MHz real-time counter
-            const sq_rsrc_t rw = sq_rsrc(lf.sk_ws);
-            const int S = lf.sk_S, me = sk_slice;
-            const int lo_me = 8 * me / S, hi_me = 8 * (me + 1) / S;
-            sk_own = ((1u << hi_me) - 1u) & ~((1u << lo_me) - 1u);
-            const int my = ((sk_tile * S + me) * 32) * PTHREADS * 16;   // byte offset: [tile][slice][mi * 4 + ni][thread] x 16 B
-            unsigned* const w0 = lf.sk_cnt + 2 * sk_tile;               // the state word; w0[1]: slices per XCD, 3 bits each
-            unsigned* flag = (unsigned*)(smem + 8 * PSLOT);
-            auto finished = [&](bool same_xcd) {   // tid 0: this slice needs nothing from the workspace any more
-                const unsigned v = __hip_atomic_fetch_add(w0, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (((v >> 16) & 0xffu) == (unsigned)(S - 1)) {   // the last to finish leaves the words at zero for the next launch
-                    __hip_atomic_store(w0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(w0 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicAdd(lf.sk_stat + (same_xcd ? 0 : 1), 1u);
-                }
-            };
-            // one block (16 rows of either half) summed in slice order: any slice's share, one block at a time (take-over only)
-            auto take_block = [&](auto MI, bool same_xcd) {
-                constexpr int mi = decltype(MI)::value;
-                f4v t[4];
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) t[ni] = f4v{0.f, 0.f, 0.f, 0.f};
-                for (int sl = 0; sl < S; ++sl) {
-                    if (sl == me) {
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[ni][e] += acc[mi][ni][e];
-                    } else {
-                        const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
-                        f4v v[4];
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            v[ni] = same_xcd ? __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 1))
-                                             : __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[ni][e] += v[ni][e];
-                    }
-                }
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = t[ni];
-            };
-            auto coop = [&](auto LO, auto HI) -> bool {   // true: the share has been handed over, the workgroup leaves
-                constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
-                if (!(lf.sk_dbg & 1)) {
-#pragma unroll
-                    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            if (mi < lo || mi >= hi)
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have reached memory ...
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned xcc;
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                    xcc &= 7u;
-                    (void)__hip_atomic_fetch_add(w0 + 1, 1u << (3 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned a = __hip_atomic_fetch_add(w0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
-                    const bool last = (a & 0xffu) == (unsigned)(S - 1);
-                    unsigned give_up = 0u;
-                    if (!last) {
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), bound = (lf.sk_dbg & 16) ? 0ull : kSkWaitTicks;
-                        for (;;) {
-                            if ((__hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) >= (unsigned)S) break;
-                            if (__builtin_amdgcn_s_memrealtime() - t0 >= bound) { give_up = 1u; break; }
-                            __builtin_amdgcn_s_sleep(4);
-                        }
-                    }
-                    flag[0] = give_up;
-                    flag[2] = last ? ((a >> 8) & 0xffu) : 0u;   // the last arrival: whose blocks are left for it
-                    flag[3] = xcc;
-                }
-                __syncthreads();
-                if (flag[0]) {   // waited long enough: my own blocks go to the workspace too, then the mark
-                    if (!(lf.sk_dbg & 1)) {
-#pragma unroll
-                        for (int mi = lo; mi < hi; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni)
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc[mi][ni]), rw, my + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) {
-                        const unsigned b = __hip_atomic_fetch_or(w0, 1u << (8 + me), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                        flag[0] = (b & 0xffu) >= (unsigned)S ? 0u : 1u;   // everybody is here after all: nobody will finish my blocks for me
-                        if (flag[0]) finished(false);
-                    }
-                    __syncthreads();
-                    if (flag[0]) return true;
-                }
-                if (tid == 0) {   // all S slices have arrived: the per-XCD counts are complete
-                    const unsigned per_xcd = __hip_atomic_load(w0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[1] = ((per_xcd >> (3 * flag[3])) & 7u) == (unsigned)S ? 1u : 0u;   // every slice ran on this XCD: the partials are in ITS L2
-                }
-                __syncthreads();
-                const bool same_xcd = flag[1] != 0u;
-                // two blocks at a time (64 more registers beside the 128 accumulators; the whole share at once spilled)
-                auto reduce2 = [&](auto B0, auto NB) {
-                    constexpr int b0 = decltype(B0)::value, nb = decltype(NB)::value;
-                    f4v t[nb][4];
-#pragma unroll
-                    for (int m = 0; m < nb; ++m)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) t[m][ni] = f4v{0.f, 0.f, 0.f, 0.f};
-                    auto add_slice = [&](int sl) {
-                        const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
-                        f4v v[nb][4];
-                        if (same_xcd) {   // sc0: past this CU's L1, into the L2 the slices' stores went through
-#pragma unroll
-                            for (int m = 0; m < nb; ++m)
-#pragma unroll
-                                for (int ni = 0; ni < 4; ++ni)
-                                    v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 1));
-                        } else {          // sc1: memory side
-#pragma unroll
-                            for (int m = 0; m < nb; ++m)
-#pragma unroll
-                                for (int ni = 0; ni < 4; ++ni)
-                                    v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
-                        }
-#pragma unroll
-                        for (int m = 0; m < nb; ++m)
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) t[m][ni][e] += v[m][ni][e];
-                    };
-                    if (!(lf.sk_dbg & 2))
-                        for (int sl = 0; sl < me; ++sl) add_slice(sl);
-#pragma unroll
-                    for (int m = 0; m < nb; ++m)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[m][ni][e] += acc[b0 + m][ni][e];
-                    if (!(lf.sk_dbg & 2))
-                        for (int sl = me + 1; sl < S; ++sl) add_slice(sl);
-#pragma unroll
-                    for (int m = 0; m < nb; ++m)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) acc[b0 + m][ni] = t[m][ni];
-                };
-                using std::integral_constant;
-                reduce2(integral_constant<int, lo>{}, integral_constant<int, (hi - lo >= 2 ? 2 : 1)>{});
-                if constexpr (hi - lo == 3) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 1>{});
-                if constexpr (hi - lo == 4) reduce2(integral_constant<int, lo + 2>{}, integral_constant<int, 2>{});
-                return false;
-            };
-            using std::integral_constant;
-            bool leave = false;
-            switch (lo_me * 16 + hi_me) {   // the eight (first block, end) pairs of S = 2, 3, 4
-                case 0 * 16 + 4: leave = coop(integral_constant<int, 0>{}, integral_constant<int, 4>{}); break;
-                case 4 * 16 + 8: leave = coop(integral_constant<int, 4>{}, integral_constant<int, 8>{}); break;
-                case 0 * 16 + 2: leave = coop(integral_constant<int, 0>{}, integral_constant<int, 2>{}); break;
-                case 2 * 16 + 5: leave = coop(integral_constant<int, 2>{}, integral_constant<int, 5>{}); break;
-                case 5 * 16 + 8: leave = coop(integral_constant<int, 5>{}, integral_constant<int, 8>{}); break;
-                case 2 * 16 + 4: leave = coop(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
-                case 4 * 16 + 6: leave = coop(integral_constant<int, 4>{}, integral_constant<int, 6>{}); break;
-                case 6 * 16 + 8: leave = coop(integral_constant<int, 6>{}, integral_constant<int, 8>{}); break;
-                default: __builtin_trap();   // the host only launches S in {2, 3, 4}
-            }
-            if (leave) return;
-            const bool same_xcd = flag[1] != 0u;
-            const unsigned gone = flag[2];
-            if (gone) {   // the last arrival finishes the blocks of the slices that have left (their whole partial is in the workspace)
-                unsigned take = 0u;
-                for (int x = 0; x < S; ++x)
-                    if ((gone >> x) & 1u) take |= ((1u << (8 * (x + 1) / S)) - 1u) & ~((1u << (8 * x / S)) - 1u);
-                take &= ~sk_own;
-                if (take & 1u) take_block(integral_constant<int, 0>{}, same_xcd);
-                if (take & 2u) take_block(integral_constant<int, 1>{}, same_xcd);
-                if (take & 4u) take_block(integral_constant<int, 2>{}, same_xcd);
-                if (take & 8u) take_block(integral_constant<int, 3>{}, same_xcd);
-                if (take & 16u) take_block(integral_constant<int, 4>{}, same_xcd);
-                if (take & 32u) take_block(integral_constant<int, 5>{}, same_xcd);
-                if (take & 64u) take_block(integral_constant<int, 6>{}, same_xcd);
-                if (take & 128u) take_block(integral_constant<int, 7>{}, same_xcd);
-                sk_own |= take;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) finished(same_xcd);
+            const SkCtx skc{lf.sk_ws, lf.sk_cnt, lf.sk_stat, lf.sk_S, lf.sk_dbg};
+            if (sk_coop_finish(acc, skc, sk_tile, sk_slice, sk_own, (unsigned*)(smem + 8 * PSLOT), tid)) return;
         }
     }
     if (EPI == EPI_RESIDUAL_F32) {
@@ -1493,10 +1507,11 @@ __device__ __forceinline__ void q_tile_of(int orig, int Mt, int Nt, int& mt, int
 constexpr int RLDS = PLDS + 2048 + 1024;   // + two tiles' bias (2 x 256 floats) + wall-clock stamps of 16 tiles (debug)
 constexpr int k9StampTiles = 16, k9Stamps = 6;
 
-template <int EPI>
+template <int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                         half_t* __restrict__ C, int M, int N, int K, int stagger_ticks, unsigned long long* __restrict__ dbg) {
+                                                         half_t* __restrict__ C, int M, int N, int K, int stagger_ticks, unsigned long long* __restrict__ dbg,
+                                                         SkCtx sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + 2 x bias + stamps
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1525,10 +1540,27 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
     // Round 4 also built the remainder tiles of long-K products as K-slices inside this kernel -- partials through the handle's workspace,
     // last arriver reduces in slice order -- correct and deterministic, and SLOWER in the forward than handing those products to the
     // 8-phase kernel's split-K tail: 11.67 vs 11.48 ms at 768 wide, 36.4 vs 35.6 at 1024; profiles/r04_gemm9_tail_slices.log.  Removed.)
+    // Round 5, sk.S in {2, 3, 4}: a product of LESS than a round with a long K (FFN-down of a data-parallel rank's 13 pairs: 78 tiles,
+    // K = 3072 -- a third of the CUs at work for 63 us) is cut whole: the grid is 8 x ceil(tiles / 8) x S workgroups, ONE item each --
+    // slice i % S of the tile at XCD-local index i / S, i = blockIdx / 8 (the slices of a tile share blockIdx % 8 = one XCD under the
+    // round-robin placement: their partials meet in that L2) -- and the tile leaves through sk_coop_finish (the 8-phase kernel's
+    // co-operative finish) instead of the plain epilogue, each slice finishing the 16-row blocks it owns.
     const int G_ = (int)gridDim.x, wg = (int)blockIdx.x;
-    const int n_items = wg < ntiles ? (ntiles - wg + G_ - 1) / G_ : 0;
+    const int sk_S = SPLIT && sk.S > 1 ? sk.S : 1;   // (SPLIT is its own instantiation: the multi-item kernel's loop and registers stay as they were)
+    int sk_tile = -1, sk_slice = 0;
+    if (sk_S > 1) {
+        const int i = wg >> 3;
+        sk_slice = i % sk_S;
+        const int t_local = i / sk_S, xcd = wg & 7;
+        if (t_local >= (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0)) return;   // padding of the sliced grid (before any barrier)
+        sk_tile = t_local * 8 + xcd;
+    }
+    const int n_items = sk_S > 1 ? 1 : (wg < ntiles ? (ntiles - wg + G_ - 1) / G_ : 0);
     if (n_items == 0) return;                                   // (before any barrier)
-    auto item = [&](int idx, int& mt_, int& nt_, int& klo_, int& nk_) { q_tile_of(wg + idx * G_, Mt, Nt, mt_, nt_); klo_ = 0; nk_ = nk; };
+    auto item = [&](int idx, int& mt_, int& nt_, int& klo_, int& nk_) {
+        if (sk_S > 1) { q_tile_of(sk_tile, Mt, Nt, mt_, nt_); klo_ = nk * sk_slice / sk_S; nk_ = nk * (sk_slice + 1) / sk_S - klo_; }
+        else { q_tile_of(wg + idx * G_, Mt, Nt, mt_, nt_); klo_ = 0; nk_ = nk; }
+    };
     int mt_c, nt_c, klo_c, nk_c;
     item(0, mt_c, nt_c, klo_c, nk_c);
     int ktg = 0;   // K-tiles consumed by this workgroup so far: LDS buffer of local K-tile kt is (ktg + kt) & 1
@@ -1649,11 +1681,13 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     h8 rr[4][2];
+    unsigned sk_own = 0xffu;   // 16-row blocks this workgroup finishes and stores: all of them, or a split-K slice's share (wave-uniform)
 #define VF9_EPI_LOAD_R(MH_, M0_, N0_)                                                                                  \
     if constexpr (EPI == EPI_BIAS_RESIDUAL) {                                                                          \
         _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                                               \
             _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_)                                                        \
-                rr[t_][hf_] = *(const h8*)(R + ((M0_) + wr * 128 + (4 * (MH_) + t_) * 16 + r15) * N + (N0_) + wc * 64 + 8 * kb + hf_ * 32); \
+                if (!SPLIT || ((sk_own >> (4 * (MH_) + t_)) & 1u))                                                      \
+                    rr[t_][hf_] = *(const h8*)(R + ((M0_) + wr * 128 + (4 * (MH_) + t_) * 16 + r15) * N + (N0_) + wc * 64 + 8 * kb + hf_ * 32); \
     }
 #define VF9_EPI_HALF(MH_, M0_, N0_, PAR_)                                                                              \
     {                                                                                                                  \
@@ -1685,7 +1719,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
                     }                                                                                                  \
                     o_[2 * q_] = __builtin_bit_cast(unsigned, p0_); o_[2 * q_ + 1] = __builtin_bit_cast(unsigned, p1_); \
                 }                                                                                                      \
-                *(u4v*)(cbase_ + (long long)t_ * 16 * N + hf_ * 32) = o_;                                              \
+                if (!SPLIT || ((sk_own >> mi_) & 1u)) *(u4v*)(cbase_ + (long long)t_ * 16 * N + hf_ * 32) = o_;   /* (a split-K slice stores the blocks it owns) */ \
             }                                                                                                          \
             _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) acc[mi_][b_] = f4v{0.f, 0.f, 0.f, 0.f};                   \
         }                                                                                                              \
@@ -1716,13 +1750,13 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if constexpr (EPI == EPI_BIAS_RESIDUAL) {   // residual rows first, consumed at once: nothing younger to wait behind, no register held across the stage
-                if (first) { VF9_EPI_LOAD_R(0, m0p, n0p) VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }
+                if (!SPLIT && first) { VF9_EPI_LOAD_R(0, m0p, n0p) VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }
                 __builtin_amdgcn_sched_barrier(0);
             }
             VF9_STAGE(3)
             if (kt == 0 && wid == 0 && bias) dma16u((unsigned long long)(bias + n0), (unsigned)lane * 16u, lds_smem + (unsigned)PLDS + (unsigned)(it & 1) * 1024u);
             if constexpr (EPI != EPI_BIAS_RESIDUAL) {
-                if (first) { VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }   // (before the fragment reads: their 64 registers are dead here)
+                if (!SPLIT && first) { VF9_EPI_HALF(0, m0p, n0p, (it - 1) & 1) }   // (before the fragment reads: their 64 registers are dead here)
                 __builtin_amdgcn_sched_barrier(0);
             }
             VF9_READ_B(B0f, base + 1 * PSLOT)
@@ -1736,14 +1770,14 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if constexpr (EPI == EPI_BIAS_RESIDUAL) {
-                if (first) { VF9_EPI_LOAD_R(1, m0p, n0p) VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }
+                if (!SPLIT && first) { VF9_EPI_LOAD_R(1, m0p, n0p) VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }
                 __builtin_amdgcn_sched_barrier(0);
             }
             VF9_STAGE(0)
             VF9_STAGE(1)
             VF9_STAGE(2)
             if constexpr (EPI != EPI_BIAS_RESIDUAL) {
-                if (first) { VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }   // (the A fragments are dead here)
+                if (!SPLIT && first) { VF9_EPI_HALF(1, m0p, n0p, (it - 1) & 1) }   // (the A fragments are dead here)
             }
             __builtin_amdgcn_sched_barrier(0);
             VF9_READ_A(base + 3 * PSLOT)
@@ -1759,6 +1793,11 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
         item(it + 1, mt_c, nt_c, klo_c, nk_c);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+    if (SPLIT && sk_S > 1) {   // a slice: partials out, partners' partials of the owned blocks in (the dump slot's first bytes are the flag words)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
+        __syncthreads();
+        if (sk_coop_finish(acc, sk, sk_tile, sk_slice, sk_own, (unsigned*)(smem + 8 * PSLOT), tid)) return;
+    }
     // the last item's epilogue
     VF9_EPI_LOAD_R(0, m0p, n0p)
     VF9_EPI_HALF(0, m0p, n0p, it & 1)
@@ -2530,7 +2569,9 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
 
 // ------------------------------------------------------------------------------------------------
 // pooling / heads: one 256-thread block per sequence -> out[b, :]
-//   pooling 0 CLS (token 0), 1 unmasked mean over T (continuous_retrieval.py:148 quirk), 2 last
+//   pooling 0 CLS (token 0), 1 unmasked mean over T (continuous_retrieval.py:148 quirk), 3 MASKED mean (sentence-transformers'
+//   Pooling module with pooling_mode_mean_tokens: what HuggingFaceEmbeddings(model_name) of ragManager.py:50 runs for a model
+//   whose 1_Pooling/config.json says so, or that ships no modules.json at all), 2 last
 //   token per last_token_pool (step3_mul.py:181-188: position T-1 if EVERY row's last mask bit is 1,
 //   else sum(mask)-1);  normalize: L2 (sentence-transformers Normalize module)
 //   head 1: RobertaClassificationHead  logit = out_proj(tanh(dense(x_cls)))
@@ -2561,6 +2602,11 @@ __global__ __launch_bounds__(256) void k_pool(const half_t* x, const int* mask, 
         if (pooling == 1) {
             for (int t = 0; t < Tv; ++t) s += (float)xb[(long long)t * H + j];
             s /= Tv;
+        } else if (pooling == 3) {   // sentence-transformers' pooling_mode_mean_tokens: sum of the unmasked tokens / max(count, 1e-9)
+            float cnt = 0.f;
+            for (int t = 0; t < Tv; ++t)
+                if (mask[base + t] != 0) { s += (float)xb[(long long)t * H + j]; cnt += 1.f; }
+            s /= fmaxf(cnt, 1e-9f);
         } else {
             s = (float)xb[(long long)tok * H + j];
         }
@@ -2788,7 +2834,7 @@ __global__ __launch_bounds__(64) void k_token_logit(const half_t* x, const int* 
 // handle + C ABI
 // ------------------------------------------------------------------------------------------------
 using namespace vft;
-static hipError_t gws_ensure(GemmWs& g);
+static hipError_t gws_ensure(GemmWs& g, hipStream_t zero_on = nullptr);
 static void gws_free(GemmWs& g);
 
 // ------------------------------------------------------------------------------------------------
@@ -2811,6 +2857,9 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
@@ -2859,6 +2908,14 @@ static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, 
 constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
 constexpr int kEncResidentT = 512;   // longest sequence whose K / V^T fit the resident-attention kernel's LDS
 constexpr int kEncMaxT = 8192;       // longest sequence the encoder takes (streaming attention beyond kEncResidentT)
+
+// Every handle works on a stream of its OWN (created non-blocking on first use), never on the legacy NULL stream: two handles used
+// from two threads on one device (a replica per request thread; ReplicaSet with a device listed twice) otherwise serialise on the NULL
+// stream -- and an operation on it while ANOTHER handle's thread is capturing its small-batch graph fails outright ("operation would
+// make the legacy stream depend on a capturing blocking stream": round 5, found by the from_config test with device_ids [0, 0]).
+static hipError_t handle_stream(hipStream_t* s) {
+    return *s ? hipSuccess : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 
 struct vf_encoder {
     GemmWs gws;
@@ -2962,7 +3019,7 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
     if (c.heads <= 0 || c.hidden / c.heads != 64 || c.hidden % c.heads) return fail(VF_EUNSUPPORTED, "head dim must be 64");
     if (c.ffn <= 0 || c.ffn % 128 != 0) return fail(VF_EUNSUPPORTED, "ffn must be a multiple of 128");
     if (c.layers <= 0 || c.vocab <= 0 || c.max_pos <= 0 || c.type_vocab <= 0) return fail(VF_EINVAL, "bad encoder config");
-    if (c.pooling < 0 || c.pooling > 2 || c.head < 0 || c.head > 1) return fail(VF_EINVAL, "bad pooling / head");
+    if (c.pooling < 0 || c.pooling > 3 || c.head < 0 || c.head > 1) return fail(VF_EINVAL, "bad pooling / head");
     if ((size_t)n16 != enc_n16(c) || (size_t)n32 != enc_n32(c))
         return fail(VF_EINVAL, "vf_encoder_create: weight blob sizes do not match the config (see vf_encoder_weight_sizes)");
     int ndev = 0;
@@ -2989,7 +3046,8 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
         const size_t nmax = std::max<size_t>(3 * (size_t)cfg->hidden, (size_t)cfg->ffn);
         if (er == hipSuccess) er = hipMalloc((void**)&e->sk_part, (size_t)kSplitMax * kSplitMaxRows * nmax * sizeof(float));
         if (er == hipSuccess) er = hipMalloc((void**)&e->sk_cnt, 4096 * sizeof(unsigned));
-        if (er == hipSuccess) er = hipMemset(e->sk_cnt, 0, 4096 * sizeof(unsigned));
+        if (er == hipSuccess) er = handle_stream(&e->gstream);
+        if (er == hipSuccess) er = hipMemsetAsync(e->sk_cnt, 0, 4096 * sizeof(unsigned), e->gstream);   // (not the legacy stream: see handle_stream)
     }
     if (er == hipSuccess) er = hipMemcpy(e->w16, w16, (size_t)n16 * 2, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemcpy(e->w32, w32, (size_t)n32 * 4, hipMemcpyHostToDevice);
@@ -3014,6 +3072,7 @@ extern "C" int vf_encoder_create(vf_encoder** out, const vf_encoder_config* cfg,
 }
 
 static int enc_ensure_ws(vf_encoder* e, int B, int T) {
+    VFT_HIP(handle_stream(&e->gstream));   // (the zero fills below run on the handle's stream, in front of its forward)
     int tokens = (B * T + 255) / 256 * 256;
     if (tokens <= e->cap_tokens && B <= e->cap_b) return VF_OK;
     // grow monotonically on BOTH axes: alternating call shapes (100 x 512 re-rank, then 256 x 64 embed) must not free and
@@ -3037,17 +3096,17 @@ static int enc_ensure_ws(vf_encoder* e, int B, int T) {
     if (H % 256 == 0) {
         VFT_HIP(hipMalloc((void**)&e->stats_a, (H / 256) * Mp * 2 * sizeof(float)));
         VFT_HIP(hipMalloc((void**)&e->stats_b, (H / 256) * Mp * 2 * sizeof(float)));
-        VFT_HIP(hipMemset(e->stats_a, 0, (H / 256) * Mp * 2 * sizeof(float)));
-        VFT_HIP(hipMemset(e->stats_b, 0, (H / 256) * Mp * 2 * sizeof(float)));
+        VFT_HIP(hipMemsetAsync(e->stats_a, 0, (H / 256) * Mp * 2 * sizeof(float), e->gstream));
+        VFT_HIP(hipMemsetAsync(e->stats_b, 0, (H / 256) * Mp * 2 * sizeof(float), e->gstream));
     }
     // padded rows are read by the GEMMs: keep them finite
-    VFT_HIP(hipMemset(e->x, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(e->y, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(e->qkv, 0, Mp * 3 * H * 2));
-    VFT_HIP(hipMemset(e->ctx, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(e->hbuf, 0, Mp * F * 2));
+    VFT_HIP(hipMemsetAsync(e->x, 0, Mp * H * 2, e->gstream));
+    VFT_HIP(hipMemsetAsync(e->y, 0, Mp * H * 2, e->gstream));
+    VFT_HIP(hipMemsetAsync(e->qkv, 0, Mp * 3 * H * 2, e->gstream));
+    VFT_HIP(hipMemsetAsync(e->ctx, 0, Mp * H * 2, e->gstream));
+    VFT_HIP(hipMemsetAsync(e->hbuf, 0, Mp * F * 2, e->gstream));
     e->cap_tokens = tokens; e->cap_b = B;
-    VFT_HIP(gws_ensure(e->gws));
+    VFT_HIP(gws_ensure(e->gws, e->gstream));
     return VF_OK;
 }
 
@@ -3087,6 +3146,10 @@ extern "C" int vf_debug_gemm_8p_loop2(int on) { return on >= 0 ? g_loop2.exchang
 static std::atomic<unsigned long long*> g_gemm9_dbg{nullptr};
 // test hook: device buffer [workgroups][16 tiles][6] for k_gemm9_tn's wall-clock stamps (100 MHz), or null (tools/gemm9_stamps.py)
 extern "C" void vf_debug_gemm9_stamps(void* buf) { g_gemm9_dbg.store((unsigned long long*)buf); }
+static std::atomic<long long> g_gemm9_split_launches{0};
+extern "C" long long vf_debug_gemm9_split_launches(void) { return g_gemm9_split_launches.load(std::memory_order_relaxed); }   // products cut whole along K so far
+static std::atomic<int> g_gemm9_split{-1};   // -1: VF_GEMM_9_SPLIT decides; 0 / 1: forced by the test hook
+extern "C" int vf_debug_gemm9_split(int on) { return g_gemm9_split.exchange(on < 0 ? -1 : (on ? 1 : 0)); }   // A/B: the whole-product K cut inside the persistent kernel
 static std::atomic<int> g_gemm9{-1};   // -1: VF_GEMM_9 decides; 0 / 1: forced by the test hook
 extern "C" int vf_debug_gemm9(int on) { return g_gemm9.exchange(on < 0 ? -1 : (on ? 1 : 0)); }   // A/B: the persistent register-epilogue kernel as the default large product
 static LnFold lf_plain() { LnFold l{}; l.loop2 = g_loop2.load(std::memory_order_relaxed); return l; }
@@ -3103,12 +3166,12 @@ static std::atomic<int> g_sk_dbg{0};
 static bool splitk_tail_on() { return g_splitk_tail.load(std::memory_order_relaxed) != 0; }
 static std::mutex g_gws_mu;
 static std::vector<GemmWs*> g_gws_all;    // every live workspace (statistics hook only)
-static hipError_t gws_ensure(GemmWs& g) {   // current device = the handle's
+static hipError_t gws_ensure(GemmWs& g, hipStream_t zero_on) {   // current device = the handle's; zero_on: the handle's stream (the counters are zeroed in front of its first product)
     if (g.ws) return hipSuccess;
     const size_t nb = (size_t)std::max(device_cus(), kSkMaxTiles) * PBM * PBN * sizeof(float);
     hipError_t e = hipMalloc((void**)&g.ws, nb);
     if (e == hipSuccess) e = hipMalloc((void**)&g.cnt, ((size_t)kSkMaxTiles * 2 + 4) * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(g.cnt, 0, ((size_t)kSkMaxTiles * 2 + 4) * sizeof(unsigned));
+    if (e == hipSuccess) e = zero_on ? hipMemsetAsync(g.cnt, 0, ((size_t)kSkMaxTiles * 2 + 4) * sizeof(unsigned), zero_on) : hipMemset(g.cnt, 0, ((size_t)kSkMaxTiles * 2 + 4) * sizeof(unsigned));
     if (e != hipSuccess) {
         if (g.ws) (void)hipFree(g.ws);
         if (g.cnt) (void)hipFree(g.cnt);
@@ -3201,6 +3264,27 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         // The old gate (1.5 rounds of tiles, shared with the 8-phase kernel) left 10-50 % on mid-size batches.
         static const long long p9_min = getenv("VF_GEMM_9_MIN_WGS") ? atoll(getenv("VF_GEMM_9_MIN_WGS")) : 128;
         const long long tiles_ll = (long long)(M / PBM) * (N / PBN);
+        // Round 5: LESS than a round of tiles with a long K -- FFN-down of the 13 pairs one rank of an 8-GPU data-parallel re-rank scores
+        // (6 656 x 768 x 3072: 78 tiles = a third of the CUs busy for 62.8 us where the vendor library takes 36.5) -- is cut whole
+        // along K inside the persistent kernel: S slices per tile (8 x ceil(tiles / 8) x S workgroups <= the CUs, each slice >= 8
+        // K-tiles), finished co-operatively through the handle's workspace (sk_coop_finish).  VF_GEMM_9_SPLIT=0 switches it off (A/B).
+        if constexpr (EPI != EPI_BIAS_QGELU) {
+            static const int p9_split = getenv("VF_GEMM_9_SPLIT") ? atoi(getenv("VF_GEMM_9_SPLIT")) : 1;
+            const int split_now = g_gemm9_split.load(std::memory_order_relaxed) >= 0 ? g_gemm9_split.load(std::memory_order_relaxed) : p9_split;
+            if (big_ok && K % PBK == 0 && K >= 2048 && (kind == 0 || kind == 11) && p9_now && split_now && !p8_min_forced() && splitk_tail_on() && gws && gws->ws &&
+                tiles_ll <= kSkMaxTiles) {
+                const int tiles = (int)tiles_ll, ncu = device_cus() & ~7, nkt = K / PBK, pad = (tiles + 7) & ~7;
+                int S = 0;
+                for (int c = 4; c >= 2; --c)
+                    if (pad * c <= ncu && nkt / c >= 8 && (size_t)tiles * c * PBM * PBN * sizeof(float) <= gws->bytes) { S = c; break; }
+                if (S >= 2) {
+                    const SkCtx sk{gws->ws, gws->cnt, gws->cnt + 2 * (size_t)kSkMaxTiles, S, g_sk_dbg.load(std::memory_order_relaxed)};
+                    g_gemm9_split_launches.fetch_add(1, std::memory_order_relaxed);
+                    hipLaunchKernelGGL((k_gemm9_tn<EPI, true>), dim3(pad * S), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, 0, nullptr, sk);
+                    return hipGetLastError();
+                }
+            }
+        }
         const bool p9_size = p8_min_forced() ? tiles_ll >= p8_min : tiles_ll >= p9_min;
         if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && p9_size))) {
             const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7, nkt = K / PBK;
@@ -3212,7 +3296,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
                 // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
                 static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
                 const int ticks = tiles > ncu ? (int)((150ll * nkt + 200) * stg / 100) : 0;
-                hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(G), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, ticks, g_gemm9_dbg.load(std::memory_order_relaxed));
+                hipLaunchKernelGGL(k_gemm9_tn<EPI>, dim3(G), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, ticks, g_gemm9_dbg.load(std::memory_order_relaxed), SkCtx{nullptr, nullptr, nullptr, 0, 0});
                 return hipGetLastError();
             }
         }
@@ -3547,9 +3631,10 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
     const size_t n = (size_t)b * t;
     const int out_dim = e->cfg.head == 1 ? 1 : e->cfg.hidden;
     static const bool no_graph = getenv("VF_NO_GRAPH") != nullptr;   // A/B switch
+    VFT_HIP(handle_stream(&e->gstream));
+    hipStream_t es = e->gstream;
     if (!no_graph && n <= 256 && e->cfg.pooling != 2) {   // (last-token pooling reads a flag back mid-forward: not capturable)
-        if (!e->gstream) VFT_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
-        hipStream_t gs = e->gstream;
+        hipStream_t gs = es;
         const vf_encoder::GraphKey key{b, t, t_valid, type_ids != nullptr, e->cfg.pooling, e->cfg.normalize};
         hipGraphExec_t exec = nullptr;
         for (auto& g : e->graphs) if (g.key == key) { exec = g.exec; break; }
@@ -3612,26 +3697,26 @@ static int forward_impl(vf_encoder* e, const int32_t* ids, const int32_t* mask, 
                     if (type_ids) ptt[r0 + j] = type_ids[(size_t)i * t + j];
                 }
             }
-            VFT_HIP(hipMemcpyAsync(e->d_seq, off, ((size_t)b + 1) * 4, hipMemcpyHostToDevice, nullptr));
-            VFT_HIP(hipMemcpyAsync(e->d_ids, pid, R * 4, hipMemcpyHostToDevice, nullptr));
-            VFT_HIP(hipMemcpyAsync(e->d_mask, pmk, R * 4, hipMemcpyHostToDevice, nullptr));
-            VFT_HIP(hipMemcpyAsync(e->d_pos, ppos, R * 4, hipMemcpyHostToDevice, nullptr));
-            if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, ptt, R * 4, hipMemcpyHostToDevice, nullptr));
-            rc = enc_forward_device(e, b, tmax, tmax, type_ids != nullptr, nullptr, e->d_seq, (int)rows);
+            VFT_HIP(hipMemcpyAsync(e->d_seq, off, ((size_t)b + 1) * 4, hipMemcpyHostToDevice, es));
+            VFT_HIP(hipMemcpyAsync(e->d_ids, pid, R * 4, hipMemcpyHostToDevice, es));
+            VFT_HIP(hipMemcpyAsync(e->d_mask, pmk, R * 4, hipMemcpyHostToDevice, es));
+            VFT_HIP(hipMemcpyAsync(e->d_pos, ppos, R * 4, hipMemcpyHostToDevice, es));
+            if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, ptt, R * 4, hipMemcpyHostToDevice, es));
+            rc = enc_forward_device(e, b, tmax, tmax, type_ids != nullptr, es, e->d_seq, (int)rows);
             if (rc != VF_OK) return rc;
             g_packed_forwards.fetch_add(1, std::memory_order_relaxed);
-            VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
-            VFT_HIP(hipStreamSynchronize(nullptr));
+            VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, es));
+            VFT_HIP(hipStreamSynchronize(es));
             return VF_OK;
         }
     }
-    VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, nullptr));
-    VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, nullptr));
-    if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, nullptr));
-    rc = enc_forward_device(e, b, t, t_valid, type_ids != nullptr, nullptr);
+    VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, es));
+    VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, es));
+    if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, es));
+    rc = enc_forward_device(e, b, t, t_valid, type_ids != nullptr, es);
     if (rc != VF_OK) return rc;
-    VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, nullptr));
-    VFT_HIP(hipStreamSynchronize(nullptr));
+    VFT_HIP(hipMemcpyAsync(out, e->d_out, (size_t)b * out_dim * 4, hipMemcpyDeviceToHost, es));
+    VFT_HIP(hipStreamSynchronize(es));
     return VF_OK;
 }
 
@@ -3648,8 +3733,8 @@ extern "C" int vf_encoder_forward_pooled(vf_encoder* e, const int32_t* ids, cons
                                          float* out) {
     if (!e) return fail(VF_EINVAL, "vf_encoder_forward_pooled: null handle");
     if (e->cfg.head != 0) return fail(VF_EINVAL, "vf_encoder_forward_pooled: handle is a re-ranker");
-    if (pooling < -1 || pooling > 2 || normalize < -1 || normalize > 1)
-        return fail(VF_EINVAL, "vf_encoder_forward_pooled: pooling must be -1..2, normalize -1..1");
+    if (pooling < -1 || pooling > 3 || normalize < -1 || normalize > 1)
+        return fail(VF_EINVAL, "vf_encoder_forward_pooled: pooling must be -1..3, normalize -1..1");
     return forward_impl(e, ids, mask, type_ids, b, t, t_valid, pooling, normalize, out);
 }
 
@@ -3675,15 +3760,17 @@ extern "C" int vf_encoder_forward_hidden(vf_encoder* e, const int32_t* ids, cons
     int rc = enc_ensure_ws(e, b, t);
     if (rc != VF_OK) return rc;
     const size_t n = (size_t)b * t;
-    VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, nullptr));
-    VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, nullptr));
-    if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, nullptr));
-    rc = enc_forward_device(e, b, t, t, type_ids != nullptr, nullptr);
+    VFT_HIP(handle_stream(&e->gstream));
+    hipStream_t es = e->gstream;
+    VFT_HIP(hipMemcpyAsync(e->d_ids, ids, n * 4, hipMemcpyHostToDevice, es));
+    VFT_HIP(hipMemcpyAsync(e->d_mask, mask, n * 4, hipMemcpyHostToDevice, es));
+    if (type_ids) VFT_HIP(hipMemcpyAsync(e->d_tt, type_ids, n * 4, hipMemcpyHostToDevice, es));
+    rc = enc_forward_device(e, b, t, t, type_ids != nullptr, es);
     if (rc != VF_OK) return rc;
     const long long tot = (long long)n * e->cfg.hidden;
-    hipLaunchKernelGGL(k_to_f32, dim3(1024), dim3(256), 0, nullptr, e->x, tot, e->d_hidden);
-    VFT_HIP(hipMemcpyAsync(out_hidden, e->d_hidden, (size_t)tot * 4, hipMemcpyDeviceToHost, nullptr));
-    VFT_HIP(hipStreamSynchronize(nullptr));
+    hipLaunchKernelGGL(k_to_f32, dim3(1024), dim3(256), 0, es, e->x, tot, e->d_hidden);
+    VFT_HIP(hipMemcpyAsync(out_hidden, e->d_hidden, (size_t)tot * 4, hipMemcpyDeviceToHost, es));
+    VFT_HIP(hipStreamSynchronize(es));
     return VF_OK;
 }
 
@@ -3714,6 +3801,7 @@ extern "C" int vf_reranker_destroy(vf_encoder* e) { return vf_encoder_destroy(e)
 constexpr int kDecMaxT = 4096;  // the reference truncates at max_length=4096 (step3_mul.py:200); streaming attention has no residency limit, the RoPE table is sized for this
 
 struct vf_decoder {
+    hipStream_t stream = nullptr;     // this handle's own stream (handle_stream)
     GemmWs gws;
     vf_decoder_config cfg{};
     int device = 0;
@@ -3785,6 +3873,7 @@ extern "C" int vf_decoder_destroy(vf_decoder* d) {
     (void)hipDeviceSynchronize();
     dec_free_ws(d);
     gws_free(d->gws);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
     if (d->w16) (void)hipFree(d->w16);
     if (d->w32) (void)hipFree(d->w32);
     if (d->d_flag) (void)hipFree(d->d_flag);
@@ -3828,6 +3917,7 @@ extern "C" int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg,
 }
 
 static int dec_ensure_ws(vf_decoder* d, int B, int T) {
+    VFT_HIP(handle_stream(&d->stream));   // (the zero fills below run on the handle's stream, in front of its forward)
     int tokens = (B * T + 255) / 256 * 256;
     if (tokens <= d->cap_tokens && B <= d->cap_b && T <= d->rope_T) return VF_OK;
     tokens = std::max(tokens, d->cap_tokens); B = std::max(B, d->cap_b);   // monotone growth (see enc_ensure_ws)
@@ -3849,18 +3939,18 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     VFT_HIP(hipMalloc((void**)&d->d_out, (size_t)B * (c.head == 2 ? 1 : H) * 4));
     VFT_HIP(hipMalloc((void**)&d->rope, (size_t)kDecMaxT * (c.head_dim / 2) * sizeof(float2)));
     // padded rows are read by the GEMMs: keep them finite
-    VFT_HIP(hipMemset(d->x, 0, Mp * H * 4));
-    VFT_HIP(hipMemset(d->y, 0, Mp * H * 4));
-    VFT_HIP(hipMemset(d->n, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(d->qkv, 0, Mp * QKV * 2));
-    VFT_HIP(hipMemset(d->ctx, 0, Mp * QD * 2));
-    VFT_HIP(hipMemset(d->gu, 0, Mp * 2 * F * 2));
-    VFT_HIP(hipMemset(d->act, 0, Mp * F * 2));
+    VFT_HIP(hipMemsetAsync(d->x, 0, Mp * H * 4, d->stream));
+    VFT_HIP(hipMemsetAsync(d->y, 0, Mp * H * 4, d->stream));
+    VFT_HIP(hipMemsetAsync(d->n, 0, Mp * H * 2, d->stream));
+    VFT_HIP(hipMemsetAsync(d->qkv, 0, Mp * QKV * 2, d->stream));
+    VFT_HIP(hipMemsetAsync(d->ctx, 0, Mp * QD * 2, d->stream));
+    VFT_HIP(hipMemsetAsync(d->gu, 0, Mp * 2 * F * 2, d->stream));
+    VFT_HIP(hipMemsetAsync(d->act, 0, Mp * F * 2, d->stream));
     const int cells = kDecMaxT * (c.head_dim / 2);
     hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, nullptr, c.rope_theta, kDecMaxT, c.head_dim, d->rope);
     VFT_HIP(hipGetLastError());
     d->cap_tokens = tokens; d->cap_b = B; d->rope_T = kDecMaxT;
-    VFT_HIP(gws_ensure(d->gws));
+    VFT_HIP(gws_ensure(d->gws, d->stream));
     return VF_OK;
 }
 
@@ -3941,7 +4031,8 @@ extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32
     if (rc != VF_OK) return rc;
     const vf_decoder_config& c = d->cfg;
     const int H = c.hidden, M = b * t;
-    hipStream_t st = nullptr;
+    VFT_HIP(handle_stream(&d->stream));
+    hipStream_t st = d->stream;
     const size_t ntok = (size_t)b * t;
     // Ragged batch, padded on ONE side throughout (the tokenizer's left or right padding), last-token pooling or the
     // token-logit head: the rows are PACKED -- a sequence keeps ceil32(length) rows, valid tokens first, each carrying its
@@ -4053,7 +4144,8 @@ extern "C" int vf_decoder_forward_hidden(vf_decoder* d, const int32_t* ids, cons
     if (rc != VF_OK) return rc;
     const vf_decoder_config& c = d->cfg;
     const int H = c.hidden, M = b * t;
-    hipStream_t st = nullptr;
+    VFT_HIP(handle_stream(&d->stream));
+    hipStream_t st = d->stream;
     const size_t ntok = (size_t)b * t;
     VFT_HIP(hipMemcpyAsync(d->d_ids, ids, ntok * 4, hipMemcpyHostToDevice, st));
     VFT_HIP(hipMemcpyAsync(d->d_mask, mask, ntok * 4, hipMemcpyHostToDevice, st));
@@ -4079,6 +4171,7 @@ extern "C" int vf_decoder_forward_hidden(vf_decoder* d, const int32_t* ids, cons
 // activation), and the class-token head.
 // ------------------------------------------------------------------------------------------------
 struct vf_vit {
+    hipStream_t stream = nullptr;     // this handle's own stream (handle_stream)
     GemmWs gws;
     vf_vit_config cfg{};
     int device = 0;
@@ -4232,6 +4325,7 @@ extern "C" int vf_vit_destroy(vf_vit* v) {
     (void)hipDeviceSynchronize();
     vit_free_ws(v);
     gws_free(v->gws);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
     if (v->w16) (void)hipFree(v->w16);
     if (v->w32) (void)hipFree(v->w32);
     delete v;
@@ -4294,6 +4388,7 @@ extern "C" int vf_vit_create(vf_vit** out, const vf_vit_config* cfg, const void*
 }
 
 static int vit_ensure_ws(vf_vit* v, int B) {
+    VFT_HIP(handle_stream(&v->stream));   // (the zero fills below run on the handle's stream, in front of its forward)
     if (B <= v->cap_b) return VF_OK;
     vit_free_ws(v);
     const vf_vit_config& c = v->cfg;
@@ -4311,15 +4406,15 @@ static int vit_ensure_ws(vf_vit* v, int B) {
     VFT_HIP(hipMalloc((void**)&v->d_mask, Mp * 4));
     VFT_HIP(hipMalloc((void**)&v->d_out, (size_t)B * c.proj_dim * 4));
     // rows past B Tp are read by the products: keep them finite
-    VFT_HIP(hipMemset(v->x, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->y, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->t, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->qkv, 0, Mp * 3 * H * 2));
-    VFT_HIP(hipMemset(v->ctx, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->hbuf, 0, Mp * F * 2));
-    VFT_HIP(hipMemset(v->d_mask, 0, Mp * 4));
+    VFT_HIP(hipMemsetAsync(v->x, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->y, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->t, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->qkv, 0, Mp * 3 * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->ctx, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->hbuf, 0, Mp * F * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->d_mask, 0, Mp * 4, v->stream));
     v->cap_b = B;
-    VFT_HIP(gws_ensure(v->gws));
+    VFT_HIP(gws_ensure(v->gws, v->stream));
     return VF_OK;
 }
 
@@ -4348,7 +4443,8 @@ static int vit_forward_impl(vf_vit* v, const float* pixels, const unsigned char*
     const vf_vit_config& c = v->cfg;
     const int H = c.hidden, F = c.ffn, P = v->P, Tp = v->Tp, Kp = v->Kp;
     const int M = b * Tp, Mp = (M + 255) / 256 * 256, Rp = (b * P + 255) / 256 * 256;
-    hipStream_t st = nullptr;
+    VFT_HIP(handle_stream(&v->stream));
+    hipStream_t st = v->stream;
     const size_t npix = (size_t)b * c.channels * c.image * c.image;
     if (u8) {
         VFT_HIP(hipMemcpyAsync(v->d_pix, u8, npix, hipMemcpyHostToDevice, st));
@@ -4401,6 +4497,7 @@ extern "C" int vf_vit_forward_u8(vf_vit* v, const unsigned char* pixels, const f
 // k_vit_head reading row eos[b] instead of row 0.
 // ------------------------------------------------------------------------------------------------
 struct vf_clip_text {
+    hipStream_t stream = nullptr;     // this handle's own stream (handle_stream)
     GemmWs gws;
     vf_clip_text_config cfg{};
     int device = 0;
@@ -4474,6 +4571,7 @@ extern "C" int vf_clip_text_destroy(vf_clip_text* v) {
     (void)hipDeviceSynchronize();
     ct_free_ws(v);
     gws_free(v->gws);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
     if (v->w16) (void)hipFree(v->w16);
     if (v->w32) (void)hipFree(v->w32);
     delete v;
@@ -4525,6 +4623,7 @@ extern "C" int vf_clip_text_create(vf_clip_text** out, const vf_clip_text_config
 }
 
 static int ct_ensure_ws(vf_clip_text* v, int B, int Tp) {
+    VFT_HIP(handle_stream(&v->stream));   // (the zero fills below run on the handle's stream, in front of its forward)
     int tokens = (B * Tp + 255) / 256 * 256;
     if (tokens <= v->cap_tokens && B <= v->cap_b) return VF_OK;
     tokens = std::max(tokens, v->cap_tokens); B = std::max(B, v->cap_b);
@@ -4542,15 +4641,15 @@ static int ct_ensure_ws(vf_clip_text* v, int B, int Tp) {
     VFT_HIP(hipMalloc((void**)&v->d_eos, (size_t)B * 4));
     VFT_HIP(hipMalloc((void**)&v->d_out, (size_t)B * v->cfg.proj_dim * 4));
     // rows past B Tp are read by the products: keep them finite
-    VFT_HIP(hipMemset(v->x, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->y, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->t, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->qkv, 0, Mp * 3 * H * 2));
-    VFT_HIP(hipMemset(v->ctx, 0, Mp * H * 2));
-    VFT_HIP(hipMemset(v->hbuf, 0, Mp * F * 2));
-    VFT_HIP(hipMemset(v->d_mask, 0, Mp * 4));
+    VFT_HIP(hipMemsetAsync(v->x, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->y, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->t, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->qkv, 0, Mp * 3 * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->ctx, 0, Mp * H * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->hbuf, 0, Mp * F * 2, v->stream));
+    VFT_HIP(hipMemsetAsync(v->d_mask, 0, Mp * 4, v->stream));
     v->cap_tokens = tokens; v->cap_b = B;
-    VFT_HIP(gws_ensure(v->gws));
+    VFT_HIP(gws_ensure(v->gws, v->stream));
     return VF_OK;
 }
 
@@ -4587,7 +4686,8 @@ extern "C" int vf_clip_text_forward(vf_clip_text* v, const int32_t* ids, const i
     VFT_TRY(ct_ensure_ws(v, b, Tp));
     const int H = c.hidden, F = c.ffn;
     const int M = b * Tp, Mp = (M + 255) / 256 * 256;
-    hipStream_t st = nullptr;
+    VFT_HIP(handle_stream(&v->stream));
+    hipStream_t st = v->stream;
     VFT_HIP(hipMemcpyAsync(v->d_ids, ids, (size_t)b * t * 4, hipMemcpyHostToDevice, st));
     VFT_HIP(hipMemcpyAsync(v->d_mask_in, mask, (size_t)b * t * 4, hipMemcpyHostToDevice, st));
     VFT_HIP(hipMemcpyAsync(v->d_eos, eos.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));

@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _ffi
 
-POOL_CLS, POOL_MEAN_UNMASKED, POOL_LAST_TOKEN = 0, 1, 2
+POOL_CLS, POOL_MEAN_UNMASKED, POOL_LAST_TOKEN, POOL_MEAN_MASKED = 0, 1, 2, 3   # 3: sentence-transformers' mean over the unmasked tokens
 
 
 def _np16(t):
@@ -196,6 +196,14 @@ class HipEmbeddings:
         self.tokenizer, self.encoder = tokenizer, encoder
         self.max_length, self.batch_size = max_length, batch_size
 
+    @classmethod
+    def from_pretrained(cls, model_name: str, **kw):
+        """``HuggingFaceEmbeddings(model_name=...)`` (src/utils/ragManager.py:50) in one line: a sentence-transformers directory or hub
+        name -> tokenizer + weights + pooling / Normalize read from ``modules.json`` / ``1_Pooling/config.json`` (pretrained.py).
+        A decoder embedder (last-token pooling) comes back as ``HipDecoderEmbeddings``; ``device_ids=[...]`` gives a replica per GPU."""
+        from .pretrained import load_embeddings
+        return load_embeddings(model_name, **kw)
+
     def _embed(self, texts):
         out = []
         for i in range(0, len(texts), self.batch_size):
@@ -230,6 +238,13 @@ class HipReranker:
             raise ValueError("HipReranker needs an encoder built from a sequence-classification model")
         self.tokenizer, self.encoder, self.max_length = tokenizer, encoder, max_length
         self.fuse_batches, self.max_batch_tokens = fuse_batches, max_batch_tokens
+
+    @classmethod
+    def from_pretrained(cls, model_name_or_path: str, **kw):
+        """``FlagReranker(name)`` / ``FlagLLMReranker(name, devices='cuda', use_fp16=True)`` (src/utils/vllmChatService.py:90) in one
+        line (pretrained.py): an encoder cross-encoder checkpoint gives a ``HipReranker``, a decoder one a ``HipLLMReranker``."""
+        from .pretrained import load_reranker
+        return load_reranker(model_name_or_path, **kw)
 
     def compute_score(self, sentence_pairs, batch_size: int = 8, max_length: int = None, normalize: bool = False):
         if len(sentence_pairs) and isinstance(sentence_pairs[0], str):
@@ -456,6 +471,8 @@ class HipLLMReranker:
         self.tokenizer, self.decoder, self.max_length, self.prompt = tokenizer, decoder, max_length, prompt
         self.fuse_batches, self.max_batch_tokens = fuse_batches, max_batch_tokens
         self.pad_id = getattr(tokenizer, "pad_token_id", None) or 0
+
+    from_pretrained = HipReranker.from_pretrained      # (the loader picks the class from the checkpoint)
 
     def compute_score(self, sentence_pairs, batch_size: int = 8, max_length: int = None, normalize: bool = False):
         if len(sentence_pairs) and isinstance(sentence_pairs[0], str):

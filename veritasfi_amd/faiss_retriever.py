@@ -18,16 +18,28 @@ logger = logging.getLogger(__name__)
 class FaissRetriever:
     """Exact cosine retriever; the corpus lives in HBM, search runs as hand-written gfx950 kernels."""
 
-    def __init__(self, embeddings, embedding_fn, device_id: int = 0, device_ids=None):
+    def __init__(self, embeddings, embedding_fn, device_id: int = 0, device_ids=None, corpus_dtype: str = "f32"):
         # reference :13-24: np.array(embeddings) -> astype('float32') -> normalize_L2 -> IndexFlatIP.add
         self.embeddings = embedding_fn
         embeddings = np.array(embeddings)
         if embeddings.ndim != 2:
             raise ValueError("embeddings must be a 2-D array-like [n, d]")
         dimension = embeddings.shape[1]
-        x = embeddings if embeddings.dtype == np.float16 else embeddings.astype("float32")
+        # corpus_dtype (the optional configuration key of SURVEY.md section 5): how the rows are HELD in HBM -- "f32" as faiss holds
+        # them (fp16 input stays fp16), "f16" halves the bytes the scan reads, "fp8" (OCP e4m3) quarters them (BASELINE configs[4]).
+        # Scores are the canonical cosine of the STORED values either way.
         # device_ids=[0..7]: the corpus is row-sharded over those GPUs behind the same handle (one process, no torchrun)
-        self.index = DenseIndex(x, device_id=device_id, device_ids=device_ids)
+        if corpus_dtype == "f32":
+            x = embeddings if embeddings.dtype == np.float16 else embeddings.astype("float32")
+            self.index = DenseIndex(x, device_id=device_id, device_ids=device_ids)
+        elif corpus_dtype == "f16":
+            self.index = DenseIndex(embeddings.astype(np.float16), device_id=device_id, device_ids=device_ids)
+        elif corpus_dtype == "fp8":
+            import torch
+            codes = torch.from_numpy(np.ascontiguousarray(embeddings.astype(np.float32))).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+            self.index = DenseIndex.from_e4m3(codes, device_id=device_id, device_ids=device_ids)
+        else:
+            raise ValueError(f"corpus_dtype {corpus_dtype!r}: one of f32, f16, fp8")
         logger.info(f"Building HIP dense index with {len(embeddings)} vectors of dimension {dimension}")
 
     def invoke(self, querys: list, k: int):
