@@ -32,6 +32,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The small-shard loop keeps two batches in flight on
+# four library streams beside the caller's, and a process that has opened other indexes / replicas before sits on more streams than
+# queues: streams that should overlap then share a queue (round 5, same box: the 1M-row loop 0.336 ms per batch in a process that had
+# run the 10M-row headline first, 0.296 in a process of its own, 0.316 with 8-16 queues, 0.356 with 2: profiles/r05_legs_in_process.log,
+# r05_hw_queues.log).  Read by the runtime when it initialises, i.e. before torch / the library touch the GPU; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 GEN_CHUNK = 125_000    # rows per generator call; shard boundaries are multiples of it at 1/2/4/8 GPUs
@@ -455,113 +461,39 @@ def _shard_traffic(tag):
         return {"traffic": None}
 
 
-def small_shard_leg(args, torch, vf, device, corpus, rows, tag, with_exchange, steps=200, warm=20):
-    """The headline loop on the first `rows` rows of the same corpus (make_shard builds it in 125000-row chunks seeded by chunk number,
-    so the prefix IS make_shard(0, rows)): configs[1] (1M x 768, one GPU: `c2`) and what ONE rank of configs[2] does per step on its
-    1.25M-row shard (`shard8`: the packed per-shard top-k of 4 batches through an RCCL all-gather -- world 1 here, the driver's
-    8-GPU run measures the real one -- and the merge kernel, inside the timed loop).  Batches pipelined two deep, inputs resident."""
-    import numpy as np
-    import torch.distributed as dist
-    nq, k, dim = args.batch, args.k, int(corpus.shape[1])
-    E = 4 if with_exchange else 1
-    own_pg = False
-    if with_exchange and not dist.is_initialized():
-        import socket
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-        own_pg = True
-    index = vf.DenseIndex(corpus[:rows])
-    try:
-        g = torch.Generator(device=device)
-        g.manual_seed(4321)
-        qpool = [torch.randn((nq, dim), generator=g, device=device, dtype=torch.float32) for _ in range(4)]
-        buckets = [vf.packed_result_buffer(E * nq, k, device) for _ in range(2 if E > 1 else 3)]
-        if with_exchange:
-            g_blob = torch.empty(vf.packed_part_bytes(E * nq, k), dtype=torch.uint8, device=device)
-            m_ids = torch.empty((E * nq, k), dtype=torch.int64, device=device)
-            m_sc = torch.empty((E * nq, k), dtype=torch.float32, device=device)
-        merged = [None]
-
-        def views(i):
-            blob, ids, sc = buckets[(i // E) % len(buckets)]
-            e = i % E
-            return ids[e * nq:(e + 1) * nq], sc[e * nq:(e + 1) * nq]
-
-        def finish(slot, i, last):
-            index.search_end(slot)
-            if with_exchange and (i % E == E - 1 or last):
-                dist.all_gather_into_tensor(g_blob, buckets[(i // E) % len(buckets)][0])
-                merged[0] = vf.merge_topk_packed_device(g_blob, 1, E * nq, k, m_ids, m_sc)
-
-        def run(n):
-            pending = []
-            for i in range(n):
-                if len(pending) == 2:
-                    finish(*pending.pop(0), False)
-                oi, osc = views(i)
-                index.search_begin(i % 2, qpool[i % 4], k, oi, osc)
-                pending.append((i % 2, i))
-            while pending:
-                finish(*pending.pop(0), len(pending) == 1)
-
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            run(warm)
-            torch.cuda.synchronize()
-            index.set_option("profile", 1)
-            t0 = time.perf_counter()
-            run(steps)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            prof, st = index.profile(), index.stats()
-            iso = None
-            if st.get("scans_overlap"):      # the isolated kernel: the same workload with the scans ordered by events
-                index.set_option("overlap_scans", 0)
-                run(10)
-                torch.cuda.synchronize()
-                index.set_option("profile", 1)
-                run(60)
-                torch.cuda.synchronize()
-                iso = index.profile()
-                index.set_option("overlap_scans", -1)
-            index.set_option("profile", 0)
-            verified = None
-            if with_exchange:                # one full bucket: the exchanged + merged result equals the direct one, bit for bit
-                run(E)
-                torch.cuda.synchronize()
-                mi, ms = merged[0]
-                verified = all(torch.equal(index.search_device(qpool[e % 4], k)[0], mi[e * nq:(e + 1) * nq]) and
-                               torch.equal(index.search_device(qpool[e % 4], k)[1], ms[e * nq:(e + 1) * nq]) for e in range(E))
-        torch.cuda.current_stream(device).wait_stream(side)
-        n_l = max(1, prof["scan_launches"])
-        interval = prof["span_ms"] / n_l if (st.get("scans_overlap") and prof.get("span_ms")) else prof["scan_ms_total"] / n_l
-        gbs = prof["scan_bytes_per_launch"] / (interval * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": {2: "vf::k_scan2<2> (whole-line LDS-DMA corpus loads)", 1: "vf::k_scan<main> (register loads)"}.get(st.get("scan_kernel"), "?"),
-                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(interval, 4),
-                "launches_timed": n_l, "algorithmic_bytes_per_launch": prof["scan_bytes_per_launch"],
-                "measured_in": ("launch interval = makespan of the timed launches (HIP events on the scan streams) / launches: consecutive scans overlap "
-                                f"on this shard size (CU split {st.get('aux_cus', 0)})") if st.get("scans_overlap") else "HIP-event bracket per launch, timed region",
-                **_shard_traffic(tag)}
-        if iso is not None and iso["scan_launches"] > 0:
-            ims = iso["scan_ms_total"] / iso["scan_launches"]
-            roof["isolated_launch"] = {"avg_launch_ms": round(ims, 4), "achieved": round(iso["scan_bytes_per_launch"] / (ims * 1e-3) / 1e9, 1),
-                                       "frac": round(iso["scan_bytes_per_launch"] / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": iso["scan_launches"]}
-        out = {"workload": f"{rows}x{dim} fp16 corpus, batch-{nq} queries, exact cosine top-{k}, 1 GPU" +
-                           (f"; every {E} batches one RCCL all-gather of the packed per-shard top-k (world 1) + the merge kernel, inside the timed loop" if with_exchange else ""),
-               "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warm, "roofline": roof,
-               "search_stats": {"candidates_per_query": round(st["candidates"] / max(1, st["n_queries"]), 1), "exact_reruns_last_batch": st["exact_reruns"],
-                                "aux_cus": st.get("aux_cus", 0), "scans_overlap": st.get("scans_overlap", 0)}}
-        if with_exchange:
-            out["exchange"] = {"batches_per_exchange": E, "bytes_per_rank": vf.packed_part_bytes(E * nq, k), "backend": dist.get_backend(),
-                               "world": dist.get_world_size(), "merged_equals_direct": verified}
-        return out
-    finally:
-        index.close()
-        if own_pg:
-            dist.destroy_process_group()
+def small_shard_leg(rows, tag, with_exchange, steps=200, warm=20):
+    """configs[1] (1M x 768 on one GPU: `c2`) and what ONE rank of configs[2] does per step on its 1.25M-row shard (`shard8`: the packed
+    per-shard top-k of 4 batches through an RCCL all-gather -- world 1 here, the driver's 8-GPU run measures the real one -- and the merge
+    kernel, inside the timed loop, the merged result checked against the direct one) under the driver's clock: each is THIS script run
+    on that workload as a CHILD process -- the same command a reader would type, so the figure is reproducible on its own
+    (profiles/r05_kernel_stats_c2_1Mx768.csv / _shard8_1250k.csv are rocprofv3 runs of exactly these commands).  Run inside this process,
+    behind the 10M-row headline, the same loops measured 7-13 % slower (two indexes' worth of streams on the process's hardware queues:
+    profiles/r05_legs_in_process.log, r05_hw_queues.log).  The parent keeps its corpus in HBM meanwhile (17 of 288 GB); it launches
+    nothing while the child runs."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--rows", str(rows), "--steps", str(steps), "--warmup", str(warm),
+           "--no-rerank", "--no-cpu-baseline", "--no-shard-legs"]
+    env = dict(os.environ)
+    if with_exchange:
+        cmd.append("--verify")
+        env.update(VF_BENCH_LAUNCH="1", VF_BENCH_FORCE_EXCHANGE="1")     # one self-launched rank: RCCL initialised, every bucket exchanged + merged
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"child bench failed (rc {out.returncode}): {out.stderr[-400:]}")
+    j = json.loads(lines[-1])
+    roof = dict(j["roofline"] or {})
+    if roof.get("traffic") is None:
+        roof.update(_shard_traffic(tag))
+    leg = {"workload": j["config"]["workload"], "queries_per_s": j["value"], "ms_per_step": j["ms_per_step"], "p50_ms_per_step": j.get("p50_ms_per_step"),
+           "steps": j["steps"], "warmup": j["warmup"], "roofline": roof, "search_stats": j["search_stats"],
+           "command": " ".join(("VF_BENCH_LAUNCH=1 VF_BENCH_FORCE_EXCHANGE=1 " if with_exchange else "") .split() + ["python", "bench.py"] + cmd[2:]),
+           "child_wall_s": round(time.perf_counter() - t0, 1)}
+    if with_exchange:
+        leg["exchange"] = {"rccl": {k: (j.get("rccl") or {}).get(k) for k in ("backend", "world", "rccl_version", "collective")},
+                           "batches_per_exchange": j["config"].get("batches_per_exchange"), "verify": j.get("verify"),
+                           "merged_equals_direct": "verify ok" in out.stderr}
+    return leg
 
 
 def c4_chain(args, torch, vf, corpus):
@@ -1020,20 +952,6 @@ def main():
                 c5_info = c5_leg(args, torch, vf, device)
             except Exception as e:  # noqa: BLE001
                 c5_info = {"error": f"{type(e).__name__}: {e}"}
-    # configs[1] and one rank's share of configs[2] on the same corpus (the default line only; no transformer needed)
-    c2_info, shard8_info = None, None
-    if rank == 0 and world == 1 and not devs and corpus is not None and args.corpus_dtype == "f16" and not args.no_shard_legs and \
-            (args.rows, args.dim, args.batch, args.k) == (10_000_000, 768, 64, 100) and not dist.is_initialized():
-        for name_, rows_, tag_, exch_ in (("c2", 1_000_000, "1000k", False), ("shard8", 1_250_000, "1250k", True)):
-            try:
-                info_ = small_shard_leg(args, torch, vf, device, corpus, rows_, tag_, exch_)
-            except Exception as e:  # noqa: BLE001
-                info_ = {"error": f"{type(e).__name__}: {e}"}
-            if name_ == "c2":
-                c2_info = info_
-            else:
-                shard8_info = info_
-
     if rank == 0:
         qps = args.steps * args.batch / elapsed
         roof = None
@@ -1151,8 +1069,8 @@ def main():
             "rerank": rr_info,
             "rerank_large": rr_large,
             "rerank_llm": llm_info,
-            "c2": c2_info,
-            "shard8": shard8_info,
+            "c2": None,
+            "shard8": None,
             "c4": c4_info,
             "c5": c5_info,
             "embed": emb_info,
@@ -1167,6 +1085,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {type(e).__name__}: {e}"}
+        # configs[1] and one rank's share of configs[2] (the default line only), each as a child process running this script on that
+        # workload (small_shard_leg); last, with this process's index closed
+        index.close()
+        c2_info, shard8_info = None, None
+        if rank == 0 and world == 1 and not devs and corpus is not None and args.corpus_dtype == "f16" and not args.no_shard_legs and \
+                (args.rows, args.dim, args.batch, args.k) == (10_000_000, 768, 64, 100) and not dist.is_initialized():
+            for name_, rows_, tag_, exch_ in (("c2", 1_000_000, "1000k", False), ("shard8", 1_250_000, "1250k", True)):
+                try:
+                    info_ = small_shard_leg(rows_, tag_, exch_)
+                except Exception as e:  # noqa: BLE001
+                    info_ = {"error": f"{type(e).__name__}: {e}"}
+                if name_ == "c2":
+                    c2_info = info_
+                else:
+                    shard8_info = info_
+        line["c2"], line["shard8"] = c2_info, shard8_info
         print(json.dumps(line), flush=True)
     index.close()
     if dist.is_initialized():

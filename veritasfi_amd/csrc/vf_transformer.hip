@@ -3280,7 +3280,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
                 if (S >= 2) {
                     const SkCtx sk{gws->ws, gws->cnt, gws->cnt + 2 * (size_t)kSkMaxTiles, S, g_sk_dbg.load(std::memory_order_relaxed)};
                     g_gemm9_split_launches.fetch_add(1, std::memory_order_relaxed);
-                    hipLaunchKernelGGL((k_gemm9_tn<EPI, true>), dim3(pad * S), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, 0, nullptr, sk);
+                    hipLaunchKernelGGL((k_gemm9_tn<EPI, true>), dim3(pad * S), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, 0, g_gemm9_dbg.load(std::memory_order_relaxed), sk);
                     return hipGetLastError();
                 }
             }
