@@ -22,6 +22,15 @@ Drop-in names (same signatures as the reference):
 * ``set_profiler``                       -- routes the reference's stage names ("retrieve", "retrieve_faiss", "retrieve_faiss_ts",
                                             "rerank"; ``src/utils/profiler.py``) out of the drop-in classes (off by default)
 """
+import os as _os
+
+# HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  An index keeps two batches in flight on four
+# streams of its own, every model handle has one, the caller brings more: past four, streams that are meant to overlap share a queue
+# (round 5: a 1M-row search loop 13 % slower in a process that had opened a second index; profiles/r05_hw_queues.log).  Read once,
+# when the runtime initialises -- so this only helps when the package is imported before anything touches the GPU; an explicit
+# setting of the variable always wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .index import (DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device,  # noqa: F401
                     merge_topk_packed_device, packed_part_bytes, packed_result_buffer)
 from .faiss_retriever import FaissRetriever  # noqa: F401
