@@ -2424,15 +2424,26 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
     const int srow = tid / CPR, slot = tid % CPR;
     constexpr int RSTEP = 256 / CPR;      // rows between a thread's DMA rounds: 16 (head dim 128) or 8 (256)
     float rmb = 0.f;
+    // The source address of a DMA is a SCALAR base (the sequence's K / V column block) + a 32-bit lane offset, recomputed per tile from
+    // the key index (a sequence is <= 4096 rows of <= 64 KB: the offset fits 32 bits).  As eight 64-bit per-lane pointers the compiler
+    // kept them -- loop invariants -- across the tile loop, and at head dim 256 (128 output accumulators + 64 query-fragment registers:
+    // gemma, the reference's configured re-ranker) parked 14 registers in scratch, reloaded in EVERY tile in front of the hand-written
+    // wait (round 5: ScratchSize 60 -> 0).
+    const unsigned long long kbase = (unsigned long long)Kg, vbase = (unsigned long long)Vg;
+    const unsigned ld2 = (unsigned)ld * 2u;
+    const unsigned lds_k0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)L.k[0] + (unsigned)(64 * wid) * 16u;
+    const unsigned lds_v0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)L.v[0] + (unsigned)(64 * wid) * 16u;
+    constexpr unsigned kBufBytes = (unsigned)(KT * DH * 2);
     auto stage = [&](int tile, int buf) {
         const int kt = tile * KT;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = srow + RSTEP * j;
-            const int key = kt + row < T ? kt + row : T - 1;
-            const int klc = slot ^ s2_kswz<DH>(row), vlc = slot ^ s2_vswz<DH>(row);
-            a2_dma16(Kg + (long long)key * ld + klc * 8, L.k[buf] + (64 * wid + 256 * j) * 16);
-            a2_dma16(Vg + (long long)key * ld + vlc * 8, L.v[buf] + (64 * wid + 256 * j) * 16);
+            const unsigned key = (unsigned)(kt + row < T ? kt + row : T - 1);
+            const unsigned klc = (unsigned)(slot ^ s2_kswz<DH>(row)), vlc = (unsigned)(slot ^ s2_vswz<DH>(row));
+            const unsigned rowoff = key * ld2;
+            dma16u(kbase, rowoff + klc * 16u, lds_k0 + (unsigned)buf * kBufBytes + (unsigned)(256 * j) * 16u);
+            dma16u(vbase, rowoff + vlc * 16u, lds_v0 + (unsigned)buf * kBufBytes + (unsigned)(256 * j) * 16u);
         }
         if (tid < KT) rmb = (kt + tid < T && mask[row0 + kt + tid]) ? 0.f : -30000.f;
     };
@@ -2476,6 +2487,12 @@ __global__ __launch_bounds__(256, 2) void k_attention_stream2(const half_t* __re
         if (visit) {
             const char* Kb = L.k[buf];
             const char* Vb = L.v[buf];
+            // (head dim 256 only: the fragment addresses below -- 16 swizzled K offsets, 16 V address pairs, all functions of the lane --
+            //  are recomputed in every tile from an opaque copy of the lane id, a few VALU operations beside 32 MFMAs; hoisted out of the
+            //  tile loop they were the other ten registers the allocator could not hold beside 128 accumulators and 64 query registers)
+            int lane_t = lane;
+            if constexpr (DH == 256) asm volatile("" : "+v"(lane_t));
+            const int r31 = lane_t & 31, h = lane_t >> 5, vq = (lane_t >> 2) & 3, vp = lane_t & 3, vg = (lane_t >> 4) & 1;
             f16v s[NS];
 #pragma unroll
             for (int sx = 0; sx < NS; ++sx) {
