@@ -1436,3 +1436,61 @@ def test_long_ragged_batch_packs_through_the_streaming_attention(vf):
         assert float(np.abs(got - ref).max()) < 8e-4, float(np.abs(got - ref).max())
     finally:
         enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,epi,kind", [
+    (6656, 3072, 768, 1, 0),      # FFN-up of 13 pairs: 312 tiles = 1.2 rounds
+    (12800, 3072, 768, 1, 0),     # FFN-up of 25 pairs: 600 tiles = 2.3 rounds
+    (12800, 768, 3072, 2, 0),     # FFN-down of 25 pairs: 150 tiles, long K (three workgroups per tile)
+    (25600, 768, 3072, 2, 0),     # FFN-down of 50 pairs
+    (6656, 2304, 768, 0, 12),     # forced: 234 tiles (every workgroup's range inside one or two tiles)
+    (6912, 768, 3072, 2, 12),     # forced: 81 tiles (not a multiple of 8: XCD chunks of 11 and 10), four workgroups per tile
+    (2048, 1024, 1024, 0, 12),    # forced: 32 tiles, 16 K-tiles each: 2 K-tiles per workgroup -- below the gate, must fall back
+])
+def test_gemm9_stream_k_matches_torch_and_is_deterministic(vf, M, N, K, epi, kind):
+    """Round 5: stream-K inside the persistent product kernel (k_gemm9_tn<EPI, 2>): the K-tiles of an XCD's tiles are dealt out evenly,
+    a workgroup dumps the head of the tile it cannot complete first and finishes the tile begun below it last.  Against torch fp32 on
+    the same fp16 operands, against the whole-tile launch, and twice for determinism (the partials are added in a fixed order)."""
+    import ctypes
+    import torch
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_gemm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    L.vf_debug_gemm9_streamk_launches.restype = ctypes.c_longlong
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(7 * epi + K + M + N)
+    A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.05).half()
+    bias = torch.randn(N, device=dev, generator=g) * 0.1
+    R = (torch.randn(M, N, device=dev, generator=g)).half()
+
+    def run(k):
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        rc = L.vf_debug_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), R.data_ptr(), C.data_ptr(), M, N, K, epi,
+                             torch.cuda.current_stream().cuda_stream, k)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return C
+
+    n0 = L.vf_debug_gemm9_streamk_launches()
+    c1, c2, c3 = run(kind), run(kind), run(kind)
+    took = L.vf_debug_gemm9_streamk_launches() - n0
+    below_gate = (M // 256) * (N // 256) // 8 * (K // 64) // 32 < 6
+    assert took == (0 if below_gate else 3), f"{took} of 3 launches went stream-K"
+    prev = L.vf_debug_gemm9_streamk(0)
+    try:
+        c0 = run(0)                                        # whole tiles
+    finally:
+        L.vf_debug_gemm9_streamk(prev)
+    assert L.vf_debug_gemm9_streamk_launches() - n0 == took
+    assert not torch.isnan(c1).any()
+    assert torch.equal(c1, c2) and torch.equal(c1, c3), "stream-K is not deterministic"
+    ref = A.float() @ W.float().T + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + R.float()
+    err, d01 = float((c1.float() - ref).abs().max()), float((c1.float() - c0.float()).abs().max())
+    print("gemm9 stream-K", (M, N, K, epi, kind), "max err vs torch", err, "vs whole tiles", d01)
+    assert err < 2e-2 and d01 < 1.6e-2

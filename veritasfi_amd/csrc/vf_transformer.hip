@@ -863,7 +863,7 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
         }
     };
     // one block (16 rows of either half) summed in slice order: any slice's share, one block at a time (take-over only)
-    auto take_block = [&](auto MI, bool same_xcd) {
+    auto take_block = [&](auto MI, bool) {
         constexpr int mi = decltype(MI)::value;
         f4v t[4];
 #pragma unroll
@@ -879,8 +879,7 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
                 f4v v[4];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
-                    v[ni] = same_xcd ? __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 1))
-                                     : __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
+                    v[ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + ((mi * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -907,13 +906,19 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 7u;
             (void)__hip_atomic_fetch_add(w0 + 1, 1u << (3 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned a = __hip_atomic_fetch_add(w0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // ... before the slice counts
+            // ... before the slice counts.  Round 5: RELAXED, here and in the poll.  An agent-scope release is a buffer_wbl2 (a
+            // write-back of this XCD's whole L2), an acquiring poll a buffer_inv per turn -- and neither is needed: the partials are
+            // stored sc1 (write-through) and every wave has waited for its stores (above, then the barrier); they are read sc1
+            // (past this CU's L1, every load of them), by the polling lane after its poll has matched and by the other waves behind
+            // the barrier it then joins -- the hand-off form MI355X_MICROARCH.md lists as valid without fences.  Worth 6-7 us of
+            // the FFN-down launch at 6 656 rows (53.7 -> 46-47 us; profiles/r05_splitk_relaxed_arrival_l2_vs_writethrough.log).
+            const unsigned a = __hip_atomic_fetch_add(w0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool last = (a & 0xffu) == (unsigned)(S - 1);
             unsigned give_up = 0u;
             if (!last) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), bound = (sk.dbg & 16) ? 0ull : kSkWaitTicks;
                 for (;;) {
-                    if ((__hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) >= (unsigned)S) break;
+                    if ((__hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) >= (unsigned)S) break;
                     if (__builtin_amdgcn_s_memrealtime() - t0 >= bound) { give_up = 1u; break; }
                     __builtin_amdgcn_s_sleep(4);
                 }
@@ -934,19 +939,13 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                const unsigned b = __hip_atomic_fetch_or(w0, 1u << (8 + me), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned b = __hip_atomic_fetch_or(w0, 1u << (8 + me), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 flag[0] = (b & 0xffu) >= (unsigned)S ? 0u : 1u;   // everybody is here after all: nobody will finish my blocks for me
                 if (flag[0]) finished(false);
             }
             __syncthreads();
             if (flag[0]) return true;
         }
-        if (tid == 0) {   // all S slices have arrived: the per-XCD counts are complete
-            const unsigned per_xcd = __hip_atomic_load(w0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flag[1] = ((per_xcd >> (3 * flag[3])) & 7u) == (unsigned)S ? 1u : 0u;   // every slice ran on this XCD: the partials are in ITS L2
-        }
-        __syncthreads();
-        const bool same_xcd = flag[1] != 0u;
         // two blocks at a time (64 more registers beside the 128 accumulators; the whole share at once spilled)
         auto reduce2 = [&](auto B0, auto NB) {
             constexpr int b0 = decltype(B0)::value, nb = decltype(NB)::value;
@@ -958,19 +957,12 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
             auto add_slice = [&](int sl) {
                 const int off = ((sk_tile * S + sl) * 32) * PTHREADS * 16;
                 f4v v[nb][4];
-                if (same_xcd) {   // sc0: past this CU's L1, into the L2 the slices' stores went through
+                // sc1 loads, all of them (sc0 loads may be served by this CU's L1 like plain ones)
 #pragma unroll
-                    for (int m = 0; m < nb; ++m)
+                for (int m = 0; m < nb; ++m)
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 1));
-                } else {          // sc1: memory side
-#pragma unroll
-                    for (int m = 0; m < nb; ++m)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
-                }
+                    for (int ni = 0; ni < 4; ++ni)
+                        v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rw, off + (((b0 + m) * 4 + ni) * PTHREADS + tid) * 16, 0, 16));
 #pragma unroll
                 for (int m = 0; m < nb; ++m)
 #pragma unroll
@@ -1013,7 +1005,7 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
         default: __builtin_trap();   // the host only launches S in {2, 3, 4}
     }
     if (leave) return true;
-    const bool same_xcd = flag[1] != 0u;
+    const bool same_xcd = false;   // (take_block's second argument: every read of a partial is an sc1 load wherever its slice ran)
     const unsigned gone = flag[2];
     if (gone) {   // the last arrival finishes the blocks of the slices that have left (their whole partial is in the workspace)
         unsigned take = 0u;
@@ -1032,7 +1024,10 @@ __device__ __forceinline__ bool sk_coop_finish(f4v (&acc)[8][4], const SkCtx& sk
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) finished(same_xcd);
+    if (tid == 0) {   // statistics only: did every slice of this tile run on this XCD (the placement both callers arrange)?
+        const unsigned per_xcd = __hip_atomic_load(w0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finished(((per_xcd >> (3 * flag[3])) & 7u) == (unsigned)S);
+    }
     return false;
 }
 
@@ -1507,12 +1502,13 @@ __device__ __forceinline__ void q_tile_of(int orig, int Mt, int Nt, int& mt, int
 constexpr int RLDS = PLDS + 2048 + 1024;   // + two tiles' bias (2 x 256 floats) + wall-clock stamps of 16 tiles (debug)
 constexpr int k9StampTiles = 16, k9Stamps = 6;
 
-template <int EPI, bool SPLIT = false>
+template <int EPI, int MODE = 0>   // MODE 0: whole tiles, data-parallel; 1: the whole product cut along K (one slice per workgroup); 2: stream-K
 __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
                                                          half_t* __restrict__ C, int M, int N, int K, int stagger_ticks, unsigned long long* __restrict__ dbg,
                                                          SkCtx sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 K-tiles][4 half-tiles][16 KB] + dump + 2 x bias + stamps
+    constexpr bool SPLIT = MODE == 1, STREAMK = MODE == 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, kb = lane >> 4, wr = wid >> 2, wc = wid & 3;
@@ -1555,11 +1551,100 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
         if (t_local >= (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0)) return;   // padding of the sliced grid (before any barrier)
         sk_tile = t_local * 8 + xcd;
     }
-    const int n_items = sk_S > 1 ? 1 : (wg < ntiles ? (ntiles - wg + G_ - 1) / G_ : 0);
+    // ---- STREAM-K (MODE 2, round 5).  The K-tiles of an XCD's tiles (the contiguous chunk q_tile_of gives it), laid end to end, are
+    // dealt out EVENLY to the XCD's workgroups: a workgroup's range [lo, hi) starts and ends anywhere inside a tile, so a product
+    // of 1.2 or 2.3 rounds costs 1.2 or 2.3 tiles' time per workgroup instead of 2 or 3.  A range is cut at the tile boundaries into
+    // SEGMENTS (its items); one that does not reach its tile's last K-tile leaves the accumulators in the workgroup's slot of the
+    // handle's workspace (write-through stores, then one count on the finisher's word) -- a DUMP --, the one that does reach it
+    // without having started the tile waits for those counts, adds the partials in ascending-K order (a fixed order: bit-equal
+    // from run to run) and runs the epilogue -- the FINISH.  A workgroup walks its segments from the END of its range to the
+    // start: its dump (the head of a tile other workgroups complete) comes FIRST, its finish (the tail of a tile started by
+    // workgroups with LOWER indices) LAST -- so a finisher only ever waits for workgroups dispatched before it, which dump
+    // before they do anything else: no circular wait, whatever else occupies the chip.  Range ends are nudged off a tile's
+    // first and last K-tile (every segment >= 2 K-tiles: the loop's counted waits assume it).  The order of an XCD's tiles is
+    // transposed so that, as in the data-parallel walk, the tiles in flight at any moment are neighbours that share
+    // operand panels in L2.
+    // Everything a workgroup needs to know about its range is worked out ONCE, in front of the loop, lane-parallel, and kept in two
+    // vector registers (x_t0, x_t1: lane i < 16 = the i-th segment walked -- tile coordinates, first K-tile, K-tiles; lane 32 = the
+    // workgroup whose word this one's dump counts on; lane 33 = how many partials its finish waits for): the loop reads them with
+    // v_readlane.  (Kept as scalars, this state -- a dozen values and the divisions behind them -- overflowed the scalar file, and
+    // the spill code around the loop pushed 70-230 vector registers to scratch.)
+    int x_t0 = 0, x_t1 = 0, x_items = 0;
+    bool x_dump0 = false, x_fin = false;
+    if constexpr (STREAMK) {
+        const int xcd = wg & 7, wl = wg >> 3, GL = G_ >> 3;
+        const int q8 = ntiles >> 3, r8 = ntiles & 7;
+        const int nx = q8 + (xcd < r8 ? 1 : 0), base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        auto bound = [&](int w) -> int {   // (32-bit: w nx nk < 2^21 for any product the host sends here)
+            unsigned bb = (unsigned)w * (unsigned)(nx * nk) / (unsigned)GL;
+            const unsigned r = bb % (unsigned)nk;
+            if (r == 1u) bb -= 1u; else if (r == (unsigned)nk - 1u) bb += 1u;
+            return (int)bb;
+        };
+        const int lo = bound(wl), hi = bound(wl + 1);
+        const int first_t = lo / nk, last_t = hi > lo ? (hi - 1) / nk : first_t;
+        x_items = hi > lo ? last_t - first_t + 1 : 0;
+        // roles: the first segment walked is a DUMP when it stops short of its tile's end (hi inside a tile); the last one a FINISH when it
+        // starts inside its tile (lo inside a tile) and reaches the end; a lone segment can be either, or a whole tile
+        x_dump0 = (hi % nk) != 0;
+        x_fin = (lo % nk) != 0 && !(x_items == 1 && x_dump0);
+        {
+            int tl = last_t - (lane & 15);
+            if (tl < first_t) tl = first_t;
+            const int s_ = lo > tl * nk ? lo : tl * nk, e_ = hi < (tl + 1) * nk ? hi : (tl + 1) * nk;
+            // tl-th tile of this XCD in stream order -> tile coordinates: a ragged R x GL grid walked column-major, tiles numbered row-major
+            const int R = (nx + GL - 1) / GL, lastc = nx - (R - 1) * GL, Rm1 = R > 1 ? R - 1 : 1;
+            int col, row;
+            if (tl < lastc * R) { col = tl / R; row = tl - col * R; }
+            else { const int v2 = tl - lastc * R; col = lastc + v2 / Rm1; row = v2 - (col - lastc) * Rm1; }
+            const int pt = base + row * GL + col;
+            constexpr int GM = 4;
+            const int g = pt / (GM * Nt), r = pt - g * (GM * Nt);
+            const int gm = (Mt - g * GM) < GM ? (Mt - g * GM) : GM;
+            const int nt_ = r / gm, mt_ = g * GM + (r - nt_ * gm);
+            x_t0 = mt_ | (nt_ << 16);
+            x_t1 = (s_ - tl * nk) | ((e_ - s_) << 16);
+        }
+        if (x_dump0) {   // the workgroup that reaches the end of the tile this one dumps the head (or a middle) of
+            const int tile_end = (last_t + 1) * nk;
+            int f = wl + 1;
+            while (bound(f + 1) < tile_end) ++f;
+            if (lane == 32) x_t0 = f * 8 + xcd;
+        }
+        if (x_fin) {     // the workgroups below that hold the rest of the tile this one finishes
+            const int tile_start = first_t * nk;
+            int P = 1;
+            while (bound(wl - P) > tile_start) ++P;
+            if (lane == 33) x_t0 = P;
+        }
+    }
+    const int n_items = STREAMK ? x_items : sk_S > 1 ? 1 : (wg < ntiles ? (ntiles - wg + G_ - 1) / G_ : 0);
     if (n_items == 0) return;                                   // (before any barrier)
     auto item = [&](int idx, int& mt_, int& nt_, int& klo_, int& nk_) {
-        if (sk_S > 1) { q_tile_of(sk_tile, Mt, Nt, mt_, nt_); klo_ = nk * sk_slice / sk_S; nk_ = nk * (sk_slice + 1) / sk_S - klo_; }
+        if (STREAMK) {
+            const int a_ = __builtin_amdgcn_readlane(x_t0, idx), b_ = __builtin_amdgcn_readlane(x_t1, idx);
+            mt_ = a_ & 0xffff; nt_ = a_ >> 16; klo_ = b_ & 0xffff; nk_ = b_ >> 16;
+        }
+        else if (sk_S > 1) { q_tile_of(sk_tile, Mt, Nt, mt_, nt_); klo_ = nk * sk_slice / sk_S; nk_ = nk * (sk_slice + 1) / sk_S - klo_; }
         else { q_tile_of(wg + idx * G_, Mt, Nt, mt_, nt_); klo_ = 0; nk_ = nk; }
+    };
+    const sq_rsrc_t x_rw = sq_rsrc(sk.ws);
+    auto x_dump = [&](f4v (&acc_)[8][4]) {   // every thread: the accumulators to this workgroup's slot, [mi * 4 + ni][thread] x 16 B
+        int my = wg * 32 * PTHREADS * 16;   // (scalar offset + one per-thread offset: no address registers)
+        asm volatile("" : "+s"(my));           // (opaque: left visible, the 32 scalar offsets are hoisted out of the main loop and spilled)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, acc_[mi][ni]), x_rw, tid * 16, my + (mi * 4 + ni) * PTHREADS * 16, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // (read in UNIFORM control flow, all lanes enabled: a cross-lane read inside `if (tid == 0)` can meet a register the allocator has
+    //  just reloaded from scratch for the active lanes only -- lane 32 of it is then whatever was there: the first build of this
+    //  faulted on exactly that address)
+    const int x_tgt = STREAMK ? __builtin_amdgcn_readlane(x_t0, 32) : 0, x_P = STREAMK && x_fin ? __builtin_amdgcn_readlane(x_t0, 33) : 0;
+    auto x_count = [&]() {   // tid 0, behind a rendezvous of all waves: one count on the word of the workgroup that finishes the dumped tile
+        (void)__hip_atomic_fetch_add(sk.cnt + x_tgt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     int mt_c, nt_c, klo_c, nk_c;
     item(0, mt_c, nt_c, klo_c, nk_c);
@@ -1732,6 +1817,7 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
     // the compiler fold the cleared accumulators into C = 0 MFMAs with fresh destinations, and the allocator spilled).
     long long m0p = 0, n0p = 0;   // the previous item's tile
     int it = 0;
+    bool x_pend = false;          // stream-K: the previous item left a tile whose epilogue is due (not so behind a dump)
     for (;; ++it) {
         const long long m0 = (long long)mt_c * PBM, n0 = (long long)nt_c * PBN;
         VF9_STAMP(0)
@@ -1739,7 +1825,8 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
             if (kt == 1) { VF9_STAMP(1) }
             if (kt == 2) { VF9_STAMP(2) }
             const char* base = smem + ((ktg + kt) & 1) * (4 * PSLOT);
-            const bool first = kt == 0 && it > 0, second = kt == 1 && it > 0;
+            const bool pend = STREAMK ? x_pend : it > 0;
+            const bool first = kt == 0 && pend, second = kt == 1 && pend;
             // Counted waits (vmcnt is in order and counts the epilogue's stores).  Queue around an item boundary, oldest first:
             // X(last): 2 DMAs | Y(last): 6 DMAs | X(0): 2 DMAs, 8 stores | Y(0): 6 DMAs, 8 stores | X(1): 2 DMAs | Y(1): 6 DMAs ...
             //   X(0) needs the DMAs of X(last): as ever (6);   Y(0) those of Y(last) -> 2 + 8 may fly;   X(1) those of X(0) -> 8 + 6 + 8;
@@ -1790,9 +1877,71 @@ __global__ __launch_bounds__(PTHREADS) void k_gemm9_tn(const half_t* __restrict_
         VF9_STAMP(3)
         m0p = m0; n0p = n0;
         if (it + 1 >= n_items) break;
+        if (STREAMK) {
+            x_pend = true;
+            if (it == 0 && x_dump0) {   // the head of a tile other workgroups complete: out with it, and on with cleared accumulators
+                x_dump(acc);
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+                // waves 4..7 run one barrier behind: wave 0 has seen THEIR stores land once it is through the second of two barriers
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+                if (tid == 0) x_count();
+                x_pend = false;
+            }
+        }
         item(it + 1, mt_c, nt_c, klo_c, nk_c);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+    if (STREAMK) {
+        if (n_items == 1 && x_dump0) {   // a lone segment that stops short of its tile's end: dump, count, done
+            x_dump(acc);                 // (its wait covers the dump-slot DMAs as well)
+            __syncthreads();
+            if (tid == 0) x_count();
+            return;
+        }
+        {   // a FINISH: the tail of a tile begun by the P workgroups below -- their partials, in ascending K, onto this one's own.
+            // (Written without a branch around it -- P = 0 for everybody else -- because a conditional update of the 128
+            // accumulators in front of the epilogue made the allocator keep two copies of them: 125-230 registers in scratch.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
+            __syncthreads();
+            const int P = x_P;
+            if (tid == 0 && P > 0) {
+                unsigned* const w0 = sk.cnt + wg;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P) {
+                    // cannot happen (the P workgroups were dispatched before this one and dump first); if it ever does, say so and go on
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { atomicAdd(sk.stat + 3, 1u); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __hip_atomic_store(w0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            }
+            __syncthreads();
+            // ((own + lowest) + next ...): a fixed order.  A quarter of a partial (32 registers) per trip.
+            constexpr int XB = 2;
+            for (int j = P; j >= 1; --j) {
+                int off = (wg - 8 * j) * 32 * PTHREADS * 16;   // (the workgroups below on this XCD)
+                asm volatile("" : "+s"(off));
+#pragma unroll
+                for (int b0 = 0; b0 < 8; b0 += XB) {
+                    f4v v[XB][4];
+#pragma unroll
+                    for (int m = 0; m < XB; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            v[m][ni] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(x_rw, tid * 16, off + ((b0 + m) * 4 + ni) * PTHREADS * 16, 16));
+#pragma unroll
+                    for (int m = 0; m < XB; ++m)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[b0 + m][ni][e] += v[m][ni][e];
+                }
+            }
+        }
+    }
     if (SPLIT && sk_S > 1) {   // a slice: partials out, partners' partials of the owned blocks in (the dump slot's first bytes are the flag words)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump-slot DMAs
         __syncthreads();
@@ -2874,6 +3023,9 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
@@ -3165,6 +3317,10 @@ static std::atomic<unsigned long long*> g_gemm9_dbg{nullptr};
 extern "C" void vf_debug_gemm9_stamps(void* buf) { g_gemm9_dbg.store((unsigned long long*)buf); }
 static std::atomic<long long> g_gemm9_split_launches{0};
 extern "C" long long vf_debug_gemm9_split_launches(void) { return g_gemm9_split_launches.load(std::memory_order_relaxed); }   // products cut whole along K so far
+static std::atomic<long long> g_gemm9_streamk_launches{0};
+extern "C" long long vf_debug_gemm9_streamk_launches(void) { return g_gemm9_streamk_launches.load(std::memory_order_relaxed); }   // stream-K launches so far
+static std::atomic<int> g_gemm9_streamk{-1};   // -1: VF_GEMM_9_STREAMK decides; 0 / 1: forced by the test hook
+extern "C" int vf_debug_gemm9_streamk(int on) { return g_gemm9_streamk.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
 static std::atomic<int> g_gemm9_split{-1};   // -1: VF_GEMM_9_SPLIT decides; 0 / 1: forced by the test hook
 extern "C" int vf_debug_gemm9_split(int on) { return g_gemm9_split.exchange(on < 0 ? -1 : (on ? 1 : 0)); }   // A/B: the whole-product K cut inside the persistent kernel
 static std::atomic<int> g_gemm9{-1};   // -1: VF_GEMM_9 decides; 0 / 1: forced by the test hook
@@ -3179,7 +3335,7 @@ static int device_cus();
 // Sized for the largest cut gemm() makes: tail tiles x slices <= the CU count, 256 KB of partials each.
 static std::atomic<int> g_splitk_tail{getenv("VF_NO_SPLITK_TAIL") ? 0 : getenv("VF_SPLITK_TAIL") ? std::min(2, std::max(0, atoi(getenv("VF_SPLITK_TAIL")))) : 1};
 extern "C" int vf_debug_splitk_tail(int on) { return on >= 0 ? g_splitk_tail.exchange(on > 2 ? 2 : on) : g_splitk_tail.load(); }   // 0 off, 1 long-K products only (default), 2 every product with a partial last round
-static std::atomic<int> g_sk_dbg{0};
+static std::atomic<int> g_sk_dbg{getenv("VF_SK_DBG") ? atoi(getenv("VF_SK_DBG")) : 0};   // sk_coop_finish's experiment / test bits
 static bool splitk_tail_on() { return g_splitk_tail.load(std::memory_order_relaxed) != 0; }
 static std::mutex g_gws_mu;
 static std::vector<GemmWs*> g_gws_all;    // every live workspace (statistics hook only)
@@ -3288,16 +3444,37 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         if constexpr (EPI != EPI_BIAS_QGELU) {
             static const int p9_split = getenv("VF_GEMM_9_SPLIT") ? atoi(getenv("VF_GEMM_9_SPLIT")) : 1;
             const int split_now = g_gemm9_split.load(std::memory_order_relaxed) >= 0 ? g_gemm9_split.load(std::memory_order_relaxed) : p9_split;
-            if (big_ok && K % PBK == 0 && K >= 2048 && (kind == 0 || kind == 11) && p9_now && split_now && !p8_min_forced() && splitk_tail_on() && gws && gws->ws &&
+            static const int split_min_k = getenv("VF_GEMM_9_SPLIT_MINK") ? atoi(getenv("VF_GEMM_9_SPLIT_MINK")) : 2048;      // experiments
+            static const int split_min_kt = getenv("VF_GEMM_9_SPLIT_MINKT") ? atoi(getenv("VF_GEMM_9_SPLIT_MINKT")) : 8;
+            if (big_ok && K % PBK == 0 && K >= split_min_k && (kind == 0 || kind == 11) && p9_now && split_now && !p8_min_forced() && splitk_tail_on() && gws && gws->ws &&
                 tiles_ll <= kSkMaxTiles) {
                 const int tiles = (int)tiles_ll, ncu = device_cus() & ~7, nkt = K / PBK, pad = (tiles + 7) & ~7;
                 int S = 0;
                 for (int c = 4; c >= 2; --c)
-                    if (pad * c <= ncu && nkt / c >= 8 && (size_t)tiles * c * PBM * PBN * sizeof(float) <= gws->bytes) { S = c; break; }
+                    if (pad * c <= ncu && nkt / c >= split_min_kt && (size_t)tiles * c * PBM * PBN * sizeof(float) <= gws->bytes) { S = c; break; }
                 if (S >= 2) {
                     const SkCtx sk{gws->ws, gws->cnt, gws->cnt + 2 * (size_t)kSkMaxTiles, S, g_sk_dbg.load(std::memory_order_relaxed)};
                     g_gemm9_split_launches.fetch_add(1, std::memory_order_relaxed);
                     hipLaunchKernelGGL((k_gemm9_tn<EPI, true>), dim3(pad * S), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, 0, g_gemm9_dbg.load(std::memory_order_relaxed), sk);
+                    return hipGetLastError();
+                }
+            }
+        }
+        // Round 5, stream-K (k_gemm9_tn<EPI, 2>): a product whose LAST round is mostly empty -- 1.2 rounds of FFN-up at 13 pairs, 2.3 of
+        // FFN-up / 0.6 of FFN-down at 25, 2.3 of FFN-down at 100 -- deals the K-tiles out evenly instead of the tiles.  Taken when it
+        // saves at least VF_GEMM_9_STREAMK_MIN_SAVED K-tiles of a workgroup's time over whole tiles (a dump + a finish cost about that).
+        if constexpr (EPI != EPI_BIAS_QGELU) {
+            static const int p9_sk = getenv("VF_GEMM_9_STREAMK") ? atoi(getenv("VF_GEMM_9_STREAMK")) : 1;
+            static const int sk_min_saved = getenv("VF_GEMM_9_STREAMK_MIN_SAVED") ? atoi(getenv("VF_GEMM_9_STREAMK_MIN_SAVED")) : 5;
+            const int sk_now = g_gemm9_streamk.load(std::memory_order_relaxed) >= 0 ? g_gemm9_streamk.load(std::memory_order_relaxed) : p9_sk;
+            if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 12 || (kind == 0 && p9_now && sk_now && !p8_min_forced())) && gws && gws->ws) {
+                const int ncu = device_cus() & ~7, nkt = K / PBK;
+                const long long dp_len = (tiles_ll + ncu - 1) / ncu * nkt, sk_len = (tiles_ll * nkt + ncu - 1) / ncu;
+                if ((kind == 12 || dp_len - sk_len >= sk_min_saved) && ncu >= 8 && ncu <= kSkMaxTiles && tiles_ll >= 8 && tiles_ll <= 12ll * ncu /* <= 16 segments per workgroup */ &&
+                    (tiles_ll / 8) * nkt / (ncu / 8) >= 6 && (size_t)ncu * PBM * PBN * sizeof(float) <= gws->bytes) {
+                    const SkCtx sk{gws->ws, gws->cnt, gws->cnt + 2 * (size_t)kSkMaxTiles, 0, g_sk_dbg.load(std::memory_order_relaxed)};
+                    g_gemm9_streamk_launches.fetch_add(1, std::memory_order_relaxed);
+                    hipLaunchKernelGGL((k_gemm9_tn<EPI, 2>), dim3(ncu), dim3(PTHREADS), RLDS, st, A, W, bias, R, C, M, N, K, 0, g_gemm9_dbg.load(std::memory_order_relaxed), sk);
                     return hipGetLastError();
                 }
             }
@@ -4745,6 +4922,7 @@ extern "C" int vf_debug_gemm(const void* A, const void* W, const float* bias, co
     if (kind == 6 && (M % DBM || N % 128)) return -2;
     if ((kind == 2 || kind == 7 || kind == 8 || kind == 10) && (M % LBM || N % LBN)) return -2;
     if ((kind == 7 || kind == 8) && K < 128) return -2;
+    if ((kind == 11 || kind == 12) && (M % LBM || N % LBN || K < 256)) return -2;   // 11: the whole-product K cut, 12: stream-K (where their gates admit the shape)
     if (kind == 10 && (K < 256 || (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_QGELU && epi != EPI_BIAS_RESIDUAL))) return -2;
     hipStream_t st = (hipStream_t)stream;
     const half_t *a = (const half_t*)A, *w = (const half_t*)W, *r = (const half_t*)R;
