@@ -1474,7 +1474,11 @@ def test_gemm9_stream_k_matches_torch_and_is_deterministic(vf, M, N, K, epi, kin
         return C
 
     n0 = L.vf_debug_gemm9_streamk_launches()
-    c1, c2, c3 = run(kind), run(kind), run(kind)
+    was = L.vf_debug_gemm9_streamk(1)                      # (off by default: measured slower on every shape of the forward)
+    try:
+        c1, c2, c3 = run(kind), run(kind), run(kind)
+    finally:
+        L.vf_debug_gemm9_streamk(was)
     took = L.vf_debug_gemm9_streamk_launches() - n0
     below_gate = (M // 256) * (N // 256) // 8 * (K // 64) // 32 < 6
     assert took == (0 if below_gate else 3), f"{took} of 3 launches went stream-K"

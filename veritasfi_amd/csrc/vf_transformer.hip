@@ -3461,10 +3461,16 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
             }
         }
         // Round 5, stream-K (k_gemm9_tn<EPI, 2>): a product whose LAST round is mostly empty -- 1.2 rounds of FFN-up at 13 pairs, 2.3 of
-        // FFN-up / 0.6 of FFN-down at 25, 2.3 of FFN-down at 100 -- deals the K-tiles out evenly instead of the tiles.  Taken when it
-        // saves at least VF_GEMM_9_STREAMK_MIN_SAVED K-tiles of a workgroup's time over whole tiles (a dump + a finish cost about that).
+        // FFN-up / 0.6 of FFN-down at 25, 2.3 of FFN-down at 100 -- deals the K-tiles out evenly instead of the tiles, when that saves at
+        // least VF_GEMM_9_STREAMK_MIN_SAVED K-tiles of a workgroup's time over whole tiles.  Built, exact, deterministic -- and SLOWER on
+        // every shape of the forward, so OFF unless asked for (VF_GEMM_9_STREAMK=1, vf_debug_gemm9_streamk(1), kind 12): nearly every
+        // workgroup dumps one 256-KB fp32 partial and reads one back -- 64 MB written through and 64 MB read per launch, ~27 us at what the
+        // chip sustains for that -- against the 10-20 us the even deal saves: 6 656 x 3072 x 768 64.7 us against 49.7 with whole tiles,
+        // 12 800 x 768 x 3072 90.8 against 79.0, the 13- / 25- / 100-pair forwards 2.62 / 4.38 / 13.0 ms against 2.39 / 3.77 / 11.3, same
+        // box, same call (profiles/r05_streamk.log).  The whole-product cut above pays the same toll per slice but only where two thirds of
+        // the chip would otherwise idle.
         if constexpr (EPI != EPI_BIAS_QGELU) {
-            static const int p9_sk = getenv("VF_GEMM_9_STREAMK") ? atoi(getenv("VF_GEMM_9_STREAMK")) : 1;
+            static const int p9_sk = getenv("VF_GEMM_9_STREAMK") ? atoi(getenv("VF_GEMM_9_STREAMK")) : 0;
             static const int sk_min_saved = getenv("VF_GEMM_9_STREAMK_MIN_SAVED") ? atoi(getenv("VF_GEMM_9_STREAMK_MIN_SAVED")) : 5;
             const int sk_now = g_gemm9_streamk.load(std::memory_order_relaxed) >= 0 ? g_gemm9_streamk.load(std::memory_order_relaxed) : p9_sk;
             if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 12 || (kind == 0 && p9_now && sk_now && !p8_min_forced())) && gws && gws->ws) {
@@ -3486,7 +3492,12 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
             // long-K products of MORE than two rounds with a remainder keep the 8-phase kernel (split-K tail): 800 tiles at K = 4096 360 vs
             // 391 us, 600 at K = 3072 231 vs 235; up to two rounds the persistent kernel is level or ahead (400 tiles at K = 4096: 178 vs
             // 188 us; 300 at K = 3072: 131 vs 126; profiles/r04_midsize_kernels.log, r04_midsize_large.log)
-            if (kind == 10 || K < 2048 || tiles % G == 0 || tiles <= 2 * ncu) {
+            // Round 5, after the relaxed arrival made the finish cheaper: between one and two rounds, when the remainder can be cut at least
+            // in two (<= half the CUs), the 8-phase kernel's tail wins as well -- 300 tiles at K = 3072 (FFN-down of 50 pairs) 136 vs
+            // 145-147 us; a remainder too large to cut stays here (450 tiles: 180-183 vs 186-187; profiles/r05_tail8p_vs_gemm9.log)
+            const int rem_pad = ((tiles % ncu) + 7) & ~7;
+            const bool tail_cuttable = K >= 2048 && tiles > ncu && tiles % ncu != 0 && 2 * rem_pad <= ncu && splitk_tail_on() && gws && gws->ws;
+            if (kind == 10 || K < 2048 || tiles % G == 0 || (tiles <= 2 * ncu && !tail_cuttable)) {
                 // a tile's time in ticks of the 100 MHz real-time counter: ~1.5 us per K-tile + 2 (the stagger spreads the workgroups over it)
                 static const int stg = getenv("VF_GEMM_9_STAGGER") ? atoi(getenv("VF_GEMM_9_STAGGER")) : 100;   // per cent of a tile's time; 0 = off
                 const int ticks = tiles > ncu ? (int)((150ll * nkt + 200) * stg / 100) : 0;
@@ -3509,7 +3520,14 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         sub_split = kind == 0 && !p8_min_forced() && big_ok && K % PBK == 0 && K >= 4096 && t_ll > 0 && s_ll >= 2 &&
                     splitk_tail_on() && gws && gws->ws && t_ll <= kSkMaxTiles && (size_t)t_ll * s_ll * PBM * PBN * sizeof(float) <= gws->bytes;
     }
-    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || sub_split || (kind == 0 && ((long long)(M / PBM) * (N / PBN) >= p8_min ||
+    bool tail8 = false;   // one to two rounds, long K, a remainder that can be cut at least in two: this kernel's split-K tail (see the persistent kernel's gate above)
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
+        const long long t_ll = big_ok ? (long long)(M / PBM) * (N / PBN) : 0;
+        const int ncu8 = device_cus() & ~7;
+        tail8 = kind == 0 && ncu8 > 0 && K >= 2048 && K % PBK == 0 && t_ll > ncu8 && t_ll <= 2ll * ncu8 && t_ll % ncu8 != 0 && 2 * (((int)(t_ll % ncu8) + 7) & ~7) <= ncu8 &&
+                splitk_tail_on() && gws && gws->ws && !p8_min_forced();
+    }
+    if (big_ok && K % PBK == 0 && K >= 2 * PBK && (kind == 7 || sub_split || tail8 || (kind == 0 && ((long long)(M / PBM) * (N / PBN) >= p8_min ||
                                                                                (K >= 2048 && (long long)(M / PBM) * (N / PBN) > 2 * (device_cus() & ~7) && !p8_min_forced()))))) {
         // (Peeling the rows of a partial last round -- 600 tiles on 256 CUs are 2.34 rounds of work in 3 -- into the 128 x 256
         // kernel was measured: no gain, the half-size workgroups alone on their CUs run at a quarter of the MFMA rate.)
