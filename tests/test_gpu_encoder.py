@@ -1498,3 +1498,40 @@ def test_gemm9_stream_k_matches_torch_and_is_deterministic(vf, M, N, K, epi, kin
     err, d01 = float((c1.float() - ref).abs().max()), float((c1.float() - c0.float()).abs().max())
     print("gemm9 stream-K", (M, N, K, epi, kind), "max err vs torch", err, "vs whole tiles", d01)
     assert err < 2e-2 and d01 < 1.6e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t,heads,ragged", [
+    (25, 512, 12, False),    # one rank's share at 4 GPUs: 300 pairs = 256 + 44 -> the last 44 as 88 half items
+    (50, 512, 12, True),     # 600 = 2 x 256 + 88
+    (6, 512, 12, True),      # 72 pairs, at most half the CUs: every pair as two half items
+    (30, 384, 12, True),     # six waves: halves of three
+    (13, 512, 12, False),    # 156 pairs: more than half the CUs, one round -- no half items
+])
+def test_attention_half_items_are_bit_equal_to_whole_pairs(vf, b, t, heads, ragged):
+    """Round 5: the pairs of a partial last round (and small batches altogether) are walked by k_attention2 as two half items each, half the
+    waves active in either.  A query's arithmetic does not depend on which workgroup runs it: bit-equal to the run with whole pairs."""
+    import ctypes
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_attention import make_case, run
+    from veritasfi_amd import _ffi
+    L = _ffi.lib()
+    L.vf_debug_attention.restype = ctypes.c_int
+    L.vf_debug_attention.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_int]
+    dev = torch.device("cuda:0")
+    qkv, mask = make_case(b, t, heads, dev, seed=5, scale=1.0, ragged=ragged, growing=False)
+    outs = []
+    for on in (1, 0, 1):
+        was = L.vf_debug_attention_halves(on)
+        try:
+            ctx = torch.zeros(b * t, heads * 64, dtype=torch.float16, device=dev)
+            run(L, 2, qkv, mask, b, t, heads, ctx)
+            torch.cuda.synchronize()
+        finally:
+            L.vf_debug_attention_halves(was)
+        outs.append(ctx)
+    valid = mask.bool()
+    assert bool(torch.isfinite(outs[0].float()[valid]).all())
+    assert torch.equal(outs[0][valid], outs[1][valid]) and torch.equal(outs[0][valid], outs[2][valid])

@@ -2225,7 +2225,7 @@ __device__ __forceinline__ void a2_store_group(const f16v (&o)[2], float inv, in
 // with the two pairs' own chunk counts.
 template <int MODE>
 __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ qkv, const int* __restrict__ mask, int B, int T, int H,
-                                                    int ct, const int* __restrict__ seq_off, half_t* __restrict__ ctx) {
+                                                    int ct, const int* __restrict__ seq_off, half_t* __restrict__ ctx, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                  // [T] rows of 128 B, swizzled (a2_koff)
     char* Vs = smem + (size_t)T * 128;                // [T] rows of 128 B, swizzled (a2_voff)
@@ -2239,8 +2239,16 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     const unsigned cmask = ct >= 32 ? 0xffffffffu : ((1u << ct) - 1u);
     const unsigned MASK_ON = 0x00003c00u, MASK_OFF = 0xf7533c00u;   // {1.0h, 0h} / {1.0h, -30000h}
     constexpr int ALL_PUBLISHED = 1 << 20;
-    int pair = blockIdx.x;
-    if (pair >= npairs) return;
+    // Round 5: the LAST nsplit pairs are walked as two HALF items each -- the same keys and values staged, the first half of the
+    // workgroup's waves active in one, the second half in the other -- so that the partial last round of a batch (300 pairs on 256
+    // CUs: 44 of them alone on the chip for a whole pair's time) runs one wave per SIMD on twice the CUs, in little more than half
+    // the time.  An item index vp < npairs - nsplit is that pair; beyond, pair (npairs - nsplit) + (vp - ...) / 2, half (vp - ...) & 1.
+    const int nfullp = npairs - nsplit, nitems = npairs + nsplit, hwaves = (int)(blockDim.x >> 7);
+    auto pair_of = [&](int v) { return v < nfullp ? v : nfullp + ((v - nfullp) >> 1); };
+    auto wave_on = [&](int v) { return v < nfullp || (wid >= hwaves) == (bool)((v - nfullp) & 1); };
+    int vp = blockIdx.x;
+    if (vp >= nitems) return;
+    int pair = pair_of(vp);
     unsigned long long tk_start = 0, rt_start = 0;
     if (MODE == 6) { tk_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
 
@@ -2298,8 +2306,8 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     //      behind the barrier and land under the first chunk's tiles (published by the first boundary, or on demand)
     stage_chunk(row0, Tb, pair % heads, 0);
     if (tid < Tb) mbuf[tid] = mask[row0 + tid] ? MASK_ON : MASK_OFF;
-    if (pair + (int)gridDim.x < npairs) {
-        seq_of(pair + gridDim.x, row0n, Tbn);
+    if (vp + (int)gridDim.x < nitems) {
+        seq_of(pair_of(vp + gridDim.x), row0n, Tbn);
         if (tid < Tbn) mbuf[T + tid] = mask[row0n + tid] ? MASK_ON : MASK_OFF;
     }
     load_q(row0, Tb, pair % heads);
@@ -2316,12 +2324,13 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
     // it are therefore loaded in the quiet window at the pair's end (after the closing barrier, nothing else in flight)
     // and settled there, under the O epilogue.
     for (int cur = 0;; cur ^= 1) {
-        const int nxt_pair = pair + gridDim.x, nxt2_pair = nxt_pair + gridDim.x;
-        const bool has_next = nxt_pair < npairs;
+        const int nxt_vp = vp + gridDim.x, nxt2_vp = nxt_vp + gridDim.x;
+        const bool has_next = nxt_vp < nitems;
+        const int nxt_pair = pair_of(nxt_vp), nxt2_pair = pair_of(nxt2_vp);
         const int hd = pair % heads, hdn = nxt_pair % heads;
         const int nchunks = ((Tb >> 5) + ct - 1) >> cts;            // of this pair
         const int nchunks_n = has_next ? (((Tbn >> 5) + ct - 1) >> cts) : 0;
-        const bool wact = qa0 < Tb;                                 // this wave has queries in this pair
+        const bool wact = qa0 < Tb && wave_on(vp);                  // this wave has queries in this pair (and, of a half item, in its half)
         const unsigned* mh = mbuf + cur * T;
         const unsigned* mhn = mbuf + (cur ^ 1) * T;
         unsigned act_n = 0;
@@ -2442,7 +2451,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
             if (MODE == 6) tk_bar += __builtin_amdgcn_s_memtime() - t1;
             if (nchunks == 1) act_n = classify(mhn, Tbn >> 5);
             load_q(row0n, Tbn, hdn);                                // quiet window: nothing else in flight
-            if (nxt2_pair < npairs) {
+            if (nxt2_vp < nitems) {
                 seq_of(nxt2_pair, row0n2, Tbn2);
                 if (tid < Tbn2) rmask = mask[row0n2 + tid];
             }
@@ -2471,7 +2480,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
                 out[0] = tk_bar; out[1] = tk_loop; out[2] = tk_tail;
                 out[3] = __builtin_amdgcn_s_memtime() - tk_start;
                 out[4] = __builtin_amdgcn_s_memrealtime() - rt_start;
-                out[5] = (unsigned long long)(pair / gridDim.x + 1);
+                out[5] = (unsigned long long)(vp / gridDim.x + 1);
                 out[6] = rt_start;
                 out[7] = __builtin_amdgcn_s_memrealtime();
             }
@@ -2482,7 +2491,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         asm volatile("" : "+v"(rmask));       // (keeps the mask's compare-and-select below the wait)
         if (!has_next) break;
-        if (nxt2_pair < npairs && tid < Tbn2) mbuf[cur * T + tid] = rmask ? MASK_ON : MASK_OFF;   // read (as mhn) after a barrier of the next pair
+        if (nxt2_vp < nitems && tid < Tbn2) mbuf[cur * T + tid] = rmask ? MASK_ON : MASK_OFF;   // read (as mhn) after a barrier of the next pair
         // the pair's last chunk, and the chunks only the next pair has, refill now
         for (int g = nchunks - 1; g < nchunks_n; ++g)
             if ((act_n >> (ct * g)) & cmask) stage_chunk(row0n, Tbn, hdn, g);
@@ -2492,6 +2501,7 @@ __global__ __launch_bounds__(512) void k_attention2(const half_t* __restrict__ q
             __syncthreads();
             pub_from = ALL_PUBLISHED;
         }
+        vp = nxt_vp;
         pair = nxt_pair;
         act = act_n;
         row0 = row0n;
@@ -3054,6 +3064,8 @@ static hipError_t configure_once() {
 
 // k_attention2 launcher: persistent workgroups, as many as stay co-resident (LDS: K, V, two masks, O staging; registers:
 // two waves per SIMD), each walking (sequence, head) pairs blockIdx.x, + gridDim.x, ...
+static std::atomic<int> g_att_halves{1};
+extern "C" int vf_debug_attention_halves(int on) { return g_att_halves.exchange(on ? 1 : 0); }   // A/B and parity: half items of k_attention2 on / off
 template <int MODE>
 static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, int heads, half_t* ctx, hipStream_t st,
                               const int* seq_off = nullptr) {
@@ -3069,9 +3081,18 @@ static void launch_attention2(const half_t* qkv, const int* mask, int B, int T, 
     if (per_cu > 8 / waves) per_cu = 8 / waves;
     if (per_cu < 1) per_cu = 1;
     const int npairs = B * heads;
-    const int grid = npairs < n_cu * per_cu ? npairs : n_cu * per_cu;
+    // half items (see the kernel): the pairs of a partial last round that fills at most half the CUs; a batch of at most half the CUs
+    // altogether.  One workgroup per CU, an even number of waves (T > 192).  VF_ATT_HALVES=0 switches it off (A/B).
+    static const int halves_on = getenv("VF_ATT_HALVES") ? atoi(getenv("VF_ATT_HALVES")) : 1;
+    int nsplit = 0;
+    if (halves_on && g_att_halves.load(std::memory_order_relaxed) && per_cu == 1 && waves >= 4 && waves % 2 == 0) {
+        const int rem = npairs % n_cu;
+        if (npairs > n_cu ? (rem > 0 && 2 * rem <= n_cu) : 2 * npairs <= n_cu) nsplit = npairs > n_cu ? rem : npairs;
+    }
+    const int nitems = npairs + nsplit;
+    const int grid = nitems < n_cu * per_cu ? nitems : n_cu * per_cu;
     static const int ct = [] { const char* e = getenv("VF_ATT_CHUNK"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 16) ? v : 4; }();
-    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, seq_off, ctx);
+    hipLaunchKernelGGL(k_attention2<MODE>, dim3(grid), dim3(64 * waves), lds, st, qkv, mask, B, T, heads * ADH, ct, seq_off, ctx, nsplit);
 }
 
 constexpr int kSplitMax = 8, kSplitMaxRows = 64;  // split-K only for single short sequences (measured: slower from 256 tokens)
