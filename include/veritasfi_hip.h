@@ -170,6 +170,12 @@ int vf_cosine_matrix(const float* x, int32_t n, int32_t d, float* out, int32_t d
  * retrieved chunks again; their embeddings are rows of the HBM-resident corpus).  Valid when the embedder treats documents and
  * queries alike (the reference embeds both with embed_query, :275 and faissRetriever.py:33).  Single-device handles. */
 int vf_cosine_matrix_rows(vf_index* idx, const int64_t* ids, int32_t n, float* out);
+/* Mixed form: ids[i] >= 0 names a corpus row, ids[i] == -1 takes the NEXT vector of extra [n_extra, d] fp32 host (in order of
+ * appearance; the count of -1 entries must equal n_extra) -- a chunk text the corpus does not hold, embedded by the caller.  This is
+ * what serves the reference's own call, compute_similarity_mtx(chunk_texts) (src/utils/vllmManager.py:462 ->
+ * src/utils/ensembleRetriever.py:265-281: texts only), from the rows in HBM: known texts by row, unknown ones embedded.  An
+ * all-extra call returns vf_cosine_matrix's bits, an all-row call vf_cosine_matrix_rows's.  Single-device and sharded handles. */
+int vf_cosine_matrix_rows_mixed(vf_index* idx, const int64_t* ids, int32_t n, const float* extra, int32_t n_extra, float* out);
 
 /* experiments/retriever/step3_mul.py:275 (similarities_matrix = cosine_similarity(E, C)):
  * a [na,d], b [nb,d] fp32 host -> out [na,nb] fp32 host. */
@@ -270,6 +276,11 @@ int vf_decoder_create(vf_decoder** out, const vf_decoder_config* cfg, const void
  * (what HF does when no position_ids are passed); out [b, hidden] (head 0) or [b] (head 2) fp32 host. */
 int vf_decoder_forward(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
                        float* out);
+/* vf_decoder_forward with the L2 normalisation of the pooled row chosen per call (normalize: -1 the handle's, 0, 1; ignored by the
+ * token-logit head): HipDecoderEmbeddings -- last_token_pool + F.normalize (experiments/retriever/continuous_retrieval.py:55-60,
+ * step3_mul.py:181-209) -- takes unit vectors from the pooling kernel whatever the handle was created with. */
+int vf_decoder_forward_pooled(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
+                              int32_t normalize, float* out);
 /* last_hidden_state [b, t, hidden] fp32 host (after the final RMSNorm), for callers that pool themselves -- the
  * reference's generic route outputs.last_hidden_state -> last_token_pool (experiments/retriever/step3_mul.py:203-207). */
 int vf_decoder_forward_hidden(vf_decoder* dec, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,

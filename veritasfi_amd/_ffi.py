@@ -89,6 +89,7 @@ SIGNATURES = {
     "vf_index_destroy": (ctypes.c_int, [vp]),
     "vf_cosine_matrix": (ctypes.c_int, [vp, c_i32, c_i32, vp, c_i32]),
     "vf_cosine_matrix_rows": (ctypes.c_int, [vp, vp, c_i32, vp]),
+    "vf_cosine_matrix_rows_mixed": (ctypes.c_int, [vp, vp, c_i32, vp, c_i32, vp]),
     "vf_cosine_scores": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32]),
     "vf_merge_topk_device": (ctypes.c_int, [vp, vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
     "vf_merge_topk_packed_device": (ctypes.c_int, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "vf_decoder_weight_sizes": (ctypes.c_int, [vp, p_i64, p_i64]),
     "vf_decoder_create": (ctypes.c_int, [ctypes.POINTER(vp), vp, vp, c_i64, vp, c_i64, c_i32]),
     "vf_decoder_forward": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, c_i32, vp]),
+    "vf_decoder_forward_pooled": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, c_i32, c_i32, vp]),
     "vf_decoder_forward_hidden": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp]),
     "vf_decoder_destroy": (ctypes.c_int, [vp]),
     "vf_vit_weight_sizes": (ctypes.c_int, [ctypes.POINTER(VitConfig), p_i64, p_i64]),

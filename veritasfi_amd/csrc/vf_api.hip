@@ -1534,20 +1534,30 @@ static int gather_normalised(vf_index* sh, Lease& ws, const std::vector<long lon
 // A SHARDED handle (round 5): every shard normalises its own rows on its own device (the norms are per row, so the values are the
 // single-device ones bit for bit), the blocks travel to the home device -- peer copy, or through the host where the link is
 // missing -- and are put back into the caller's order there by the same gather kernel (norm 1: x * (float)(1.0 / 1.0) = x).
-extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n, float* out) {
+// Mixed form (round 6): ids[i] >= 0 picks a corpus row as above; ids[i] == -1 takes the next vector of `extra` ([n_extra][d] fp32
+// host, in order of appearance) -- a chunk text the corpus does not hold, embedded by the caller.  Those vectors get the canonical
+// norm of vf_cosine_matrix (k_prep_rows on fp32 values), so an all-extra call returns vf_cosine_matrix's bits and an all-row call
+// vf_cosine_matrix_rows's.  This is what lets EnsembleRetriever.compute_similarity_mtx(texts) -- the reference's call, texts only
+// (src/utils/vllmManager.py:462) -- serve known texts from HBM and embed only the unknown ones.
+static int cosine_matrix_rows_impl(vf_index* ix, const int64_t* ids, int32_t n, const float* extra, int32_t n_extra, float* out,
+                                   const char* who) {
     DeviceGuard restore_callers_device;
-    if (!ix) return fail(VF_EINVAL, "vf_cosine_matrix_rows: null handle");
-    if (n < 0) return fail(VF_EINVAL, "vf_cosine_matrix_rows: negative n");
+    if (!ix) return fail(VF_EINVAL, std::string(who) + ": null handle");
+    if (n < 0 || n_extra < 0) return fail(VF_EINVAL, std::string(who) + ": negative n");
     if (n == 0) return VF_OK;
-    if (!ids || !out) return fail(VF_EINVAL, "vf_cosine_matrix_rows: null buffer");
-    if (n > 4096) return fail(VF_EINVAL, "vf_cosine_matrix_rows: n must be <= 4096");
+    if (!ids || !out) return fail(VF_EINVAL, std::string(who) + ": null buffer");
+    if (n > 4096) return fail(VF_EINVAL, std::string(who) + ": n must be <= 4096");
+    if (n_extra > 0 && !extra) return fail(VF_EINVAL, std::string(who) + ": n_extra > 0 with a null extra buffer");
     const size_t nd = (size_t)n * ix->d;
     std::lock_guard<std::mutex> lk(ix->mu);
-    if (ix->shards.empty()) {
+    int n_minus = 0;
+    for (int i = 0; i < n; ++i) if (ids[i] == -1) ++n_minus;
+    if (n_minus != n_extra) return fail(VF_EINVAL, std::string(who) + ": the ids hold " + std::to_string(n_minus) + " entries of -1 but n_extra is " + std::to_string(n_extra));
+    if (ix->shards.empty() && n_extra == 0) {
         std::vector<long long> sel((size_t)n);
         for (int i = 0; i < n; ++i) {
             const int64_t r = ids[i] - ix->id_offset;
-            if (r < 0 || r >= ix->n) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
+            if (r < 0 || r >= ix->n) return fail(VF_EINVAL, std::string(who) + ": id outside the index");
             sel[(size_t)i] = r;
         }
         VF_HIP(hipSetDevice(ix->device));
@@ -1559,28 +1569,37 @@ extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n
         VF_HIP(hipMemcpy(out, dout, (size_t)n * n * 4, hipMemcpyDeviceToHost));
         return VF_OK;
     }
-    const size_t G = ix->shards.size();
+    // general form: the blocks of the G shards (a plain handle is its own only shard), then the block of the extra vectors, meet in
+    // `cat` on the home device and are put into the caller's order by one gather
+    std::vector<vf_index*> parts = ix->shards;
+    if (parts.empty()) parts.push_back(ix);
+    const size_t G = parts.size();
     std::vector<std::vector<long long>> sel(G);
     std::vector<int> owner((size_t)n), rank_in((size_t)n);
+    int seen_extra = 0;
     for (int i = 0; i < n; ++i) {
+        if (ids[i] == -1) { owner[(size_t)i] = (int)G; rank_in[(size_t)i] = seen_extra++; continue; }
         size_t g = 0;
-        while (g < G && !(ids[i] >= ix->shards[g]->id_offset && ids[i] < ix->shards[g]->id_offset + ix->shards[g]->n)) ++g;
-        if (g == G) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
+        while (g < G && !(ids[i] >= parts[g]->id_offset && ids[i] < parts[g]->id_offset + parts[g]->n)) ++g;
+        if (g == G) return fail(VF_EINVAL, std::string(who) + ": id outside the index");
         owner[(size_t)i] = (int)g; rank_in[(size_t)i] = (int)sel[g].size();
-        sel[g].push_back(ids[i] - ix->shards[g]->id_offset);
+        sel[g].push_back(ids[i] - parts[g]->id_offset);
     }
-    std::vector<long long> start(G + 1, 0), where((size_t)n);   // block of shard g in the concatenation; position i's row in it
+    std::vector<long long> start(G + 2, 0), where((size_t)n);   // block of shard g in the concatenation (block G: the extras); position i's row in it
     for (size_t g = 0; g < G; ++g) start[g + 1] = start[g] + (long long)sel[g].size();
+    start[G + 1] = start[G] + n_extra;
     for (int i = 0; i < n; ++i) where[(size_t)i] = start[(size_t)owner[(size_t)i]] + rank_in[(size_t)i];
+    const size_t ed = (size_t)n_extra * ix->d;
     VF_HIP(hipSetDevice(ix->device));
     Lease home;
-    VF_TRY(home.acquire(ix->device, 2 * Lease::padded(nd * 4) + Lease::padded((size_t)n * 4) + Lease::padded((size_t)n * 8) + Lease::padded((size_t)n * n * 4)));
+    VF_TRY(home.acquire(ix->device, 2 * Lease::padded(nd * 4) + Lease::padded((size_t)n * 4) + Lease::padded((size_t)n * 8) + Lease::padded((size_t)n * n * 4) +
+                                    Lease::padded(ed * 4) + 2 * Lease::padded((size_t)n_extra * 4)));
     float* cat = home.take<float>(nd); float* xn = home.take<float>(nd); float* ones = home.take<float>(n);
     long long* dwhere = home.take<long long>(n); float* dout = home.take<float>((size_t)n * n);
     std::vector<float> stage;
     for (size_t g = 0; g < G; ++g) {
         if (sel[g].empty()) continue;
-        vf_index* sh = ix->shards[g];
+        vf_index* sh = parts[g];
         const size_t cnt = sel[g].size(), bytes = cnt * ix->d * 4;
         float* dst = cat + (size_t)start[g] * ix->d;
         VF_HIP(hipSetDevice(sh->device));
@@ -1606,6 +1625,12 @@ extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n
         }
     }
     VF_HIP(hipSetDevice(ix->device));
+    if (n_extra > 0) {   // the caller's vectors: canonical norms of their fp32 values (vf_cosine_matrix's arithmetic), normalised into block G
+        float* raw = home.take<float>(ed); float* norm_e = home.take<float>(n_extra); float* tmp = home.take<float>(n_extra);
+        VF_HIP(hipMemcpy(raw, extra, ed * 4, hipMemcpyHostToDevice));
+        VF_HIP(launch_prep_rows(raw, 0, n_extra, ix->d, ix->d, nullptr, norm_e, tmp, nullptr));
+        VF_HIP(launch_normalize_rows(raw, 0, 0, n_extra, ix->d, norm_e, cat + (size_t)start[G] * ix->d, nullptr));
+    }
     const std::vector<float> one((size_t)n, 1.0f);
     VF_HIP(hipMemcpy(ones, one.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     VF_HIP(hipMemcpy(dwhere, where.data(), (size_t)n * 8, hipMemcpyHostToDevice));
@@ -1613,6 +1638,16 @@ extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n
     VF_HIP(launch_dense_dot16(xn, n, xn, n, ix->d, dout, n, nullptr));
     VF_HIP(hipMemcpy(out, dout, (size_t)n * n * 4, hipMemcpyDeviceToHost));
     return VF_OK;
+}
+
+extern "C" int vf_cosine_matrix_rows(vf_index* ix, const int64_t* ids, int32_t n, float* out) {
+    if (ids && n > 0 && n <= 4096)   // -1 is the mixed form's marker; here every id must name a row
+        for (int i = 0; i < n; ++i) if (ids[i] == -1) return fail(VF_EINVAL, "vf_cosine_matrix_rows: id outside the index");
+    return cosine_matrix_rows_impl(ix, ids, n, nullptr, 0, out, "vf_cosine_matrix_rows");
+}
+
+extern "C" int vf_cosine_matrix_rows_mixed(vf_index* ix, const int64_t* ids, int32_t n, const float* extra, int32_t n_extra, float* out) {
+    return cosine_matrix_rows_impl(ix, ids, n, extra, n_extra, out, "vf_cosine_matrix_rows_mixed");
 }
 
 extern "C" int vf_merge_topk_device(const int64_t* d_ids_parts, const float* d_score_parts, int32_t nparts, int32_t nq,

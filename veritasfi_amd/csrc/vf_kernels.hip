@@ -1289,9 +1289,15 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
         if (sync_tau) dma4(a.tau_bin + (lane < QN ? lane : QN - 1), scratch_l + par * 512);
     };
 
-    int cur_tile = wid;
+    // Tile order within the workgroup's range: the LDS counter hands out LOGICAL tiles 0, 1, 2, ...; the rows of logical tile t are
+    // those of tile (t + rot) mod ntiles.  rot = 0 walks every range from its first row -- all workgroups then sit at the same
+    // offset of ranges that lie a constant stride apart; debug bit 4 (value 16) rotates each range by a per-workgroup amount
+    // (round 6 experiment: are the slow first tiles of a small shard's launch HBM-channel conflicts of that lockstep?)
+    const int rot = ((a.debug & 16) && ntiles > 0) ? (int)(((unsigned)blockIdx.x * 2654435761u >> 8) % (unsigned)ntiles) : 0;
+    auto phys = [&](int t) { const int p_ = t + rot; return p_ >= ntiles ? p_ - ntiles : p_; };
     const bool service = kScan2Service && wid == kScan2Waves;          // wave 4: publishes blocks, refreshes and syncs thresholds (k_scan2_service)
-    bool active = !service && cur_tile < ntiles;
+    bool active = !service && wid < ntiles;
+    int cur_tile = active ? phys(wid) : wid;
     const char* src_cur[4];
     const char* src_nxt[4];
     if (active) {
@@ -1324,7 +1330,12 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     const int dbg_rec = (a.debug & 512) ? 72 : 4;   // bit 9: + the start time of the wave's first 64 tiles, [68] kernel entry, [69] tiles taken
     unsigned long long* dbg = ((a.debug & 128) && a.dbg && lane == 0 && !service) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * dbg_rec : nullptr;
     if (dbg) dbg[0] = wall_clock64();
-    if (dbg && dbg_rec > 4) dbg[68] = t_entry;
+    if (dbg && dbg_rec > 4) {
+        dbg[68] = t_entry;
+        unsigned hw_id, xcc_id;   // where this wave ran (CU / SE / SIMD / wave slot, XCD): tools/stamps_gap.py pairs a CU's consecutive workgroups
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+        dbg[70] = ((unsigned long long)xcc_id << 32) | hw_id;
+    }
     if (service) k_scan2_service<NT>(a, ctl, lane);
     if (active) {
         f16v acc[NT];
@@ -1343,7 +1354,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                 claimed = __builtin_amdgcn_readfirstlane(v_);
             }
             const bool more = claimed < ntiles;
-            const int nxt = more ? claimed : cur_tile;
+            const int nxt = more ? phys(claimed) : cur_tile;
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
             // the service wave folds the global thresholds into tau_lds; without it the waves take turns
@@ -1425,7 +1436,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                 for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
             ++tiles_done;
             if (!more) break;
-            cur_tile = claimed;
+            cur_tile = nxt;
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
         }

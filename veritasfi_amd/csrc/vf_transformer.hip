@@ -4180,7 +4180,9 @@ static int dec_ensure_ws(vf_decoder* d, int B, int T) {
     VFT_HIP(hipMemsetAsync(d->gu, 0, Mp * 2 * F * 2, d->stream));
     VFT_HIP(hipMemsetAsync(d->act, 0, Mp * F * 2, d->stream));
     const int cells = kDecMaxT * (c.head_dim / 2);
-    hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, nullptr, c.rope_theta, kDecMaxT, c.head_dim, d->rope);
+    // on the handle's own stream, like the memsets above: the forwards run there, and a non-blocking stream does not order itself behind
+    // the NULL stream (round-5 advisor: the first forward after a (re)allocation could read a table not written yet)
+    hipLaunchKernelGGL(k_rope_table, dim3((cells + 255) / 256), dim3(256), 0, d->stream, c.rope_theta, kDecMaxT, c.head_dim, d->rope);
     VFT_HIP(hipGetLastError());
     d->cap_tokens = tokens; d->cap_b = B; d->rope_T = kDecMaxT;
     VFT_HIP(gws_ensure(d->gws, d->stream));
@@ -4253,12 +4255,34 @@ static int dec_check_call(vf_decoder* d, const int32_t* ids, const int32_t* mask
 
 // ids / mask [b, t] int32 host (t % 32 == 0, t <= 4096; right- or left-padded with mask 0); t_valid = columns the
 // tokenizer produced.  out: [b, hidden] fp32 (head 0) or [b] fp32 (head 2).
+static int dec_forward_impl(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid, int32_t normalize,
+                            float* out);
+
 extern "C" int vf_decoder_forward(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t,
                                   int32_t t_valid, float* out) {
+    return dec_forward_impl(d, ids, mask, b, t, t_valid, -1, out);
+}
+
+// The same forward with the L2 normalisation of the pooled row chosen per call (-1: the handle's, 0 / 1): an embedder wrapper
+// (HipDecoderEmbeddings: last_token_pool + normalize, continuous_retrieval.py:55-60) gets unit vectors out of the pooling kernel
+// whatever the handle was created with, instead of a NumPy pass on the host.  Head 2 (the token logit) has nothing to normalise.
+extern "C" int vf_decoder_forward_pooled(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid,
+                                         int32_t normalize, float* out) {
+    if (normalize < -1 || normalize > 1) return fail(VF_EINVAL, "vf_decoder_forward_pooled: normalize must be -1, 0 or 1");
+    return dec_forward_impl(d, ids, mask, b, t, t_valid, normalize, out);
+}
+
+static int dec_forward_impl(vf_decoder* d, const int32_t* ids, const int32_t* mask, int32_t b, int32_t t, int32_t t_valid, int32_t normalize,
+                            float* out) {
     VFT_TRY(dec_check_call(d, ids, mask, b, t, out, "vf_decoder_forward"));
     if (b == 0) return VF_OK;
     if (t_valid <= 0 || t_valid > t) return fail(VF_EINVAL, "vf_decoder_forward: t_valid must be in [1, t]");
     std::lock_guard<std::mutex> g(d->mu);
+    struct Restore {   // per-call normalisation: swapped in under the handle's lock, restored on every exit path
+        vf_decoder_config& c; int n;
+        ~Restore() { c.normalize = n; }
+    } restore{d->cfg, d->cfg.normalize};
+    if (normalize >= 0 && d->cfg.head != 2) d->cfg.normalize = normalize;
     VFT_HIP(hipSetDevice(d->device));
     int rc = dec_ensure_ws(d, b, t);
     if (rc != VF_OK) return rc;

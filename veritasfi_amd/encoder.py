@@ -24,6 +24,7 @@ import types
 import numpy as np
 
 from . import _ffi
+from .host_tokenize import BatchTokenizer, pipelined, split_for_overlap
 
 POOL_CLS, POOL_MEAN_UNMASKED, POOL_LAST_TOKEN, POOL_MEAN_MASKED = 0, 1, 2, 3   # 3: sentence-transformers' mean over the unmasked tokens
 
@@ -192,9 +193,13 @@ class HipEmbeddings:
     """``HuggingFaceEmbeddings``-shaped embedder.  ``tokenizer(texts, padding=True, truncation=True,
     max_length=..., return_tensors="np")`` must return input_ids / attention_mask."""
 
-    def __init__(self, tokenizer, encoder: HipEncoder, max_length: int = 512, batch_size: int = 32):
+    def __init__(self, tokenizer, encoder: HipEncoder, max_length: int = 512, batch_size: int = 32, overlap_tokenize: bool = True):
         self.tokenizer, self.encoder = tokenizer, encoder
         self.max_length, self.batch_size = max_length, batch_size
+        # batch i + 1 is tokenised (Rust backend of a fast tokenizer, host_tokenize.py) while batch i is on the device; a call that
+        # fits one batch is cut in two halves for the same reason.  The partition does not depend on the flag: same bits either way.
+        self.overlap_tokenize = overlap_tokenize
+        self._tok = BatchTokenizer(tokenizer, max_length)
 
     @classmethod
     def from_pretrained(cls, model_name: str, **kw):
@@ -205,13 +210,13 @@ class HipEmbeddings:
         return load_embeddings(model_name, **kw)
 
     def _embed(self, texts):
-        out = []
-        for i in range(0, len(texts), self.batch_size):
-            enc = self.tokenizer(list(texts[i:i + self.batch_size]), padding=True, truncation=True,
-                                 max_length=self.max_length, return_tensors="np")
-            ids, mask, tt = _tok_arrays(enc)
-            out.append(self.encoder.forward(ids, mask, tt))
-        return np.vstack(out) if out else np.zeros((0, self.encoder.hidden), np.float32)
+        if not texts:
+            return np.zeros((0, self.encoder.hidden), np.float32)
+        if self._tok.max_length != self.max_length or self._tok.tokenizer is not self.tokenizer:
+            self._tok = BatchTokenizer(self.tokenizer, self.max_length)
+        pieces = split_for_overlap(len(texts), int(self.batch_size))
+        out = pipelined(pieces, lambda p: self._tok.encode(texts[p[0]:p[1]]), lambda a: self.encoder.forward(*a), self.overlap_tokenize)
+        return np.vstack(out)
 
     def embed_documents(self, texts):
         return self._embed(list(texts)).tolist()
@@ -233,11 +238,13 @@ class HipReranker:
     ``fuse_batches=False`` to run exactly ``batch_size`` pairs per forward."""
 
     def __init__(self, tokenizer, encoder: HipEncoder, max_length: int = 512, fuse_batches: bool = True,
-                 max_batch_tokens: int = 65536):
+                 max_batch_tokens: int = 65536, overlap_tokenize: bool = True):
         if encoder.cfg.get("head", 0) != 1:
             raise ValueError("HipReranker needs an encoder built from a sequence-classification model")
         self.tokenizer, self.encoder, self.max_length = tokenizer, encoder, max_length
         self.fuse_batches, self.max_batch_tokens = fuse_batches, max_batch_tokens
+        self.overlap_tokenize = overlap_tokenize       # tokenise piece i + 1 under piece i's forward (host_tokenize.py)
+        self._toks = {}
 
     @classmethod
     def from_pretrained(cls, model_name_or_path: str, **kw):
@@ -246,6 +253,12 @@ class HipReranker:
         from .pretrained import load_reranker
         return load_reranker(model_name_or_path, **kw)
 
+    def _tok_for(self, max_length: int) -> BatchTokenizer:
+        tk = self._toks.get(max_length)
+        if tk is None or tk.tokenizer is not self.tokenizer:
+            tk = self._toks[max_length] = BatchTokenizer(self.tokenizer, max_length)
+        return tk
+
     def compute_score(self, sentence_pairs, batch_size: int = 8, max_length: int = None, normalize: bool = False):
         if len(sentence_pairs) and isinstance(sentence_pairs[0], str):
             sentence_pairs = [sentence_pairs]
@@ -253,14 +266,14 @@ class HipReranker:
         step = int(batch_size)
         if self.fuse_batches:
             step = max(step, (self.max_batch_tokens // max_length) // step * step)
-        scores = []
-        for i in range(0, len(sentence_pairs), step):
-            batch = sentence_pairs[i:i + step]
-            enc = self.tokenizer([p[0] for p in batch], [p[1] for p in batch], padding=True, truncation=True,
-                                 max_length=max_length, return_tensors="np")
-            ids, mask, tt = _tok_arrays(enc)
-            s = self.encoder.forward(ids, mask, tt)
-            scores.extend(float(v) for v in np.atleast_1d(s))
+        tk = self._tok_for(max_length)
+        # device batches of `step` pairs; with fused batches a call that fits ONE of them (the reference's 100 pairs) goes as two
+        # halves so that the second is tokenised while the first runs.  fuse_batches=False keeps exactly batch_size pairs per forward.
+        pieces = split_for_overlap(len(sentence_pairs), step) if self.fuse_batches else \
+            [(lo, min(lo + step, len(sentence_pairs))) for lo in range(0, len(sentence_pairs), step)]
+        outs = pipelined(pieces, lambda p: tk.encode([q for q, _ in sentence_pairs[p[0]:p[1]]], [d for _, d in sentence_pairs[p[0]:p[1]]]),
+                         lambda a: self.encoder.forward(*a), self.overlap_tokenize)
+        scores = [float(v) for s_ in outs for v in np.atleast_1d(s_)]
         if normalize:
             scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]
         return scores
@@ -328,7 +341,9 @@ class HipDecoder:
     def from_hf(cls, model, pooling=POOL_LAST_TOKEN, normalize=False, score_token=None, device_id: int = 0):
         return cls(*pack_hf_decoder_weights(model, pooling, normalize, score_token), device_id=device_id)
 
-    def forward(self, ids, mask) -> np.ndarray:
+    def forward(self, ids, mask, normalize=None) -> np.ndarray:
+        """normalize: None = as the handle was created; True / False = L2-normalise the pooled rows (or not) for this call, in the
+        pooling kernel (``vf_decoder_forward_pooled``)."""
         ids = np.asarray(ids, dtype=np.int32)
         mask = np.asarray(mask, dtype=np.int32)
         b, t = ids.shape
@@ -341,8 +356,12 @@ class HipDecoder:
             ids, mask = pi, pm
         ids, mask = np.ascontiguousarray(ids), np.ascontiguousarray(mask)
         out = np.empty((b, self.out_dim), dtype=np.float32)
-        _ffi.check(_ffi.lib().vf_decoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, b, tp, t, out.ctypes.data),
-                   "vf_decoder_forward")
+        if normalize is None:
+            _ffi.check(_ffi.lib().vf_decoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, b, tp, t, out.ctypes.data),
+                       "vf_decoder_forward")
+        else:
+            _ffi.check(_ffi.lib().vf_decoder_forward_pooled(self._h, ids.ctypes.data, mask.ctypes.data, b, tp, t, int(bool(normalize)),
+                                                            out.ctypes.data), "vf_decoder_forward_pooled")
         return out[:, 0] if self.out_dim == 1 else out
 
     def hidden_states(self, ids, mask) -> np.ndarray:
@@ -400,29 +419,36 @@ class HipDecoderEmbeddings:
     decoder embedder, continuous_retrieval.py:55-60).  ``query_instruction`` is prepended to queries only (instruction-tuned
     embedders such as Qwen3-Embedding expect one); documents are embedded as given."""
 
-    def __init__(self, tokenizer, decoder: HipDecoder, max_length: int = 512, batch_size: int = 16, query_instruction: str = ""):
+    def __init__(self, tokenizer, decoder: HipDecoder, max_length: int = 512, batch_size: int = 16, query_instruction: str = "",
+                 overlap_tokenize: bool = True):
         if decoder.cfg.get("head", 0) != 0 or decoder.cfg.get("pooling", 2) != 2:
             raise ValueError("HipDecoderEmbeddings needs a decoder built with pooling=2 (last token) and no scoring head")
         self.tokenizer, self.decoder = tokenizer, decoder
         self.max_length, self.batch_size, self.query_instruction = max_length, batch_size, query_instruction
         self.pad_id = getattr(tokenizer, "pad_token_id", None) or 0
+        self.overlap_tokenize = overlap_tokenize
+        self._tok = BatchTokenizer(tokenizer, max_length)
+
+    def _tokenize(self, texts):
+        rows = self._tok.encode_plain(texts, self.max_length, add_special_tokens=True)
+        width = max(len(r) for r in rows)
+        ids = np.full((len(rows), width), self.pad_id, np.int32)
+        mask = np.zeros((len(rows), width), np.int32)
+        for j, r in enumerate(rows):                      # left padding: every row ends in a real token
+            ids[j, width - len(r):] = r
+            mask[j, width - len(r):] = 1
+        return ids, mask
 
     def _embed(self, texts):
-        out = []
-        for i in range(0, len(texts), self.batch_size):
-            rows = [list(self.tokenizer(t, return_tensors=None, truncation=True, max_length=self.max_length)["input_ids"])
-                    for t in texts[i:i + self.batch_size]]
-            width = max(len(r) for r in rows)
-            ids = np.full((len(rows), width), self.pad_id, np.int32)
-            mask = np.zeros((len(rows), width), np.int32)
-            for j, r in enumerate(rows):                      # left padding: every row ends in a real token
-                ids[j, width - len(r):] = r
-                mask[j, width - len(r):] = 1
-            e = self.decoder.forward(ids, mask)
-            if not self.decoder.cfg.get("normalize", 0):
-                e = e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-12)
-            out.append(e)
-        return np.vstack(out) if out else np.zeros((0, self.decoder.hidden), np.float32)
+        if not texts:
+            return np.zeros((0, self.decoder.hidden), np.float32)
+        if self._tok.tokenizer is not self.tokenizer:
+            self._tok = BatchTokenizer(self.tokenizer, self.max_length)
+        pieces = split_for_overlap(len(texts), int(self.batch_size), min_piece=8)
+        # L2 normalisation in the pooling kernel (vf_decoder_forward_pooled), whatever the handle was created with
+        out = pipelined(pieces, lambda p: self._tokenize(texts[p[0]:p[1]]), lambda a: self.decoder.forward(a[0], a[1], normalize=True),
+                        self.overlap_tokenize)
+        return np.vstack(out)
 
     def embed_documents(self, texts):
         return self._embed(list(texts)).tolist()
@@ -438,18 +464,20 @@ DEFAULT_RERANK_PROMPT = ("Given a query A and a passage B, determine whether the
                          "providing a prediction of either 'Yes' or 'No'.")
 
 
-def build_llm_reranker_inputs(pairs, tokenizer, prompt=None, max_length=1024):
+def build_llm_reranker_inputs(pairs, tokenizer, prompt=None, max_length=1024, batch_tokenizer=None):
     """Token ids of the LLM re-ranker's inputs, as ``get_inputs`` builds them (experiments/profile/stress_test.py:97-134;
     FlagLLMReranker): ``[bos] + tok("A: " + query)`` (query truncated to 3/4 of max_length) followed by
     ``tok("\n") + tok("B: " + passage)`` with ONLY THE SECOND part truncated so that the pair fits max_length, then
-    ``tok("\n") + tok(prompt)``.  Returns a list of id lists (unpadded)."""
+    ``tok("\n") + tok(prompt)``.  Returns a list of id lists (unpadded).  The queries and the passages of a call are each tokenised
+    in ONE batch (host_tokenize.BatchTokenizer: the Rust backend of a fast tokenizer; per text otherwise)."""
     prompt = DEFAULT_RERANK_PROMPT if prompt is None else prompt
-    tok = lambda text, **kw: list(tokenizer(text, return_tensors=None, add_special_tokens=False, **kw)["input_ids"])
-    prompt_ids, sep_ids = tok(prompt), tok("\n")
+    bt = batch_tokenizer if batch_tokenizer is not None else BatchTokenizer(tokenizer, max_length)
+    prompt_ids, sep_ids = bt.encode_plain([prompt, "\n"])
+    pairs = list(pairs)
+    q_all = bt.encode_plain([f"A: {query}" for query, _ in pairs], max_length * 3 // 4)
+    p_all = bt.encode_plain([f"B: {passage}" for _, passage in pairs], max_length)
     out = []
-    for query, passage in pairs:
-        q_ids = tok(f"A: {query}", max_length=max_length * 3 // 4, truncation=True)
-        p_ids = tok(f"B: {passage}", max_length=max_length, truncation=True)
+    for q_ids, p_ids in zip(q_all, p_all):
         first = [tokenizer.bos_token_id] + q_ids
         second = sep_ids + p_ids
         room = max_length - len(first)
@@ -465,33 +493,44 @@ class HipLLMReranker:
     pair.  ``decoder`` is a ``HipDecoder`` built with ``score_token=<id of "Yes">``."""
 
     def __init__(self, tokenizer, decoder: HipDecoder, max_length: int = 1024, prompt: str = None, fuse_batches: bool = True,
-                 max_batch_tokens: int = 32768):
+                 max_batch_tokens: int = 32768, overlap_tokenize: bool = True):
         if decoder.cfg.get("head", 0) != 2:
             raise ValueError("HipLLMReranker needs a decoder built with score_token=...")
         self.tokenizer, self.decoder, self.max_length, self.prompt = tokenizer, decoder, max_length, prompt
         self.fuse_batches, self.max_batch_tokens = fuse_batches, max_batch_tokens
         self.pad_id = getattr(tokenizer, "pad_token_id", None) or 0
+        self.overlap_tokenize = overlap_tokenize
+        self._tok = BatchTokenizer(tokenizer, max_length)
 
     from_pretrained = HipReranker.from_pretrained      # (the loader picks the class from the checkpoint)
+
+    def _pad_left(self, batch):
+        width = -(-max(len(r) for r in batch) // 8) * 8          # pad_to_multiple_of=8, LEFT padding: the score is read
+        ids = np.full((len(batch), width), self.pad_id, np.int32)  # at the last column (logits[:, -1, yes_loc])
+        mask = np.zeros((len(batch), width), np.int32)
+        for j, r in enumerate(batch):
+            ids[j, width - len(r):] = r
+            mask[j, width - len(r):] = 1
+        return ids, mask
 
     def compute_score(self, sentence_pairs, batch_size: int = 8, max_length: int = None, normalize: bool = False):
         if len(sentence_pairs) and isinstance(sentence_pairs[0], str):
             sentence_pairs = [sentence_pairs]
-        rows = build_llm_reranker_inputs(sentence_pairs, self.tokenizer, self.prompt, max_length or self.max_length)
+        max_length = max_length or self.max_length
+        if self._tok.tokenizer is not self.tokenizer:
+            self._tok = BatchTokenizer(self.tokenizer, self.max_length)
+        n = len(sentence_pairs)
         step = int(batch_size)
-        if self.fuse_batches and rows:
-            longest = max(len(r) for r in rows)
-            step = max(step, (self.max_batch_tokens // max(longest, 1)) // step * step)
-        scores = []
-        for i in range(0, len(rows), step):
-            batch = rows[i:i + step]
-            width = -(-max(len(r) for r in batch) // 8) * 8          # pad_to_multiple_of=8, LEFT padding: the score is read
-            ids = np.full((len(batch), width), self.pad_id, np.int32)  # at the last column (logits[:, -1, yes_loc])
-            mask = np.zeros((len(batch), width), np.int32)
-            for j, r in enumerate(batch):
-                ids[j, width - len(r):] = r
-                mask[j, width - len(r):] = 1
-            scores.extend(float(v) for v in np.atleast_1d(self.decoder.forward(ids, mask)))
+        if self.fuse_batches and n:
+            # device batches sized from the longest POSSIBLE row (max_length + prompt), so that the partition is known before
+            # anything is tokenised and piece i + 1 can be tokenised under piece i's forward
+            step = max(step, (self.max_batch_tokens // max(max_length, 1)) // step * step)
+        pieces = split_for_overlap(n, step, min_piece=8) if self.fuse_batches else [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+
+        def prepare(p):
+            return self._pad_left(build_llm_reranker_inputs(sentence_pairs[p[0]:p[1]], self.tokenizer, self.prompt, max_length, self._tok))
+        outs = pipelined(pieces, prepare, lambda a: self.decoder.forward(a[0], a[1]), self.overlap_tokenize)
+        scores = [float(v) for s_ in outs for v in np.atleast_1d(s_)]
         if normalize:
             scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]
         return scores

@@ -18,15 +18,42 @@ Chroma's ``get(include=[...])`` / ``get(ids=[...], include=[...])``.
 from __future__ import annotations
 
 import importlib
+import threading
+from collections import OrderedDict
 from typing import Dict, List
+
+import numpy as np
 
 from . import stages
 from .faiss_retriever import FaissRetriever
-from .similarity import compute_similarity, compute_similarity_mtx
+from .similarity import _embed_all, compute_similarity, compute_similarity_mtx
 
 EXPAND_SCORE, NEIGHBOUR_SCORE, MAX_EXPANDED, SEARCH_DEPTH = 0.72, 0.66, 4, 2048
 # where the host application's BM25Retriever lives, as seen from its entry points (src/ on sys.path, or the repo root)
 BM25_MODULES = ("utils.bm25Retriever", "src.utils.bm25Retriever", "bm25Retriever")
+TEXT_ROWS_KEPT = 65536   # chunk texts whose corpus row is remembered (a request emits tens to ~155)
+
+
+class _TextRows:
+    """chunk text -> corpus row, for the texts this retriever has emitted (bounded, least recently emitted first out).
+    Request threads share a retriever without a lock upstream (ragManager.py:17-30), so this has its own."""
+
+    def __init__(self, cap: int = TEXT_ROWS_KEPT):
+        self._cap, self._map, self._mu = cap, OrderedDict(), threading.Lock()
+
+    def remember(self, texts, rows) -> None:
+        with self._mu:
+            for text, row in zip(texts, rows):
+                if row is None or row < 0:
+                    continue
+                self._map[text] = row
+                self._map.move_to_end(text)
+            while len(self._map) > self._cap:
+                self._map.popitem(last=False)
+
+    def rows_of(self, texts) -> List[int]:
+        with self._mu:
+            return [self._map.get(t, -1) for t in texts]
 
 
 def _host_bm25(bm25_dir):
@@ -47,13 +74,19 @@ def _host_bm25(bm25_dir):
 class EnsembleRetriever:
     def __init__(self, bm25_dir, chroma, ts_chroma, k: int, embeddings, faiss_k: int = None, bm25_k: int = None,
                  faiss_ts_k: int = None, enable_expand: bool = False, bm25_retriever=None, retriever_cls=FaissRetriever,
-                 prefetch_documents: bool = False):
+                 prefetch_documents: bool = False, similarity_from_rows: bool = None):
         """Positional arguments as upstream (``ragManager.py:112`` passes bm25_dir, chroma, ts_chroma, k, embeddings).
         ``bm25_dir`` goes to the host application's ``BM25Retriever`` exactly as upstream (``:37``) unless
         ``bm25_retriever`` is given.
         ``prefetch_documents=True`` loads every chunk's text once and serves bundles from memory in the requested
         row order instead of one ``chroma.get(ids=...)`` per bundle (Chroma returns rows in ITS order, so leave this
-        off when byte-identical ordering inside a bundle matters)."""
+        off when byte-identical ordering inside a bundle matters).
+        ``similarity_from_rows``: ``compute_similarity_mtx(texts)`` -- the reference's call, texts only (vllmManager.py:462) --
+        serves every text this retriever has emitted from ITS ROW of the HBM-resident corpus (``vf_cosine_matrix_rows_mixed``) and
+        embeds only texts it does not know, instead of embedding all n again (ensembleRetriever.py:275).  None (default) = on when
+        that is the same matrix: the rows are held as given (not rounded to a narrower ``corpus_dtype``) and the embedder has no
+        query instruction (upstream stores ``embed_documents(text)`` and compares ``embed_query(text)``: the same vector unless
+        the embedder prefixes queries).  False = always re-embed; True = rows even where auto would decline."""
         self.embeddings = embeddings
         self.faiss_k = faiss_k if faiss_k is not None else k
         self.bm25_k = bm25_k if bm25_k is not None else k
@@ -85,6 +118,19 @@ class EnsembleRetriever:
             if b is not None:
                 self._bundle_rows.setdefault(b, []).append(row)
             self._title_rows.setdefault(md.get("title_summary", ""), []).append(row)
+        self._text_rows = _TextRows()
+        self.similarity_from_rows = self._rows_serve_similarity() if similarity_from_rows is None else bool(similarity_from_rows)
+
+    def _rows_serve_similarity(self) -> bool:
+        ix = getattr(self.faiss_retriever, "index", None)
+        if ix is None or not hasattr(ix, "cosine_matrix_rows"):
+            return False
+        if not getattr(self.faiss_retriever, "rows_as_given", False):
+            return False
+        for name in ("query_instruction", "query_instruction_for_retrieval", "embed_instruction"):
+            if getattr(self.embeddings, name, None):
+                return False
+        return True
 
     # -- pieces -------------------------------------------------------------------------------------
     def _bundle_of(self, row: int, seen: set) -> List[int]:
@@ -104,6 +150,8 @@ class EnsembleRetriever:
 
     def _emit(self, out: list, name: str, score, rows: List[int], bundle_cnt: int) -> None:
         documents, metadatas = self._fetch(rows)
+        if self.similarity_from_rows:   # the store answers in ITS order: a text's row comes from its own metadata
+            self._text_rows.remember(documents, [self.docid2idx.get(md.get("doc_id"), -1) for md in metadatas])
         for text, md in zip(documents, metadatas):
             out.append({"retriever": name, "score": float(score), "page_content": text, "metadata": md,
                         "bundle_id": bundle_cnt})
@@ -197,4 +245,16 @@ class EnsembleRetriever:
         return compute_similarity(self.embeddings, chunks, selected_indices, candidate_index)
 
     def compute_similarity_mtx(self, chunks):
-        return compute_similarity_mtx(self.embeddings, chunks)
+        """The reference's signature and return (``[n, n]`` tensor indexed ``similar_mtx[idx, selected] > 0.9``,
+        vllmManager.py:462,476).  Texts this retriever emitted are read from their corpus rows in HBM; the others are embedded in
+        ONE batched call; with ``similarity_from_rows`` off (or nothing known) every text is embedded, as upstream."""
+        chunks = list(chunks)
+        rows = self._text_rows.rows_of(chunks) if self.similarity_from_rows else []
+        if not chunks or not any(r >= 0 for r in rows):
+            return compute_similarity_mtx(self.embeddings, chunks)
+        unknown = [t for t, r in zip(chunks, rows) if r < 0]
+        extra = _embed_all(self.embeddings, unknown) if unknown else None
+        ix = self.faiss_retriever.index
+        ids = np.asarray([r + ix.id_offset if r >= 0 else -1 for r in rows], dtype=np.int64)
+        import torch
+        return torch.from_numpy(ix.cosine_matrix_rows(ids, extra))

@@ -29,6 +29,9 @@ class FaissRetriever:
         # them (fp16 input stays fp16), "f16" halves the bytes the scan reads, "fp8" (OCP e4m3) quarters them (BASELINE configs[4]).
         # Scores are the canonical cosine of the STORED values either way.
         # device_ids=[0..7]: the corpus is row-sharded over those GPUs behind the same handle (one process, no torchrun)
+        # rows_as_given: the index holds the embeddings' own values (nothing was rounded to a narrower type), so a cosine taken from
+        # the rows is the cosine of the embeddings (EnsembleRetriever.compute_similarity_mtx serves known texts from them)
+        self.rows_as_given = corpus_dtype == "f32" or (corpus_dtype == "f16" and embeddings.dtype == np.float16)
         if corpus_dtype == "f32":
             x = embeddings if embeddings.dtype == np.float16 else embeddings.astype("float32")
             self.index = DenseIndex(x, device_id=device_id, device_ids=device_ids)
@@ -36,7 +39,18 @@ class FaissRetriever:
             self.index = DenseIndex(embeddings.astype(np.float16), device_id=device_id, device_ids=device_ids)
         elif corpus_dtype == "fp8":
             import torch
-            codes = torch.from_numpy(np.ascontiguousarray(embeddings.astype(np.float32))).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+            # torch's cast to e4m3 does not saturate (|x| > 448 becomes a NaN code) and flushes small magnitudes; a cosine does not
+            # change under a positive per-row scale, so every row is scaled to put its largest magnitude on 448 -- the whole e4m3
+            # range is used whatever the embedder's output scale (un-normalised rows included), and nothing can overflow
+            x = np.ascontiguousarray(embeddings.astype(np.float32))
+            if not np.isfinite(x).all():
+                raise ValueError("corpus_dtype='fp8': the embeddings hold non-finite values")
+            peak = np.abs(x).max(axis=1, keepdims=True)
+            x = x * (448.0 / np.where(peak > 0, peak, 1.0)).astype(np.float32)
+            np.clip(x, -448.0, 448.0, out=x)
+            codes = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+            if ((codes & 0x7F) == 0x7F).any():
+                raise ValueError("corpus_dtype='fp8': the cast produced NaN codes")
             self.index = DenseIndex.from_e4m3(codes, device_id=device_id, device_ids=device_ids)
         else:
             raise ValueError(f"corpus_dtype {corpus_dtype!r}: one of f32, f16, fp8")

@@ -1,0 +1,136 @@
+"""Host side of the three model loops: text -> token arrays, overlapped with the device.
+
+The reference's loops tokenise a batch, run it, tokenise the next (``src/load_data.py:98-99,120-128`` through
+``Chroma.add_texts`` -> ``embed_documents``; ``src/utils/vllmManager.py:450-452`` -> ``compute_score``), and so did this
+package until round 6: the device idled while Python tokenised and the tokenizer idled while the device ran.  Two things here:
+
+* ``BatchTokenizer`` -- a Hugging Face *fast* tokenizer is driven at its Rust backend (``encode_batch_fast`` on a private copy
+  configured once with the truncation / padding the HF call would set): the ``BatchEncoding`` assembly of the Python wrapper costs
+  5-8 x the tokenisation itself (100 pairs x 512 tokens, XLM-R Unigram, 8 cores: 100 ms through ``tokenizer(...)``, 13 + 4 ms
+  here; same ids, masks and token types -- ``tests/test_host_tokenize.py``).  Any other tokenizer object is called the HF way.
+* ``pipelined`` -- a one-deep prefetch: batch i + 1 is tokenised on a worker thread while batch i is on the device (the Rust
+  tokenizer and a ctypes call both release the GIL).  The batch partition does not depend on whether the overlap is on, so the
+  results are bit-equal to the serial loop's.
+"""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_pool = None
+_pool_mu = threading.Lock()
+
+
+def _worker() -> ThreadPoolExecutor:
+    """ONE shared prefetch thread pool (two workers: nested loops -- a ReplicaSet fanning batches out -- never wait on themselves)."""
+    global _pool
+    with _pool_mu:
+        if _pool is None:
+            _pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="vf-tokenize")
+        return _pool
+
+
+def pipelined(batches, prepare, run, overlap: bool = True) -> list:
+    """[run(prepare(b)) for b in batches] with prepare(batch i + 1) running beside run(batch i)."""
+    batches = list(batches)
+    if not overlap or len(batches) <= 1:
+        return [run(prepare(b)) for b in batches]
+    pool = _worker()
+    out = []
+    nxt = pool.submit(prepare, batches[0])
+    for i in range(len(batches)):
+        ready = nxt.result()
+        if i + 1 < len(batches):
+            nxt = pool.submit(prepare, batches[i + 1])
+        out.append(run(ready))
+    return out
+
+
+def split_for_overlap(n: int, step: int, min_piece: int = 16) -> list:
+    """(lo, hi) pieces of n items in device batches of at most `step`: a call that fits ONE device batch is cut in two halves (whole
+    multiples of 8 pairs) when both halves keep at least `min_piece` items, so that the second half is tokenised under the first
+    half's forward; larger calls keep their `step`-sized batches (already more than one)."""
+    if n <= 0:
+        return []
+    if n > step:
+        return [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+    half = (n // 2 + 7) // 8 * 8
+    if half >= min_piece and n - half >= min_piece:
+        return [(0, half), (half, n)]
+    return [(0, n)]
+
+
+def _backend(tokenizer):
+    """The Rust tokenizer behind a HF fast tokenizer, or None."""
+    if not getattr(tokenizer, "is_fast", False):
+        return None
+    return getattr(tokenizer, "backend_tokenizer", None) or getattr(tokenizer, "_tokenizer", None)
+
+
+class BatchTokenizer:
+    """``encode(texts)`` / ``encode(texts, second_texts)`` -> (input_ids int32 [b, t], attention_mask int32 [b, t], token_type_ids or
+    None): what ``tokenizer(texts, [second,] padding=True, truncation=True, max_length=..., return_tensors="np")`` returns."""
+
+    def __init__(self, tokenizer, max_length: int):
+        self.tokenizer, self.max_length = tokenizer, int(max_length)
+        self._rust = None
+        self._mu = threading.Lock()
+        be = _backend(tokenizer)
+        if be is not None and getattr(tokenizer, "pad_token_id", None) is not None:
+            try:
+                from tokenizers import Tokenizer
+                rust = Tokenizer.from_str(be.to_str())   # a private copy: the caller's tokenizer keeps its own truncation / padding state
+                # exactly what PreTrainedTokenizerFast.set_truncation_and_padding configures for padding=True, truncation=True
+                rust.enable_truncation(max_length=self.max_length, stride=0, strategy="longest_first",
+                                       direction=getattr(tokenizer, "truncation_side", "right"))
+                rust.enable_padding(direction=getattr(tokenizer, "padding_side", "right"), pad_id=int(tokenizer.pad_token_id),
+                                    pad_type_id=int(getattr(tokenizer, "pad_token_type_id", 0) or 0), pad_token=str(tokenizer.pad_token))
+                self._rust = rust
+                self._types = "token_type_ids" in getattr(tokenizer, "model_input_names", ())
+            except Exception:  # noqa: BLE001 -- an exotic tokenizer the copy cannot express: take the HF call
+                self._rust = None
+
+    @property
+    def direct(self) -> bool:
+        return self._rust is not None
+
+    def encode(self, texts, second=None):
+        texts = list(texts)
+        if self._rust is None:
+            from .encoder import _tok_arrays
+            if second is None:
+                enc = self.tokenizer(texts, padding=True, truncation=True, max_length=self.max_length, return_tensors="np")
+            else:
+                enc = self.tokenizer(texts, list(second), padding=True, truncation=True, max_length=self.max_length, return_tensors="np")
+            return _tok_arrays(enc)
+        items = texts if second is None else list(zip(texts, second))
+        with self._mu:   # a Rust tokenizer is Sync, but encode_batch on one object from two threads serialises on its own pool anyway
+            fast = getattr(self._rust, "encode_batch_fast", None) or self._rust.encode_batch
+            encs = fast(items, add_special_tokens=True)
+        ids = np.array([e.ids for e in encs], dtype=np.int32)
+        mask = np.array([e.attention_mask for e in encs], dtype=np.int32)
+        tt = np.array([e.type_ids for e in encs], dtype=np.int32) if self._types else None
+        return ids, mask, tt
+
+    def encode_plain(self, texts, max_length=None, add_special_tokens: bool = False):
+        """Unpadded id lists, each truncated to max_length -- WITHOUT special tokens by default (the LLM re-ranker's prompt pieces):
+        ``tokenizer(text, add_special_tokens=..., truncation=True, max_length=...)["input_ids"]`` for every text."""
+        texts = list(texts)
+        be = _backend(self.tokenizer)
+        if be is None:
+            kw = {} if max_length is None else {"max_length": max_length, "truncation": True}
+            return [list(self.tokenizer(t, return_tensors=None, add_special_tokens=add_special_tokens, **kw)["input_ids"]) for t in texts]
+        with self._mu:
+            if getattr(self, "_plain", None) is None:
+                from tokenizers import Tokenizer
+                self._plain = Tokenizer.from_str(be.to_str())
+                self._plain.no_padding()
+            if max_length is None:
+                self._plain.no_truncation()
+            else:
+                self._plain.enable_truncation(max_length=int(max_length), stride=0, strategy="longest_first",
+                                              direction=getattr(self.tokenizer, "truncation_side", "right"))
+            fast = getattr(self._plain, "encode_batch_fast", None) or self._plain.encode_batch
+            return [list(e.ids) for e in fast(texts, add_special_tokens=bool(add_special_tokens))]

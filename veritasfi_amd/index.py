@@ -257,14 +257,24 @@ class DenseIndex:
     def set_option(self, name: str, value: int) -> None:
         _ffi.check(_ffi.lib().vf_index_set_option(self._h, name.encode(), int(value)), "vf_index_set_option")
 
-    def cosine_matrix_rows(self, ids) -> np.ndarray:
+    def cosine_matrix_rows(self, ids, extra=None) -> np.ndarray:
         """[n, n] canonical cosine matrix of rows already in this index, picked by global id (``vf_cosine_matrix_rows``): the
-        similarity matrix of retrieved chunks without re-embedding their texts."""
+        similarity matrix of retrieved chunks without re-embedding their texts.
+        ``extra`` ([m, d] fp32): positions whose id is -1 take the next row of ``extra`` instead (``vf_cosine_matrix_rows_mixed``)
+        -- texts the corpus does not hold, embedded by the caller."""
         ids = np.ascontiguousarray(ids, dtype=np.int64).ravel()
         out = np.empty((ids.size, ids.size), np.float32)
-        if ids.size:
+        if not ids.size:
+            return out
+        if extra is None or len(extra) == 0:
             _ffi.check(_ffi.lib().vf_cosine_matrix_rows(self._h, ids.ctypes.data, int(ids.size), out.ctypes.data),
                        "vf_cosine_matrix_rows")
+            return out
+        extra = np.ascontiguousarray(extra, dtype=np.float32)
+        if extra.ndim != 2 or extra.shape[1] != self.d:
+            raise ValueError(f"extra must be [m, {self.d}]")
+        _ffi.check(_ffi.lib().vf_cosine_matrix_rows_mixed(self._h, ids.ctypes.data, int(ids.size), extra.ctypes.data,
+                                                          int(extra.shape[0]), out.ctypes.data), "vf_cosine_matrix_rows_mixed")
         return out
 
     def close(self) -> None:

@@ -28,7 +28,10 @@ def rank_chunk(chunks, question: str, query_time: datetime, reranker, embedding_
                similar_threshhold: float = 0.9, reranker_lock=None, device_id: int = 0, similarity_index=None,
                row_id_key: str = "row_id"):
     """chunks: list of dicts with 'page_content', 'bundle_id', 'metadata'['date_published' = 'YYYY-MM-DD'].
-    similarity_index (opt-in, see compute_similarity_mtx): the DenseIndex the chunks were retrieved from, each chunk carrying its
+    embedding_fn: an embedder (embed_documents / embed_query) -- or, as upstream passes it (vllmManager.py:430: the method's fourth
+    argument is the RETRIEVER and :462 calls retriever.compute_similarity_mtx(texts)), any object with compute_similarity_mtx:
+    this package's EnsembleRetriever then serves the texts it emitted from their corpus rows in HBM and embeds only the rest.
+    similarity_index (explicit, see compute_similarity_mtx): the DenseIndex the chunks were retrieved from, each chunk carrying its
     row as chunk[row_id_key] -- the similarity matrix then comes from the corpus rows in HBM instead of re-embedding n texts.
     Stage brackets (stages.py; no-ops unless a profiler was set): "rerank" around the call -- the name upstream gives the function
     that wraps this method (vllmChatService.py:31) -- and "rerank_score" / "rerank_similarity" around its two device legs."""
@@ -56,6 +59,9 @@ def _rank_chunk(chunks, question, query_time, reranker, embedding_fn, chunk_topk
         if similarity_index is not None:
             sim = compute_similarity_mtx(embedding_fn, texts, device_id, as_torch=False, index=similarity_index,
                                          row_ids=[chunk[row_id_key] for chunk in chunks])
+        elif hasattr(embedding_fn, "compute_similarity_mtx"):                                     # :462 retriever.compute_similarity_mtx
+            sim = embedding_fn.compute_similarity_mtx(texts)
+            sim = sim.numpy() if hasattr(sim, "numpy") else np.asarray(sim)
         else:
             sim = compute_similarity_mtx(embedding_fn, texts, device_id, as_torch=False)          # :462
     # :464-481 greedy pick, best fused score first: a bundle is taken whole if it is new, still fits chunk_topk, and its chunk is not
