@@ -293,3 +293,26 @@ def test_isa_lint_follows_loop_back_edges():
         s_endpgm
     """
     assert lint.lint_function(early) == (0, 1)      # only the branch target's barrier sees the read
+
+
+def test_configure_is_explicit_and_warns_when_too_late(monkeypatch):
+    """Importing the package leaves the environment alone (round 5 review); configure() sets GPU_MAX_HW_QUEUES once, respects the host's
+    own setting, and says so when the runtime is already up."""
+    import subprocess
+    import sys
+    import warnings
+    import veritasfi_amd as vf
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import veritasfi_amd as vf; a = os.environ.get('GPU_MAX_HW_QUEUES'); "
+            "r = vf.configure(); print(a, r, os.environ.get('GPU_MAX_HW_QUEUES'))")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, check=True).stdout.split()
+    assert out == ["None", "True", "8"]
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "3")
+    assert vf.configure() is True and os.environ["GPU_MAX_HW_QUEUES"] == "3"          # the host's setting wins
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    from veritasfi_amd import _ffi
+    monkeypatch.setattr(_ffi, "loaded", lambda: True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert vf.configure() is False and "GPU_MAX_HW_QUEUES" not in os.environ
+    assert any("already initialised" in str(x.message) for x in w)

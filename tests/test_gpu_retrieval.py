@@ -1379,3 +1379,56 @@ def test_repeat_runs_of_one_search_are_all_exact(vf, oracle):
         assert sr.main() == 0
     finally:
         sys.argv = old_argv
+
+
+@pytest.mark.gpu
+def test_fp8_corpus_of_unnormalised_rows_neither_overflows_nor_flushes(oracle):
+    """FaissRetriever(corpus_dtype="fp8") on rows of any scale (round-5 advisor): torch's cast to e4m3 does not saturate -- |x| > 448
+    became a NaN code and the row dropped out of every result -- and tiny rows flushed to zero.  Rows are scaled per row by a power
+    of two first (a cosine does not see it): rows scaled by 5000 and by 1e-6 are found like the others, and the scores are the
+    canonical cosine of the stored codes."""
+    import torch
+    import veritasfi_amd as vf
+    from oracle import ref_numpy
+    rng = np.random.default_rng(11)  # (the `oracle` fixture: oracle.canonical)
+    rows = rng.standard_normal((20_000, 256)).astype(np.float32)
+    rows[::3] *= 5000.0
+    rows[1::3] *= 1e-6
+    rows[7] = 0.0
+
+    class Emb:
+        def embed_query(self, t):
+            return rows[int(t)].tolist()
+
+    fr = vf.FaissRetriever(rows, Emb(), corpus_dtype="fp8")
+    probe = [0, 1, 2, 3, 4, 5, 9_999, 19_999]
+    ids, sc = fr.invoke([str(i) for i in probe], 5)
+    assert [int(i) for i in ids[:, 0]] == probe and np.all(sc[:, 0] > 0.995) and np.isfinite(sc).all()
+    # the scores are those of the stored codes: decode what the constructor stored and ask the oracle
+    peak = np.abs(rows).max(axis=1, keepdims=True).astype(np.float64)
+    scaled = rows * np.exp2(np.floor(np.log2(448.0 / np.where(peak > 0, peak, 448.0)))).astype(np.float32)
+    codes = torch.from_numpy(scaled).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert not ((codes & 0x7F) == 0x7F).any()
+    want_ids, want_sc = oracle.search(ref_numpy.decode_e4m3(codes).astype(np.float16), rows[probe], 5)
+    assert np.array_equal(ids, want_ids) and np.array_equal(_bits(sc), _bits(want_sc))
+    with pytest.raises(ValueError, match="non-finite"):
+        vf.FaissRetriever(np.array([[1.0, np.inf], [0.0, 1.0]], np.float32), Emb(), corpus_dtype="fp8")
+    fr.index.close()
+
+
+@pytest.mark.gpu
+def test_deep_searches_with_few_queries_stay_on_the_fused_path(oracle):
+    """The reference's own call shape -- k = 2048 with one to four queries (src/utils/ensembleRetriever.py:64-66) -- over a LARGE shard:
+    a query's candidate list grows like k' (1 + ln(n / sample)), and until round 6 it was sized 4 k' (at most 16384), so k = 2048 from
+    1M rows up and k = 1000 overflowed it and every such search took the exact re-run (correct, 56-72 ms at 5M rows instead of 2).
+    Exact results AND no re-run."""
+    import veritasfi_amd as vf
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((1_000_000, 64)).astype(np.float32).astype(np.float16)
+    q = rng.standard_normal((4, 64)).astype(np.float32)
+    with vf.DenseIndex(rows) as ix:
+        for nq, k in ((1, 1000), (4, 1000), (1, 2048), (4, 2048)):
+            ids, sc = ix.search(q[:nq], k)
+            st = ix.stats()
+            assert st["path"] == 1 and st["overflowed"] == 0 and st["exact_reruns"] == 0, (nq, k, st)
+            _assert_exact(oracle, rows, q[:nq], k, ids, sc)

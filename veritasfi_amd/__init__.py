@@ -19,17 +19,48 @@ Drop-in names (same signatures as the reference):
 * ``HuggingFaceEmbeddings(model_name=...)`` / ``FlagLLMReranker(name, ...)`` / ``from_config(cfg)``
                                          -- the reference's two constructor calls (``ragManager.py:50``, ``vllmChatService.py:90``) and
                                             its YAML keys (``config/example.yaml``), returning the HIP-backed objects (pretrained.py)
+* ``configure()``                        -- optional, explicit: more HIP hardware queues for processes that hold several handles (call before the
+                                            first GPU call; importing the package sets nothing)
 * ``set_profiler``                       -- routes the reference's stage names ("retrieve", "retrieve_faiss", "retrieve_faiss_ts",
                                             "rerank"; ``src/utils/profiler.py``) out of the drop-in classes (off by default)
 """
 import os as _os
 
-# HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  An index keeps two batches in flight on four
-# streams of its own, every model handle has one, the caller brings more: past four, streams that are meant to overlap share a queue
-# (round 5: a 1M-row search loop 13 % slower in a process that had opened a second index; profiles/r05_hw_queues.log).  Read once,
-# when the runtime initialises -- so this only helps when the package is imported before anything touches the GPU; an explicit
-# setting of the variable always wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+def configure(hw_queues: int = 8, warn: bool = True) -> bool:
+    """Process-wide runtime settings this package's streams profit from.  EXPLICIT: importing the package changes nothing in the host
+    application's environment (until round 6 it set GPU_MAX_HW_QUEUES at import -- a side effect of a drop-in library, and silently
+    without effect when the host had touched the GPU first).
+
+    HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  An index keeps two batches in flight on four
+    streams of its own, every model handle has one, the caller brings more: past four, streams that are meant to overlap share a queue
+    (round 5: a 1M-row search loop 13 % slower in a process that had opened a second index; profiles/r05_hw_queues.log).  The variable is
+    read ONCE, when the HIP runtime initialises: call this before anything touches the GPU (before the first torch.cuda call / the
+    first index or model of this package).  An explicit setting of the variable by the host wins.  Returns True when the setting will
+    take effect; warns (and returns False) when the runtime is already up."""
+    import warnings
+    if "GPU_MAX_HW_QUEUES" in _os.environ:
+        return True
+    up = False
+    try:
+        from . import _ffi
+        up = _ffi.loaded()
+    except Exception:  # noqa: BLE001
+        up = False
+    try:
+        import sys as _sys
+        torch = _sys.modules.get("torch")
+        up = up or bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:  # noqa: BLE001
+        pass
+    if up:
+        if warn:
+            warnings.warn("veritasfi_amd.configure(): the HIP runtime is already initialised in this process; GPU_MAX_HW_QUEUES "
+                          f"={hw_queues} would not be read any more -- call configure() before the first GPU call", RuntimeWarning, stacklevel=2)
+        return False
+    _os.environ["GPU_MAX_HW_QUEUES"] = str(int(hw_queues))
+    return True
+
 
 from .index import (DenseIndex, cosine_matrix, cosine_scores, fuse_rank, merge_topk_device,  # noqa: F401
                     merge_topk_packed_device, packed_part_bytes, packed_result_buffer)

@@ -151,6 +151,11 @@ def lib():
     return _lib
 
 
+def loaded() -> bool:
+    """The library has been loaded in this process (an index, a model handle or a small dense op was created)."""
+    return _lib is not None
+
+
 def last_error() -> str:
     msg = lib().vf_last_error()
     return msg.decode("utf-8", "replace") if msg else ""

@@ -3,6 +3,14 @@
 ``python -m veritasfi_amd.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without a
 GPU, so this runs in the build container; the .so is git-ignored and travels to the GPU box with the
 repo snapshot.
+
+Two libraries come out of it:
+* ``libveritasfi_hip.so`` -- the product: exports exactly the entry points ``include/veritasfi_hip.h`` declares (a linker version
+  script written from the header) plus the two test hooks of the default suite (``KEPT_HOOKS``); kernels that were measured and
+  rejected are not compiled in.
+* ``libvf_test.so`` (``build_test_variant``) -- the same sources with ``-DVF_EXPERIMENTS``: every ``vf_debug_*`` hook exported (kernel-
+  level parity tests drive single kernels through them) and the rejected variants built for A/B runs.  Selected with
+  ``VF_LIB_PATH``; ``tests/test_gpu_hooks.py`` runs the hook-driven tests against it in a child process.
 """
 from __future__ import annotations
 
@@ -37,6 +45,42 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+KEPT_HOOKS = ("vf_debug_force_no_peer", "vf_debug_small_allocs")   # the staged-exchange rehearsal and the arena steady-state test
+TEST_LIB = os.path.join(LIBDIR, "libvf_test.so")
+
+
+def api_symbols() -> list:
+    """Entry points declared in include/veritasfi_hip.h, in order of appearance."""
+    import re
+    text = open(os.path.join(CSRC, HEADERS[1])).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    seen = []
+    for name in re.findall(r"\b(vf_[a-z0-9_]+)\s*\(", text):
+        if name not in seen:
+            seen.append(name)
+    return seen
+
+
+def _version_script(path: str, everything: bool) -> str:
+    names = ["vf_*"] if everything else api_symbols() + list(KEPT_HOOKS)
+    body = "{\n  global:\n" + "".join(f"    {n};\n" for n in names) + "  local: *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != body:
+        with open(path, "w") as f:
+            f.write(body)
+    return path
+
+
+def build_test_variant(force: bool = False, verbose: bool = False) -> str:
+    """libvf_test.so: -DVF_EXPERIMENTS, every hook exported (a child of this process compiles it, so the module's globals stay put)."""
+    env = dict(os.environ, VF_BUILD_LIB=os.path.basename(TEST_LIB), VF_BUILD_TAG="_test",
+               VF_BUILD_FLAGS=(os.environ.get("VF_BUILD_FLAGS", "") + " -DVF_EXPERIMENTS").strip(), VF_BUILD_EXPORT_ALL="1")
+    cmd = [sys.executable, "-m", "veritasfi_amd.build"] + (["--force"] if force else [])
+    out = subprocess.run(cmd, env=env, cwd=os.path.dirname(HERE), capture_output=not verbose, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("building libvf_test.so failed" + ("" if verbose else ": " + (out.stderr or "")[-2000:]))
+    return TEST_LIB
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -55,8 +99,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    export_all = os.environ.get("VF_BUILD_EXPORT_ALL") == "1" or "-DVF_EXPERIMENTS" in EXTRA
+    vs = _version_script(os.path.join(LIBDIR, os.path.basename(LIB) + ".map"), export_all)
+    if force or _stale(LIB, objs + [vs]):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={vs}", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -65,3 +111,5 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    if "--with-test-variant" in sys.argv:
+        print(build_test_variant(force="--force" in sys.argv, verbose=True))

@@ -592,8 +592,15 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     else if (s == "refresh_every") { if (!in_range(1, 256)) return fail(VF_EINVAL, "refresh_every must be in [1, 256]"); ix->refresh_every = value; }
     else if (s == "steal") { if (!in_range(0, 1)) return fail(VF_EINVAL, "steal must be 0 or 1"); ix->steal_opt = value; }
     else if (s == "wide") { if (!in_range(0, 4096)) return fail(VF_EINVAL, "wide must be 0 (off), 1 (auto) or a query count"); ix->wide_opt = value; }
-    else if (s == "wide8_stage") { if (!in_range(0, 3584)) return fail(VF_EINVAL, "wide8_stage must be 0 (auto) or 64..3584 candidate-stage entries"); ix->wide8_stage = value; }
-    else if (s == "wide8_waves") { if (value != 4 && value != 8) return fail(VF_EINVAL, "wide8_waves must be 4 (two 256-thread workgroups per CU, 128-query tiles: the default) or 8 (one 512-thread workgroup, 256-query tiles)"); ix->wide8_waves = value; }
+    else if (s == "wide8_stage") { if (value != 0 && !in_range(64, 3584)) return fail(VF_EINVAL, "wide8_stage must be 0 (auto) or 64..3584 candidate-stage entries"); ix->wide8_stage = value; }
+    else if (s == "wide8_waves") {
+#ifdef VF_EXPERIMENTS
+        if (value != 4 && value != 8) return fail(VF_EINVAL, "wide8_waves must be 8 (one 512-thread workgroup per CU, 256-query tiles: the default) or 4 (two 256-thread workgroups, 128-query tiles: measured slower, DESIGN.md 4)");
+#else
+        if (value != 8) return fail(VF_EINVAL, "wide8_waves must be 8 (the 4-wave form was measured slower and is built with -DVF_EXPERIMENTS only: DESIGN.md 4)");
+#endif
+        ix->wide8_waves = value;
+    }
     else if (s == "wide_mfma") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "wide_mfma must be -1 (auto: the fp8 instruction for e4m3 rows), 0 (fp16 matrix instruction on converted rows) or 1 (the fp8 instruction on the e4m3 row bytes: k_scan_wide8)"); ix->wide_mfma = value; }
     else if (s == "wide_sync") { if (!in_range(-1, 8)) return fail(VF_EINVAL, "wide_sync must be -1 (off) or a slack of 0..8 super-tiles"); ix->wide_sync = value; }
     else if (s == "aux_cus") {   // takes effect for slots created afterwards (set it before the first search)
@@ -713,7 +720,21 @@ static FusedPlan make_plan(const vf_index* ix, int k) {
     // (1M x 768) 0.304 -> 0.290 ms per batch; from 1.25M rows on the step is the scan's and nothing changes, at 10M the larger
     // candidate lists cost 1.7 % (profiles/r04_sample_rows_sweep.log)
     // (only while the sample still holds 16 k' rows: a top-2048 search seeds its threshold from the k'-th best sample score)
-    p.samp = ix->sample_rows > 0 ? (int)ix->sample_rows : ((ix->n <= 1100000 && 4ll * p.total_waves >= 16ll * p.kprime) ? 4 : 16);
+    // Round 6, one box, fresh index per setting (profiles/r06_small_sweep_*.log): 1M rows 4 / 8 / 16 per wave = 0.2965 / 0.2915-0.2951 /
+    // 0.3111 ms per batch, 1.25M rows 0.3559 / 0.3515-0.3534 / 0.3539-0.3550, 1.25M x 1024 0.4447 / 0.4479 / 0.4470: 8 is level with the best
+    // of the other two at every small-shard size, so it is the rule up to 1.5M rows (16 beyond: the scan hides the pass there).
+    p.samp = ix->sample_rows > 0 ? (int)ix->sample_rows : ((ix->n <= 1500000 && 8ll * p.total_waves >= 16ll * p.kprime) ? 8 : 16);
+    // A query's candidate list holds about k' (1 + ln(n / sample rows)) entries -- the k'-th best of a growing prefix moves up like that --
+    // times the lag of the threshold refresh (measured 1.2-1.3 at k = 100 .. 2048).  The 4 k' rule above is short of that for deep
+    // searches over large shards: round 6 found the reference's own call shape, k = 2048 with one to four queries
+    // (src/utils/ensembleRetriever.py:64-66), overflowing its 16384-entry lists from 1M rows up and k = 1000 its 8192 -- correct results
+    // through the exact re-run, at 56-72 ms instead of 2 (5M rows).  The list is sized for 1.6 x the expectation, up to 32768 entries
+    // (what the wide passes use; k_final reads the list from global memory, so its length costs HBM, not LDS).
+    if (ix->cap_opt <= 0) {
+        const double sample_rows = (double)p.total_waves * p.samp;
+        const double expect = p.kprime * (1.0 + log(std::max(1.0, (double)ix->n / std::max(1.0, sample_rows))));
+        while (p.cap < (int)(1.6 * expect) && p.cap < 32768) p.cap <<= 1;
+    }
     // |approx - canonical| bound (DESIGN.md "Exactness certificate").  fp16 has an 11-bit significand, so
     // round-to-nearest moves an element by at most 2^-11 of its magnitude: rounding the normalised query moves the
     // dot product by <= 2^-11 * sum|q_j c_j| <= 2^-11 (Cauchy-Schwarz, both vectors of unit norm); rounding an fp32
@@ -752,7 +773,7 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
     const int J = qtot / kWideTile;
     const int RG = std::max(1, ix->n_cu / J);
     FusedPlan p = p0;
-    if (p.kprime > 256) p.cap = 16384;   // k ~ 1000: ~k' (1 + ln(n / sample)) candidates per query
+    if (p.kprime > 256) p.cap = std::max(p.cap, 16384);   // k ~ 1000: ~k' (1 + ln(n / sample)) candidates per query
     // k_scan_wide8 (the fp8 matrix instruction): e4m3 rows, K-tiles of 64, a row group's bytes within a 32-bit lane offset
     const bool w8 = ix->wide_mfma != 0 && ix->dtype == VF_DTYPE_FP8_E4M3 && ix->dp % 64 == 0 &&
                     (ix->n / RG + 2 * 256) * (int64_t)ix->dp < (int64_t)0xFFFFFFFFll;
@@ -760,7 +781,7 @@ static int wide_pass(vf_index* ix, Slot& s, const FusedPlan& p0, const float* d_
         // the query's hi + lo split leaves ||delta|| ~ 6e-4 of the query's norm (eps_q ~ 1.1e-3 at dp = 1024 against the fp16 path's
         // 6.1e-4): the plan's k' = k + k / 4 still clears it on ordinary data (the k -> k' gap is ~2.4e-3); a deeper k' (k + k / 2) was the
         // first setting and cost 14 % more candidates for nothing (profiles/r04_wide8_kprime.log)
-        if (p.kprime > 256) p.cap = 32768;
+        if (p.kprime > 256) p.cap = std::max(p.cap, 32768);
     }
     const int samp = J >= 2 ? 64 : 32;   // sample rows per row group = samp * 8: 32768 / 65536 rows in all
     const size_t slen = (size_t)RG * samp * 8;
@@ -964,6 +985,14 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
             ScanArgs a2 = a;
             a2.stage_cap = cap2;
+#ifdef VF_EXPERIMENTS
+            if (ix->debug & 32) {   // timing experiment: compute unit -> range table (k_scan2, debug bit 5)
+                const bool fresh = s.sib.bytes < 4096;
+                VF_TRY(s.sib.ensure(4096));
+                if (fresh) VF_HIP(hipMemsetAsync(s.sib.p, 0xFF, 4096, st));
+                a2.sib = s.sib.as<u32>();
+            }
+#endif
             VF_HIP(launch_scan2(a2, qt, p.grid, f8, sst));
             s.scan_kernel = 2;
         } else {

@@ -1257,7 +1257,21 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     const int r31 = lane & 31, h = lane >> 5;
     const long long grid = gridDim.x;
     const long long swg = (long long)a.samp * (kScanThreads / 64);   // the sample part is defined by the sample pass's geometry
-    const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
+    long long range_v = blockIdx.x;
+#ifdef VF_EXPERIMENTS
+    // timing experiment (debug bit 5, INVALID RESULTS: ranges may be taken twice or not at all): the range a workgroup scans is a function
+    // of the COMPUTE UNIT it landed on, so that a CU reads the same rows launch after launch -- is the slow start of a launch a per-CU
+    // state (its translation cache) that a workgroup resident across batches would keep?
+    if ((a.debug & 32) && a.sib) {   // a.sib: [1024] u32 table CU -> range, 0xFFFFFFFF = not seen yet (the first launch fills it from blockIdx)
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+        const unsigned key = (xcc_id & 0x7u) * 128u + ((hw_id >> 13) & 3u) * 32u + ((hw_id >> 12) & 1u) * 16u + ((hw_id >> 8) & 0xFu);
+        const unsigned seen = __hip_atomic_load(a.sib + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen != 0xFFFFFFFFu && seen < (unsigned)grid) range_v = seen;
+        else if (threadIdx.x == 0) __hip_atomic_store(a.sib + key, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+    const long long Ra = a.n * range_v / grid, Rb = a.n * (range_v + 1) / grid;
     const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
     const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
     const int S = a.dp >> (F8 ? 7 : 6);                               // 128-byte segments per row (64 halves, or 128 e4m3 codes)
@@ -1285,19 +1299,17 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     // 1 / norm of a tile's rows (+ the global thresholds) into the scratch half of that tile's parity: a tile's operands are
     // issued while the PREVIOUS tile is still being consumed and may land before that tile's epilogue has read its own
     auto issue_epi = [&](long long t0, bool sync_tau, int par) {
+        par = __builtin_amdgcn_readfirstlane(par);                    // (wave-uniform by construction; M0 wants to be told)
         dma4(a.inv_scan + t0 + r31, scratch_l + par * 512 + 256);     // 64 words: lanes 32..63 repeat the 32 rows
         if (sync_tau) dma4(a.tau_bin + (lane < QN ? lane : QN - 1), scratch_l + par * 512);
     };
 
-    // Tile order within the workgroup's range: the LDS counter hands out LOGICAL tiles 0, 1, 2, ...; the rows of logical tile t are
-    // those of tile (t + rot) mod ntiles.  rot = 0 walks every range from its first row -- all workgroups then sit at the same
-    // offset of ranges that lie a constant stride apart; debug bit 4 (value 16) rotates each range by a per-workgroup amount
-    // (round 6 experiment: are the slow first tiles of a small shard's launch HBM-channel conflicts of that lockstep?)
-    const int rot = ((a.debug & 16) && ntiles > 0) ? (int)(((unsigned)blockIdx.x * 2654435761u >> 8) % (unsigned)ntiles) : 0;
-    auto phys = [&](int t) { const int p_ = t + rot; return p_ >= ntiles ? p_ - ntiles : p_; };
+    // (Round 6 measured two start-up orders and kept neither: every workgroup's range walked from a per-workgroup rotated tile instead of
+    //  its first row, and the four waves of a workgroup started a quarter of a tile time apart -- the slow first tiles of a small
+    //  shard's launch are neither a lockstep of the ranges nor of the waves: profiles/r06_scan2_rotation_and_stagger.log)
     const bool service = kScan2Service && wid == kScan2Waves;          // wave 4: publishes blocks, refreshes and syncs thresholds (k_scan2_service)
-    bool active = !service && wid < ntiles;
-    int cur_tile = active ? phys(wid) : wid;
+    int cur_tile = wid;
+    bool active = !service && cur_tile < ntiles;
     const char* src_cur[4];
     const char* src_nxt[4];
     if (active) {
@@ -1337,6 +1349,29 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
         dbg[70] = ((unsigned long long)xcc_id << 32) | hw_id;
     }
     if (service) k_scan2_service<NT>(a, ctl, lane);
+#ifdef VF_EXPERIMENTS
+    // timing experiment (debug bit 6, INVALID RESULTS): the workgroup walks its range twice in one life -- is the slow start of a
+    // launch tied to the workgroup's start (then the second pass runs at the steady rate) or to the start of a stream of rows?
+    const int passes = (a.debug & 64) ? 2 : 1;
+#else
+    constexpr int passes = 1;
+#endif
+    int tiles_done = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+    if (pass > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *next_tile = (u32)kScan2Waves;
+        __syncthreads();
+        cur_tile = wid;
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
+            issue_epi(lo + (long long)cur_tile * kRowTile, !kScan2Service, tiles_done & 1);
+#pragma unroll
+            for (int sg = 0; sg < kRing; ++sg) issue_seg(src_cur, sg, sg);
+        }
+    }
     if (active) {
         f16v acc[NT];
 #pragma unroll
@@ -1344,7 +1379,6 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
         int buf = 0;                                                   // ring buffer of the segment about to be consumed
-        int tiles_done = 0;
         while (true) {
             const long long t0 = lo + (long long)cur_tile * kRowTile;
             int claimed;
@@ -1354,7 +1388,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
                 claimed = __builtin_amdgcn_readfirstlane(v_);
             }
             const bool more = claimed < ntiles;
-            const int nxt = more ? phys(claimed) : cur_tile;
+            const int nxt = more ? claimed : cur_tile;
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
             // the service wave folds the global thresholds into tau_lds; without it the waves take turns
@@ -1440,8 +1474,9 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
         }
-        if (dbg && dbg_rec > 4) dbg[69] = (unsigned long long)tiles_done;
     }
+    }
+    if (dbg && dbg_rec > 4) dbg[69] = (unsigned long long)tiles_done;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) prefetches have landed before LDS is reused
     if (!service && lane == 0) atomicAdd((u32*)(ctl + 8), 1u);   // this streaming wave is done: the service wave leaves after the fourth
     if (dbg) dbg[1] = wall_clock64();
@@ -2607,16 +2642,26 @@ int scan_wide8_stage_cap(int waves) { return waves == 8 ? 3584 : 896; }   // wha
 int scan_wide8_occupancy(int waves, int stage_cap) {
     int n = -1;
     const size_t lds = scan_wide8_lds_bytes(waves, stage_cap);
+#ifdef VF_EXPERIMENTS
     hipError_t e = waves == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_wide8<4>, 256, lds)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_wide8<8>, 512, lds);
+#else
+    if (waves != 8) return -1;   // the 4-wave form (measured and rejected) is built with -DVF_EXPERIMENTS only
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_wide8<8>, 512, lds);
+#endif
     return e == hipSuccess ? n : -(int)e;
 }
 
 hipError_t launch_scan_wide8(const ScanArgs& a, int waves, hipStream_t s) {
     const int grid = 8 * a.jtiles * ((a.rgroups + 7) / 8);
+#ifdef VF_EXPERIMENTS
     static const size_t pad4 = [] { const char* e = getenv("VF_W8_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // experiment: extra LDS per 4-wave workgroup (forces one per CU)
     if (waves == 4) hipLaunchKernelGGL(k_scan_wide8<4>, dim3(grid), dim3(256), scan_wide8_lds_bytes(4, a.stage_cap) + pad4, s, a);
-    else hipLaunchKernelGGL(k_scan_wide8<8>, dim3(grid), dim3(512), scan_wide8_lds_bytes(8, a.stage_cap), s, a);
+    else
+#else
+    if (waves != 8) return hipErrorInvalidValue;
+#endif
+    hipLaunchKernelGGL(k_scan_wide8<8>, dim3(grid), dim3(512), scan_wide8_lds_bytes(8, a.stage_cap), s, a);
     return hipGetLastError();
 }
 
@@ -3191,7 +3236,9 @@ hipError_t scan_configure() {
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide<kModeMain, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#ifdef VF_EXPERIMENTS
     if ((e = hipFuncSetAttribute((const void*)k_scan_wide8<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#endif
     if ((e = hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

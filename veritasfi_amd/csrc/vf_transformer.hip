@@ -3033,9 +3033,15 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+#endif
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+#endif
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm9_tn<EPI_BIAS_RESIDUAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS);
@@ -3044,10 +3050,18 @@ static hipError_t configure_once() {
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_QGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#endif
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNA_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#endif
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_RES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#endif
+#ifdef VF_EXPERIMENTS
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_LNRES_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+#endif
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm8p_tn<EPI_GATED_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
     if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_gemm_tn<EPI_RESIDUAL_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -3490,6 +3504,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
         // 12 800 x 768 x 3072 90.8 against 79.0, the 13- / 25- / 100-pair forwards 2.62 / 4.38 / 13.0 ms against 2.39 / 3.77 / 11.3, same
         // box, same call (profiles/r05_streamk.log).  The whole-product cut above pays the same toll per slice but only where two thirds of
         // the chip would otherwise idle.
+#ifdef VF_EXPERIMENTS   // (off even there unless asked for; the default build does not carry the kernel)
         if constexpr (EPI != EPI_BIAS_QGELU) {
             static const int p9_sk = getenv("VF_GEMM_9_STREAMK") ? atoi(getenv("VF_GEMM_9_STREAMK")) : 0;
             static const int sk_min_saved = getenv("VF_GEMM_9_STREAMK_MIN_SAVED") ? atoi(getenv("VF_GEMM_9_STREAMK_MIN_SAVED")) : 5;
@@ -3506,6 +3521,7 @@ static hipError_t gemm(const half_t* A, const half_t* W, const float* bias, cons
                 }
             }
         }
+#endif
         const bool p9_size = p8_min_forced() ? tiles_ll >= p8_min : tiles_ll >= p9_min;
         if (big_ok && K % PBK == 0 && K >= 4 * PBK && (kind == 10 || (kind == 0 && p9_now && p9_size))) {
             const int tiles = (M / PBM) * (N / PBN), ncu = device_cus() & ~7, nkt = K / PBK;
@@ -3738,8 +3754,12 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
     // write the RAW sums and their row sums, the next product reads the raw sum as its A operand through gamma-folded
     // weights, the next residual product normalises its residual element by element.  e->y holds y1 (attention sum),
     // e->x holds y2 (FFN sum) of the previous layer; the last layer writes y2 over y1 and one k_layernorm produces e->x.
+#ifdef VF_EXPERIMENTS
     const bool fold = !skinny && !small && enc_fold_ok(e, Mp);
     if (fold) { VFT_TRY(enc_ensure_fold(e, st)); g_ln_fold_forwards.fetch_add(1, std::memory_order_relaxed); }
+#else
+    constexpr bool fold = false;   // measured slower at every batch size: the folded epilogues are built with -DVF_EXPERIMENTS only
+#endif
     LnFold lf0{};
     lf0.n_parts = H / 256; lf0.Mp = e->cap_tokens; lf0.inv_h = 1.0f / (float)H; lf0.eps = c.ln_eps;
     for (int l = 0; l < c.layers; ++l) {
@@ -3751,11 +3771,13 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
         const half_t* f16 = fold ? e->fold16 + (size_t)l * fold16_layer(c) : nullptr;
         const float* f32 = fold ? e->fold32 + (size_t)l * fold32_layer(c) : nullptr;
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, M, 3 * H, H, st));
+#ifdef VF_EXPERIMENTS
         else if (fold && l > 0) {   // A = the previous layer's raw FFN sum; its LayerNorm sits in the folded weights + epilogue
             LnFold lf = lf0;
             lf.stats_in = e->stats_b; lf.colsum = f32;
             VFT_HIP(gemm8p_fold<EPI_LNA>(e->x, f16, f32 + 3 * H, nullptr, e->qkv, Mp, 3 * H, H, lf, st));
         }
+#endif
         else VFT_HIP(gemm<EPI_BIAS>(e->x, Wqkv, bqkv, nullptr, e->qkv, Mp, 3 * H, H, st, 0, &e->gws));
         static const bool att_stream = getenv("VF_ATT_STREAM") != nullptr;  // A/B switch: streaming kernel on the BERT path
         // Sequences longer than 512 tokens (bge-m3 = XLM-R-large with an 8194-entry position table: config/example.yaml:3,
@@ -3770,6 +3792,7 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             if (!e->q_folded) return fail(VF_EUNSUPPORTED, "the resident attention kernel needs the softmax scale folded into the query projection");
             launch_attention2<0>(e->qkv, e->d_mask, B, T, c.heads, e->ctx, st, seq_off);
         }
+#ifdef VF_EXPERIMENTS
         if (fold) {
             LnFold lf = lf0;
             lf.stats_out = e->stats_a;
@@ -3789,6 +3812,9 @@ static int enc_forward_device(vf_encoder* e, int B, int T, int Tv, bool has_tt, 
             if (l + 1 == c.layers) hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g2, b2n, c.ln_eps, M, H, e->x);
             continue;
         }
+#else
+        (void)f16; (void)f32; (void)lf0;
+#endif
         if (skinny) VFT_HIP(gemm_skinny<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, M, H, H, st));
         else VFT_HIP(gemm<EPI_BIAS_RESIDUAL>(e->ctx, Wo, bo, e->x, e->y, Mp, H, H, st, 0, &e->gws));
         hipLaunchKernelGGL(k_layernorm, dim3((M + 7) / 8), dim3(256), 0, st, e->y, g1, b1n, c.ln_eps, M, H, e->x);

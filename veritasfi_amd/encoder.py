@@ -209,24 +209,27 @@ class HipEmbeddings:
         from .pretrained import load_embeddings
         return load_embeddings(model_name, **kw)
 
-    def _embed(self, texts):
+    def _embed(self, texts, as_lists: bool = False):
         if not texts:
-            return np.zeros((0, self.encoder.hidden), np.float32)
+            return [] if as_lists else np.zeros((0, self.encoder.hidden), np.float32)
         if self._tok.max_length != self.max_length or self._tok.tokenizer is not self.tokenizer:
             self._tok = BatchTokenizer(self.tokenizer, self.max_length)
         pieces = split_for_overlap(len(texts), int(self.batch_size))
-        out = pipelined(pieces, lambda p: self._tok.encode(texts[p[0]:p[1]]), lambda a: self.encoder.forward(*a), self.overlap_tokenize)
+        out = pipelined(pieces, lambda p: self._tok.encode(texts[p[0]:p[1]]), lambda a: self.encoder.forward(*a), self.overlap_tokenize,
+                        finish=(lambda a: a.tolist()) if as_lists else None)
+        if as_lists:     # list[list[float]], what the langchain interface returns; each piece was converted beside the next piece's forward
+            return [row for piece in out for row in piece]
         return np.vstack(out)
 
     def embed_documents(self, texts):
-        return self._embed(list(texts)).tolist()
+        return self._embed(list(texts), as_lists=True)
 
     def embed_query(self, text):
         return self._embed([text])[0].tolist()
 
     def embed_queries(self, texts):
         """Batched queries (one forward) -- used by FaissRetriever.invoke instead of len(texts) forwards."""
-        return self._embed(list(texts)).tolist()
+        return self._embed(list(texts), as_lists=True)
 
 
 class HipReranker:

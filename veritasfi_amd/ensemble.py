@@ -201,7 +201,10 @@ class EnsembleRetriever:
 
     def _faiss_branch(self, input, hyde_chunks, seen, out, bundle_cnt):
         inputs = [input] + list(hyde_chunks)
-        ids_list, scores_list = self.faiss_retriever.invoke(inputs, SEARCH_DEPTH)
+        # upstream always searches 2048 deep (:64-66) and reads the tail only as the neighbour expansion's score map (:85-107): without
+        # enable_expand the first faiss_k entries are all that is looked at, and an exact search's top-k is a prefix of its top-2048
+        depth = SEARCH_DEPTH if self.enable_expand else min(SEARCH_DEPTH, max(1, int(self.faiss_k)))
+        ids_list, scores_list = self.faiss_retriever.invoke(inputs, depth)
         for ids, scores in zip(ids_list, scores_list):
             ids = [int(i) for i in ids]
             score_map = dict(zip(ids, scores))

@@ -39,14 +39,15 @@ class FaissRetriever:
             self.index = DenseIndex(embeddings.astype(np.float16), device_id=device_id, device_ids=device_ids)
         elif corpus_dtype == "fp8":
             import torch
-            # torch's cast to e4m3 does not saturate (|x| > 448 becomes a NaN code) and flushes small magnitudes; a cosine does not
-            # change under a positive per-row scale, so every row is scaled to put its largest magnitude on 448 -- the whole e4m3
-            # range is used whatever the embedder's output scale (un-normalised rows included), and nothing can overflow
+            # torch's cast to e4m3 does not saturate (|x| > 448 becomes a NaN code) and flushes small magnitudes (the components of a
+            # unit vector of 768+ dimensions sit around the subnormal edge 2^-6).  A cosine does not change under a positive per-row
+            # scale, so every row is scaled by the POWER OF TWO that puts its largest magnitude into [224, 448]: exact in fp32 (the
+            # rounding of in-range values is what it was), nothing can overflow, and the small components keep their three bits
             x = np.ascontiguousarray(embeddings.astype(np.float32))
             if not np.isfinite(x).all():
                 raise ValueError("corpus_dtype='fp8': the embeddings hold non-finite values")
-            peak = np.abs(x).max(axis=1, keepdims=True)
-            x = x * (448.0 / np.where(peak > 0, peak, 1.0)).astype(np.float32)
+            peak = np.abs(x).max(axis=1, keepdims=True).astype(np.float64)
+            x = x * np.exp2(np.floor(np.log2(448.0 / np.where(peak > 0, peak, 448.0)))).astype(np.float32)
             np.clip(x, -448.0, 448.0, out=x)
             codes = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
             if ((codes & 0x7F) == 0x7F).any():
@@ -55,6 +56,16 @@ class FaissRetriever:
         else:
             raise ValueError(f"corpus_dtype {corpus_dtype!r}: one of f32, f16, fp8")
         logger.info(f"Building HIP dense index with {len(embeddings)} vectors of dimension {dimension}")
+
+    @classmethod
+    def from_index(cls, index: DenseIndex, embedding_fn, rows_as_given: bool = True):
+        """The same retriever over an index that already exists -- ``DenseIndex.from_file`` (the corpus file the embed loop wrote,
+        corpus_file.py: no Chroma round trip at start-up, ensembleRetriever.py:39-43), a device tensor, a sharded group.  Use it as
+        ``EnsembleRetriever(..., retriever_cls=lambda _embeddings, fn: FaissRetriever.from_index(ix, fn))``.
+        rows_as_given: the index holds the embedder's own values (see __init__)."""
+        self = cls.__new__(cls)
+        self.embeddings, self.index, self.rows_as_given = embedding_fn, index, bool(rows_as_given)
+        return self
 
     def invoke(self, querys: list, k: int):
         """(I, D) = ids and cosine scores, best first, shape [len(querys), k]; -1 / -FLT_MAX pad a corpus with fewer than k rows

@@ -32,11 +32,13 @@ def _worker() -> ThreadPoolExecutor:
         return _pool
 
 
-def pipelined(batches, prepare, run, overlap: bool = True) -> list:
-    """[run(prepare(b)) for b in batches] with prepare(batch i + 1) running beside run(batch i)."""
+def pipelined(batches, prepare, run, overlap: bool = True, finish=None) -> list:
+    """[finish(run(prepare(b))) for b in batches] with prepare(batch i + 1) -- and finish(batch i - 1), the conversion of a result into
+    what the caller's interface wants (``ndarray.tolist()`` for ``embed_documents``: 2.4 ms per 100 x 768) -- running beside run(batch i)."""
     batches = list(batches)
     if not overlap or len(batches) <= 1:
-        return [run(prepare(b)) for b in batches]
+        outs = [run(prepare(b)) for b in batches]
+        return outs if finish is None else [finish(o) for o in outs]
     pool = _worker()
     out = []
     nxt = pool.submit(prepare, batches[0])
@@ -44,8 +46,9 @@ def pipelined(batches, prepare, run, overlap: bool = True) -> list:
         ready = nxt.result()
         if i + 1 < len(batches):
             nxt = pool.submit(prepare, batches[i + 1])
-        out.append(run(ready))
-    return out
+        res = run(ready)
+        out.append(res if finish is None else pool.submit(finish, res))
+    return out if finish is None else [f.result() for f in out]
 
 
 def split_for_overlap(n: int, step: int, min_piece: int = 16) -> list:

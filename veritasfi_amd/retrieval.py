@@ -14,42 +14,54 @@ import numpy as np
 from .index import DenseIndex
 
 
+def _host_array(x) -> np.ndarray:
+    """ndarray view of a tokenizer / model output (numpy array, or a CPU torch tensor as HF-style callables return)."""
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
 def last_token_pool(last_hidden_states, attention_mask):
-    """step3_mul.py:181-188, including its quirk: ``[:, -1]`` only when EVERY row ends in a 1."""
-    import torch
-    left_padding = (attention_mask[:, -1].sum() == attention_mask.shape[0])
-    if left_padding:
+    """The hidden state of each sequence's LAST token, with the reference's rule for telling the padding side
+    (``experiments/retriever/step3_mul.py:181-188``): when the final column of the mask is 1 in EVERY row the batch counts as
+    left-padded and column -1 is taken for all rows; otherwise row i yields position ``mask[i].sum() - 1`` (so a right-padded batch
+    in which one row happens to be full length still takes the second branch -- and a mixed batch follows the same arithmetic as
+    upstream, quirk included).  Works on numpy arrays and on torch tensors alike (indexing only); the type of the input comes back."""
+    rows = attention_mask.shape[0]
+    if int(attention_mask[:, -1].sum()) == rows:
         return last_hidden_states[:, -1]
-    sequence_lengths = attention_mask.sum(dim=1) - 1
-    batch_size = last_hidden_states.shape[0]
-    return last_hidden_states[torch.arange(batch_size, device=last_hidden_states.device), sequence_lengths]
+    ends = attention_mask.sum(1) - 1
+    return last_hidden_states[list(range(rows)), ends]
 
 
-def get_embeddings(texts, model, tokenizer, device, batch_size=32, pooling="last_token", max_length=None):
-    """step3_mul.py:191-209 (``pooling="last_token"``, max_length 4096) and
-    continuous_retrieval.py:127-152 (``pooling="mean"``: unmasked ``mean(dim=1)``, max_length 512).
-    ``model`` is any callable with the HF signature (our HIP encoder wrapper or an HF module)."""
-    import torch
+def get_embeddings(texts, model, tokenizer, device=None, batch_size=32, pooling="last_token", max_length=None):
+    """``get_embeddings(texts, model, tokenizer, device, batch_size)`` of both experiment scripts -- ``step3_mul.py:191-209``
+    (``pooling="last_token"``, truncation at 4096) and ``continuous_retrieval.py:127-152`` (``pooling="mean"``: the UNMASKED
+    ``mean(dim=1)`` over whatever the tokenizer padded to, truncation at 512) -- returning float32 ``[n, hidden]``.
+
+    ``model`` is one of this package's HF-signature wrappers (``HipModel`` / ``HipDecoderModel``): the forward runs on the GPU.  With
+    ``model.pooled`` the pooling happens there too (one call per batch, nothing but ``[b, hidden]`` comes back); a callable that only
+    offers ``model(**inputs).last_hidden_state`` -- the reference's generic shape -- has its states pooled here on the host with the
+    rule above.  ``device`` is accepted for signature compatibility; the handles know their device."""
+    texts = list(texts)
     if not texts:
         return np.array([])
-    if max_length is None:
-        max_length = 4096 if pooling == "last_token" else 512
-    all_embeddings = []
-    for i in range(0, len(texts), batch_size):
-        batch_texts = texts[i:i + batch_size]
-        inputs = tokenizer(batch_texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length)
-        if hasattr(model, "pooled"):  # this package's HipModel: forward + pooling in one GPU call
-            all_embeddings.append(np.asarray(model.pooled(pooling, **inputs), dtype=np.float32))
+    limit = max_length if max_length is not None else (4096 if pooling == "last_token" else 512)
+    if pooling not in ("last_token", "mean"):
+        raise ValueError("pooling must be 'last_token' or 'mean'")
+    on_device = getattr(model, "pooled", None)
+    pieces = []
+    for start in range(0, len(texts), batch_size):
+        enc = tokenizer(texts[start:start + batch_size], padding=True, truncation=True, return_tensors="pt", max_length=limit)
+        if on_device is not None:
+            pieces.append(np.asarray(on_device(pooling, **enc), dtype=np.float32))
             continue
-        inputs = {k: v.to(device) for k, v in inputs.items()}
-        with torch.no_grad():
-            outputs = model(**inputs)
-            if pooling == "last_token":
-                embeddings = last_token_pool(outputs.last_hidden_state, inputs["attention_mask"])
-            else:
-                embeddings = outputs.last_hidden_state.mean(dim=1)
-            all_embeddings.append(embeddings.float().cpu().numpy())
-    return np.vstack(all_embeddings)
+        states = _host_array(model(**enc).last_hidden_state).astype(np.float32, copy=False)
+        if pooling == "mean":
+            pieces.append(states.mean(axis=1, dtype=np.float32))
+        else:
+            pieces.append(np.asarray(last_token_pool(states, _host_array(enc["attention_mask"])), dtype=np.float32))
+    return np.vstack(pieces)
 
 
 def top_chunks_from_embeddings(evidence_embs, chunks_emb, top_k: int, device_id: int = 0):
