@@ -86,13 +86,35 @@ def parse():
     return ap.parse_args()
 
 
+SHARE_DEVICE = os.environ.get("VF_BENCH_SHARE_DEVICE") == "1"   # rehearsal: every rank on device 0, collectives over gloo (host copies)
+MAX_PROCS_ON_ONE_GPU = 6                                         # the pool's process guard
+
+
+def exchange_plan(world, nslots, exchange_every, exchange):
+    """Batches per all-gather + merge (E) and the number of result buckets -- the rank-count-dependent sizes of the serving loop."""
+    E = exchange_every if exchange_every > 0 else (4 if exchange else 1)
+    nbuckets = 2 if E >= max(1, nslots - 1) else nslots + 1
+    return E, nbuckets
+
+
+def _barrier(dist, local):
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[local])
+    else:
+        dist.barrier()
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks OURSELVES, as the reference's
     multi-GPU entry spawns its own workers (experiments/retriever/step3_mul.py:405-452), relay rank 0's JSON line and
     fail if any rank failed.  This parent never touches the GPU (torch.cuda.device_count() does not initialise it on this
     image) and never exec()s: the ranks are children of `python -m torch.distributed.run`."""
     import torch
-    if not args.dry_launch:
+    if SHARE_DEVICE and not args.dry_launch and args.gpus > MAX_PROCS_ON_ONE_GPU:
+        print(f"bench.py: VF_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and this pool allows {MAX_PROCS_ON_ONE_GPU} processes on a "
+              f"GPU: --gpus {args.gpus} refused", file=sys.stderr)
+        return 2
+    if not args.dry_launch and not SHARE_DEVICE:
         seen = torch.cuda.device_count()
         if seen < args.gpus:
             print(f"bench.py: --gpus {args.gpus} asked for, {seen} GPU(s) visible -- refusing to run a smaller job under "
@@ -129,16 +151,51 @@ def dry_launch(args):
     if rank == args.dry_fail_rank:
         print(f"rank {rank}: failing on request", file=sys.stderr)
         os._exit(3)
-    per = (args.rows + world - 1) // world
-    lo, hi = min(args.rows, rank * per), min(args.rows, (rank + 1) * per)
+    import numpy as np
+    import torch
+    from veritasfi_amd.sharded import ShardedScorer, shard_bounds
+    lo, hi = shard_bounds(args.rows, world, rank)
     got = [None] * world
     dist.all_gather_object(got, {"rank": rank, "pid": os.getpid(), "rows": [lo, hi], "local_rank": int(os.environ["LOCAL_RANK"])})
     dist.barrier()
+    # the rank-count-dependent pieces of a real run, on host tensors: the exchange plan, ONE all-gather of every rank's packed part
+    # (its layout: [ids int64 (E * nq, k) | scores fp32 (E * nq, k)], the bytes index.packed_part_bytes names), the `world`-part merge
+    # order, the data-parallel split of the re-rank pairs and the per-rank share of the host cores the oracle check takes
+    E, nbuckets = exchange_plan(world, 2, args.exchange_every, world > 1)
+    nq, k = E * args.batch, args.k
+    part_bytes = nq * k * 12
+    rng = np.random.default_rng(1000 + rank)
+    sc = np.sort(rng.standard_normal((nq, k)).astype(np.float32), axis=1)[:, ::-1].copy()
+    ids = (lo + rng.integers(0, max(1, hi - lo), size=(nq, k))).astype(np.int64)
+    blob = torch.from_numpy(np.concatenate([ids.view(np.uint8).ravel(), sc.view(np.uint8).ravel()]))
+    assert blob.numel() == part_bytes
+    allb = torch.empty(world * part_bytes, dtype=torch.uint8)
+    dist.all_gather_into_tensor(allb, blob)
+    parts = allb.numpy().reshape(world, part_bytes)
+    g_ids = np.stack([p[:nq * k * 8].view(np.int64).reshape(nq, k) for p in parts])
+    g_sc = np.stack([p[nq * k * 8:].view(np.float32).reshape(nq, k) for p in parts])
+    assert np.array_equal(g_ids[rank], ids) and np.array_equal(g_sc[rank], sc)
+    for g in range(world):            # every part carries ids of ITS shard only: the merge may rely on disjoint id ranges
+        glo, ghi = shard_bounds(args.rows, world, g)
+        assert ghi == glo or ((g_ids[g] >= glo) & (g_ids[g] < ghi)).all()
+    flat_sc, flat_id = np.concatenate(list(g_sc), axis=1), np.concatenate(list(g_ids), axis=1)
+    order = np.lexsort((flat_id, -flat_sc), axis=1)[:, :k]       # score descending, lower id first: the product's declared order
+    merged = np.take_along_axis(flat_sc, order, axis=1)
+    assert (merged[:, :-1] >= merged[:, 1:]).all()
+    scorer = ShardedScorer(lambda a, b: np.arange(a, b, dtype=np.float32))
+    pairs = scorer(args.rerank_pairs)
+    assert np.array_equal(pairs, np.arange(args.rerank_pairs, dtype=np.float32))
+    plo, phi = shard_bounds(args.rerank_pairs, world, rank)
+    shares = [None] * world
+    dist.all_gather_object(shares, phi - plo)
     if rank == 0:
         assert [g["rank"] for g in got] == list(range(world)) and got[0]["rows"][0] == 0 and got[-1]["rows"][1] == args.rows
         assert all(a["rows"][1] == b["rows"][0] for a, b in zip(got, got[1:])), "shards are not contiguous"
         print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": dist.get_backend(), "ranks": got,
-                          "rows_per_gpu": [g["rows"][1] - g["rows"][0] for g in got]}), flush=True)
+                          "rows_per_gpu": [g["rows"][1] - g["rows"][0] for g in got],
+                          "batches_per_exchange": E, "result_buckets": nbuckets, "packed_part_bytes": part_bytes,
+                          "all_gather_bytes": world * part_bytes, "merge_parts": world, "rerank_pairs_per_rank": shares,
+                          "oracle_threads_per_rank": max(1, (os.cpu_count() or 8) // world)}), flush=True)
     dist.destroy_process_group()
     return 0
 
@@ -678,7 +735,8 @@ def rerank_p50_sharded(args, device):
         enc, cfg = random_encoder(shape, head=1, vocab=32000)
     except Exception as e:  # noqa: BLE001
         err = f"{type(e).__name__}: {e}"
-    ok = torch.tensor([0 if enc is None else 1], dtype=torch.int32, device=device)   # a rank without a replica must not leave
+    nccl = dist.get_backend() == "nccl"
+    ok = torch.tensor([0 if enc is None else 1], dtype=torch.int32, device=device if nccl else "cpu")   # a rank without a replica must not leave
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)                                         # the others waiting in a collective
     if int(ok.item()) == 0:
         if enc is not None:
@@ -691,7 +749,7 @@ def rerank_p50_sharded(args, device):
     first = scorer(args.rerank_pairs)
     ts = []
     for _ in range(12):
-        dist.barrier(device_ids=[device.index])
+        _barrier(dist, device.index)
         t0 = time.perf_counter()
         out = scorer(args.rerank_pairs)
         ts.append((time.perf_counter() - t0) * 1e3)
@@ -773,7 +831,7 @@ def texts_legs(args):
     hf_ms = p50(lambda: bt(docs[:100], padding=True, truncation=True, max_length=512, return_tensors="np"), n=3)
     out["embed_texts"] = {
         "model_shape": "bert-base", "tokens": 512, "texts_per_s": round(1000 / stream, 1), "what": "embed_documents(1000 texts), device batches of 100, "
-        "batch i + 1 tokenised under batch i's forward; texts_per_s_one_call = one embed_documents(100 texts) call (two halves)",
+        "batch i + 1 tokenised under batch i's forward, batch i - 1's tolist() beside it; texts_per_s_one_call = one embed_documents(100 texts) call (one device batch: nothing to overlap)",
         "texts_per_s_one_call": round(100 / one, 1), "pre_tokenised_chunks_per_s": round(100 / pre, 1),
         "ratio_to_pre_tokenised": round((1000 / stream) / (100 / pre), 4), "serial_loop_texts_per_s": round(1000 / stream_serial, 1),
         "serial_one_call_texts_per_s": round(100 / one_serial, 1), "tokenize_100_ms": round(tok_ms * 1e3, 3),
@@ -897,6 +955,8 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if SHARE_DEVICE:
+        local = 0                 # rehearsal of world > 1 on a one-GPU box: every rank drives device 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # VF_BENCH_FORCE_EXCHANGE=1 runs the all-gather + merge even with one rank (rehearsal of the N>1 path)
@@ -906,7 +966,7 @@ def main():
     # same binary; profiles/r02b_pg_init_order.log): the allocations made after an eagerly bound communicator exists
     # read slower.  Lazy initialisation (communicator created at the first collective) leaves them alone.
     if world > 1 or (exchange and "RANK" in os.environ):
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if SHARE_DEVICE else "nccl")   # (RCCL refuses two ranks on one device; gloo carries the blobs through the host)
     devs = None
     if args.single_process:
         assert world == 1, "--single-process runs without torchrun"
@@ -936,8 +996,7 @@ def main():
     # collects E consecutive batches and is shipped with ONE all-gather + ONE merge launch over E * nq queries
     # (--exchange-every E; E = 1 is one exchange per batch).  Every result is exchanged and merged either way; bucketing
     # only divides the fixed cost of the collective.  Two buckets alternate (the previous one is in flight on the wire).
-    E = args.exchange_every if args.exchange_every > 0 else (4 if exchange else 1)
-    nbuckets = 2 if E >= max(1, nslots - 1) else nslots + 1
+    E, nbuckets = exchange_plan(world, nslots, args.exchange_every, exchange)
     buckets = [vf.packed_result_buffer(E * args.batch, args.k, device) for _ in range(nbuckets)]
     def views(i):
         blob, ids, sc = buckets[(i // E) % nbuckets]
@@ -948,13 +1007,19 @@ def main():
         m_ids = torch.empty((E * args.batch, args.k), dtype=torch.int64, device=device)
         m_sc = torch.empty((E * args.batch, args.k), dtype=torch.float32, device=device)
     merged = [None]
+    direct_exchange = not dist.is_initialized() or dist.get_backend() == "nccl"
 
     def finish(slot, i, last):
         index.search_end(slot)
         if not exchange:
             merged[0] = views(i)
         elif i % E == E - 1 or last:  # bucket complete: ONE all-gather of the packed per-shard top-k over xGMI + the merge kernel
-            dist.all_gather_into_tensor(g_blob, buckets[(i // E) % nbuckets][0])
+            if direct_exchange:
+                dist.all_gather_into_tensor(g_blob, buckets[(i // E) % nbuckets][0])
+            else:                 # gloo (the shared-device rehearsal): the same single collective over host copies
+                h_all = torch.empty(g_blob.shape, dtype=torch.uint8)
+                dist.all_gather_into_tensor(h_all, buckets[(i // E) % nbuckets][0].cpu())
+                g_blob.copy_(h_all)
             merged[0] = vf.merge_topk_packed_device(g_blob, world, E * args.batch, args.k, m_ids, m_sc)
 
     def run(steps, stamps=None):
@@ -982,7 +1047,7 @@ def main():
             torch.cuda.synchronize(dv)
         torch.cuda.synchronize()
         if dist.is_initialized():
-            dist.barrier(device_ids=[local])
+            _barrier(dist, local)
             torch.cuda.synchronize()
 
     # The serving loop runs on its OWN stream, not the legacy default stream: the library's main scans live on CU-masked
@@ -1004,7 +1069,7 @@ def main():
     p50_step_ms = None if gaps is None or len(gaps) < 3 else float(np.median(gaps[1:]))   # (the first gap holds the pipeline fill)
     torch.cuda.current_stream(device).wait_stream(side)
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if direct_exchange else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = index.profile()
@@ -1297,7 +1362,7 @@ def main():
         print(json.dumps(line), flush=True)
     index.close()
     if dist.is_initialized():
-        dist.barrier(device_ids=[local])
+        _barrier(dist, local)
         dist.destroy_process_group()
 
 

@@ -39,3 +39,19 @@ def test_refuses_more_gpus_than_visible():
     n = torch.cuda.device_count()
     r = _bench("--gpus", str(n + 2), "--steps", "1", "--warmup", "0", timeout=120)
     assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_dry_launch_eight_ranks_run_every_rank_count_dependent_piece():
+    """World 8 over gloo on the CPU: the sharding of configs[2] (10M rows -> 8 x 1.25M), the exchange plan (4 batches per all-gather,
+    two result buckets), ONE all-gather of eight packed parts in the product's blob layout and their 8-part merge order, the
+    data-parallel split of 100 re-rank pairs (13 x 7 + 9) and the per-rank share of the host cores -- every piece of bench.py's rank
+    code whose arithmetic depends on the number of ranks has run once before a node appears (no GPU here: a one-GPU box takes at most
+    six ranks on its card, tests/test_gpu_bench_paths.py rehearses the device side with four)."""
+    r = _bench("--gpus", "8", "--dry-launch", timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["rows_per_gpu"] == [1_250_000] * 8
+    assert out["batches_per_exchange"] == 4 and out["result_buckets"] == 2
+    assert out["packed_part_bytes"] == 4 * 64 * 100 * 12 and out["all_gather_bytes"] == 8 * out["packed_part_bytes"] and out["merge_parts"] == 8
+    assert out["rerank_pairs_per_rank"] == [13] * 7 + [9]
+    assert out["oracle_threads_per_rank"] == max(1, (os.cpu_count() or 8) // 8)

@@ -43,3 +43,19 @@ def test_bench_single_process_two_shards_on_one_device():
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert "ONE handle" in out["config"]["workload"]
     assert out["search_stats"]["exact_reruns_last_batch"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_share_the_one_gpu():
+    """`bench.py --gpus 4` as the driver starts it on a node -- the launcher, four rank processes, row shards, every bucket through ONE
+    all-gather + ONE 4-part merge launch, the data-parallel re-rank (25 pairs per rank + an all-gather of the logits), the per-shard
+    oracle check of the merged result -- rehearsed on the one-GPU box: VF_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and carries
+    the collectives over gloo (RCCL refuses two ranks on one device; the pool allows six processes on a card, so four ranks + this
+    process).  Nothing here is a performance figure."""
+    out, err = _bench(["--gpus", "4", "--rows", "500000", "--steps", "8", "--warmup", "2", "--rerank-pairs", "100", "--rerank-tokens", "64"],
+                      {"VF_BENCH_SHARE_DEVICE": "1"}, timeout=800)
+    assert out["n_gpus"] == 4 and out["config"]["rows_per_gpu"] == [125_000] * 4 and out["config"]["batches_per_exchange"] == 4
+    assert out["rccl"]["backend"] == "gloo" and out["rccl"]["world"] == 4 and len({d["pid"] for d in out["rccl"]["devices"]}) == 4
+    assert out["verify"] is not None and out["verify"]["verified"] is True, out["verify"]
+    assert out["rerank"]["pairs_on_rank0"] == 25 and out["rerank_p50_ms"] > 0, out["rerank"]
+    assert out["value"] > 0

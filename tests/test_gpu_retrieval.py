@@ -1343,7 +1343,7 @@ def test_wide_scan_hostile_data(vf, oracle):
 # ---- differential fuzz across the dispatch boundaries ------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_fuzz_across_dispatch_boundaries_bit_exact(vf, oracle):
-    """tools/fuzz_search.py for 45 s on a fixed seed: random rows / dim / queries / k / dtype / data shape / options drawn to sit on
+    """tools/fuzz_search.py for 20 s (VF_TEST_FUZZ_SECONDS) on a fixed seed: random rows / dim / queries / k / dtype / data shape / options drawn to sit on
     the dispatch boundaries, every result compared bit for bit with the oracle (a 330-s run: profiles/r04_fuzz_seed1.log)."""
     import importlib.util, time
     spec = importlib.util.spec_from_file_location("fuzz_search", os.path.join(ROOT, "tools", "fuzz_search.py"))
@@ -1351,7 +1351,7 @@ def test_fuzz_across_dispatch_boundaries_bit_exact(vf, oracle):
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(20260404)
     t0, n_cases, fails, kernels = time.time(), 0, [], set()
-    while time.time() - t0 < 45.0:
+    while time.time() - t0 < float(os.environ.get("VF_TEST_FUZZ_SECONDS", "20")):   # (45 s until round 6; the soak runs are tools/fuzz_search.py's)
         case = fz.draw_case(rng, 1e10)
         ok, st, why = fz.run_case(vf, oracle, case, repeat=2)
         n_cases += 1
@@ -1360,7 +1360,7 @@ def test_fuzz_across_dispatch_boundaries_bit_exact(vf, oracle):
             fails.append((case, why, st))
     print("fuzz:", n_cases, "cases; (path, scan kernel) seen:", sorted(kernels, key=str))
     assert not fails, fails[:3]
-    assert n_cases >= 40 and len(kernels) >= 4
+    assert n_cases >= 15 and len(kernels) >= 3
 
 
 @pytest.mark.gpu

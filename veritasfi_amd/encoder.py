@@ -196,8 +196,8 @@ class HipEmbeddings:
     def __init__(self, tokenizer, encoder: HipEncoder, max_length: int = 512, batch_size: int = 32, overlap_tokenize: bool = True):
         self.tokenizer, self.encoder = tokenizer, encoder
         self.max_length, self.batch_size = max_length, batch_size
-        # batch i + 1 is tokenised (Rust backend of a fast tokenizer, host_tokenize.py) while batch i is on the device; a call that
-        # fits one batch is cut in two halves for the same reason.  The partition does not depend on the flag: same bits either way.
+        # batch i + 1 is tokenised (Rust backend of a fast tokenizer, host_tokenize.py) while batch i is on the device and batch i - 1's
+        # result is converted to lists.  The partition does not depend on the flag: same bits either way.
         self.overlap_tokenize = overlap_tokenize
         self._tok = BatchTokenizer(tokenizer, max_length)
 
@@ -214,8 +214,13 @@ class HipEmbeddings:
             return [] if as_lists else np.zeros((0, self.encoder.hidden), np.float32)
         if self._tok.max_length != self.max_length or self._tok.tokenizer is not self.tokenizer:
             self._tok = BatchTokenizer(self.tokenizer, self.max_length)
-        pieces = split_for_overlap(len(texts), int(self.batch_size))
-        out = pipelined(pieces, lambda p: self._tok.encode(texts[p[0]:p[1]]), lambda a: self.encoder.forward(*a), self.overlap_tokenize,
+        # device batches of exactly batch_size texts, as before round 6: an embedding's last bits follow the batch it was computed in (the
+        # product kernels' tile count), and a text must embed to the same bits whether it arrives in a call of 100 or of 1000 -- so a
+        # single-batch call is NOT cut in halves here (the re-ranker's scores carry no such identity: HipReranker does cut)
+        step = max(1, int(self.batch_size))
+        pieces = [(lo, min(lo + step, len(texts))) for lo in range(0, len(texts), step)]
+        out = pipelined(pieces, lambda p: self._tok.encode(texts[p[0]:p[1]]), lambda a: self.encoder.forward(*a),
+                        self.overlap_tokenize and self._tok.direct,     # (a pure-Python tokenizer holds the interpreter lock: serial loop)
                         finish=(lambda a: a.tolist()) if as_lists else None)
         if as_lists:     # list[list[float]], what the langchain interface returns; each piece was converted beside the next piece's forward
             return [row for piece in out for row in piece]
@@ -272,10 +277,14 @@ class HipReranker:
         tk = self._tok_for(max_length)
         # device batches of `step` pairs; with fused batches a call that fits ONE of them (the reference's 100 pairs) goes as two
         # halves so that the second is tokenised while the first runs.  fuse_batches=False keeps exactly batch_size pairs per forward.
-        pieces = split_for_overlap(len(sentence_pairs), step) if self.fuse_batches else \
+        # A tokenizer that runs in Python (no Rust backend) holds the interpreter lock while it works: a prefetch thread would make the
+        # thread that drives the device wait for it (up to the 5-ms switch interval) instead of hiding it -- such a tokenizer keeps whole
+        # batches and the serial loop.  The partition depends on the tokenizer's kind, never on overlap_tokenize.
+        halves = self.fuse_batches and tk.direct
+        pieces = split_for_overlap(len(sentence_pairs), step) if halves else \
             [(lo, min(lo + step, len(sentence_pairs))) for lo in range(0, len(sentence_pairs), step)]
         outs = pipelined(pieces, lambda p: tk.encode([q for q, _ in sentence_pairs[p[0]:p[1]]], [d for _, d in sentence_pairs[p[0]:p[1]]]),
-                         lambda a: self.encoder.forward(*a), self.overlap_tokenize)
+                         lambda a: self.encoder.forward(*a), self.overlap_tokenize and tk.direct)
         scores = [float(v) for s_ in outs for v in np.atleast_1d(s_)]
         if normalize:
             scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]
@@ -447,10 +456,11 @@ class HipDecoderEmbeddings:
             return np.zeros((0, self.decoder.hidden), np.float32)
         if self._tok.tokenizer is not self.tokenizer:
             self._tok = BatchTokenizer(self.tokenizer, self.max_length)
-        pieces = split_for_overlap(len(texts), int(self.batch_size), min_piece=8)
+        step = max(1, int(self.batch_size))
+        pieces = [(lo, min(lo + step, len(texts))) for lo in range(0, len(texts), step)]     # (whole batches: see HipEmbeddings._embed)
         # L2 normalisation in the pooling kernel (vf_decoder_forward_pooled), whatever the handle was created with
         out = pipelined(pieces, lambda p: self._tokenize(texts[p[0]:p[1]]), lambda a: self.decoder.forward(a[0], a[1], normalize=True),
-                        self.overlap_tokenize)
+                        self.overlap_tokenize and self._tok.rust_backed)
         return np.vstack(out)
 
     def embed_documents(self, texts):
@@ -528,11 +538,12 @@ class HipLLMReranker:
             # device batches sized from the longest POSSIBLE row (max_length + prompt), so that the partition is known before
             # anything is tokenised and piece i + 1 can be tokenised under piece i's forward
             step = max(step, (self.max_batch_tokens // max(max_length, 1)) // step * step)
-        pieces = split_for_overlap(n, step, min_piece=8) if self.fuse_batches else [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+        pieces = split_for_overlap(n, step, min_piece=8) if (self.fuse_batches and self._tok.rust_backed) else \
+            [(lo, min(lo + step, n)) for lo in range(0, n, step)]
 
         def prepare(p):
             return self._pad_left(build_llm_reranker_inputs(sentence_pairs[p[0]:p[1]], self.tokenizer, self.prompt, max_length, self._tok))
-        outs = pipelined(pieces, prepare, lambda a: self.decoder.forward(a[0], a[1]), self.overlap_tokenize)
+        outs = pipelined(pieces, prepare, lambda a: self.decoder.forward(a[0], a[1]), self.overlap_tokenize and self._tok.rust_backed)
         scores = [float(v) for s_ in outs for v in np.atleast_1d(s_)]
         if normalize:
             scores = [1.0 / (1.0 + np.exp(-v)) for v in scores]

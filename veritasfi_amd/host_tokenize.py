@@ -97,7 +97,13 @@ class BatchTokenizer:
 
     @property
     def direct(self) -> bool:
+        """encode() goes straight to the Rust backend (a HF fast tokenizer with a pad token)."""
         return self._rust is not None
+
+    @property
+    def rust_backed(self) -> bool:
+        """The tokenizer has a Rust backend at all (encode_plain uses it, pad token or not): its work releases the interpreter lock."""
+        return _backend(self.tokenizer) is not None
 
     def encode(self, texts, second=None):
         texts = list(texts)
