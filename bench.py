@@ -1199,12 +1199,12 @@ def main():
         # inside the bench): reported only when the committed measurement is for exactly this workload
         traffic = None
         try:
-            traffic_file = os.path.join("profiles", "pmc_traffic_scan2_10Mx768.json" if stats.get("scan_kernel") == 2 else "pmc_traffic_scan_10Mx768.json")
+            traffic_file = os.path.join("profiles", "pmc_traffic_scan2_10Mx768.json" if stats.get("scan_kernel") in (2, 5) else "pmc_traffic_scan_10Mx768.json")
             rec = json.load(open(os.path.join(ROOT, traffic_file)))
             w = rec["workload"]
             if args.corpus_dtype == "f16" and not devs and (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (args.rows, args.dim, args.batch, args.k, world):
                 traffic = round(rec["hbm_bytes_per_launch"])
-            elif args.corpus_dtype == "f16" and not devs and stats.get("scan_kernel") == 2:
+            elif args.corpus_dtype == "f16" and not devs and stats.get("scan_kernel") in (2, 5):
                 # a rank of the 8-GPU configuration (or a one-GPU run of its shard size): the PMC passes of that shard size
                 for tag in ("1250k", "2500k", "5000k"):      # the per-GPU shards of 10M rows on 8 / 4 / 2 GPUs
                     tf2 = os.path.join("profiles", f"pmc_traffic_scan2_{tag}.json")
@@ -1250,7 +1250,8 @@ def main():
                     "hbm_floor_ms": round(prof["scan_bytes_per_launch"] / HBM_PEAK_GBS / 1e6, 4),
                     "pipeline_ms_per_batch": round(prof["pipeline_ms_total"] / prof["scan_launches"], 4)}
         elif prof["scan_launches"] > 0:
-            kname = {2: "vf::k_scan2<2> (whole-line LDS-DMA corpus loads)", 1: "vf::k_scan<main> (register loads)"}.get(stats.get("scan_kernel"), "vf::k_scan")
+            kname = {2: "vf::k_scan2<2> (whole-line LDS-DMA corpus loads)", 1: "vf::k_scan<main> (register loads)",
+                     5: "vf::k_scan2r<2> (k_scan2 with half of the query image in registers, six-segment rings)"}.get(stats.get("scan_kernel"), "vf::k_scan")
             iso_ms = prof["scan_ms_total"] / prof["scan_launches"]
             iso_gbs = prof["scan_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9
             common = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,

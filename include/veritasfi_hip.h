@@ -56,7 +56,7 @@ typedef struct vf_search_stats {
     int64_t wide_queries;    /* queries those passes served (up to 1024 per pass) */
     int64_t aux_cus;         /* CUs the main scan left to the small kernels of the other slots (0 = no CU split) */
     int64_t scans_overlap;   /* 1 = main scans of consecutive slots were not ordered against each other */
-    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide, 4 k_scan_wide8 (fp8 matrix instruction) */
+    int64_t scan_kernel;     /* main-scan kernel of the call: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA), 3 k_scan_wide, 4 k_scan_wide8 (fp8 matrix instruction), 5 k_scan2r (k_scan2, half the query image in registers) */
     int64_t reserved[4];
 } vf_search_stats;
 
@@ -140,10 +140,11 @@ int vf_index_stats(vf_index* idx, vf_search_stats* out);
  *   instruction on the row bytes as stored (k_scan_wide8: the query goes in as a hi + lo pair of e4m3 codes and its exactly
  *   known residual is the query's certificate bound), 0 the fp16 instruction on converted rows (k_scan_wide).  Results are
  *   identical bit for bit; vf_search_stats.scan_kernel says which one ran.
- * "sample_rows": rows per wave the sample pass scores to seed the thresholds: -1 auto (4 for shards of up to 1.1M rows while the
+ * "sample_rows": rows per wave the sample pass scores to seed the thresholds: -1 auto (8 for shards of up to 1.5M rows while the
  *   sample still holds 16 k' rows, else 16), or 1..64.  A speed setting: a looser seed admits more candidates, results do not change.
- * "scan_impl": the narrow scan's kernel: 1 k_scan (register loads), 2 k_scan2 (whole-line LDS-DMA loads) for fp16 rows (default),
- *   3 k_scan2 wherever it fits (e4m3 rows converted in registers).  Same results from each. */
+ * "scan_impl": the narrow scan's kernel: 1 k_scan (register loads); 2 (default) k_scan2 (whole-line LDS-DMA loads) for fp16 rows, and
+ *   its register-image form k_scan2r for the shard sizes it measured faster on (fp16 rows of 768 elements, 1.1M < n <= 6M); 3 k_scan2
+ *   wherever it fits (e4m3 rows converted in registers); 4 k_scan2, never k_scan2r; 5 k_scan2r wherever it fits.  Same results from each. */
 int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
 /* Live kernel timing with HIP events on the stream the kernels run on (bench.py roofline):
  * after vf_index_set_option(idx, "profile", 1) every fused search records events around its main

@@ -694,6 +694,38 @@ def test_scan_kernels_agree_and_match_oracle(vf, oracle, n, d, nq, k, want_kerne
         assert ix.stats()["aux_cus"] == 0 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
 
 
+@pytest.mark.parametrize("n,nq,k", [(60_000, 64, 100), (40_003, 64, 100), (50_000, 20, 10), (30_000, 1, 2048), (300_000, 33, 100)])
+def test_scan2r_half_image_in_registers_matches_oracle_and_scan2(vf, oracle, n, nq, k):
+    """k_scan2r (round 6, option scan_impl = 5): fp16 rows of 768 elements with the B fragments of a row's first six segments held in
+    registers and six-segment rings -- the same products in the same order as k_scan2, so ids, score bits AND the candidate counts of
+    the two kernels agree, and both equal the oracle; other widths fall back to k_scan2."""
+    c, q = _data(123, n, 768, nq, np.float16)
+    want_i, want_s = oracle.search(c, q, k)
+    with vf.DenseIndex(c) as ix:
+        ix.set_option("force_path", 1)
+        got = {}
+        for impl in (5, 2, 5):
+            ix.set_option("scan_impl", impl)
+            i, s_ = ix.search(q, k)
+            st = ix.stats()
+            assert st["path"] == 1 and st["exact_reruns"] == 0 and st["scan_kernel"] == impl, st
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), impl
+            got[impl] = st["candidates"]
+        assert abs(got[5] - got[2]) <= max(8, got[2] // 4), got     # (the thresholds' refresh timing differs from run to run, the filter does not)
+        ix.set_option("scan_impl", 5)
+        for _ in range(12):      # a timing-dependent fault (an LDS-DMA landing on fragments still being read) shows as SOME runs differing
+            i, s_ = ix.search(q, k)
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+    c2, q2 = _data(124, 40_000, 640, 64, np.float16)
+    with vf.DenseIndex(c2) as ix:
+        ix.set_option("force_path", 1)
+        ix.set_option("scan_impl", 5)
+        i, s_ = ix.search(q2, 50)
+        assert ix.stats()["scan_kernel"] == 2                        # dp = 640: not this kernel
+        wi, ws = oracle.search(c2, q2, 50)
+        assert np.array_equal(i, wi) and np.array_equal(_bits(s_), _bits(ws))
+
+
 @pytest.mark.parametrize("n,d,nq,k,want_kernel", [
     (60_000, 768, 64, 100, 2),      # six 128-code segments per row beside a 96 KB fp16 query image
     (50_000, 1024, 24, 10, 2),      # one N-tile: 64 KB image
@@ -720,8 +752,8 @@ def test_scan_kernels_agree_on_fp8_rows(vf, oracle, n, d, nq, k, want_kernel):
             assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), impl
             want = {3: want_kernel}.get(impl, 1)
             assert st["path"] == 1 and st["exact_reruns"] == 0 and st["scan_kernel"] == want, (impl, st)
-        with pytest.raises(RuntimeError):                   # (4 was the fp8-matrix-instruction form of k_scan2: removed in round 4)
-            ix.set_option("scan_impl", 4)
+        with pytest.raises(RuntimeError):                   # (1 .. 5 exist; 4 = k_scan2 and never k_scan2r, which e4m3 rows do not take anyway)
+            ix.set_option("scan_impl", 6)
     finally:
         ix.close()
 

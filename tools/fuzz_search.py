@@ -30,7 +30,7 @@ def draw_case(rng, max_work):
     data = pick(["normal", "normal", "dupes", "clusters", "scaled", "zeros", "sorted", "lowrank"])
     opts = {}
     if rng.random() < 0.3:
-        opts["scan_impl"] = pick([1, 2, 3])
+        opts["scan_impl"] = pick([1, 2, 3, 4, 5])
     if rng.random() < 0.2:
         opts["wide_mfma"] = pick([0, 1])
     if rng.random() < 0.2:

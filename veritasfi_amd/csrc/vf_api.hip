@@ -243,9 +243,17 @@ static int build_common(vf_index* ix) {
 // consecutive scans overlap; larger shards keep the whole chip and ordered scans (measured, round 3: 1.25M rows 0.384 ->
 // 0.362 ms per batch, 2.5M 0.717 -> 0.682, 5M 1.280 -> 1.269, 10M no change; profiles/r03_scan2_sweep.log).
 constexpr int64_t kSplitMaxRows = 6'000'000;
+// Round 6: where k_scan2r serves the rows (fp16 rows of 768 elements; a wave keeps 24 KB in flight there) the split + overlapping scans
+// win at EVERY size -- 7.5M rows 1.878 -> 1.811 ms per batch, 10M rows 2.538 -> 2.466-2.473 (0.7585 -> 0.78 of 8 TB/s), whole chip +
+// ordered scans with k_scan2 being the 2.538; k_scan2r on the whole chip with ordered scans LOSES (2.58-2.59): profiles/r06_scan2r_10m.log
+static int64_t split_limit(const vf_index* ix) {
+    const bool r_rows = ix->dtype != VF_DTYPE_FP8_E4M3 && ix->scan_impl != 4 && ix->scan_impl != 1 && ix->scan_impl != 3 && !ix->steal_opt &&
+                        scan2r_stage_cap(ix->dp, kMaxBatch) >= 256;
+    return r_rows ? INT64_MAX : kSplitMaxRows;
+}
 static int64_t resolved_aux(const vf_index* ix) {
     if (ix->aux_applied >= 0) return ix->aux_applied;   // what the existing scan streams are masked with (0 if masking failed)
-    int64_t a = ix->aux_cus >= 0 ? ix->aux_cus : (ix->n <= kSplitMaxRows ? 32 : 0);
+    int64_t a = ix->aux_cus >= 0 ? ix->aux_cus : (ix->n <= split_limit(ix) ? 32 : 0);
     if (a <= 0 || ix->n_cu < 64 || a * 2 > ix->n_cu) return 0;
     return a;
 }
@@ -610,7 +618,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
         ix->aux_cus = value;
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
-    else if (s == "scan_impl") { if (!in_range(1, 3)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (k_scan2 for fp16 rows) or 3 (k_scan2 wherever it fits, e4m3 rows converted)"); ix->scan_impl = value; }
+    else if (s == "scan_impl") { if (!in_range(1, 5)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (auto: k_scan2 for fp16 rows, k_scan2r where it measured faster), 3 (k_scan2 wherever it fits, e4m3 rows converted), 4 (k_scan2 for fp16 rows, never k_scan2r) or 5 (k_scan2r wherever it fits: fp16 rows of 768 elements)"); ix->scan_impl = value; }
     else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") {
@@ -981,8 +989,21 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // k_scan2 serves fp16 rows by default; e4m3 rows only on request (scan_impl = 3): per byte they carry twice the MFMA and
         // LDS work plus the conversions, and with ONE wave per SIMD nothing hides it -- measured 0.53 against k_scan's 0.66 of
         // peak at 10M x 768 fp8 (profiles/r03_f8_sweep.log)
-        const int cap2 = ((ix->scan_impl == 3 || (ix->scan_impl == 2 && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
-        if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
+        const int cap2 = ((ix->scan_impl == 3 || ((ix->scan_impl == 2 || ix->scan_impl == 4 || ix->scan_impl == 5) && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
+        // k_scan2r (round 6): half of the query image in registers, six-segment rings -- fp16 rows of 768 elements.  Measured against
+        // k_scan2 in separate processes, alternating (profiles/r06_scan2r_ab.log): the 8-GPU rank's shard (1.25M rows) 0.3469-0.3528 ms
+        // per batch against 0.3538-0.3602 (2.2 % faster: a wave keeps 24 KB in flight instead of 12), 10M rows level (2.538 vs 2.548 --
+        // the scan sits on the copy ceiling there), configs[1] (1M rows) 3 % SLOWER (0.303-0.315 vs 0.293-0.303: that step is the
+        // prologue chain's, and the workgroup's start is 2.3 us longer).  So: auto (scan_impl = 2) takes it above 1.1M rows wherever the
+        // scans run on the CU split and overlap (which, for these rows, is every size: split_limit); 5 forces it, 4 forbids it.
+        const bool r_auto = ix->scan_impl == 2 && ix->n > 1100000 && s.scan_stream != s.stream && resolved_overlap(ix);   // (with the CU split and overlapping scans only: above)
+        const int capr = ((ix->scan_impl == 5 || r_auto) && !f8 && !ix->steal_opt && !(ix->debug & (32 | 64))) ? scan2r_stage_cap(ix->dp, qt) : 0;
+        if (capr >= 256) {
+            ScanArgs a2 = a;
+            a2.stage_cap = capr;
+            VF_HIP(launch_scan2r(a2, qt, p.grid, sst));
+            s.scan_kernel = 5;
+        } else if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
             ScanArgs a2 = a;
             a2.stage_cap = cap2;
 #ifdef VF_EXPERIMENTS

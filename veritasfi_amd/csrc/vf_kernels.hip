@@ -1515,6 +1515,243 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_scan2r (round 6): k_scan2 with HALF of the query image in REGISTERS and a ring twice as deep.
+//
+// What round 6 measured on the 8-GPU rank's shard (1.25M x 768, tools/stamps_gap.py, profiles/r06_*): a wave of k_scan2 keeps three
+// 4-KB segments in flight and its rate is ring / loaded latency -- 12 KB / 1.7-2.4 us -- so every cycle it spends off the streaming
+// path (the candidate path of a tile with a candidate: ~0.3 us, entered in most tiles of a small shard) comes straight off its
+// throughput: the ring is full, nothing more can be asked for, and nothing can be caught up afterwards.  A deeper ring has no room:
+// at d = 768 the 64-query image alone takes 96 of the 160 KB.  But the image is the B operand of EVERY matrix instruction and a wave
+// owns a whole SIMD's register file (one wave per SIMD: 512 registers, of which k_scan2 uses ~230): the B fragments of the first
+// RB = S / 2 segments of a row (k = 0 .. 383 at d = 768) are loaded ONCE per workgroup life into 48 x 4 registers per lane and stay
+// there; LDS holds only the other half of the image (48 KB) and the four rings grow from 3 to 6 segments (24 KB in flight per wave).
+// Half of the B fragment reads leave the LDS pipe with it.  Everything else -- row DMA with the swizzle in the source address, tile
+// claiming, epilogue operands by DMA, threshold filter, candidate stage, flush -- is k_scan2's, and so are the scores: the same
+// products accumulate in the same order (segment by segment), so the approximate scores, the candidates and the results are
+// bit-identical to k_scan2's.  Built for dp = 768 (S = 12); other widths keep k_scan2.
+// The register half is fetched with ordinary loads BEFORE anything else and settled with the s_waitcnt BUILTIN (which the compiler's
+// own wait insertion accounts for): no vector-memory load with a register destination is pending while tiles run (k_attention2's rule).
+// ------------------------------------------------------------------------------------------------
+constexpr int kRingR = 6, kRegSegs = 6;
+
+size_t scan2r_lds_bytes(int dp, int qn_tile, int stage_cap) {
+    const size_t img = (size_t)(dp - kRegSegs * 64) * qn_tile * 2;
+    return img + (size_t)kScan2Waves * (kRingR * kSegBytes + kScratchBytes) + kCtlBytes + (size_t)stage_cap * 16;
+}
+int scan2r_stage_cap(int dp, int qn_tile) {   // < 256 = "not this kernel"
+    if (dp != 2 * kRegSegs * 64) return 0;    // S = 12 segments: half in registers, half in LDS
+    const size_t fixed = scan2r_lds_bytes(dp, qn_tile, 0);
+    if (fixed + 256 * 16 > 160 * 1024) return 0;
+    const size_t area = std::min<size_t>(160 * 1024 - fixed, 32 * 1024);
+    return (int)(area / 16);
+}
+
+template <int NT>
+__global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
+    const unsigned long long t_entry = (a.debug & 512) ? wall_clock64() : 0ull;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int QN = NT * kQueryTile, RB = kRegSegs, RING = kRingR, THREADS = kScan2Waves * 64;
+    constexpr int MODE = kModeMain;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const long long grid = gridDim.x;
+    const long long swg = (long long)a.samp * (kScanThreads / 64);
+    const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
+    const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
+    const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
+    constexpr int S = 2 * RB;
+    // ---- the register half of the image: B fragments of segments 0 .. RB - 1 (k-group 8 sg + 4 h + i of query 32 nt + r31), loaded first
+    h8 breg[RB][4][NT];
+    {
+        const char* qb = (const char*)a.qimg + ((long long)(4 * h) * QN + r31) * 16;
+#pragma unroll
+        for (int sg = 0; sg < RB; ++sg)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    breg[sg][i][nt] = *(const h8*)(qb + (long long)sg * (8 * QN * 16) + i * (QN * 16) + nt * (kQueryTile * 16));
+    }
+    // LDS carve-up: four rings of RING segments | the LDS half of the image (segments RB .. S - 1) | scratch | control block | stage
+    char* ring = smem + (size_t)wid * (RING * kSegBytes);
+    char* img = smem + kScan2Waves * RING * kSegBytes;
+    constexpr size_t kImgBytes = (size_t)(S - RB) * 64 * QN * 2;
+    char* scratch = img + kImgBytes + (size_t)wid * kScratchBytes;
+    char* ctl = img + kImgBytes + kScan2Waves * kScratchBytes;
+    u32* next_tile = (u32*)(ctl + 4);
+    const unsigned ring_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(ring)), scratch_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(scratch));
+    const int drow = lane >> 3;
+    auto src_of = [&](int tile, int m) -> const char* {
+        const int row = 8 * m + drow;
+        long long r = lo + (long long)tile * kRowTile + row;
+        r = r < hi - 1 ? r : hi - 1;
+        return a.rows + r * a.row_bytes + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
+    };
+    auto issue_seg = [&](const char* const (&src)[4], int seg, int buf) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dma16(src[m] + (long long)seg * 128, ring_l + buf * kSegBytes + m * 1024);
+    };
+    auto issue_epi = [&](long long t0, bool sync_tau, int par) {
+        par = __builtin_amdgcn_readfirstlane(par);
+        dma4(a.inv_scan + t0 + r31, scratch_l + par * 512 + 256);
+        if (sync_tau) dma4(a.tau_bin + (lane < QN ? lane : QN - 1), scratch_l + par * 512);
+    };
+    int cur_tile = wid;
+    const bool active = cur_tile < ntiles;
+    const char* src_cur[4];
+    const char* src_nxt[4];
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
+        issue_epi(lo + (long long)cur_tile * kRowTile, true, 0);
+#pragma unroll
+        for (int sg = 0; sg < RING; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S = 12 >= RING)
+    }
+    {   // the LDS half of the image, verbatim (it starts RB segments into the image); control block + candidate stage zeroed
+        const char* srcq = (const char*)a.qimg + (long long)RB * (8 * QN * 16);
+        constexpr int nkb = (int)(kImgBytes >> 10);
+        const unsigned img_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(img));
+        const int wu = __builtin_amdgcn_readfirstlane(wid);
+        for (int c = wu; c < nkb; c += kScan2Waves) dma16(srcq + ((long long)c << 10) + (lane << 4), img_l + ((unsigned)c << 10));
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), the BUILTIN: the register half, this wave's share of the LDS half and its ring have landed
+        uint4* z = (uint4*)ctl;
+        const int nz = kCtlBytes / 16 + a.stage_cap;
+        for (int i = tid; i < nz; i += THREADS) z[i] = make_uint4(0u, (i == 0) ? (u32)kScan2Waves : 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (tid < QN) ((int*)(ctl + 16))[tid] = a.tau_bin[tid];
+    __syncthreads();
+
+    const char* lds_lane = img + ((4 * h) * QN + r31) * 16;            // + (sg - RB) * (8 QN 16) + i * (QN 16) + nt * (32 * 16)
+    const int asw = (r31 >> 1) & 7;
+    const char* a_lane = ring + r31 * 128;
+    const int dbg_rec = (a.debug & 512) ? 72 : 4;
+    unsigned long long* dbg = ((a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * dbg_rec : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
+    if (dbg && dbg_rec > 4) {
+        dbg[68] = t_entry;
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+        dbg[70] = ((unsigned long long)xcc_id << 32) | hw_id;
+    }
+    int tiles_done = 0;
+    if (active) {
+        f16v acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+        int buf = 0;
+        while (true) {
+            const long long t0 = lo + (long long)cur_tile * kRowTile;
+            int claimed;
+            {
+                int v_ = 0;
+                if (lane == 0) v_ = (int)atomicAdd(next_tile, 1u);
+                claimed = __builtin_amdgcn_readfirstlane(v_);
+            }
+            const bool more = claimed < ntiles;
+            const int nxt = more ? claimed : cur_tile;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
+            const bool sync_now = (tiles_done & (kScan2Waves - 1)) == wid;
+            const bool sync_next = ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
+            if (dbg && dbg_rec > 4 && tiles_done < 64) dbg[4 + tiles_done] = wall_clock64();
+            // one body for both halves: BREG picks the B fragments from the registers (compile-time segment) or from LDS
+            auto consume = [&](auto sg_c, const char* bb) {
+                constexpr int sgc = decltype(sg_c)::value;        // >= 0: register segment; -1: LDS
+                // segments sg + 1 .. sg + RING - 1 (4 (RING - 1) DMA instructions, and the <= 2 epilogue words issued among them) may still be in flight
+                asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                static_assert(4 * (RING - 1) == 20, "the counted wait above is written for RING = 6");
+                const char* ab = a_lane + buf * kSegBytes;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const h8 af = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        h8 bf;
+                        if constexpr (sgc >= 0) bf = breg[sgc][i][nt];
+                        else bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the refill overwrites the LDS these fragments were read from (k_scan2's note)
+            };
+            auto refill = [&](int sg) {
+                const int s3 = sg + RING;
+                if (s3 < S) issue_seg(src_cur, s3, buf);
+                else {
+                    if (s3 == S) issue_epi(lo + (long long)nxt * kRowTile, sync_next, (tiles_done + 1) & 1);
+                    issue_seg(src_nxt, s3 - S, buf);
+                }
+                buf = buf + 1 == RING ? 0 : buf + 1;
+            };
+#define VF_R_SEG(N) consume(std::integral_constant<int, N>{}, nullptr); refill(N);
+            VF_R_SEG(0) VF_R_SEG(1) VF_R_SEG(2) VF_R_SEG(3) VF_R_SEG(4) VF_R_SEG(5)
+#undef VF_R_SEG
+            static_assert(RB == 6, "the register segments are spelled out above");
+            for (int sg = RB; sg < S; ++sg) {
+                consume(std::integral_constant<int, -1>{}, lds_lane + (long long)(sg - RB) * (8 * QN * 16));
+                refill(sg);
+            }
+            const char* sc = scratch + (tiles_done & 1) * 512;
+            EpiRegs<NT> epi;
+            epi.inv_lane = *(const float*)(sc + 256 + r31 * 4);
+            epi.sync_tau = sync_now;
+            if (sync_now) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) epi.tau_g[nt] = *(const int*)(sc + (nt * kQueryTile + r31) * 4);
+            }
+            tile_epilogue<NT, MODE, true>(a, acc, epi, t0, hi, 0, lane, ctl);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+            ++tiles_done;
+            if (!more) break;
+            cur_tile = nxt;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
+        }
+    }
+    if (dbg && dbg_rec > 4) dbg[69] = (unsigned long long)tiles_done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd((u32*)(ctl + 8), 1u);
+    if (dbg) dbg[1] = wall_clock64();
+    __syncthreads();
+    if (dbg) dbg[2] = wall_clock64();
+    {   // flush the staged candidates (k_scan2's)
+        const u32 staged = *(const u32*)ctl;
+        const u32 nst = staged < (u32)a.stage_cap ? staged : (u32)a.stage_cap;
+        uint4* ent = (uint4*)(ctl + kCtlBytes);
+        u32* qcnt = (u32*)img;          // the LDS half of the image is dead now
+        u32* qbase = qcnt + QN;
+        if (tid < QN) qcnt[tid] = 0u;
+        __syncthreads();
+        for (u32 i = tid; i < nst; i += THREADS) {
+            const uint4 e = ent[i];
+            const u32 q = e.z & 0xFFu;
+            if (e.w != 1u || q >= (u32)QN) continue;
+            ent[i].w = 2u + atomicAdd(qcnt + q, 1u);
+        }
+        __syncthreads();
+        if (tid < QN) {
+            const u32 c = qcnt[tid];
+            qbase[tid] = c ? atomicAdd(a.cnt + tid * kCntStride, c) : 0u;
+        }
+        __syncthreads();
+        for (u32 i = tid; i < nst; i += THREADS) {
+            const uint4 e = ent[i];
+            if (e.w < 2u) continue;
+            const u32 q = e.z & 0xFFu;
+            const u32 gs = qbase[q] + (e.w - 2u);
+            if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)e.y << 32) | (u64)e.x;
+        }
+    }
+    if (dbg) dbg[3] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_scan_wide: the scan for LARGE query batches (nq > 128; BASELINE configs[4]: B = 1024, k = 1000).
 //
 // With more than ~100 queries per pass the contraction is MFMA-bound, not HBM-bound (2*nq/elt
@@ -2744,6 +2981,13 @@ hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_f
     return hipGetLastError();
 }
 
+hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
+    const size_t lds = scan2r_lds_bytes(a.dp, qn_tile, a.stage_cap);
+    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2r<1>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_scan2r<2>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int NT, int G, int MODE>
 static hipError_t configure_one() {
     hipError_t e = hipFuncSetAttribute((const void*)k_scan<NT, G, MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3227,6 +3471,8 @@ hipError_t scan_configure() {
     VF_CFG(1, 1) VF_CFG(1, 2) VF_CFG(1, 3) VF_CFG(1, 4)
     VF_CFG(2, 1) VF_CFG(2, 2) VF_CFG(2, 3) VF_CFG(2, 4)
 #undef VF_CFG
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
