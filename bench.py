@@ -1079,8 +1079,13 @@ def main():
     # shares the chip with its predecessor.  The roofline figure of the kernel is then taken in a second, ORDERED pass of
     # the same workload (scans serialised by events, as the timed region of the large-shard case runs anyway).
     prof_timed = None
-    if stats.get("scans_overlap"):
+    if stats.get("scans_overlap") and os.environ.get("VF_BENCH_NO_ISOLATED") == "1":
+        prof_timed = prof     # (profiling runs: the trace then holds the pipelined loop only; the isolated figure is absent from the line)
+    elif stats.get("scans_overlap"):
         prof_timed = prof
+        forced = stats.get("scan_kernel") == 5     # k_scan2r is the default only where scans overlap: name it for the ordered pass
+        if forced:
+            index.set_option("scan_impl", 5)
         index.set_option("overlap_scans", 0)
         with torch.cuda.stream(side):
             run(min(args.warmup, 10))
@@ -1090,6 +1095,8 @@ def main():
             fence()
         prof = index.profile()
         index.set_option("overlap_scans", -1)
+        if forced:
+            index.set_option("scan_impl", 2)
     verify_info, merged_equals_direct = None, None
     if exchange and (args.verify or (world > 1 and not args.no_verify)):
         run(E)                      # exactly one full bucket: batches 0 .. E-1 of the query pool

@@ -12,8 +12,8 @@ stats() {   # tag, kernel substring for the span, bench args...
   f=$(find gpurun_out/$tag -name "*kernel_stats.csv" | head -1); t=$(find gpurun_out/$tag -name "*kernel_trace.csv" | head -1)
   cp $f gpurun_out/${tag}_kernel_stats.csv
   head -7 $f | cut -c1-150
-  python3 tools/trace_span.py $t "$needle" 8 | tee gpurun_out/${tag}_span.txt
-  tail -1 gpurun_out/$tag/run.log | python3 -c "import json,sys; j=json.loads(sys.stdin.readline()); r=j['roofline']; print('bench under the profiler:', j['ms_per_step'], r['frac'], r.get('avg_launch_ms'), (r.get('isolated_launch') or {}).get('avg_launch_ms'))" | tee -a gpurun_out/${tag}_span.txt
+  python3 tools/trace_span.py $t "$needle" ${SKIP:-20} ${COUNT:-200} | tee gpurun_out/${tag}_span.txt
+  grep '^{' gpurun_out/$tag/run.log | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.readline()); r=j['roofline']; print('the bench line of this run (under the profiler): ms_per_step', j['ms_per_step'], 'roofline.frac', r['frac'], 'avg_launch_ms', r.get('avg_launch_ms'))" | tee -a gpurun_out/${tag}_span.txt
   find gpurun_out/$tag -name "*.csv" -delete
 }
 pmc() {   # tag, counter, bench args...
@@ -22,7 +22,7 @@ pmc() {   # tag, counter, bench args...
   ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/gpurun_out/$tag -o $tag -- python3 $R/bench.py "$@" > $R/gpurun_out/$tag/run.log 2>&1 ) || { tail -3 gpurun_out/$tag/run.log; return 1; }
   f=$(find gpurun_out/$tag -name "*counter_collection.csv" | head -1)
   cp $f gpurun_out/${tag}_${ctr}.csv
-  tail -1 gpurun_out/$tag/run.log | python3 -c "import json,sys; j=json.loads(sys.stdin.readline()); print(j['roofline']['bytes_per_launch'])" > gpurun_out/${tag}_alg_bytes.txt
+  grep '^{' gpurun_out/$tag/run.log | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.readline()); print(j['roofline']['bytes_per_launch'])" > gpurun_out/${tag}_alg_bytes.txt
   find gpurun_out/$tag -name "*.csv" -delete
 }
 if [ "$part" = "a" ]; then
@@ -33,14 +33,18 @@ if [ "$part" = "a" ]; then
   bash tools/gpu_r06_bench.sh || exit 1
 else
   N="--no-cpu-baseline --no-rerank --no-shard-legs --no-startup"
-  echo "== kernel stats, headline 10M x 768"; stats r06_10m "k_scan2" --gpus 1 --steps 20 --warmup 5 $N || exit 1
+  export VF_BENCH_NO_ISOLATED=1      # the traces hold the pipelined loop only
+  echo "== kernel stats, headline 10M x 768"; SKIP=5 COUNT=20 stats r06_10m "k_scan2" --gpus 1 --steps 20 --warmup 5 $N || exit 1
+  echo "== kernel stats, headline, ORDERED scans (one launch at a time on the scan partition: what roofline.isolated_launch times)"; SKIP=5 COUNT=20 stats r06_10m_ordered "k_scan2" --gpus 1 --steps 20 --warmup 5 $N --opt overlap_scans=0 --opt scan_impl=5 || exit 1
+  [ "$2" = "ordered-only" ] && exit 0
   echo "== kernel stats, configs[1] 1M x 768"; stats r06_c2 "k_scan2" --gpus 1 --rows 1000000 --steps 200 --warmup 20 $N || exit 1
   echo "== kernel stats, the 8-GPU rank's shard 1.25M x 768 with the RCCL exchange in the loop (one rank, no launcher: rocprofv3 does not follow one)"
   export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 VF_BENCH_FORCE_EXCHANGE=1
   stats r06_shard8 "k_scan2" --gpus 1 --rows 1250000 --steps 200 --warmup 20 --verify $N || exit 1
   unset RANK LOCAL_RANK WORLD_SIZE MASTER_ADDR MASTER_PORT VF_BENCH_FORCE_EXCHANGE
   C5="--rows 10000000 --dim 1024 --batch 1024 --k 1000 --corpus-dtype fp8 --no-cpu-baseline --no-rerank --no-startup"
-  echo "== kernel stats, configs[4]"; stats r06_c5 "k_scan_wide8" $C5 --steps 24 --warmup 3 || exit 1
+  echo "== kernel stats, configs[4]"; SKIP=3 COUNT=24 stats r06_c5 "k_scan_wide8" $C5 --steps 24 --warmup 3 || exit 1
+  [ "$2" = "stats-only" ] && exit 0
   S="--steps 12 --warmup 3 $N --opt overlap_scans=0"
   # (ordered scans for the counter passes: one launch per bracket; k_scan2r is the default only where scans overlap, so it is named)
   for w in "10m 10000000 5" "c2 1000000 2" "s8 1250000 5"; do

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Launch interval of a kernel from a rocprofv3 kernel trace (CSV): (last end - first start) / dispatches, next to the
 average dispatch duration.  With overlapping dispatches (small shards: CU split + overlapping main scans) the interval is
-what a launch costs; bench.py's roofline uses the same definition.  usage: trace_span.py <kernel_trace.csv> <name substring> [skip]"""
+what a launch costs; bench.py's roofline uses the same definition.  usage: trace_span.py <kernel_trace.csv> <name substring> [skip [count]]
+(skip = the warm-up dispatches, count = the timed ones: what follows the timed loop in a bench run -- verification, the host-buffer entry,
+one call at a time -- is not part of the interval)"""
 import csv
 import sys
 
@@ -12,6 +14,8 @@ def main():
     rows = [r for r in csv.DictReader(open(path)) if needle in r.get("Kernel_Name", "")]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[skip:]
+    if len(sys.argv) > 4:
+        rows = rows[:int(sys.argv[4])]
     if not rows:
         print("no dispatch of", needle)
         return

@@ -221,7 +221,7 @@ class HipEmbeddings:
         pieces = [(lo, min(lo + step, len(texts))) for lo in range(0, len(texts), step)]
         out = pipelined(pieces, lambda p: self._tok.encode(texts[p[0]:p[1]]), lambda a: self.encoder.forward(*a),
                         self.overlap_tokenize and self._tok.direct,     # (a pure-Python tokenizer holds the interpreter lock: serial loop)
-                        finish=(lambda a: a.tolist()) if as_lists else None)
+                        finish=(lambda a: [row.tolist() for row in a]) if as_lists else None)   # (row by row: switch points for the driving thread)
         if as_lists:     # list[list[float]], what the langchain interface returns; each piece was converted beside the next piece's forward
             return [row for piece in out for row in piece]
         return np.vstack(out)

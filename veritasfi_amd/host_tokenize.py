@@ -41,14 +41,23 @@ def pipelined(batches, prepare, run, overlap: bool = True, finish=None) -> list:
         return outs if finish is None else [finish(o) for o in outs]
     pool = _worker()
     out = []
-    nxt = pool.submit(prepare, batches[0])
-    for i in range(len(batches)):
-        ready = nxt.result()
-        if i + 1 < len(batches):
-            nxt = pool.submit(prepare, batches[i + 1])
-        res = run(ready)
-        out.append(res if finish is None else pool.submit(finish, res))
-    return out if finish is None else [f.result() for f in out]
+    # The worker's Python sections (list -> array conversions) hold the interpreter lock; a thread that wants it back waits a whole
+    # switch interval (5 ms by default) before it even asks.  The driving thread needs the lock for microseconds between two device
+    # calls of ~10 ms: for the duration of this loop the interval is 0.2 ms (restored on every exit path).
+    import sys
+    keep = sys.getswitchinterval()
+    sys.setswitchinterval(min(keep, 2e-4))
+    try:
+        nxt = pool.submit(prepare, batches[0])
+        for i in range(len(batches)):
+            ready = nxt.result()
+            if i + 1 < len(batches):
+                nxt = pool.submit(prepare, batches[i + 1])
+            res = run(ready)
+            out.append(res if finish is None else pool.submit(finish, res))
+        return out if finish is None else [f.result() for f in out]
+    finally:
+        sys.setswitchinterval(keep)
 
 
 def split_for_overlap(n: int, step: int, min_piece: int = 16) -> list:
@@ -88,8 +97,14 @@ class BatchTokenizer:
                 # exactly what PreTrainedTokenizerFast.set_truncation_and_padding configures for padding=True, truncation=True
                 rust.enable_truncation(max_length=self.max_length, stride=0, strategy="longest_first",
                                        direction=getattr(tokenizer, "truncation_side", "right"))
-                rust.enable_padding(direction=getattr(tokenizer, "padding_side", "right"), pad_id=int(tokenizer.pad_token_id),
-                                    pad_type_id=int(getattr(tokenizer, "pad_token_type_id", 0) or 0), pad_token=str(tokenizer.pad_token))
+                # padding to the batch's longest row is done HERE, in numpy (same result as the backend's enable_padding: pad_id,
+                # pad_type_id, the tokenizer's padding side): the unpadded id lists are shorter to convert, the mask follows from the
+                # lengths and a single sequence's token types are all zero -- one list -> array conversion per row instead of three,
+                # and conversions are what this path costs beside the Rust call (they hold the interpreter lock)
+                rust.no_padding()
+                self._pad_left = getattr(tokenizer, "padding_side", "right") == "left"
+                self._pad_id = int(tokenizer.pad_token_id)
+                self._pad_type = int(getattr(tokenizer, "pad_token_type_id", 0) or 0)
                 self._rust = rust
                 self._types = "token_type_ids" in getattr(tokenizer, "model_input_names", ())
             except Exception:  # noqa: BLE001 -- an exotic tokenizer the copy cannot express: take the HF call
@@ -118,9 +133,31 @@ class BatchTokenizer:
         with self._mu:   # a Rust tokenizer is Sync, but encode_batch on one object from two threads serialises on its own pool anyway
             fast = getattr(self._rust, "encode_batch_fast", None) or self._rust.encode_batch
             encs = fast(items, add_special_tokens=True)
-        ids = np.array([e.ids for e in encs], dtype=np.int32)
-        mask = np.array([e.attention_mask for e in encs], dtype=np.int32)
-        tt = np.array([e.type_ids for e in encs], dtype=np.int32) if self._types else None
+        # row by row into preallocated arrays: ~20-us C calls with interpreter switch points between them -- one np.array() over the
+        # nested lists is a single 2-ms call during which the thread that drives the device cannot take the interpreter lock back
+        n = len(encs)
+        rows = [e.ids for e in encs]
+        lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=n)
+        t = int(lens.max()) if n else 0
+        ids = np.full((n, t), self._pad_id, np.int32)
+        col = np.arange(t, dtype=np.int64)[None, :]
+        mask = ((col >= (t - lens)[:, None]) if self._pad_left else (col < lens[:, None])).astype(np.int32)
+        tt = None
+        if self._types:
+            tt = np.full((n, t), self._pad_type, np.int32)
+            if second is None:
+                tt[mask.astype(bool)] = 0            # a single sequence: every token (and its special tokens) is type 0
+        for i, r in enumerate(rows):
+            if self._pad_left:
+                ids[i, t - len(r):] = r
+            else:
+                ids[i, :len(r)] = r
+            if tt is not None and second is not None:
+                ty = encs[i].type_ids
+                if self._pad_left:
+                    tt[i, t - len(ty):] = ty
+                else:
+                    tt[i, :len(ty)] = ty
         return ids, mask, tt
 
     def encode_plain(self, texts, max_length=None, add_special_tokens: bool = False):
