@@ -716,6 +716,20 @@ def test_scan2r_half_image_in_registers_matches_oracle_and_scan2(vf, oracle, n, 
         for _ in range(12):      # a timing-dependent fault (an LDS-DMA landing on fragments still being read) shows as SOME runs differing
             i, s_ = ix.search(q, k)
             assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+        # the SAMPLE pass on the same operand path (sample_impl = 1) against k_scan's (0): same sample rows, same slots -- the seeds agree to
+        # the rounding of a different summation order, the results bit for bit, for every sample size and sample grid
+        seen = {}
+        for impl, samp, sgrid in ((0, 8, -1), (1, 8, -1), (1, 16, -1), (1, 4, 7), (1, 64, 32), (1, 4, 1), (0, 16, -1)) if k <= 100 else \
+                ((0, 64, -1), (1, 64, -1), (1, 64, 5), (1, 64, 1), (0, 64, -1)):     # (a deep search needs a sample that holds k' rows)
+            ix.set_option("sample_impl", impl)
+            ix.set_option("sample_rows", samp)
+            ix.set_option("sample_grid", sgrid)
+            i, s_ = ix.search(q, k)
+            st = ix.stats()
+            assert st["exact_reruns"] == 0 and st["overflowed"] == 0 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), (impl, samp, sgrid, st)
+            seen[(impl, samp)] = st["candidates"]
+        if k <= 100:
+            assert abs(seen[(1, 8)] - seen[(0, 8)]) <= max(8, seen[(0, 8)] // 4) and abs(seen[(1, 16)] - seen[(0, 16)]) <= max(8, seen[(0, 16)] // 4), seen
     c2, q2 = _data(124, 40_000, 640, 64, np.float16)
     with vf.DenseIndex(c2) as ix:
         ix.set_option("force_path", 1)

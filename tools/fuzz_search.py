@@ -31,6 +31,7 @@ def draw_case(rng, max_work):
     opts = {}
     if rng.random() < 0.3:
         opts["scan_impl"] = pick([1, 2, 3, 4, 5])
+        opts["sample_impl"] = pick([-1, 0, 1])
     if rng.random() < 0.2:
         opts["wide_mfma"] = pick([0, 1])
     if rng.random() < 0.2:

@@ -169,7 +169,7 @@ struct vf_index {
     // options
     int64_t force_path = -1, sample_rows = -1, margin = -1, cap_opt = 0, waves_opt = 0, scan_g = 0,
             refresh_every = 128, debug = 0, steal_opt = 0, wide_opt = 1, wide_sync = -1, wide_mfma = -1, wide8_waves = 8, wide8_stage = 0,
-            aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
+            aux_cus = -1, sample_grid = -1, overlap_scans = -1, scan_impl = 2, sample_impl = -1;   // aux_cus / overlap_scans: -1 = auto (resolved_split)   // scan_impl: 1 = k_scan (register loads), 2 = k_scan2 (whole-line LDS-DMA) where it fits   // aux_cus: CUs the main scan leaves to the small kernels of the other slots (0 = no split)   // wide_sync: -1 siblings of a wide row group run free (default: fastest), >= 0 = the slack in super-tiles  // steal_opt: cross-workgroup tile pool in the main scan (measured slower: DESIGN.md 5)  // wide_opt: 0 never, 1 auto (nq >= 129), > 1 = from that many queries
     vf_search_stats stats{};
     bool profile = false;
     double prof_scan_ms = 0.0, prof_pipe_ms = 0.0;
@@ -619,6 +619,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
     else if (s == "scan_impl") { if (!in_range(1, 5)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (auto: k_scan2 for fp16 rows, k_scan2r where it measured faster), 3 (k_scan2 wherever it fits, e4m3 rows converted), 4 (k_scan2 for fp16 rows, never k_scan2r) or 5 (k_scan2r wherever it fits: fp16 rows of 768 elements)"); ix->scan_impl = value; }
+    else if (s == "sample_impl") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "sample_impl must be -1 (auto: k_scan2r's operand path for the sample pass where it exists and the CU split is on), 0 (k_scan) or 1 (k_scan2r wherever it fits)"); ix->sample_impl = value; }
     else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
     else if (s == "profile") {
@@ -961,9 +962,22 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qt * p.total_waves * p.samp * sizeof(float), st));
         // sample pass: a FEW workgroups walk the sample parts of all ranges (each stages the query image once)
         // (auto: 4 workgroups per spare CU when the CU split is on, one per range otherwise)
+        // Round 6: where k_scan2r's operand path exists (fp16 rows of 768 elements) the sample pass takes it too -- ONE workgroup per spare
+        // CU, each walking the sample parts of p.grid / 32 ranges with six-segment rings: the pass is bound by what a CU keeps in flight
+        // (k_scan's register-staged loads: 68-71 us for 8 rows per wave in four rounds of 128 workgroups).  sample_impl: -1 auto, 0 k_scan, 1 k_scan2r
+        const bool f8rows = ix->dtype == VF_DTYPE_FP8_E4M3;
+        const bool sample_r = ix->sample_impl != 0 && !f8rows && ix->scan_impl != 1 && scan2r_stage_cap(ix->dp, qt) >= 256 &&
+                              (ix->sample_impl == 1 || s.scan_stream != s.stream);
+        if (sample_r) {
+            const int64_t sg_r = ix->sample_grid > 0 ? ix->sample_grid : (s.scan_stream != s.stream ? resolved_aux(ix) : p.grid);
+            ScanArgs as = a;
+            as.stage_cap = 0;
+            VF_HIP(launch_scan2r_sample(as, qt, (int)std::min<int64_t>(std::max<int64_t>(sg_r, 1), p.grid), st));
+        } else {
         const int64_t sg_opt = ix->sample_grid >= 0 ? ix->sample_grid : (s.scan_stream != s.stream ? 4 * resolved_aux(ix) : 0);
         const int sgrid = sg_opt > 0 ? (int)std::min<int64_t>(sg_opt, p.grid) : p.grid;
         VF_HIP(launch_scan(a, kModeSample, qt, sgrid, (int)ix->scan_g, ix->dtype == VF_DTYPE_FP8_E4M3, st));
+        }
         VF_HIP(launch_sel0(a, qt, st));
         hipStream_t sst = s.scan_stream;
         if (sst != st) {   // the main scan runs on the CU-masked stream, behind this slot's prologue

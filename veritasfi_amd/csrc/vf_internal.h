@@ -117,6 +117,7 @@ int scan2_stage_cap(int dp, int qn_tile, int rows_are_fp8);
 size_t scan2r_lds_bytes(int dp, int qn_tile, int stage_cap);
 int scan2r_stage_cap(int dp, int qn_tile);
 hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, hipStream_t s);
+hipError_t launch_scan2r_sample(const ScanArgs& a, int qn_tile, int grid, hipStream_t s);
 hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s);
 size_t scan_wide_lds_bytes(int stage_cap);
 // k_scan_wide8: the wide main scan on the fp8 matrix instruction (e4m3 rows; a.qimg = the hi / lo code image of launch_prep_wide8)

@@ -1546,19 +1546,45 @@ int scan2r_stage_cap(int dp, int qn_tile) {   // < 256 = "not this kernel"
     return (int)(area / 16);
 }
 
-template <int NT>
+template <int NT, int MODE>
 __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
     const unsigned long long t_entry = (a.debug & 512) ? wall_clock64() : 0ull;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int QN = NT * kQueryTile, RB = kRegSegs, RING = kRingR, THREADS = kScan2Waves * 64;
-    constexpr int MODE = kModeMain;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
-    const long long grid = gridDim.x;
+    // Main mode: gridDim.x ranges, workgroup b owns range b minus its sample part.  SAMPLE mode (round 6): a.scan_grid ranges, workgroup b
+    // walks the sample parts (the first samp x 8 rows) of ranges b, b + gridDim.x, ... -- k_scan's sample geometry and s0 slots, so k_sel0
+    // and the main scan see what they saw -- with THIS kernel's operand path: the pass runs on the 32 CUs the main scans leave free, a
+    // CU's rate is bytes in flight / latency, and k_scan's register-staged loads kept ~15 GB/s per CU (4 rounds of 128 workgroups, 70 us
+    // for 11 MB at 8 rows per wave) where a six-segment ring per wave keeps 96 KB in flight.
+    const long long grid = (MODE == kModeSample && a.scan_grid > 0) ? a.scan_grid : gridDim.x;
     const long long swg = (long long)a.samp * (kScanThreads / 64);
-    const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
-    const long long lo = (Ra + swg < Rb) ? Ra + swg : Rb, hi = Rb;
-    const int ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
+    const int tps = (int)((swg + kRowTile - 1) / kRowTile);            // tiles of a range's sample part
+    long long lo = 0, hi = 0;
+    int ntiles;
+    if (MODE == kModeSample) {
+        const long long mine = (grid - (long long)blockIdx.x + gridDim.x - 1) / gridDim.x;
+        ntiles = (int)(mine > 0 ? mine : 0) * tps;
+    } else {
+        const long long Ra = a.n * blockIdx.x / grid, Rb = a.n * (blockIdx.x + 1) / grid;
+        lo = (Ra + swg < Rb) ? Ra + swg : Rb; hi = Rb;
+        ntiles = (int)((hi - lo + kRowTile - 1) / kRowTile);
+    }
+    // (first row, end of the part, sample-slot base) of a tile
+    auto tile_rows = [&](int tile, long long& t0, long long& thi, long long& sbase) {
+        if (MODE == kModeSample) {
+            const int m = tile / tps, j = tile - m * tps;
+            long long v = (long long)blockIdx.x + (long long)m * gridDim.x;
+            v = v < grid ? v : grid - 1;
+            const long long Ra = a.n * v / grid, Rb = a.n * (v + 1) / grid;
+            thi = (Ra + swg < Rb) ? Ra + swg : Rb;
+            t0 = Ra + (long long)j * kRowTile;
+            sbase = v * swg + (long long)j * kRowTile;
+        } else {
+            t0 = lo + (long long)tile * kRowTile; thi = hi; sbase = 0;
+        }
+    };
     constexpr int S = 2 * RB;
     // ---- the register half of the image: B fragments of segments 0 .. RB - 1 (k-group 8 sg + 4 h + i of query 32 nt + r31), loaded first
     h8 breg[RB][4][NT];
@@ -1583,10 +1609,14 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
     const int drow = lane >> 3;
     auto src_of = [&](int tile, int m) -> const char* {
         const int row = 8 * m + drow;
-        long long r = lo + (long long)tile * kRowTile + row;
-        r = r < hi - 1 ? r : hi - 1;
+        long long t0_, thi_, sb_;
+        tile_rows(tile, t0_, thi_, sb_);
+        long long r = t0_ + row;
+        r = r < thi_ - 1 ? r : thi_ - 1;                               // rows past the part's end re-read its last row (masked in the epilogue)
+        r = r > 0 ? r : 0;
         return a.rows + r * a.row_bytes + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
     };
+    auto first_row = [&](int tile) { long long t0_, thi_, sb_; tile_rows(tile, t0_, thi_, sb_); return t0_; };
     auto issue_seg = [&](const char* const (&src)[4], int seg, int buf) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) dma16(src[m] + (long long)seg * 128, ring_l + buf * kSegBytes + m * 1024);
@@ -1603,7 +1633,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
     if (active) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
-        issue_epi(lo + (long long)cur_tile * kRowTile, true, 0);
+        issue_epi(first_row(cur_tile), MODE == kModeMain, 0);
 #pragma unroll
         for (int sg = 0; sg < RING; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S = 12 >= RING)
     }
@@ -1615,18 +1645,20 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
         for (int c = wu; c < nkb; c += kScan2Waves) dma16(srcq + ((long long)c << 10) + (lane << 4), img_l + ((unsigned)c << 10));
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), the BUILTIN: the register half, this wave's share of the LDS half and its ring have landed
         uint4* z = (uint4*)ctl;
-        const int nz = kCtlBytes / 16 + a.stage_cap;
+        const int nz = kCtlBytes / 16 + (MODE == kModeMain ? a.stage_cap : 0);
         for (int i = tid; i < nz; i += THREADS) z[i] = make_uint4(0u, (i == 0) ? (u32)kScan2Waves : 0u, 0u, 0u);
     }
     __syncthreads();
-    if (tid < QN) ((int*)(ctl + 16))[tid] = a.tau_bin[tid];
-    __syncthreads();
+    if (MODE == kModeMain) {
+        if (tid < QN) ((int*)(ctl + 16))[tid] = a.tau_bin[tid];
+        __syncthreads();
+    }
 
     const char* lds_lane = img + ((4 * h) * QN + r31) * 16;            // + (sg - RB) * (8 QN 16) + i * (QN 16) + nt * (32 * 16)
     const int asw = (r31 >> 1) & 7;
     const char* a_lane = ring + r31 * 128;
     const int dbg_rec = (a.debug & 512) ? 72 : 4;
-    unsigned long long* dbg = ((a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * dbg_rec : nullptr;
+    unsigned long long* dbg = (MODE == kModeMain && (a.debug & 128) && a.dbg && lane == 0) ? a.dbg + ((long long)blockIdx.x * kScan2Waves + wid) * dbg_rec : nullptr;
     if (dbg) dbg[0] = wall_clock64();
     if (dbg && dbg_rec > 4) {
         dbg[68] = t_entry;
@@ -1643,7 +1675,8 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
         int buf = 0;
         while (true) {
-            const long long t0 = lo + (long long)cur_tile * kRowTile;
+            long long t0, t_hi, t_s0;
+            tile_rows(cur_tile, t0, t_hi, t_s0);
             int claimed;
             {
                 int v_ = 0;
@@ -1654,8 +1687,8 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             const int nxt = more ? claimed : cur_tile;
 #pragma unroll
             for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
-            const bool sync_now = (tiles_done & (kScan2Waves - 1)) == wid;
-            const bool sync_next = ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
+            const bool sync_now = MODE == kModeMain && (tiles_done & (kScan2Waves - 1)) == wid;
+            const bool sync_next = MODE == kModeMain && ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
             if (dbg && dbg_rec > 4 && tiles_done < 64) dbg[4 + tiles_done] = wall_clock64();
             // one body for both halves: BREG picks the B fragments from the registers (compile-time segment) or from LDS
             auto consume = [&](auto sg_c, const char* bb) {
@@ -1681,7 +1714,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
                 const int s3 = sg + RING;
                 if (s3 < S) issue_seg(src_cur, s3, buf);
                 else {
-                    if (s3 == S) issue_epi(lo + (long long)nxt * kRowTile, sync_next, (tiles_done + 1) & 1);
+                    if (s3 == S) issue_epi(first_row(nxt), sync_next, (tiles_done + 1) & 1);
                     issue_seg(src_nxt, s3 - S, buf);
                 }
                 buf = buf + 1 == RING ? 0 : buf + 1;
@@ -1702,7 +1735,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) epi.tau_g[nt] = *(const int*)(sc + (nt * kQueryTile + r31) * 4);
             }
-            tile_epilogue<NT, MODE, true>(a, acc, epi, t0, hi, 0, lane, ctl);
+            tile_epilogue<NT, MODE, true>(a, acc, epi, t0, t_hi, t_s0, lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1716,6 +1749,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
     }
     if (dbg && dbg_rec > 4) dbg[69] = (unsigned long long)tiles_done;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE == kModeSample) return;                                   // no candidates in the sample pass: nothing to flush
     if (lane == 0) atomicAdd((u32*)(ctl + 8), 1u);
     if (dbg) dbg[1] = wall_clock64();
     __syncthreads();
@@ -2983,8 +3017,15 @@ hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_f
 
 hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
     const size_t lds = scan2r_lds_bytes(a.dp, qn_tile, a.stage_cap);
-    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2r<1>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_scan2r<2>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
+    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2r<1, kModeMain>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_scan2r<2, kModeMain>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
+    return hipGetLastError();
+}
+// the sample pass on k_scan2r's operand path: `grid` workgroups walk the sample parts of a.scan_grid ranges (a.samp rows per wave of k_scan's geometry)
+hipError_t launch_scan2r_sample(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
+    const size_t lds = scan2r_lds_bytes(a.dp, qn_tile, 0);
+    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2r<1, kModeSample>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_scan2r<2, kModeSample>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -3471,8 +3512,10 @@ hipError_t scan_configure() {
     VF_CFG(1, 1) VF_CFG(1, 2) VF_CFG(1, 3) VF_CFG(1, 4)
     VF_CFG(2, 1) VF_CFG(2, 2) VF_CFG(2, 3) VF_CFG(2, 4)
 #undef VF_CFG
-    if ((e = hipFuncSetAttribute((const void*)k_scan2r<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2r<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<1, kModeMain>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<2, kModeMain>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<1, kModeSample>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<2, kModeSample>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
