@@ -1535,3 +1535,46 @@ def test_attention_half_items_are_bit_equal_to_whole_pairs(vf, b, t, heads, ragg
     valid = mask.bool()
     assert bool(torch.isfinite(outs[0].float()[valid]).all())
     assert torch.equal(outs[0][valid], outs[1][valid]) and torch.equal(outs[0][valid], outs[2][valid])
+
+
+def test_decoder_first_forward_is_right_while_another_handle_is_busy(vf):
+    """The decoder's RoPE table is written when its workspace is (re)allocated -- on the handle's OWN stream since round 6 (it was launched on
+    the legacy NULL stream, which a non-blocking stream does not order itself behind: the first forward after an allocation could read a
+    table not written yet -- round-5 advisor).  Here the FIRST forward of fresh decoder handles runs while an encoder handle on another
+    thread replays captured graphs back to back; every first result must equal the handle's later ones bit for bit, and a larger batch
+    (a re-allocation: a new table) likewise."""
+    import threading
+    sys_path_tools = os.path.join(_ROOT, "tools")
+    if sys_path_tools not in sys.path:
+        sys.path.insert(0, sys_path_tools)
+    from bench_rerank import random_encoder
+    busy, _cfg = random_encoder("bert-base", head=0, vocab=1000)
+    rng = np.random.default_rng(9)
+    bids = rng.integers(5, 1000, size=(2, 64)).astype(np.int32)          # 128 rows: the graph-replay path
+    stop = threading.Event()
+
+    def hammer():
+        while not stop.is_set():
+            busy.forward(bids, np.ones_like(bids))
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        model = _hf_qwen3(128, 2, 2, 1, 64, 256)
+        ids = rng.integers(5, 800, size=(6, 96)).astype(np.int32)
+        mask = np.ones_like(ids)
+        big_ids = rng.integers(5, 800, size=(24, 160)).astype(np.int32)
+        for _ in range(4):
+            dec = vf.HipDecoder.from_hf(model, pooling=2, normalize=False)
+            first = dec.forward(ids, mask).copy()                         # first call: allocates the workspace, writes the table
+            again = dec.forward(ids, mask)
+            assert np.isfinite(first).all() and np.array_equal(first.view(np.uint32), again.view(np.uint32))
+            grown = dec.forward(big_ids, np.ones_like(big_ids)).copy()    # a larger batch: re-allocation
+            assert np.array_equal(grown.view(np.uint32), dec.forward(big_ids, np.ones_like(big_ids)).view(np.uint32))
+            assert np.array_equal(first.view(np.uint32), dec.forward(ids, mask).view(np.uint32))
+            dec.close()
+    finally:
+        stop.set()
+        th.join(timeout=60)
+        busy.close()
+    assert not th.is_alive()

@@ -15,6 +15,7 @@ package until round 6: the device idled while Python tokenised and the tokenizer
 from __future__ import annotations
 
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -47,14 +48,24 @@ def pipelined(batches, prepare, run, overlap: bool = True, finish=None) -> list:
     import sys
     keep = sys.getswitchinterval()
     sys.setswitchinterval(min(keep, 2e-4))
+    # ... and the worker starts its job half a millisecond late: a tokenizer call begins (and ends) with a phase that holds the interpreter
+    # lock -- Python strings in, Encoding objects out, 2-4 ms of a 100 x 512-token batch -- and a worker that starts at the same moment as
+    # the driving thread takes the lock first: the device call then starts that much later, every batch (measured: a 2.6-ms hole per
+    # 11-ms forward).  Half a millisecond is what the driving thread needs to get from submit() into the C call, where it needs no lock.
+    def late(fn):
+        def job(x):
+            time.sleep(5e-4)
+            return fn(x)
+        return job
+    prepare_l, finish_l = late(prepare), (late(finish) if finish is not None else None)
     try:
         nxt = pool.submit(prepare, batches[0])
         for i in range(len(batches)):
             ready = nxt.result()
             if i + 1 < len(batches):
-                nxt = pool.submit(prepare, batches[i + 1])
+                nxt = pool.submit(prepare_l, batches[i + 1])
             res = run(ready)
-            out.append(res if finish is None else pool.submit(finish, res))
+            out.append(res if finish is None else pool.submit(finish_l if i + 1 < len(batches) else finish, res))
         return out if finish is None else [f.result() for f in out]
     finally:
         sys.setswitchinterval(keep)
