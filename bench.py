@@ -856,8 +856,8 @@ def texts_legs(args):
                            "pre_tokenised_p50_ms": round(pre * 1e3, 3), "serial_loop_p50_ms": round(ser * 1e3, 3),
                            "tokenize_pairs_ms": round(tok_ms * 1e3, 3), "tokenize_pairs_ms_through_the_hf_call": round(hf_ms * 1e3, 3),
                            "bit_equal_to_serial_loop": sa == sb,
-                           "what": "compute_score(100 string pairs): two halves, the second tokenised under the first's forward; the Rust "
-                                   "tokenizer runs on this box's host cores (its time is not the device's: tokenize_pairs_ms)"}
+                           "what": "compute_score(100 string pairs): three pieces (24 + 40 + 36), each tokenised under the previous one's forward; "
+                                   "the Rust tokenizer runs on this box's host cores (its time is not the device's: tokenize_pairs_ms)"}
     renc.close()
     return out
 

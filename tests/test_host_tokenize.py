@@ -60,7 +60,8 @@ def test_objects_that_are_not_fast_tokenizers_are_called_the_hf_way():
 
 def test_split_for_overlap():
     assert split_for_overlap(0, 128) == []
-    assert split_for_overlap(100, 128) == [(0, 56), (56, 100)]             # the reference's 100 pairs: two halves (multiples of 8)
+    assert split_for_overlap(100, 128) == [(0, 24), (24, 64), (64, 100)]   # the reference's 100 pairs: a small first piece, then two larger ones
+    assert split_for_overlap(64, 128) == [(0, 32), (32, 64)]               # two halves below 96
     assert split_for_overlap(13, 128) == [(0, 13)]                          # a data-parallel share stays whole
     assert split_for_overlap(300, 128) == [(0, 128), (128, 256), (256, 300)]
     assert split_for_overlap(100, 32) == [(0, 32), (32, 64), (64, 96), (96, 100)]

@@ -72,13 +72,20 @@ def pipelined(batches, prepare, run, overlap: bool = True, finish=None) -> list:
 
 
 def split_for_overlap(n: int, step: int, min_piece: int = 16) -> list:
-    """(lo, hi) pieces of n items in device batches of at most `step`: a call that fits ONE device batch is cut in two halves (whole
-    multiples of 8 pairs) when both halves keep at least `min_piece` items, so that the second half is tokenised under the first
-    half's forward; larger calls keep their `step`-sized batches (already more than one)."""
+    """(lo, hi) pieces of n items in device batches of at most `step`.  A call that fits ONE device batch is cut so that tokenisation runs
+    under a forward: in three pieces of about 1/4, 2/5 and the rest (whole multiples of 8) from 96 items up -- a SMALL first piece puts
+    the device to work early, and the call's time tends to (tokenisation of everything) + (forward of the last piece) when the
+    tokenizer is the slower side, as it is for 100 pairs of 512 tokens -- in two halves when both keep at least `min_piece` items;
+    larger calls keep their `step`-sized batches (already more than one)."""
     if n <= 0:
         return []
     if n > step:
         return [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+    if n >= 96:
+        a = max(min_piece, (n // 4) // 8 * 8)
+        b = a + max(min_piece, (2 * n // 5) // 8 * 8)
+        if n - b >= min_piece:
+            return [(0, a), (a, b), (b, n)]
     half = (n // 2 + 7) // 8 * 8
     if half >= min_piece and n - half >= min_piece:
         return [(0, half), (half, n)]
