@@ -144,7 +144,9 @@ int vf_index_stats(vf_index* idx, vf_search_stats* out);
  *   sample still holds 16 k' rows, else 16), or 1..64.  A speed setting: a looser seed admits more candidates, results do not change.
  * "scan_impl": the narrow scan's kernel: 1 k_scan (register loads); 2 (default) k_scan2 (whole-line LDS-DMA loads) for fp16 rows, and
  *   its register-image form k_scan2r for the shard sizes it measured faster on (fp16 rows of 768 elements, 1.1M < n <= 6M); 3 k_scan2
- *   wherever it fits (e4m3 rows converted in registers); 4 k_scan2, never k_scan2r; 5 k_scan2r wherever it fits.  Same results from each. */
+ *   wherever it fits (e4m3 rows converted in registers); 4 k_scan2, never k_scan2r; 5 k_scan2r wherever it fits.  Same results from each.
+ * "sample_impl": the sample pass's kernel: -1 auto (k_scan2r's operand path where it exists and the CU split is on), 0 k_scan, 1 k_scan2r
+ *   wherever it fits.  Same sample rows and slots either way; results do not change. */
 int vf_index_set_option(vf_index* idx, const char* name, int64_t value);
 /* Live kernel timing with HIP events on the stream the kernels run on (bench.py roofline):
  * after vf_index_set_option(idx, "profile", 1) every fused search records events around its main

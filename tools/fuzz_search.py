@@ -29,7 +29,13 @@ def draw_case(rng, max_work):
     k = max(1, min(k, 2048))
     data = pick(["normal", "normal", "dupes", "clusters", "scaled", "zeros", "sorted", "lowrank"])
     opts = {}
-    if rng.random() < 0.3:
+    if os.environ.get("VF_FUZZ_SCAN2R") == "1":   # soak of round 6's kernels: 768-wide fp16 rows, k_scan2r for the scan and for the sample pass
+        d = 768
+        if rng.random() < 0.7:
+            dtype = "f16"
+        opts["scan_impl"] = 5
+        opts["sample_impl"] = 1
+    elif rng.random() < 0.3:
         opts["scan_impl"] = pick([1, 2, 3, 4, 5])
         opts["sample_impl"] = pick([-1, 0, 1])
     if rng.random() < 0.2:

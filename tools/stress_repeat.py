@@ -20,6 +20,9 @@ CASES = [
     ("wide fp8 rows on the fp16 instruction (k_scan_wide)", dict(dtype="fp8", d=1024, nq=200, n=60000, k=1000, data="normal", seed=13), {"wide_mfma": 0}),
     ("wide fp16 rows, 96 queries (k_scan_wide)", dict(dtype="f16", d=768, nq=96, n=80000, k=100, data="normal", seed=15), {}),
     ("sharded handle, 3 row blocks, fp16", dict(dtype="f16", d=768, nq=64, n=150000, k=100, data="normal", seed=16, shards=3), {}),
+    ("narrow fp16 rows, 64 queries: k_scan2r for the scan and the sample pass (round 6)", dict(dtype="f16", d=768, nq=64, n=200000, k=100, data="normal", seed=18), {"scan_impl": 5, "sample_impl": 1}),
+    ("narrow fp16 rows, 20 queries, clustered data: k_scan2r<1>", dict(dtype="f16", d=768, nq=20, n=150000, k=1000, data="clusters", seed=19), {"scan_impl": 5, "sample_impl": 1}),
+    ("narrow fp32 rows (fp16 scan copy), 64 queries, duplicates: k_scan2r", dict(dtype="f32", d=768, nq=64, n=100000, k=100, data="dupes", seed=20), {"scan_impl": 5, "sample_impl": 1}),
 ]
 
 
