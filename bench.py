@@ -11,16 +11,19 @@ top-k lists are all-gathered over RCCL and merged.  Corpus, queries and outputs 
 when the timed region starts.  Two batches are kept in flight (vf_index_search_begin / _end), as a
 serving loop would.  Rank 0 prints ONE JSON line.
 
-roofline: live HIP-event timing of the dominant kernel (the main scan: k_scan2 -- whole-line LDS-DMA corpus loads -- for fp16
-rows, k_scan for fp8 rows, k_scan_wide above 128 queries; vf_search_stats.scan_kernel names it) inside the library, on the
-stream it runs on (vf_index_profile); algorithmic bytes = rows scanned x (d*2 + 4).  Shards of up to 6M rows run their scans
-OVERLAPPED on a CU partition: the launch time is then the launch interval (vf_index_profile_span) and the isolated kernel is
-reported beside it (roofline.isolated_launch).
+roofline: live HIP-event timing of the dominant kernel (the main scan: k_scan2r / k_scan2 -- whole-line LDS-DMA corpus loads -- for
+fp16 rows, k_scan for fp8 rows, k_scan_wide(8) above 128 queries; vf_search_stats.scan_kernel names it) inside the library, on the
+stream it runs on (vf_index_profile); algorithmic bytes = rows scanned x (d*2 + 4).  768-wide fp16 rows at every size (other rows
+up to 6M) run their scans OVERLAPPED on a 224-CU partition: what a launch costs is then the launch INTERVAL (first begin to last end
+of the timed launches / launches, HIP events on the scan streams: vf_index_profile_span) -- roofline.achieved / frac / avg_launch_ms --
+and the same kernel in an ordered pass, one launch per event bracket, is reported beside it (roofline.isolated_launch).
+VF_BENCH_NO_ISOLATED=1 skips that second pass (profiling runs: tools/gpu_r06_record.sh).
 cpu_baseline: the CPU oracle (oracle/vf_oracle.c, a port of the reference's CPU path) on the SAME rows and queries, copied out
 of the GPU-resident corpus: configs[1] (1M rows) measured, then the whole corpus in 1M-row blocks (measured, ~10 s on 128
 cores), and the GPU's ids / score bits checked against both ("verified") -- reported, not a target.
 Other legs (N = 1): re-rank p50 (XLM-R base / large shapes), the configured LLM re-ranker (gemma-2b shape), the configs[3]
-chain for one query, the embed loop, per-request latencies, the host-buffer entry.
+chain for one query through EnsembleRetriever.invoke + rank_chunk, the embed loop, the text-in legs (embed_texts, rerank_texts: real
+fast tokenizers, tokenisation overlapped with the device), start-up from a corpus file, per-request latencies, the host-buffer entry.
 """
 import argparse
 import json
