@@ -740,6 +740,45 @@ def test_scan2r_half_image_in_registers_matches_oracle_and_scan2(vf, oracle, n, 
         assert np.array_equal(i, wi) and np.array_equal(_bits(s_), _bits(ws))
 
 
+@pytest.mark.parametrize("n,d,nq,k", [
+    (60_000, 768, 64, 100),         # S = 6 segments of 128 codes: three in registers, six-segment rings
+    (60_013, 768, 20, 1000),        # one query tile, deep, ragged last tile
+    (50_000, 1024, 64, 100),        # S = 8: four in registers (256 of them), five-segment rings -- the shape k_scan2 has no room for
+    (50_001, 1024, 31, 10),
+])
+def test_scan2r_on_fp8_rows_matches_oracle(vf, oracle, n, d, nq, k):
+    """k_scan2r on e4m3-resident rows (scan_impl = 5; 768 and 1024 elements): the bytes go global -> LDS as whole lines through rings of
+    six / five segments, a lane converts its two 16-byte pieces per 64-element chunk in registers (exactly: every e4m3 value is an fp16
+    value), and the B fragments of the first three / four segments never leave the registers.  Main scan and sample pass, bit for
+    bit against the oracle on the decoded rows, repeatedly (a refill landing on fragments still being read shows as SOME runs differing)."""
+    from oracle import ref_numpy as R
+    codes = _e4m3_codes(n, d, 90 + d % 7)
+    rows16 = R.decode_e4m3(codes).astype(np.float16)
+    q = np.random.default_rng(91).standard_normal((nq, d)).astype(np.float32)
+    want_i, want_s = oracle.search(rows16, q, k)
+    deep = k > 100
+    with vf.DenseIndex.from_e4m3(codes) as ix:
+        ix.set_option("force_path", 1)
+        ix.set_option("scan_impl", 5)
+        if deep:
+            ix.set_option("sample_rows", 64)
+        cands = {}
+        for simpl in (0, 1, 1, 0):
+            ix.set_option("sample_impl", simpl)
+            for _ in range(4):
+                i, s_ = ix.search(q, k)
+                st = ix.stats()
+                assert st["path"] == 1 and st["scan_kernel"] == 5 and st["exact_reruns"] == 0 and st["overflowed"] == 0, (simpl, st)
+                assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), simpl
+            cands[simpl] = st["candidates"]
+        ix.set_option("scan_impl", 1)
+        ix.set_option("sample_impl", 0)
+        i, s_ = ix.search(q, k)
+        st = ix.stats()
+        assert st["scan_kernel"] == 1 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+        assert abs(cands[1] - st["candidates"]) <= max(8, st["candidates"] // 4), (cands, st)     # same filter, different refresh timing
+
+
 @pytest.mark.parametrize("n,d,nq,k,want_kernel", [
     (60_000, 768, 64, 100, 2),      # six 128-code segments per row beside a 96 KB fp16 query image
     (50_000, 1024, 24, 10, 2),      # one N-tile: 64 KB image

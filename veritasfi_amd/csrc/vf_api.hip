@@ -248,7 +248,7 @@ constexpr int64_t kSplitMaxRows = 6'000'000;
 // ordered scans with k_scan2 being the 2.538; k_scan2r on the whole chip with ordered scans LOSES (2.58-2.59): profiles/r06_scan2r_10m.log
 static int64_t split_limit(const vf_index* ix) {
     const bool r_rows = ix->dtype != VF_DTYPE_FP8_E4M3 && ix->scan_impl != 4 && ix->scan_impl != 1 && ix->scan_impl != 3 && !ix->steal_opt &&
-                        scan2r_stage_cap(ix->dp, kMaxBatch) >= 256;
+                        scan2r_stage_cap(ix->dp, kMaxBatch, 0) >= 256;
     return r_rows ? INT64_MAX : kSplitMaxRows;
 }
 static int64_t resolved_aux(const vf_index* ix) {
@@ -618,7 +618,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
         ix->aux_cus = value;
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
-    else if (s == "scan_impl") { if (!in_range(1, 5)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (auto: k_scan2 for fp16 rows, k_scan2r where it measured faster), 3 (k_scan2 wherever it fits, e4m3 rows converted), 4 (k_scan2 for fp16 rows, never k_scan2r) or 5 (k_scan2r wherever it fits: fp16 rows of 768 elements)"); ix->scan_impl = value; }
+    else if (s == "scan_impl") { if (!in_range(1, 5)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (auto: k_scan2 for fp16 rows, k_scan2r where it measured faster), 3 (k_scan2 wherever it fits, e4m3 rows converted), 4 (k_scan2 for fp16 rows, never k_scan2r) or 5 (k_scan2r wherever it fits: fp16 rows of 768 elements, e4m3 rows of 768 or 1024)"); ix->scan_impl = value; }
     else if (s == "sample_impl") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "sample_impl must be -1 (auto: k_scan2r's operand path for the sample pass where it exists and the CU split is on), 0 (k_scan) or 1 (k_scan2r wherever it fits)"); ix->sample_impl = value; }
     else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
@@ -966,13 +966,13 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // CU, each walking the sample parts of p.grid / 32 ranges with six-segment rings: the pass is bound by what a CU keeps in flight
         // (k_scan's register-staged loads: 68-71 us for 8 rows per wave in four rounds of 128 workgroups).  sample_impl: -1 auto, 0 k_scan, 1 k_scan2r
         const bool f8rows = ix->dtype == VF_DTYPE_FP8_E4M3;
-        const bool sample_r = ix->sample_impl != 0 && !f8rows && ix->scan_impl != 1 && scan2r_stage_cap(ix->dp, qt) >= 256 &&
-                              (ix->sample_impl == 1 || s.scan_stream != s.stream);
+        const bool sample_r = ix->sample_impl != 0 && ix->scan_impl != 1 && scan2r_stage_cap(ix->dp, qt, f8rows) >= 256 &&
+                              (ix->sample_impl == 1 || (!f8rows && s.scan_stream != s.stream));
         if (sample_r) {
             const int64_t sg_r = ix->sample_grid > 0 ? ix->sample_grid : (s.scan_stream != s.stream ? resolved_aux(ix) : p.grid);
             ScanArgs as = a;
             as.stage_cap = 0;
-            VF_HIP(launch_scan2r_sample(as, qt, (int)std::min<int64_t>(std::max<int64_t>(sg_r, 1), p.grid), st));
+            VF_HIP(launch_scan2r_sample(as, qt, (int)std::min<int64_t>(std::max<int64_t>(sg_r, 1), p.grid), f8rows, st));
         } else {
         const int64_t sg_opt = ix->sample_grid >= 0 ? ix->sample_grid : (s.scan_stream != s.stream ? 4 * resolved_aux(ix) : 0);
         const int sgrid = sg_opt > 0 ? (int)std::min<int64_t>(sg_opt, p.grid) : p.grid;
@@ -1000,9 +1000,10 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             VF_HIP(hipEventRecord(s.ev_t[0], sst));
         }
         const int f8 = ix->dtype == VF_DTYPE_FP8_E4M3 ? 1 : 0;
-        // k_scan2 serves fp16 rows by default; e4m3 rows only on request (scan_impl = 3): per byte they carry twice the MFMA and
-        // LDS work plus the conversions, and with ONE wave per SIMD nothing hides it -- measured 0.53 against k_scan's 0.66 of
-        // peak at 10M x 768 fp8 (profiles/r03_f8_sweep.log)
+        // k_scan2 serves fp16 rows by default; e4m3 rows only on request (scan_impl = 3, or 5 for k_scan2r's e4m3 shapes): per byte they
+        // carry twice the matrix work and the same LDS-DMA issues, and with ONE wave per SIMD nothing hides either -- measured 0.53
+        // (k_scan2, round 3) and 0.55-0.60 (k_scan2r, round 6: B fragments in accumulator registers, rings of six) against k_scan's
+        // 0.63-0.70 of peak at 10M x 768 / 1024 fp8 (profiles/r03_f8_sweep.log, r06_fp8_scan2r_ab.log)
         const int cap2 = ((ix->scan_impl == 3 || ((ix->scan_impl == 2 || ix->scan_impl == 4 || ix->scan_impl == 5) && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
         // k_scan2r (round 6): half of the query image in registers, six-segment rings -- fp16 rows of 768 elements.  Measured against
         // k_scan2 in separate processes, alternating (profiles/r06_scan2r_ab.log): the 8-GPU rank's shard (1.25M rows) 0.3469-0.3528 ms
@@ -1010,12 +1011,17 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // the scan sits on the copy ceiling there), configs[1] (1M rows) 3 % SLOWER (0.303-0.315 vs 0.293-0.303: that step is the
         // prologue chain's, and the workgroup's start is 2.3 us longer).  So: auto (scan_impl = 2) takes it above 1.1M rows wherever the
         // scans run on the CU split and overlap (which, for these rows, is every size: split_limit); 5 forces it, 4 forbids it.
-        const bool r_auto = ix->scan_impl == 2 && ix->n > 1100000 && s.scan_stream != s.stream && resolved_overlap(ix);   // (with the CU split and overlapping scans only: above)
-        const int capr = ((ix->scan_impl == 5 || r_auto) && !f8 && !ix->steal_opt && !(ix->debug & (32 | 64))) ? scan2r_stage_cap(ix->dp, qt) : 0;
+        const bool r_auto = ix->scan_impl == 2 && !f8 && ix->n > 1100000 && s.scan_stream != s.stream && resolved_overlap(ix);   // (with the CU split and overlapping scans only: above)
+#ifdef VF_EXPERIMENTS
+        const bool dbg_r = f8 || !(ix->debug & (32 | 64));   // (bits 5 / 6 are k_scan2's experiments on fp16 rows, k_scan2r's on e4m3 rows)
+#else
+        const bool dbg_r = true;
+#endif
+        const int capr = ((ix->scan_impl == 5 || r_auto) && !ix->steal_opt && dbg_r) ? scan2r_stage_cap(ix->dp, qt, f8) : 0;
         if (capr >= 256) {
             ScanArgs a2 = a;
             a2.stage_cap = capr;
-            VF_HIP(launch_scan2r(a2, qt, p.grid, sst));
+            VF_HIP(launch_scan2r(a2, qt, p.grid, f8, sst));
             s.scan_kernel = 5;
         } else if (cap2 >= 256) {   // whole-line LDS-DMA loads: image + four rings + a stage of >= 256 entries fit the 160 KB
             ScanArgs a2 = a;

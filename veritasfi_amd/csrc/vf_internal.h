@@ -113,11 +113,11 @@ hipError_t launch_debug_cvt_e4m3(const unsigned char* in, float* out, int count,
 hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_fp8, hipStream_t s);
 size_t scan2_lds_bytes(int dp, int qn_tile, int stage_cap);
 int scan2_stage_cap(int dp, int qn_tile, int rows_are_fp8);
-// k_scan2r: k_scan2 with half of the query image in registers and six-segment rings (fp16 rows, dp = 768); scan2r_stage_cap < 256 = not this kernel
-size_t scan2r_lds_bytes(int dp, int qn_tile, int stage_cap);
-int scan2r_stage_cap(int dp, int qn_tile);
-hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, hipStream_t s);
-hipError_t launch_scan2r_sample(const ScanArgs& a, int qn_tile, int grid, hipStream_t s);
+// k_scan2r: k_scan2 with part of the query image in registers and deeper rings (fp16 rows of 768 elements, e4m3 rows of 768 / 1024); scan2r_stage_cap < 256 = not this kernel
+size_t scan2r_lds_bytes(int dp, int qn_tile, int stage_cap, int f8);
+int scan2r_stage_cap(int dp, int qn_tile, int f8);
+hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, int f8, hipStream_t s);
+hipError_t launch_scan2r_sample(const ScanArgs& a, int qn_tile, int grid, int f8, hipStream_t s);
 hipError_t launch_scan_wide(const ScanArgs& a, int mode, int rows_are_fp8, hipStream_t s);
 size_t scan_wide_lds_bytes(int stage_cap);
 // k_scan_wide8: the wide main scan on the fp8 matrix instruction (e4m3 rows; a.qimg = the hi / lo code image of launch_prep_wide8)

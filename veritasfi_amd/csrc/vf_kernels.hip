@@ -1532,25 +1532,49 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 // The register half is fetched with ordinary loads BEFORE anything else and settled with the s_waitcnt BUILTIN (which the compiler's
 // own wait insertion accounts for): no vector-memory load with a register destination is pending while tiles run (k_attention2's rule).
 // ------------------------------------------------------------------------------------------------
-constexpr int kRingR = 6, kRegSegs = 6;
-
-size_t scan2r_lds_bytes(int dp, int qn_tile, int stage_cap) {
-    const size_t img = (size_t)(dp - kRegSegs * 64) * qn_tile * 2;
-    return img + (size_t)kScan2Waves * (kRingR * kSegBytes + kScratchBytes) + kCtlBytes + (size_t)stage_cap * 16;
+// The shapes it is built for -- (row bytes per 128-byte segment count S, register segments RB, ring depth RING):
+//   fp16 rows, dp =  768: S = 12, RB = 6 (192 registers of B fragments at 64 queries), RING = 6
+//   e4m3 rows, dp =  768: S =  6, RB = 3 (a segment is 128 elements: 16 KB of image, 64 registers), RING = 6
+//   e4m3 rows, dp = 1024: S =  8, RB = 3 (with the 32 accumulators the 256 accumulator registers hold no fourth), RING = 4
+// (e4m3 rows are converted in registers like k_scan2's F8 variant: every e4m3 value is an fp16 value, the image is shared.)
+struct Scan2rShape { int S, RB, RING; };
+static Scan2rShape scan2r_shape(int dp, int f8) {
+    if (!f8 && dp == 768) return {12, 6, 6};
+    if (f8 && dp == 768) return {6, 3, 6};
+    if (f8 && dp == 1024) return {8, 3, 4};
+    return {0, 0, 0};
 }
-int scan2r_stage_cap(int dp, int qn_tile) {   // < 256 = "not this kernel"
-    if (dp != 2 * kRegSegs * 64) return 0;    // S = 12 segments: half in registers, half in LDS
-    const size_t fixed = scan2r_lds_bytes(dp, qn_tile, 0);
+
+size_t scan2r_lds_bytes(int dp, int qn_tile, int stage_cap, int f8) {
+    const Scan2rShape sh = scan2r_shape(dp, f8);
+    const size_t seg_img = (size_t)(f8 ? 128 : 64) * qn_tile * 2;
+    return (size_t)(sh.S - sh.RB) * seg_img + (size_t)kScan2Waves * (sh.RING * kSegBytes + kScratchBytes) + kCtlBytes + (size_t)stage_cap * 16;
+}
+int scan2r_stage_cap(int dp, int qn_tile, int f8) {   // < 256 = "not this kernel"
+    if (scan2r_shape(dp, f8).S == 0) return 0;
+    const size_t fixed = scan2r_lds_bytes(dp, qn_tile, 0, f8);
     if (fixed + 256 * 16 > 160 * 1024) return 0;
     const size_t area = std::min<size_t>(160 * 1024 - fixed, 32 * 1024);
     return (int)(area / 16);
 }
 
-template <int NT, int MODE>
+// AR = 1 (the shipped form): the register part of the image is PINNED to the accumulator half of the register file -- an empty asm with a
+// "+a" operand per fragment, after which the fragment IS an accumulator-register value and the matrix instruction names it as its B
+// operand directly (v_mfma ... v[6:9], a[32:35], ...) -- and every LDS read of a segment is issued before its first matrix instruction.
+// Left to the allocator (AR = 0, the first form, kept under VF_EXPERIMENTS for the A/B) the fragments that did not fit the 256 ordinary
+// registers were SPILLED to accumulator registers and copied back, four v_accvgpr_read per matrix instruction, nothing was left for
+// temporaries, and every ds_read was followed by lgkmcnt(0) and ONE matrix instruction.
+template <int NT, int MODE, int F8 = 0, int S = 12, int RB = 6, int RING = 6, int AR = 1>
 __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
     const unsigned long long t_entry = (a.debug & 512) ? wall_clock64() : 0ull;
+    const unsigned long long c_entry = (a.debug & 512) ? __builtin_amdgcn_s_memtime() : 0ull;   // shader cycles: the in-kernel clock = [71] / ([3] - [68]) x 100 MHz
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int QN = NT * kQueryTile, RB = kRegSegs, RING = kRingR, THREADS = kScan2Waves * 64;
+    constexpr int QN = NT * kQueryTile, THREADS = kScan2Waves * 64;
+    constexpr int J = F8 ? 8 : 4;                       // B fragments (matrix instructions per query tile) per 128-byte row segment
+    constexpr int SEGIMG = J * 2 * QN * 16;             // image bytes of a segment: 16 (e4m3: 128 elements) or 8 k-groups x QN x 16 B
+    // fragment j of a segment: k-group 8 sg + 4 h + j (fp16 rows) or 16 sg + 8 (j >> 2) + 4 h + (j & 3) (e4m3 rows: two 64-element chunks)
+    auto frag_off = [](int j) { return F8 ? ((j >> 2) * 8 + (j & 3)) * (QN * 16) : j * (QN * 16); };
+    static_assert(S >= RING && RB <= S && RB <= 6, "ring fill and the spelled-out register segments");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r31 = lane & 31, h = lane >> 5;
     // Main mode: gridDim.x ranges, workgroup b owns range b minus its sample part.  SAMPLE mode (round 6): a.scan_grid ranges, workgroup b
@@ -1585,23 +1609,22 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             t0 = lo + (long long)tile * kRowTile; thi = hi; sbase = 0;
         }
     };
-    constexpr int S = 2 * RB;
-    // ---- the register half of the image: B fragments of segments 0 .. RB - 1 (k-group 8 sg + 4 h + i of query 32 nt + r31), loaded first
-    h8 breg[RB][4][NT];
+    // ---- the register part of the image: B fragments of segments 0 .. RB - 1 (query 32 nt + r31), loaded first
+    h8 breg[RB][J][NT];
     {
         const char* qb = (const char*)a.qimg + ((long long)(4 * h) * QN + r31) * 16;
 #pragma unroll
         for (int sg = 0; sg < RB; ++sg)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < J; ++j)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    breg[sg][i][nt] = *(const h8*)(qb + (long long)sg * (8 * QN * 16) + i * (QN * 16) + nt * (kQueryTile * 16));
+                    breg[sg][j][nt] = *(const h8*)(qb + (long long)sg * SEGIMG + frag_off(j) + nt * (kQueryTile * 16));
     }
     // LDS carve-up: four rings of RING segments | the LDS half of the image (segments RB .. S - 1) | scratch | control block | stage
     char* ring = smem + (size_t)wid * (RING * kSegBytes);
     char* img = smem + kScan2Waves * RING * kSegBytes;
-    constexpr size_t kImgBytes = (size_t)(S - RB) * 64 * QN * 2;
+    constexpr size_t kImgBytes = (size_t)(S - RB) * SEGIMG;
     char* scratch = img + kImgBytes + (size_t)wid * kScratchBytes;
     char* ctl = img + kImgBytes + kScan2Waves * kScratchBytes;
     u32* next_tile = (u32*)(ctl + 4);
@@ -1635,15 +1658,24 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
         for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
         issue_epi(first_row(cur_tile), MODE == kModeMain, 0);
 #pragma unroll
-        for (int sg = 0; sg < RING; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S = 12 >= RING)
+        for (int sg = 0; sg < RING; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S >= RING)
     }
-    {   // the LDS half of the image, verbatim (it starts RB segments into the image); control block + candidate stage zeroed
-        const char* srcq = (const char*)a.qimg + (long long)RB * (8 * QN * 16);
+    typedef unsigned int u4r __attribute__((ext_vector_type(4)));
+    {   // the LDS part of the image, verbatim (it starts RB segments into the image); control block + candidate stage zeroed
+        const char* srcq = (const char*)a.qimg + (long long)RB * SEGIMG;
         constexpr int nkb = (int)(kImgBytes >> 10);
         const unsigned img_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(img));
         const int wu = __builtin_amdgcn_readfirstlane(wid);
         for (int c = wu; c < nkb; c += kScan2Waves) dma16(srcq + ((long long)c << 10) + (lane << 4), img_l + ((unsigned)c << 10));
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), the BUILTIN: the register half, this wave's share of the LDS half and its ring have landed
+        if constexpr (AR) {
+#pragma unroll
+            for (int sg = 0; sg < RB; ++sg)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+a"(breg[sg][j][nt]));   // from here on this fragment lives in four accumulator registers
+        }
         uint4* z = (uint4*)ctl;
         const int nz = kCtlBytes / 16 + (MODE == kModeMain ? a.stage_cap : 0);
         for (int i = tid; i < nz; i += THREADS) z[i] = make_uint4(0u, (i == 0) ? (u32)kScan2Waves : 0u, 0u, 0u);
@@ -1654,7 +1686,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
         __syncthreads();
     }
 
-    const char* lds_lane = img + ((4 * h) * QN + r31) * 16;            // + (sg - RB) * (8 QN 16) + i * (QN 16) + nt * (32 * 16)
+    const char* lds_lane = img + ((4 * h) * QN + r31) * 16;            // + (sg - RB) * SEGIMG + frag_off(j) + nt * (32 * 16)
     const int asw = (r31 >> 1) & 7;
     const char* a_lane = ring + r31 * 128;
     const int dbg_rec = (a.debug & 512) ? 72 : 4;
@@ -1694,18 +1726,81 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             auto consume = [&](auto sg_c, const char* bb) {
                 constexpr int sgc = decltype(sg_c)::value;        // >= 0: register segment; -1: LDS
                 // segments sg + 1 .. sg + RING - 1 (4 (RING - 1) DMA instructions, and the <= 2 epilogue words issued among them) may still be in flight
-                asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-                static_assert(4 * (RING - 1) == 20, "the counted wait above is written for RING = 6");
+                if constexpr (RING == 6) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else if constexpr (RING == 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                static_assert(RING >= 4 && RING <= 6, "the counted waits above");
                 const char* ab = a_lane + buf * kSegBytes;
+                // B fragment j of query tile nt: from the accumulator registers, the allocator's registers (AR = 0) or LDS
+                auto bfrag = [&](int j, int nt) -> h8 {
+                    if constexpr (sgc >= 0) {
+                        return breg[sgc < 0 ? 0 : sgc][j][nt];
+                    } else {
+                        return *(const h8*)(bb + frag_off(j) + nt * (kQueryTile * 16));
+                    }
+                };
+                if constexpr (F8 == 0) {
+                    if constexpr (AR) {
+                        h8 af[4], bl[4][NT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const h8 af = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
+                        for (int i = 0; i < 4; ++i) af[i] = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
+                        if constexpr (sgc < 0) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        h8 bf;
-                        if constexpr (sgc >= 0) bf = breg[sgc][i][nt];
-                        else bf = *(const h8*)(bb + i * (QN * 16) + nt * (kQueryTile * 16));
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nt], 0, 0, 0);
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) bl[i][nt] = bfrag(i, nt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);                 // every LDS read of the segment is in flight before its first matrix instruction
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], sgc < 0 ? bl[i][nt] : bfrag(i, nt), acc[nt], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const h8 af = *(const h8*)(ab + (((4 * h + i) ^ asw) << 4));
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag(i, nt), acc[nt], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    // e4m3 rows (k_scan2's F8 body): in chunk c lane (r, h) owns the two 16-byte pieces 4 c + 2 h, + 1 of its row
+                    uint4 wv[4];
+                    h8 bl[8][NT];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        wv[2 * c] = *(const uint4*)(ab + (((4 * c + 2 * h) ^ asw) << 4));
+                        wv[2 * c + 1] = *(const uint4*)(ab + (((4 * c + 2 * h + 1) ^ asw) << 4));
+                    }
+                    if constexpr (sgc < 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) bl[j][nt] = bfrag(j, nt);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+#ifdef VF_EXPERIMENTS
+                        if (c == 1 && (a.debug & 32)) break;          // timing experiment (INVALID RESULTS): half of the matrix instructions and conversions
+#endif
+                        const uint4 w0 = wv[2 * c], w1 = wv[2 * c + 1];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint4 w = i < 2 ? w0 : w1;
+                            h8 af;
+#ifdef VF_EXPERIMENTS
+                            if (a.debug & 64) {                       // timing experiment (INVALID RESULTS): no conversions, the raw words as halves
+                                const u4r raw = {(i & 1) ? w.z : w.x, (i & 1) ? w.w : w.y, (i & 1) ? w.z : w.x, (i & 1) ? w.w : w.y};
+                                af = __builtin_bit_cast(h8, raw);
+                            } else
+#endif
+                            af = (i & 1) ? cvt8_e4m3(w.z, w.w) : cvt8_e4m3(w.x, w.y);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, sgc < 0 ? bl[4 * c + i][nt] : bfrag(4 * c + i, nt), acc[nt], 0, 0, 0);
+                        }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the refill overwrites the LDS these fragments were read from (k_scan2's note)
@@ -1719,12 +1814,11 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
                 }
                 buf = buf + 1 == RING ? 0 : buf + 1;
             };
-#define VF_R_SEG(N) consume(std::integral_constant<int, N>{}, nullptr); refill(N);
+#define VF_R_SEG(N) if constexpr (RB > N) { consume(std::integral_constant<int, N>{}, nullptr); refill(N); }
             VF_R_SEG(0) VF_R_SEG(1) VF_R_SEG(2) VF_R_SEG(3) VF_R_SEG(4) VF_R_SEG(5)
 #undef VF_R_SEG
-            static_assert(RB == 6, "the register segments are spelled out above");
             for (int sg = RB; sg < S; ++sg) {
-                consume(std::integral_constant<int, -1>{}, lds_lane + (long long)(sg - RB) * (8 * QN * 16));
+                consume(std::integral_constant<int, -1>{}, lds_lane + (long long)(sg - RB) * SEGIMG);
                 refill(sg);
             }
             const char* sc = scratch + (tiles_done & 1) * 512;
@@ -1782,6 +1876,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)e.y << 32) | (u64)e.x;
         }
     }
+    if (dbg && dbg_rec > 4) dbg[71] = __builtin_amdgcn_s_memtime() - c_entry;
     if (dbg) dbg[3] = wall_clock64();
 }
 
@@ -3015,18 +3110,34 @@ hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_f
     return hipGetLastError();
 }
 
-hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
-    const size_t lds = scan2r_lds_bytes(a.dp, qn_tile, a.stage_cap);
-    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2r<1, kModeMain>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_scan2r<2, kModeMain>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
-    return hipGetLastError();
+// every (query tile, mode, shape) instantiation of k_scan2r, as X(NT, MODE, F8, S, RB, RING)
+#ifdef VF_EXPERIMENTS
+#define VF_SCAN2R_SHAPES(X, NT, MODE) X(NT, MODE, 0, 12, 6, 6, 1) X(NT, MODE, 1, 6, 3, 6, 1) X(NT, MODE, 1, 8, 3, 4, 1) X(NT, MODE, 0, 12, 6, 6, 0) X(NT, MODE, 1, 6, 3, 4, 1)   // (+ the first form: debug bit 10; + a four-segment ring on e4m3 rows of 768: bit 11)
+#else
+#define VF_SCAN2R_SHAPES(X, NT, MODE) X(NT, MODE, 0, 12, 6, 6, 1) X(NT, MODE, 1, 6, 3, 6, 1) X(NT, MODE, 1, 8, 3, 4, 1)
+#endif
+#define VF_SCAN2R_ALL(X) VF_SCAN2R_SHAPES(X, 1, kModeMain) VF_SCAN2R_SHAPES(X, 2, kModeMain) VF_SCAN2R_SHAPES(X, 1, kModeSample) VF_SCAN2R_SHAPES(X, 2, kModeSample)
+static hipError_t launch_scan2r_any(const ScanArgs& a, int qn_tile, int mode, int grid, int f8, size_t lds, hipStream_t s) {
+    Scan2rShape sh = scan2r_shape(a.dp, f8);
+#ifdef VF_EXPERIMENTS
+    if (f8 && a.dp == 768 && (a.debug & 2048)) sh.RING = 4;   // timing experiment: is the scan bound by what a wave keeps in flight?  (LDS sized for six: harmless)
+#endif
+    const int nt = qn_tile / kQueryTile;
+    bool done = false;
+    const int ar = (!f8 && (a.debug & 1024)) ? 0 : 1;
+#define VF_X(NT, MODE, F8, S_, RB_, RING_, AR_) \
+    if (!done && nt == NT && mode == MODE && f8 == F8 && sh.S == S_ && sh.RB == RB_ && sh.RING == RING_ && ar == AR_) { \
+        hipLaunchKernelGGL((k_scan2r<NT, MODE, F8, S_, RB_, RING_, AR_>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a); done = true; }
+    VF_SCAN2R_ALL(VF_X)
+#undef VF_X
+    return done ? hipGetLastError() : hipErrorInvalidValue;
+}
+hipError_t launch_scan2r(const ScanArgs& a, int qn_tile, int grid, int f8, hipStream_t s) {
+    return launch_scan2r_any(a, qn_tile, kModeMain, grid, f8, scan2r_lds_bytes(a.dp, qn_tile, a.stage_cap, f8), s);
 }
 // the sample pass on k_scan2r's operand path: `grid` workgroups walk the sample parts of a.scan_grid ranges (a.samp rows per wave of k_scan's geometry)
-hipError_t launch_scan2r_sample(const ScanArgs& a, int qn_tile, int grid, hipStream_t s) {
-    const size_t lds = scan2r_lds_bytes(a.dp, qn_tile, 0);
-    if (qn_tile == kQueryTile) hipLaunchKernelGGL((k_scan2r<1, kModeSample>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_scan2r<2, kModeSample>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a);
-    return hipGetLastError();
+hipError_t launch_scan2r_sample(const ScanArgs& a, int qn_tile, int grid, int f8, hipStream_t s) {
+    return launch_scan2r_any(a, qn_tile, kModeSample, grid, f8, scan2r_lds_bytes(a.dp, qn_tile, 0, f8), s);
 }
 
 template <int NT, int G, int MODE>
@@ -3512,10 +3623,10 @@ hipError_t scan_configure() {
     VF_CFG(1, 1) VF_CFG(1, 2) VF_CFG(1, 3) VF_CFG(1, 4)
     VF_CFG(2, 1) VF_CFG(2, 2) VF_CFG(2, 3) VF_CFG(2, 4)
 #undef VF_CFG
-    if ((e = hipFuncSetAttribute((const void*)k_scan2r<1, kModeMain>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2r<2, kModeMain>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2r<1, kModeSample>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_scan2r<2, kModeSample>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#define VF_X(NT, MODE, F8, S_, RB_, RING_, AR_) \
+    if ((e = hipFuncSetAttribute((const void*)k_scan2r<NT, MODE, F8, S_, RB_, RING_, AR_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    VF_SCAN2R_ALL(VF_X)
+#undef VF_X
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_scan2<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
