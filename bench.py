@@ -1261,7 +1261,7 @@ def main():
                     "pipeline_ms_per_batch": round(prof["pipeline_ms_total"] / prof["scan_launches"], 4)}
         elif prof["scan_launches"] > 0:
             kname = {2: "vf::k_scan2<2> (whole-line LDS-DMA corpus loads)", 1: "vf::k_scan<main> (register loads)",
-                     5: "vf::k_scan2r<2> (k_scan2 with half of the query image in registers, six-segment rings)"}.get(stats.get("scan_kernel"), "vf::k_scan")
+                     5: "vf::k_scan2r<2> (k_scan2 with part of the query image in accumulator registers, deeper rings)"}.get(stats.get("scan_kernel"), "vf::k_scan")
             iso_ms = prof["scan_ms_total"] / prof["scan_launches"]
             iso_gbs = prof["scan_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9
             common = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,

@@ -779,6 +779,26 @@ def test_scan2r_on_fp8_rows_matches_oracle(vf, oracle, n, d, nq, k):
         assert abs(cands[1] - st["candidates"]) <= max(8, st["candidates"] // 4), (cands, st)     # same filter, different refresh timing
 
 
+def test_e4m3_rows_above_1_1m_take_scan2r_and_its_sample_pass_by_default(vf, oracle):
+    """The default for e4m3 rows of 768 / 1024 elements above 1.1M rows is k_scan2r with its own sample pass (round 6, after the filter
+    rewrite: 0.694-0.698 against k_scan's 0.627-0.656 of peak at 10M x 768): the rule's own path, no option set, against the oracle."""
+    from oracle import ref_numpy as R
+    n, d, nq, k = 1_150_016, 768, 12, 100
+    codes = _e4m3_codes(n, d, 97)
+    rows16 = R.decode_e4m3(codes).astype(np.float16)
+    q = np.random.default_rng(98).standard_normal((nq, d)).astype(np.float32)
+    want_i, want_s = oracle.search(rows16, q, k)
+    with vf.DenseIndex.from_e4m3(codes) as ix:
+        for _ in range(3):
+            i, s_ = ix.search(q, k)
+            st = ix.stats()
+            assert st["path"] == 1 and st["scan_kernel"] == 5 and st["exact_reruns"] == 0, st
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+        ix.set_option("scan_impl", 1)
+        i, s_ = ix.search(q, k)
+        assert ix.stats()["scan_kernel"] == 1 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+
+
 @pytest.mark.parametrize("n,d,nq,k,want_kernel", [
     (60_000, 768, 64, 100, 2),      # six 128-code segments per row beside a 96 KB fp16 query image
     (50_000, 1024, 24, 10, 2),      # one N-tile: 64 KB image

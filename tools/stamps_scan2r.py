@@ -36,6 +36,18 @@ def main():
     ix.close()
     us = lambda x: x / 100.0
     print(f"{rows} x {d} {dt} {' '.join(sys.argv[4:])} debug+{os.environ.get('VF_DBG_EXTRA', '0')}: kernel {st.get('scan_kernel')}, {len(t)} waves, candidates {st.get('candidates')}, reruns {st.get('exact_reruns')}")
+    if int(os.environ.get("VF_DBG_EXTRA", "0")) & 4096:      # cycle accounting (test variant): dbg[4..9] = wait, use, fill, head, epilogue cycles, segments
+        total = t[:, 71].astype(float)
+        names = ("waiting for a segment (vmcnt)", "LDS reads + matrix instructions", "LDS-DMA refills (4 per segment)", "tile head (claim, addresses)", "epilogue (filter, candidates)")
+        segs, ntile = t[:, 9].astype(float), t[:, 69].astype(float)
+        acc = 0.0
+        for k_, nm in enumerate(names):
+            v = t[:, 4 + k_].astype(float)
+            per = v / (segs if k_ < 3 else ntile)
+            acc = acc + v
+            print(f"  {nm:36s} {100 * np.median(v / total):5.1f} % of the wave's cycles   median {np.median(per):7.0f} cycles per {'segment' if k_ < 3 else 'tile'}")
+        print(f"  {'(unaccounted: start, flush, stamps)':36s} {100 * np.median(1 - acc / total):5.1f} %    segments per wave {np.median(segs):.0f}, tiles {np.median(ntile):.0f}, cycles {np.median(total):.0f}")
+        t[:, 4:68] = 0
     tiles = (t[:, 4:68] - t[:, 68:69]) / 100.0
     tiles[t[:, 4:68] == 0] = np.nan
     dd = np.diff(tiles, axis=1)

@@ -243,6 +243,7 @@ static int build_common(vf_index* ix) {
 // consecutive scans overlap; larger shards keep the whole chip and ordered scans (measured, round 3: 1.25M rows 0.384 ->
 // 0.362 ms per batch, 2.5M 0.717 -> 0.682, 5M 1.280 -> 1.269, 10M no change; profiles/r03_scan2_sweep.log).
 constexpr int64_t kSplitMaxRows = 6'000'000;
+constexpr int64_t kScan2rMinRows = 1'100'000;   // k_scan2r (where its shapes exist) above this many rows: below, the workgroup's longer start costs more than the ring gains
 // Round 6: where k_scan2r serves the rows (fp16 rows of 768 elements; a wave keeps 24 KB in flight there) the split + overlapping scans
 // win at EVERY size -- 7.5M rows 1.878 -> 1.811 ms per batch, 10M rows 2.538 -> 2.466-2.473 (0.7585 -> 0.78 of 8 TB/s), whole chip +
 // ordered scans with k_scan2 being the 2.538; k_scan2r on the whole chip with ordered scans LOSES (2.58-2.59): profiles/r06_scan2r_10m.log
@@ -954,7 +955,9 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // count, so that a query sees the same publication granularity at nq = 1 as at nq = 64.  (Unscaled, a single
         // query over 5M rows staged ~76 entries per workgroup, never completed a 128-entry block, never raised its
         // threshold above the sample's and overflowed its candidate list: exact re-run, 38 ms instead of 1.5.)
+        // (rounded down to a power of two: the kernels find a block's number with a shift)
         a.refresh_every = (int)std::min<int64_t>(256, std::max<int64_t>(4, std::max<int64_t>(1, ix->refresh_every) * nb / kMaxBatch));
+        while (a.refresh_every & (a.refresh_every - 1)) a.refresh_every &= a.refresh_every - 1;
         a.nq = nb; a.debug = (int)ix->debug;
         // sample slots no wave writes (a wave range shorter than samp) must read as empty: 0xFF bytes
         // are a NaN, which k_sel0's "v > -inf" test skips.  Never needed once n >= TW * samp.
@@ -966,8 +969,10 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // CU, each walking the sample parts of p.grid / 32 ranges with six-segment rings: the pass is bound by what a CU keeps in flight
         // (k_scan's register-staged loads: 68-71 us for 8 rows per wave in four rounds of 128 workgroups).  sample_impl: -1 auto, 0 k_scan, 1 k_scan2r
         const bool f8rows = ix->dtype == VF_DTYPE_FP8_E4M3;
+        // e4m3 rows (768 / 1024 elements) take it wherever k_scan2r is their main scan (n > 1.1M: below), whole chip or split.
+        const bool r_f8_auto = f8rows && ix->scan_impl == 2 && ix->n > kScan2rMinRows && !ix->steal_opt;
         const bool sample_r = ix->sample_impl != 0 && ix->scan_impl != 1 && scan2r_stage_cap(ix->dp, qt, f8rows) >= 256 &&
-                              (ix->sample_impl == 1 || (!f8rows && s.scan_stream != s.stream));
+                              (ix->sample_impl == 1 || (!f8rows && s.scan_stream != s.stream) || r_f8_auto);
         if (sample_r) {
             const int64_t sg_r = ix->sample_grid > 0 ? ix->sample_grid : (s.scan_stream != s.stream ? resolved_aux(ix) : p.grid);
             ScanArgs as = a;
@@ -1011,7 +1016,11 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // the scan sits on the copy ceiling there), configs[1] (1M rows) 3 % SLOWER (0.303-0.315 vs 0.293-0.303: that step is the
         // prologue chain's, and the workgroup's start is 2.3 us longer).  So: auto (scan_impl = 2) takes it above 1.1M rows wherever the
         // scans run on the CU split and overlap (which, for these rows, is every size: split_limit); 5 forces it, 4 forbids it.
-        const bool r_auto = ix->scan_impl == 2 && !f8 && ix->n > 1100000 && s.scan_stream != s.stream && resolved_overlap(ix);   // (with the CU split and overlapping scans only: above)
+        // e4m3 rows (round 6, after the filter rewrite): k_scan2r was 0.55-0.60 against k_scan's 0.63-0.70 while a tile's threshold filter
+        // cost a lone wave 4 500 cycles; with the filter at ~1 000 it is 0.694-0.698 against 0.627-0.656 at 10M x 768 and 0.717-0.719
+        // against 0.693-0.700 at 10M x 1024 (whole chip, ordered scans; split + overlap loses 3-5 % there), +2-3 % at 1.25M rows with its
+        // own sample pass, level at 1M: the same row threshold as fp16 rows, no CU-split condition (profiles/r06_after_filter_kernel_choice.log)
+        const bool r_auto = ix->scan_impl == 2 && ix->n > kScan2rMinRows && (f8 || (s.scan_stream != s.stream && resolved_overlap(ix)));   // (fp16 rows: with the CU split and overlapping scans only: above)
 #ifdef VF_EXPERIMENTS
         const bool dbg_r = f8 || !(ix->debug & (32 | 64));   // (bits 5 / 6 are k_scan2's experiments on fp16 rows, k_scan2r's on e4m3 rows)
 #else

@@ -718,6 +718,7 @@ struct EpiRegs {
     float inv_lane;
     int tau_g[NT];
     bool sync_tau;
+    const char* inv_lds = nullptr;   // k_scan2 / k_scan2r: the tile's 32 reciprocal norms as floats in LDS (the scratch half the DMA filled); nullptr: inv_lane
 };
 
 // Wave-wide OR / sum of a 32-bit value, result uniform (an SGPR): four DPP row rotations leave every lane with its row's
@@ -755,7 +756,7 @@ __device__ __forceinline__ void epi_prefetch(EpiRegs<NT>& e, const ScanArgs& a, 
 // PUBLISH = false (k_scan2): the wave only STAGES its candidates; publishing completed blocks to the global histograms and
 // refreshing thresholds is the service wave's job (k_scan2_service), so that no global atomic or dependent load of this
 // path ever sits in a streaming wave's in-order memory queue.
-template <int NT, int MODE, bool PUBLISH = true>
+template <int NT, int MODE, bool PUBLISH = true, bool INV_LDS = false>
 __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&acc)[NT], const EpiRegs<NT>& e,
                                               long long t0, long long hi, long long s0_slot, int lane, char* ctl) {
     const int r31 = lane & 31, h = lane >> 5;
@@ -786,48 +787,93 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) atomicMax(tau_lds + nt * kQueryTile + lane, e.tau_g[nt]);
     }
-    // bit (nt * 16 + reg) of `mask` = "this lane's score for (query nt*32 + r31, row reg) passes"
-    float tb[NT];
-    u32 mask = 0;
+    // The filter, written for the tile WITHOUT a candidate (round 6: the first form's per-element "(row exists) && (x >= tb)" compiled to
+    // two exec-mask branches, a 64-bit add and compare and two readlanes per element -- ~700 instructions, 4 500-6 000 cycles per tile,
+    // a third of a streaming wave's cycles by the cycle accounting of tools/stamps_scan2r.py; profiles/r06_scan2r_cycle_accounting.log):
+    //  - the 16 reciprocal norms this lane's accumulator registers need (row (reg & 3) + 8 (reg >> 2) + 4 h) come as four 16-byte LDS
+    //    reads where the tile's norms sit in LDS (k_scan2 / k_scan2r), else by two readlanes and a select each (k_scan);
+    //  - rows past the part's end get a NaN norm (one scalar branch per tile, taken by a range's last tile only): every compare is false;
+    //  - x = bin_x(acc / norm) for the 16 NT elements, their maximum per query tile, ONE compare per query tile, one ballot: no lane of
+    //    the wave passes -> done (the same mul + fma as before: the scores, and so the candidates, are bit for bit what they were);
+    //  - only a tile that holds a candidate builds the per-element mask (a compare and a select each).
+    float inv16[16];
+    if constexpr (INV_LDS) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *(const float4*)(e.inv_lds + (8 * g + 4 * h) * 4);
+            inv16[4 * g] = v.x; inv16[4 * g + 1] = v.y; inv16[4 * g + 2] = v.z; inv16[4 * g + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) inv16[reg] = inv_of(reg);
+    }
+    const long long left = hi - t0;
+    const int lf = __builtin_amdgcn_readfirstlane((int)(left < kRowTile ? left : kRowTile));   // (wave-uniform by construction: a scalar branch)
+    if (lf < kRowTile) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) inv16[reg] = ((reg & 3) + 8 * (reg >> 2) + 4 * h) < lf ? inv16[reg] : __builtin_nanf("");
+    }
+    float tb[NT], x[NT][16];
+    bool any = false;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int q = nt * kQueryTile + r31;
         const int t = tau_lds[q];
         tb[nt] = q < a.nq ? (t <= 0 ? -INFINITY : (float)t) : INFINITY;
+        float top = -INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const float x = bin_x(acc[nt][reg] * inv_of(reg));
-            mask |= ((t0 + rr < hi) && (x >= tb[nt])) ? (1u << (nt * 16 + reg)) : 0u;
+            x[nt][reg] = bin_x(acc[nt][reg] * inv16[reg]);
+            top = fmaxf(top, x[nt][reg]);                              // (a NaN -- a row that does not exist -- never wins)
         }
-        __builtin_amdgcn_sched_barrier(0);  // one N-tile at a time: keeps the live set small
+        any |= top >= tb[nt];
     }
-    // wave-uniform OR of the masks: which (query tile, row register) pairs have a passing lane ANYWHERE in the wave.  The
-    // rare path below is unrolled over the 16 NT pairs; testing each pair on this scalar costs a scalar compare-and-branch
-    // instead of a vector test + exec-mask branch per pair (round 3: on a 1.25M-row shard nearly every tile has a candidate
-    // or two, and the 32 vector tests were a third of the path's ~0.45 us per tile)
-    const u32 umask = wave_or_u32(mask);
-    if (umask == 0u) return;
-
-    // ---- rare path: stage candidates in LDS; once per block of `refresh_every` staged entries ONE
-    // wave refreshes one tau and publishes that block to the global histograms.
+    if (__ballot(any) == 0ull) return;
+    // bit (nt * 16 + reg) of `mask` = "this lane's score for (query nt*32 + r31, row reg) passes"
+    u32 mask = 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) mask |= (x[nt][reg] >= tb[nt]) ? (1u << (nt * 16 + reg)) : 0u;
+    // ---- a tile that holds a candidate: stage them in LDS; once per block of R staged entries ONE wave refreshes one tau and
+    // publishes that block to the global histograms.
     // No global memory operation is issued per candidate: vmcnt retires in order, so even a no-return
     // atomic here would hold up the consumption of the corpus stage already in flight.  The
     // workgroup flushes its stage to the global lists once, at the end.
+    // On a small shard nearly every tile takes this path with two or three candidates (1.25M x 768: 3.2 per tile), so it is written for
+    // FEW candidates (round 6; the cycle accounting put it at ~1 700 cycles per tile, a tenth of the wave's time):
+    //  - which (query tile, row register) pairs hold a passing lane anywhere in the wave, and how many candidates there are: a scalar
+    //    loop over the lanes that hold one (a readlane each) while there are at most eight, the DPP reductions otherwise;
+    //  - the block size is a power of two (begin_impl rounds it): shifts, not two 32-bit divisions.
+    const unsigned long long hot = __ballot(mask != 0u);
+    if (hot == 0ull) return;
     if (a.debug & 4) return;  // timing experiment: filter only
+    u32 umask = 0u, total = 0u;
+    if (__popcll(hot) <= 8) {
+        for (unsigned long long hb = hot; hb != 0ull; hb &= hb - 1ull) {
+            const u32 m = (u32)__builtin_amdgcn_readlane((int)mask, __builtin_ctzll(hb));
+            umask |= m;
+            total += (u32)__popc(m);
+        }
+    } else {
+        umask = wave_or_u32(mask);
+        total = wave_sum_u32((u32)__popc(mask));
+    }
     u32* stage_cnt = (u32*)ctl;
     uint4* stage_ent = (uint4*)(ctl + kCtlBytes);
-    const u32 R = (u32)a.refresh_every;  // 1..256
+    const u32 rs = 31u - (u32)__builtin_clz((u32)a.refresh_every | 1u);   // block size R = 2^rs (1..256)
+    const u32 R = 1u << rs;
     // one LDS atomic per wave claims the slots of all its candidates; lanes take theirs pair by pair (ballot prefix)
-    const u32 total = wave_sum_u32((u32)__popc(mask));
     u32 base = 0;
     if (lane == 0) base = atomicAdd(stage_cnt, total);
     base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-    const bool need = (base / R) != ((base + total) / R);   // this wave completed a block
+    const bool need = (base >> rs) != ((base + total) >> rs);   // this wave completed a block
     if (a.debug & 8) return;  // timing experiment: claim slots, write nothing (flush skips w != 1)
     u32 run = base;
-    const u32 edge = (base + total) / R * R - 1u;   // the slot that completed the block (meaningful when `need`)
+    const u32 edge = (((base + total) >> rs) << rs) - 1u;   // the slot that completed the block (meaningful when `need`)
     int qq = 0;               // the query whose tau is refreshed: that of the pair holding the completing slot (its first lane)
+    // (the pairs are tested one by one on the scalar umask, unrolled: a loop over the SET pairs -- count-trailing-zeros + a switch into
+    //  the 32 bodies -- was tried and cost 250-800 bytes of scratch per lane in every kernel that uses this epilogue)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int q = nt * kQueryTile + r31;
@@ -839,7 +885,7 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
                 if (mask & bit) {
                     const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
                     const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    const float sc = acc[nt][reg] * inv_of(reg);
+                    const float sc = acc[nt][reg] * inv16[reg];
                     const u32 bin = (u32)bin_of_x(bin_x(sc));
                     const u32 key = orderkey(sc), row = (u32)(t0 + rr);
                     if (slot < (u32)a.stage_cap) {
@@ -872,9 +918,9 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
         //     less tight.
         //     EVERY block this wave completed is published (round 4): with small blocks (refresh_every scaled down to 4 for
         //     one or two queries) a wave's candidates can span several blocks, and the ones in the middle used to be lost.
-        for (u32 blk = base / R; blk < (base + total) / R; ++blk)
+        for (u32 blk = base >> rs; blk < (base + total) >> rs; ++blk)
         for (u32 j = (u32)lane; j < R; j += 64u) {
-            const u32 idx = blk * R + j;
+            const u32 idx = (blk << rs) + j;
             if (idx >= (u32)a.stage_cap) break;
             const uint4 en = stage_ent[idx];
             if (en.w == 1u) {
@@ -1458,12 +1504,13 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
             const char* sc = scratch + (tiles_done & 1) * 512;
             EpiRegs<NT> epi;
             epi.inv_lane = *(const float*)(sc + 256 + r31 * 4);
+            epi.inv_lds = sc + 256;
             epi.sync_tau = sync_now;
             if (sync_now) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) epi.tau_g[nt] = *(const int*)(sc + (nt * kQueryTile + r31) * 4);
             }
-            tile_epilogue<NT, MODE, !kScan2Service>(a, acc, epi, t0, hi, 0, lane, ctl);
+            tile_epilogue<NT, MODE, !kScan2Service, true>(a, acc, epi, t0, hi, 0, lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1698,6 +1745,17 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
         dbg[70] = ((unsigned long long)xcc_id << 32) | hw_id;
     }
+#ifdef VF_EXPERIMENTS
+    // cycle accounting of a wave's own timeline (debug bit 12; s_memtime + lgkmcnt(0) at each phase boundary, so the run is ~10 % slower than
+    // the product's and the RATIOS are what to read): [4] waiting for a segment (vmcnt), [5] LDS reads + matrix instructions issued,
+    // [6] the four LDS-DMA refills, [7] tile head (claim, addresses), [8] epilogue, [9] segments, in shader cycles -> dbg[4..9]
+    const bool prof = (a.debug & 4096) != 0;
+    unsigned long long pc_wait = 0, pc_use = 0, pc_fill = 0, pc_head = 0, pc_epi = 0, pc_n = 0, pt0 = 0, pt1 = 0;
+    auto cyc = [&]() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; };
+#define VF_PC(stmt) if (prof) { stmt; }
+#else
+#define VF_PC(stmt)
+#endif
     int tiles_done = 0;
     if (active) {
         f16v acc[NT];
@@ -1707,6 +1765,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
         int buf = 0;
         while (true) {
+            VF_PC(pt0 = cyc())
             long long t0, t_hi, t_s0;
             tile_rows(cur_tile, t0, t_hi, t_s0);
             int claimed;
@@ -1722,14 +1781,17 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             const bool sync_now = MODE == kModeMain && (tiles_done & (kScan2Waves - 1)) == wid;
             const bool sync_next = MODE == kModeMain && ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
             if (dbg && dbg_rec > 4 && tiles_done < 64) dbg[4 + tiles_done] = wall_clock64();
+            VF_PC(pt1 = cyc(); pc_head += pt1 - pt0)
             // one body for both halves: BREG picks the B fragments from the registers (compile-time segment) or from LDS
             auto consume = [&](auto sg_c, const char* bb) {
                 constexpr int sgc = decltype(sg_c)::value;        // >= 0: register segment; -1: LDS
                 // segments sg + 1 .. sg + RING - 1 (4 (RING - 1) DMA instructions, and the <= 2 epilogue words issued among them) may still be in flight
+                VF_PC(pt0 = cyc())
                 if constexpr (RING == 6) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 else if constexpr (RING == 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 static_assert(RING >= 4 && RING <= 6, "the counted waits above");
+                VF_PC(pt1 = cyc(); pc_wait += pt1 - pt0; ++pc_n)
                 const char* ab = a_lane + buf * kSegBytes;
                 // B fragment j of query tile nt: from the accumulator registers, the allocator's registers (AR = 0) or LDS
                 auto bfrag = [&](int j, int nt) -> h8 {
@@ -1804,6 +1866,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the refill overwrites the LDS these fragments were read from (k_scan2's note)
+                VF_PC(pt0 = cyc(); pc_use += pt0 - pt1)
             };
             auto refill = [&](int sg) {
                 const int s3 = sg + RING;
@@ -1813,6 +1876,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
                     issue_seg(src_nxt, s3 - S, buf);
                 }
                 buf = buf + 1 == RING ? 0 : buf + 1;
+                VF_PC(pt1 = cyc(); pc_fill += pt1 - pt0)
             };
 #define VF_R_SEG(N) if constexpr (RB > N) { consume(std::integral_constant<int, N>{}, nullptr); refill(N); }
             VF_R_SEG(0) VF_R_SEG(1) VF_R_SEG(2) VF_R_SEG(3) VF_R_SEG(4) VF_R_SEG(5)
@@ -1821,19 +1885,22 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
                 consume(std::integral_constant<int, -1>{}, lds_lane + (long long)(sg - RB) * SEGIMG);
                 refill(sg);
             }
+            VF_PC(pt0 = cyc())
             const char* sc = scratch + (tiles_done & 1) * 512;
             EpiRegs<NT> epi;
             epi.inv_lane = *(const float*)(sc + 256 + r31 * 4);
+            epi.inv_lds = sc + 256;
             epi.sync_tau = sync_now;
             if (sync_now) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) epi.tau_g[nt] = *(const int*)(sc + (nt * kQueryTile + r31) * 4);
             }
-            tile_epilogue<NT, MODE, true>(a, acc, epi, t0, t_hi, t_s0, lane, ctl);
+            tile_epilogue<NT, MODE, true, true>(a, acc, epi, t0, t_hi, t_s0, lane, ctl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nt][e] = 0.0f;
+            VF_PC(pt1 = cyc(); pc_epi += pt1 - pt0)
             ++tiles_done;
             if (!more) break;
             cur_tile = nxt;
@@ -1877,6 +1944,10 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
         }
     }
     if (dbg && dbg_rec > 4) dbg[71] = __builtin_amdgcn_s_memtime() - c_entry;
+#ifdef VF_EXPERIMENTS
+    if (dbg && dbg_rec > 4 && prof) { dbg[4] = pc_wait; dbg[5] = pc_use; dbg[6] = pc_fill; dbg[7] = pc_head; dbg[8] = pc_epi; dbg[9] = pc_n; }
+#endif
+#undef VF_PC
     if (dbg) dbg[3] = wall_clock64();
 }
 
