@@ -143,9 +143,9 @@ int vf_index_stats(vf_index* idx, vf_search_stats* out);
  * "sample_rows": rows per wave the sample pass scores to seed the thresholds: -1 auto (8 for shards of up to 1.5M rows while the
  *   sample still holds 16 k' rows, else 16), or 1..64.  A speed setting: a looser seed admits more candidates, results do not change.
  * "scan_impl": the narrow scan's kernel: 1 k_scan (register loads); 2 (default) k_scan2 (whole-line LDS-DMA loads) for fp16 rows, and
- *   its register-image form k_scan2r for the shard sizes it measured faster on (fp16 rows of 768 elements above 1.1M rows); 3 k_scan2
- *   wherever it fits (e4m3 rows converted in registers); 4 k_scan2, never k_scan2r; 5 k_scan2r wherever it fits (fp16 rows of 768
- *   elements, e4m3 rows of 768 or 1024; e4m3 rows measured slower than k_scan there, which stays their default).  Same results from each.
+ *   its register-image form k_scan2r where it measured faster (fp16 rows of 384 / 512 / 768 / 1024 elements and e4m3 rows of 768 / 1024, above 1.1M rows); 3 k_scan2
+ *   wherever it fits (e4m3 rows converted in registers); 4 k_scan2, never k_scan2r; 5 k_scan2r wherever a shape of it exists, at any
+ *   row count.  Same results from each.
  * "sample_impl": the sample pass's kernel: -1 auto (k_scan2r's operand path where it exists and the CU split is on), 0 k_scan, 1 k_scan2r
  *   wherever it fits.  Same sample rows and slots either way; results do not change. */
 int vf_index_set_option(vf_index* idx, const char* name, int64_t value);

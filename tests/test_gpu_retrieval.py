@@ -779,6 +779,49 @@ def test_scan2r_on_fp8_rows_matches_oracle(vf, oracle, n, d, nq, k):
         assert abs(cands[1] - st["candidates"]) <= max(8, st["candidates"] // 4), (cands, st)     # same filter, different refresh timing
 
 
+@pytest.mark.parametrize("n,d,nq,k", [
+    (60_000, 1024, 64, 100),        # S = 16 segments: six in accumulator registers, ten in LDS (80 KB), rings of four -- the reference's own width (bge-m3)
+    (50_011, 1024, 17, 1000),       # one query tile, deep, ragged
+    (60_000, 512, 64, 100),         # S = 8: four in registers, rings of six
+    (60_001, 384, 40, 10),          # S = 6: three in registers: a tile's segments equal the ring's depth
+    (45_000, 1000, 64, 50),         # d = 1000 pads to 1024
+])
+def test_scan2r_other_fp16_widths_match_oracle(vf, oracle, n, d, nq, k):
+    """k_scan2r's other fp16 shapes (scan_impl = 5): main scan and sample pass against the oracle, repeatedly, and against k_scan2 / k_scan."""
+    c, q = _data(131 + d % 13, n, d, nq, np.float16)
+    want_i, want_s = oracle.search(c, q, k)
+    with vf.DenseIndex(c) as ix:
+        ix.set_option("force_path", 1)
+        if k > 100:
+            ix.set_option("sample_rows", 64)
+        for impl, simpl in ((5, 0), (5, 1), (5, 1), (4, 0), (1, 0), (5, 1)):
+            ix.set_option("scan_impl", impl)
+            ix.set_option("sample_impl", simpl)
+            for _ in range(3):
+                i, s_ = ix.search(q, k)
+                st = ix.stats()
+                assert st["path"] == 1 and st["exact_reruns"] == 0 and st["overflowed"] == 0, (impl, simpl, st)
+                assert st["scan_kernel"] == (5 if impl == 5 else st["scan_kernel"]), (impl, st)
+                assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), (impl, simpl)
+
+
+def test_fp16_rows_of_1024_above_1_1m_take_scan2r_by_default(vf, oracle):
+    """The reference's own embedding width (bge-m3: 1024, config/example.yaml:3) as fp16 rows: above 1.1M rows the default is k_scan2r on the CU
+    split (k_scan2's image does not fit this width; k_scan served it before): the rule's own path, no option set, against the oracle."""
+    n, d, nq, k = 1_150_016, 1024, 8, 100
+    c, q = _data(141, n, d, nq, np.float16)
+    want_i, want_s = oracle.search(c, q, k)
+    with vf.DenseIndex(c) as ix:
+        for _ in range(3):
+            i, s_ = ix.search(q, k)
+            st = ix.stats()
+            assert st["path"] == 1 and st["scan_kernel"] == 5 and st["exact_reruns"] == 0, st
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+        ix.set_option("scan_impl", 1)
+        i, s_ = ix.search(q, k)
+        assert ix.stats()["scan_kernel"] == 1 and np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s))
+
+
 def test_e4m3_rows_above_1_1m_take_scan2r_and_its_sample_pass_by_default(vf, oracle):
     """The default for e4m3 rows of 768 / 1024 elements above 1.1M rows is k_scan2r with its own sample pass (round 6, after the filter
     rewrite: 0.694-0.698 against k_scan's 0.627-0.656 of peak at 10M x 768): the rule's own path, no option set, against the oracle."""

@@ -29,9 +29,9 @@ def draw_case(rng, max_work):
     k = max(1, min(k, 2048))
     data = pick(["normal", "normal", "dupes", "clusters", "scaled", "zeros", "sorted", "lowrank"])
     opts = {}
-    if os.environ.get("VF_FUZZ_SCAN2R") == "1":   # soak of round 6's kernels: k_scan2r for the scan and for the sample pass -- fp16 rows of 768, e4m3 rows of 768 / 1024
+    if os.environ.get("VF_FUZZ_SCAN2R") == "1":   # soak of round 6's kernels: k_scan2r for the scan and for the sample pass -- fp16 rows of 384 / 512 / 768 / 1024 (1000 pads to it), e4m3 rows of 768 / 1024
         dtype = pick(["f16", "f16", "f32", "fp8", "fp8"])
-        d = 768 if dtype != "fp8" else pick([768, 1024])
+        d = pick([768, 768, 1024, 512, 384, 1000]) if dtype != "fp8" else pick([768, 1024])
         opts["scan_impl"] = 5
         opts["sample_impl"] = 1
     elif rng.random() < 0.3:

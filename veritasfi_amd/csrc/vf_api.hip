@@ -244,12 +244,18 @@ static int build_common(vf_index* ix) {
 // 0.362 ms per batch, 2.5M 0.717 -> 0.682, 5M 1.280 -> 1.269, 10M no change; profiles/r03_scan2_sweep.log).
 constexpr int64_t kSplitMaxRows = 6'000'000;
 constexpr int64_t kScan2rMinRows = 1'100'000;   // k_scan2r (where its shapes exist) above this many rows: below, the workgroup's longer start costs more than the ring gains
-// Round 6: where k_scan2r serves the rows (fp16 rows of 768 elements; a wave keeps 24 KB in flight there) the split + overlapping scans
+// Round 6: where k_scan2r serves the rows (fp16 rows of 384 / 512 / 768 / 1024 elements; a wave keeps 16-24 KB in flight there) the split + overlapping scans
 // win at EVERY size -- 7.5M rows 1.878 -> 1.811 ms per batch, 10M rows 2.538 -> 2.466-2.473 (0.7585 -> 0.78 of 8 TB/s), whole chip +
 // ordered scans with k_scan2 being the 2.538; k_scan2r on the whole chip with ordered scans LOSES (2.58-2.59): profiles/r06_scan2r_10m.log
+// the widths on which k_scan2r was MEASURED against the kernel it replaces and is the default (its other shapes: scan_impl = 5)
+// fp16 rows of 1024 / 512 / 384 elements (round 6, profiles/r06_scan2r_fp16_other_widths_ab.log; k_scan2r + its sample pass on the CU split
+// with overlapping scans against the default before): 8M x 1024 2.725 -> 2.63-2.65 ms per batch (0.754 -> 0.774-0.781 of 8 TB/s; k_scan served
+// that width: k_scan2's image does not fit), 1.25M x 1024 0.465-0.467 -> 0.430-0.444, 10M x 512 1.711 -> 1.620-1.643 (0.765 -> 0.785-0.796),
+// 10M x 384 1.330 -> 1.262, 1.25M x 512 0.266-0.270 -> 0.260-0.265
+static bool scan2r_auto_width(int dp, bool f8) { return f8 ? (dp == 768 || dp == 1024) : (dp == 768 || dp == 1024 || dp == 512 || dp == 384); }
 static int64_t split_limit(const vf_index* ix) {
     const bool r_rows = ix->dtype != VF_DTYPE_FP8_E4M3 && ix->scan_impl != 4 && ix->scan_impl != 1 && ix->scan_impl != 3 && !ix->steal_opt &&
-                        scan2r_stage_cap(ix->dp, kMaxBatch, 0) >= 256;
+                        scan2r_auto_width(ix->dp, false) && scan2r_stage_cap(ix->dp, kMaxBatch, 0) >= 256;
     return r_rows ? INT64_MAX : kSplitMaxRows;
 }
 static int64_t resolved_aux(const vf_index* ix) {
@@ -619,7 +625,7 @@ extern "C" int vf_index_set_option(vf_index* ix, const char* name, int64_t value
         ix->aux_cus = value;
     }
     else if (s == "sample_grid") { if (!in_range(-1, 1024)) return fail(VF_EINVAL, "sample_grid must be -1 (auto), 0 (one workgroup per range) or a workgroup count"); ix->sample_grid = value; }
-    else if (s == "scan_impl") { if (!in_range(1, 5)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (auto: k_scan2 for fp16 rows, k_scan2r where it measured faster), 3 (k_scan2 wherever it fits, e4m3 rows converted), 4 (k_scan2 for fp16 rows, never k_scan2r) or 5 (k_scan2r wherever it fits: fp16 rows of 768 elements, e4m3 rows of 768 or 1024)"); ix->scan_impl = value; }
+    else if (s == "scan_impl") { if (!in_range(1, 5)) return fail(VF_EINVAL, "scan_impl must be 1 (k_scan), 2 (auto: k_scan2 for fp16 rows, k_scan2r where it measured faster), 3 (k_scan2 wherever it fits, e4m3 rows converted), 4 (k_scan2 for fp16 rows, never k_scan2r) or 5 (k_scan2r wherever a shape of it exists: fp16 rows of 384 / 512 / 768 / 1024 elements, e4m3 rows of 768 / 1024)"); ix->scan_impl = value; }
     else if (s == "sample_impl") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "sample_impl must be -1 (auto: k_scan2r's operand path for the sample pass where it exists and the CU split is on), 0 (k_scan) or 1 (k_scan2r wherever it fits)"); ix->sample_impl = value; }
     else if (s == "overlap_scans") { if (!in_range(-1, 1)) return fail(VF_EINVAL, "overlap_scans must be -1 (auto), 0 or 1"); ix->overlap_scans = value; }
     else if (s == "debug") ix->debug = value;
@@ -965,14 +971,14 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
             VF_HIP(hipMemsetAsync(a.s0, 0xFF, (size_t)qt * p.total_waves * p.samp * sizeof(float), st));
         // sample pass: a FEW workgroups walk the sample parts of all ranges (each stages the query image once)
         // (auto: 4 workgroups per spare CU when the CU split is on, one per range otherwise)
-        // Round 6: where k_scan2r's operand path exists (fp16 rows of 768 elements) the sample pass takes it too -- ONE workgroup per spare
+        // Round 6: where k_scan2r's operand path is the default (scan2r_auto_width) the sample pass takes it too -- ONE workgroup per spare
         // CU, each walking the sample parts of p.grid / 32 ranges with six-segment rings: the pass is bound by what a CU keeps in flight
         // (k_scan's register-staged loads: 68-71 us for 8 rows per wave in four rounds of 128 workgroups).  sample_impl: -1 auto, 0 k_scan, 1 k_scan2r
         const bool f8rows = ix->dtype == VF_DTYPE_FP8_E4M3;
         // e4m3 rows (768 / 1024 elements) take it wherever k_scan2r is their main scan (n > 1.1M: below), whole chip or split.
-        const bool r_f8_auto = f8rows && ix->scan_impl == 2 && ix->n > kScan2rMinRows && !ix->steal_opt;
+        const bool r_f8_auto = f8rows && ix->scan_impl == 2 && ix->n > kScan2rMinRows && !ix->steal_opt && scan2r_auto_width(ix->dp, true);
         const bool sample_r = ix->sample_impl != 0 && ix->scan_impl != 1 && scan2r_stage_cap(ix->dp, qt, f8rows) >= 256 &&
-                              (ix->sample_impl == 1 || (!f8rows && s.scan_stream != s.stream) || r_f8_auto);
+                              (ix->sample_impl == 1 || (!f8rows && s.scan_stream != s.stream && scan2r_auto_width(ix->dp, false)) || r_f8_auto);
         if (sample_r) {
             const int64_t sg_r = ix->sample_grid > 0 ? ix->sample_grid : (s.scan_stream != s.stream ? resolved_aux(ix) : p.grid);
             ScanArgs as = a;
@@ -1010,7 +1016,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // (k_scan2, round 3) and 0.55-0.60 (k_scan2r, round 6: B fragments in accumulator registers, rings of six) against k_scan's
         // 0.63-0.70 of peak at 10M x 768 / 1024 fp8 (profiles/r03_f8_sweep.log, r06_fp8_scan2r_ab.log)
         const int cap2 = ((ix->scan_impl == 3 || ((ix->scan_impl == 2 || ix->scan_impl == 4 || ix->scan_impl == 5) && !f8)) && !ix->steal_opt) ? scan2_stage_cap(ix->dp, qt, f8) : 0;
-        // k_scan2r (round 6): half of the query image in registers, six-segment rings -- fp16 rows of 768 elements.  Measured against
+        // k_scan2r (round 6): part of the query image in accumulator registers, deeper rings.  fp16 rows of 768 elements, measured against
         // k_scan2 in separate processes, alternating (profiles/r06_scan2r_ab.log): the 8-GPU rank's shard (1.25M rows) 0.3469-0.3528 ms
         // per batch against 0.3538-0.3602 (2.2 % faster: a wave keeps 24 KB in flight instead of 12), 10M rows level (2.538 vs 2.548 --
         // the scan sits on the copy ceiling there), configs[1] (1M rows) 3 % SLOWER (0.303-0.315 vs 0.293-0.303: that step is the
@@ -1020,7 +1026,7 @@ static int begin_impl(vf_index* ix, int slot_id, const float* d_queries, int nq,
         // cost a lone wave 4 500 cycles; with the filter at ~1 000 it is 0.694-0.698 against 0.627-0.656 at 10M x 768 and 0.717-0.719
         // against 0.693-0.700 at 10M x 1024 (whole chip, ordered scans; split + overlap loses 3-5 % there), +2-3 % at 1.25M rows with its
         // own sample pass, level at 1M: the same row threshold as fp16 rows, no CU-split condition (profiles/r06_after_filter_kernel_choice.log)
-        const bool r_auto = ix->scan_impl == 2 && ix->n > kScan2rMinRows && (f8 || (s.scan_stream != s.stream && resolved_overlap(ix)));   // (fp16 rows: with the CU split and overlapping scans only: above)
+        const bool r_auto = ix->scan_impl == 2 && ix->n > kScan2rMinRows && scan2r_auto_width(ix->dp, f8 != 0) && (f8 || (s.scan_stream != s.stream && resolved_overlap(ix)));   // (fp16 rows: with the CU split and overlapping scans only: above)
 #ifdef VF_EXPERIMENTS
         const bool dbg_r = f8 || !(ix->debug & (32 | 64));   // (bits 5 / 6 are k_scan2's experiments on fp16 rows, k_scan2r's on e4m3 rows)
 #else

@@ -1581,12 +1581,17 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 // ------------------------------------------------------------------------------------------------
 // The shapes it is built for -- (row bytes per 128-byte segment count S, register segments RB, ring depth RING):
 //   fp16 rows, dp =  768: S = 12, RB = 6 (192 registers of B fragments at 64 queries), RING = 6
+//   fp16 rows, dp = 1024: S = 16, RB = 6, RING = 4 (80 KB of image in LDS: k_scan2 has no room for this width at all)
+//   fp16 rows, dp =  512: S =  8, RB = 4, RING = 6;   dp = 384: S = 6, RB = 3, RING = 6
 //   e4m3 rows, dp =  768: S =  6, RB = 3 (a segment is 128 elements: 16 KB of image, 64 registers), RING = 6
 //   e4m3 rows, dp = 1024: S =  8, RB = 3 (with the 32 accumulators the 256 accumulator registers hold no fourth), RING = 4
 // (e4m3 rows are converted in registers like k_scan2's F8 variant: every e4m3 value is an fp16 value, the image is shared.)
 struct Scan2rShape { int S, RB, RING; };
 static Scan2rShape scan2r_shape(int dp, int f8) {
     if (!f8 && dp == 768) return {12, 6, 6};
+    if (!f8 && dp == 1024) return {16, 6, 4};   // (bge-m3 / bge-large rows: the reference's own width, config/example.yaml:3)
+    if (!f8 && dp == 512) return {8, 4, 6};
+    if (!f8 && dp == 384) return {6, 3, 6};
     if (f8 && dp == 768) return {6, 3, 6};
     if (f8 && dp == 1024) return {8, 3, 4};
     return {0, 0, 0};
@@ -3182,10 +3187,11 @@ hipError_t launch_scan2(const ScanArgs& a, int qn_tile, int grid, int rows_are_f
 }
 
 // every (query tile, mode, shape) instantiation of k_scan2r, as X(NT, MODE, F8, S, RB, RING)
+#define VF_SCAN2R_PRODUCT(X, NT, MODE) X(NT, MODE, 0, 12, 6, 6, 1) X(NT, MODE, 0, 16, 6, 4, 1) X(NT, MODE, 0, 8, 4, 6, 1) X(NT, MODE, 0, 6, 3, 6, 1) X(NT, MODE, 1, 6, 3, 6, 1) X(NT, MODE, 1, 8, 3, 4, 1)
 #ifdef VF_EXPERIMENTS
-#define VF_SCAN2R_SHAPES(X, NT, MODE) X(NT, MODE, 0, 12, 6, 6, 1) X(NT, MODE, 1, 6, 3, 6, 1) X(NT, MODE, 1, 8, 3, 4, 1) X(NT, MODE, 0, 12, 6, 6, 0) X(NT, MODE, 1, 6, 3, 4, 1)   // (+ the first form: debug bit 10; + a four-segment ring on e4m3 rows of 768: bit 11)
+#define VF_SCAN2R_SHAPES(X, NT, MODE) VF_SCAN2R_PRODUCT(X, NT, MODE) X(NT, MODE, 0, 12, 6, 6, 0) X(NT, MODE, 1, 6, 3, 4, 1)   // (+ the first form: debug bit 10; + a four-segment ring on e4m3 rows of 768: bit 11)
 #else
-#define VF_SCAN2R_SHAPES(X, NT, MODE) X(NT, MODE, 0, 12, 6, 6, 1) X(NT, MODE, 1, 6, 3, 6, 1) X(NT, MODE, 1, 8, 3, 4, 1)
+#define VF_SCAN2R_SHAPES(X, NT, MODE) VF_SCAN2R_PRODUCT(X, NT, MODE)
 #endif
 #define VF_SCAN2R_ALL(X) VF_SCAN2R_SHAPES(X, 1, kModeMain) VF_SCAN2R_SHAPES(X, 2, kModeMain) VF_SCAN2R_SHAPES(X, 1, kModeSample) VF_SCAN2R_SHAPES(X, 2, kModeSample)
 static hipError_t launch_scan2r_any(const ScanArgs& a, int qn_tile, int mode, int grid, int f8, size_t lds, hipStream_t s) {
@@ -3195,7 +3201,7 @@ static hipError_t launch_scan2r_any(const ScanArgs& a, int qn_tile, int mode, in
 #endif
     const int nt = qn_tile / kQueryTile;
     bool done = false;
-    const int ar = (!f8 && (a.debug & 1024)) ? 0 : 1;
+    const int ar = (!f8 && a.dp == 768 && (a.debug & 1024)) ? 0 : 1;
 #define VF_X(NT, MODE, F8, S_, RB_, RING_, AR_) \
     if (!done && nt == NT && mode == MODE && f8 == F8 && sh.S == S_ && sh.RB == RB_ && sh.RING == RING_ && ar == AR_) { \
         hipLaunchKernelGGL((k_scan2r<NT, MODE, F8, S_, RB_, RING_, AR_>), dim3(grid), dim3(kScan2Waves * 64), lds, s, a); done = true; }
