@@ -1219,6 +1219,17 @@ __device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
 }
+// One 4-KB ring segment = four 1-KB pieces (eight rows each) in ONE asm statement: scalar 64-bit base + a 32-bit lane offset per piece
+// (no 64-bit vector add per piece), M0 saved and restored once, the LDS destination stepped in M0 itself.
+__device__ __forceinline__ void dma16x4(unsigned long long ua, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(ua), "s"(lds_base) : "memory", "scc");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
@@ -1332,15 +1343,24 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
 
     // this lane's part in the four DMA instructions of a segment: row 8 m + (lane >> 3), piece (lane & 7) ^ swizzle(row)
     const int drow = lane >> 3;
-    auto src_of = [&](int tile, int m) -> const char* {
-        const int row = 8 * m + drow;
-        long long r = lo + (long long)tile * kRowTile + row;
-        r = r < hi - 1 ? r : hi - 1;                                  // rows past the part's end re-read its last row (masked in the epilogue)
-        return a.rows + r * a.row_bytes + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
-    };
-    auto issue_seg = [&](const char* const (&src)[4], int seg, int buf) {
+    // a tile's source: a scalar base (its first row) + per piece a 32-bit lane offset; a segment's four pieces go in one asm statement (dma16x4)
+    struct TileSrc { unsigned long long ua; unsigned v[4]; };
+    auto src_of = [&](int tile) -> TileSrc {
+        const long long t0_ = lo + (long long)tile * kRowTile;
+        TileSrc ts;
+        ts.ua = (unsigned long long)(a.rows + t0_ * a.row_bytes);
+        ts.ua = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ts.ua >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ts.ua);   // (wave-uniform by construction)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) dma16(src[m] + (long long)seg * 128, ring_l + buf * kSegBytes + m * 1024);
+        for (int m = 0; m < 4; ++m) {
+            const int row = 8 * m + drow;
+            long long r = t0_ + row;
+            r = r < hi - 1 ? r : hi - 1;                              // rows past the part's end re-read its last row (masked in the epilogue)
+            ts.v[m] = (unsigned)((r - t0_) * a.row_bytes) + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
+        }
+        return ts;
+    };
+    auto issue_seg = [&](const TileSrc& src, int seg, int buf) {
+        dma16x4(src.ua + (unsigned long long)seg * 128ull, src.v[0], src.v[1], src.v[2], src.v[3], ring_l + buf * kSegBytes);
     };
     // 1 / norm of a tile's rows (+ the global thresholds) into the scratch half of that tile's parity: a tile's operands are
     // issued while the PREVIOUS tile is still being consumed and may land before that tile's epilogue has read its own
@@ -1354,13 +1374,11 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
     //  its first row, and the four waves of a workgroup started a quarter of a tile time apart -- the slow first tiles of a small
     //  shard's launch are neither a lockstep of the ranges nor of the waves: profiles/r06_scan2_rotation_and_stagger.log)
     const bool service = kScan2Service && wid == kScan2Waves;          // wave 4: publishes blocks, refreshes and syncs thresholds (k_scan2_service)
-    int cur_tile = wid;
+    int cur_tile = __builtin_amdgcn_readfirstlane(wid);                // (a scalar from here on: tile addresses stay in SGPRs)
     bool active = !service && cur_tile < ntiles;
-    const char* src_cur[4];
-    const char* src_nxt[4];
+    TileSrc src_cur{}, src_nxt{};
     if (active) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
+        src_cur = src_of(cur_tile);
         issue_epi(lo + (long long)cur_tile * kRowTile, !kScan2Service, 0);
         for (int sg = 0; sg < kRing; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S >= kRing: scan2_stage_cap)
     }
@@ -1411,8 +1429,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
         __syncthreads();
         cur_tile = wid;
         if (active) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
+            src_cur = src_of(cur_tile);
             issue_epi(lo + (long long)cur_tile * kRowTile, !kScan2Service, tiles_done & 1);
 #pragma unroll
             for (int sg = 0; sg < kRing; ++sg) issue_seg(src_cur, sg, sg);
@@ -1435,8 +1452,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
             }
             const bool more = claimed < ntiles;
             const int nxt = more ? claimed : cur_tile;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
+            src_nxt = src_of(nxt);
             // the service wave folds the global thresholds into tau_lds; without it the waves take turns
             const bool sync_now = !kScan2Service && (tiles_done & (kScan2Waves - 1)) == wid;
             const bool sync_next = !kScan2Service && ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
@@ -1518,8 +1534,7 @@ __global__ __launch_bounds__(kScan2Threads) void k_scan2(ScanArgs a) {
             ++tiles_done;
             if (!more) break;
             cur_tile = nxt;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
+            src_cur = src_nxt;
         }
     }
     }
@@ -1682,32 +1697,39 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
     u32* next_tile = (u32*)(ctl + 4);
     const unsigned ring_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(ring)), scratch_l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(scratch));
     const int drow = lane >> 3;
-    auto src_of = [&](int tile, int m) -> const char* {
-        const int row = 8 * m + drow;
+    // a tile's source: a scalar base (its first row) + per piece a 32-bit lane offset (row of the piece x row bytes + the swizzled 16-byte column)
+    struct TileSrc { unsigned long long ua; unsigned v[4]; };
+    auto src_of = [&](int tile) -> TileSrc {
         long long t0_, thi_, sb_;
         tile_rows(tile, t0_, thi_, sb_);
-        long long r = t0_ + row;
-        r = r < thi_ - 1 ? r : thi_ - 1;                               // rows past the part's end re-read its last row (masked in the epilogue)
-        r = r > 0 ? r : 0;
-        return a.rows + r * a.row_bytes + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
+        TileSrc ts;
+        const long long base_row = t0_ > 0 ? t0_ : 0;
+        ts.ua = (unsigned long long)(a.rows + base_row * a.row_bytes);
+        ts.ua = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ts.ua >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ts.ua);   // (wave-uniform by construction)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = 8 * m + drow;
+            long long r = t0_ + row;
+            r = r < thi_ - 1 ? r : thi_ - 1;                           // rows past the part's end re-read its last row (masked in the epilogue)
+            r = r > base_row ? r : base_row;
+            ts.v[m] = (unsigned)((r - base_row) * a.row_bytes) + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
+        }
+        return ts;
     };
     auto first_row = [&](int tile) { long long t0_, thi_, sb_; tile_rows(tile, t0_, thi_, sb_); return t0_; };
-    auto issue_seg = [&](const char* const (&src)[4], int seg, int buf) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) dma16(src[m] + (long long)seg * 128, ring_l + buf * kSegBytes + m * 1024);
+    auto issue_seg = [&](const TileSrc& src, int seg, int buf) {
+        dma16x4(src.ua + (unsigned long long)seg * 128ull, src.v[0], src.v[1], src.v[2], src.v[3], ring_l + buf * kSegBytes);
     };
     auto issue_epi = [&](long long t0, bool sync_tau, int par) {
         par = __builtin_amdgcn_readfirstlane(par);
         dma4(a.inv_scan + t0 + r31, scratch_l + par * 512 + 256);
         if (sync_tau) dma4(a.tau_bin + (lane < QN ? lane : QN - 1), scratch_l + par * 512);
     };
-    int cur_tile = wid;
+    int cur_tile = __builtin_amdgcn_readfirstlane(wid);                // (a scalar from here on: tile addresses stay in SGPRs)
     const bool active = cur_tile < ntiles;
-    const char* src_cur[4];
-    const char* src_nxt[4];
+    TileSrc src_cur{}, src_nxt{};
     if (active) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) src_cur[m] = src_of(cur_tile, m);
+        src_cur = src_of(cur_tile);
         issue_epi(first_row(cur_tile), MODE == kModeMain, 0);
 #pragma unroll
         for (int sg = 0; sg < RING; ++sg) issue_seg(src_cur, sg, sg);   // the whole ring (S >= RING)
@@ -1781,8 +1803,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             }
             const bool more = claimed < ntiles;
             const int nxt = more ? claimed : cur_tile;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) src_nxt[m] = src_of(nxt, m);
+            src_nxt = src_of(nxt);
             const bool sync_now = MODE == kModeMain && (tiles_done & (kScan2Waves - 1)) == wid;
             const bool sync_next = MODE == kModeMain && ((tiles_done + 1) & (kScan2Waves - 1)) == wid;
             if (dbg && dbg_rec > 4 && tiles_done < 64) dbg[4 + tiles_done] = wall_clock64();
@@ -1909,8 +1930,7 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
             ++tiles_done;
             if (!more) break;
             cur_tile = nxt;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) src_cur[m] = src_nxt[m];
+            src_cur = src_nxt;
         }
     }
     if (dbg && dbg_rec > 4) dbg[69] = (unsigned long long)tiles_done;
