@@ -813,7 +813,11 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) inv16[reg] = ((reg & 3) + 8 * (reg >> 2) + 4 * h) < lf ? inv16[reg] : __builtin_nanf("");
     }
-    float tb[NT], x[NT][16];
+    // m = acc / norm, the approximate scores, as ONE register vector (the candidate loop below indexes it with a scalar); bin_x is
+    // monotone, so "some bin_x(m) reaches the threshold" is asked of the maximum: one fma + one compare per query tile
+    typedef float mvec __attribute__((ext_vector_type(NT * 16)));
+    mvec m;
+    float tb[NT];
     bool any = false;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -823,10 +827,10 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
         float top = -INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            x[nt][reg] = bin_x(acc[nt][reg] * inv16[reg]);
-            top = fmaxf(top, x[nt][reg]);                              // (a NaN -- a row that does not exist -- never wins)
+            m[nt * 16 + reg] = acc[nt][reg] * inv16[reg];
+            top = fmaxf(top, m[nt * 16 + reg]);                        // (a NaN -- a row that does not exist -- never wins)
         }
-        any |= top >= tb[nt];
+        any |= bin_x(top) >= tb[nt];
     }
     if (__ballot(any) == 0ull) return;
     // bit (nt * 16 + reg) of `mask` = "this lane's score for (query nt*32 + r31, row reg) passes"
@@ -834,7 +838,7 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) mask |= (x[nt][reg] >= tb[nt]) ? (1u << (nt * 16 + reg)) : 0u;
+        for (int reg = 0; reg < 16; ++reg) mask |= (bin_x(m[nt * 16 + reg]) >= tb[nt]) ? (1u << (nt * 16 + reg)) : 0u;
     // ---- a tile that holds a candidate: stage them in LDS; once per block of R staged entries ONE wave refreshes one tau and
     // publishes that block to the global histograms.
     // No global memory operation is issued per candidate: vmcnt retires in order, so even a no-return
@@ -872,36 +876,33 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, const f16v (&ac
     u32 run = base;
     const u32 edge = (((base + total) >> rs) << rs) - 1u;   // the slot that completed the block (meaningful when `need`)
     int qq = 0;               // the query whose tau is refreshed: that of the pair holding the completing slot (its first lane)
-    // (the pairs are tested one by one on the scalar umask, unrolled: a loop over the SET pairs -- count-trailing-zeros + a switch into
-    //  the 32 bodies -- was tried and cost 250-800 bytes of scratch per lane in every kernel that uses this epilogue)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    // A scalar loop over the SET pairs: the pair's scores are read from the register vector with the pair number as a scalar index
+    // (s_set_gpr_idx / v_movrel: no memory).  The first form tested all 16 NT pairs one by one, a scalar compare-and-branch each,
+    // taken for every pair without a candidate -- the largest single piece of this path; a switch into unrolled bodies cost scratch.
+    for (u32 um = umask; um != 0u; um &= um - 1u) {
+        const int pair = __builtin_ctz(um);                           // scalar
+        const int nt = pair >> 4, reg = pair & 15;
         const int q = nt * kQueryTile + r31;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const u32 bit = 1u << (nt * 16 + reg);
-            if (umask & bit) {                                   // scalar
-                const unsigned long long bal = __ballot((mask & bit) != 0u);
-                if (mask & bit) {
-                    const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    const float sc = acc[nt][reg] * inv16[reg];
-                    const u32 bin = (u32)bin_of_x(bin_x(sc));
-                    const u32 key = orderkey(sc), row = (u32)(t0 + rr);
-                    if (slot < (u32)a.stage_cap) {
-                        stage_ent[slot] = make_uint4(row, key, (u32)q | (bin << 8), 1u);  // w = 1: entry written
-                    } else {  // stage full (hostile data): append straight to the global list
-                        const u32 gs = atomicAdd(a.cnt + q * kCntStride, 1u);
-                        if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)key << 32) | (u64)row;
-                        atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
-                        atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
-                    }
-                }
-                const u32 nxt = run + (u32)__popcll(bal);
-                if (run <= edge && edge < nxt) qq = nt * kQueryTile + ((__ffsll((long long)bal) - 1) & 31);
-                run = nxt;
+        const bool mine = ((mask >> pair) & 1u) != 0u;
+        const unsigned long long bal = __ballot(mine);
+        if (mine) {
+            const u32 slot = run + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+            const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const float sc = m[pair];
+            const u32 bin = (u32)bin_of_x(bin_x(sc));
+            const u32 key = orderkey(sc), row = (u32)(t0 + rr);
+            if (slot < (u32)a.stage_cap) {
+                stage_ent[slot] = make_uint4(row, key, (u32)q | (bin << 8), 1u);  // w = 1: entry written
+            } else {  // stage full (hostile data): append straight to the global list
+                const u32 gs = atomicAdd(a.cnt + q * kCntStride, 1u);
+                if (gs < (u32)a.cap) a.cand[(long long)q * a.cap + gs] = ((u64)key << 32) | (u64)row;
+                atomicAdd(a.hist + (long long)q * kHistBins + bin, 1u);
+                atomicAdd(a.hist_coarse + q * 64 + (bin >> 5), 1u);
             }
         }
+        const u32 nxt = run + (u32)__popcll(bal);
+        if (run <= edge && edge < nxt) qq = nt * kQueryTile + ((__ffsll((long long)bal) - 1) & 31);
+        run = nxt;
     }
     if (a.debug & 2) return;  // timing experiment: never publish / refresh
     if constexpr (!PUBLISH) return;
