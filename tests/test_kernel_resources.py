@@ -21,8 +21,9 @@ ALLOW = {
                          "loop (256 accumulators + fragments); no scratch access inside the K loop (checked in round 4's ISA)",
     r"k_gemm9_tn<\d+,1>": "the persistent kernel's whole-product K cut: the 24 registers are sk_coop_finish's (two blocks of partners' partials "
                            "beside the 128 accumulators), every scratch access sits behind the main loop (ISA checked, round 5)",
-    r"k_scan<(1,4,1,0|2,3,1,0|2,4,1,0|2,4,0,0)>": "k_scan on fp16 rows with 3-4 segments per stage: only reached when k_scan2's LDS "
-                                                 "image does not fit (d > 1216); register-staged loads, compiler-counted waits",
+    r"k_scan<(2,4,1,0|2,4,0,0)>": "k_scan on fp16 rows with 4 segments per stage at 64 queries: only reached when k_scan2's LDS "
+                                   "image does not fit (d > 1216); register-staged loads, compiler-counted waits "
+                                   "(the 3-segment and 32-query forms lost their scratch with round 6's epilogue)",
 }
 HOT = re.compile(r"k_scan|k_gemm|k_attention|k_final|k_sel0|k_layernorm|k_embed|k_pool|k_dec|k_rms|k_rope|k_swiglu|k_vit|k_clip")
 
