@@ -1222,12 +1222,19 @@ __device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
 }
 // One 4-KB ring segment = four 1-KB pieces (eight rows each) in ONE asm statement: scalar 64-bit base + a 32-bit lane offset per piece
 // (no 64-bit vector add per piece), M0 saved and restored once, the LDS destination stepped in M0 itself.
+// The loads carry the NON-TEMPORAL policy: a corpus row is read once per batch, by exactly one of these instructions (whole 128-byte
+// lines, the swizzle is in the source address), and 15 GB of them pass through per launch.  Same box, alternating
+// (profiles/r06_dma_nt_ab.log): 10M x 768 fp16 2.42-2.50 -> 2.20-2.30 ms per batch = 0.77-0.80 -> **0.84-0.87 of 8 TB/s** -- the
+// "copy ceiling" of ~6.3 TB/s that rounds 3-6 took for the bound is the DEFAULT policy's; 1.25M rows 0.336-0.344 -> 0.318-0.321,
+// configs[1] 0.289-0.294 -> 0.275-0.276, 10M x 1024 e4m3 1.79-1.81 -> 1.748.  (k_scan's register loads LOSE half their rate with nt --
+// a lane pair shares every line and four instructions walk it: round 3's measurement above stream_load -- which is why the hint had
+// been written off before the whole-line DMA existed.)
 __device__ __forceinline__ void dma16x4(unsigned long long ua, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5 nt\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(ua), "s"(lds_base) : "memory", "scc");
 }
@@ -2540,19 +2547,22 @@ __device__ __forceinline__ void dma16s(unsigned long long ua, unsigned voff, uns
 // M0 and had its 64-bit base and LDS address computed by the compiler: ~12 instructions per DMA, 100 per K-tile in the 4-wave form).
 // Rows: instruction i fetches the rows 16 i below instruction 0's -- the step goes into a scratch lane offset (an address register
 // is read when the instruction issues: it may be overwritten right behind it); LDS destination + 1 KB each.
+// (Default cache policy: this kernel reads a row tile once per 256-query super-tile, four times per launch, three of them out of L2 / the
+//  Infinity Cache -- with `nt`, which the narrow scans' once-read rows gained 10 % from in round 6, configs[4] went from 17.0 to 18.8 ms:
+//  profiles/r06_dma_nt_wide8_ab.log)
 template <int N>
 __device__ __forceinline__ void dma_rows(unsigned long long ua, unsigned voff0, unsigned lds_base, unsigned row_step) {
     unsigned keep, vt;
     if constexpr (N == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_add_u32 %1, %5, %2\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&v"(vt) : "v"(voff0), "s"(ua), "s"(lds_base), "s"(row_step) : "memory");
+                     : "=&s"(keep), "=&v"(vt) : "v"(voff0), "s"(ua), "s"(lds_base), "s"(row_step) : "memory", "scc");
     else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_add_u32 %1, %5, %2\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tv_add_u32 %1, %5, %1\n\t"
                      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tv_add_u32 %1, %5, %1\n\t"
                      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&v"(vt) : "v"(voff0), "s"(ua), "s"(lds_base), "s"(row_step) : "memory");
+                     : "=&s"(keep), "=&v"(vt) : "v"(voff0), "s"(ua), "s"(lds_base), "s"(row_step) : "memory", "scc");
 }
 // Query codes: 2 KB of hi codes, then the lo codes 16 KB further on in the image and in LDS.  The second instruction of each pair
 // goes through the instruction's immediate offset, which the hardware adds to the global address AND to the LDS address
