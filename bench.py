@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 # r05_hw_queues.log).  Read by the runtime when it initialises, i.e. before torch / the library touch the GPU; an explicit setting wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is a float4 copy's rate, 6700-7000 what the scan's non-temporal LDS-DMA reads reach
 GEN_CHUNK = 125_000    # rows per generator call; shard boundaries are multiples of it at 1/2/4/8 GPUs
 
 
