@@ -805,6 +805,32 @@ def test_scan2r_other_fp16_widths_match_oracle(vf, oracle, n, d, nq, k):
                 assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), (impl, simpl)
 
 
+@pytest.mark.parametrize("n,d,dtype,waves", [(21_845, 384, "f16", 8192), (17_000, 768, "f16", 8192), (20_011, 1024, "fp8", 8192), (16_500, 512, "f16", 1024)])
+def test_scan2r_sample_pass_with_ranges_shorter_than_their_sample_part(vf, oracle, n, d, dtype, waves):
+    """Ranges of ~10 rows under a sample part of 128+ (many waves over few rows, sample_rows 64): a sample tile then starts past its
+    range's end -- for the last ranges past the corpus's.  The one-statement segment DMA took its scalar base from the tile's first row
+    and read there (a GPU memory fault in the round-6 soak, fuzz seed 111); the base is clamped into the part now.  Rows end exactly at
+    the allocation here (a fresh device buffer per index), results against the oracle."""
+    from oracle import ref_numpy as R
+    rng = np.random.default_rng(151)
+    q = rng.standard_normal((3, d)).astype(np.float32)
+    if dtype == "fp8":
+        codes = _e4m3_codes(n, d, 152)
+        rows = R.decode_e4m3(codes).astype(np.float16)
+        make = lambda: vf.DenseIndex.from_e4m3(codes)
+    else:
+        rows = rng.standard_normal((n, d)).astype(np.float16)
+        make = lambda: vf.DenseIndex(rows)
+    want_i, want_s = oracle.search(rows, q, 500)
+    with make() as ix:
+        for name, val in (("force_path", 1), ("scan_impl", 5), ("sample_impl", 1), ("waves", waves), ("sample_rows", 64)):
+            ix.set_option(name, val)
+        for sgrid in (-1, 0, 1, 7, 1024):
+            ix.set_option("sample_grid", sgrid)
+            i, s_ = ix.search(q, 500)
+            assert np.array_equal(i, want_i) and np.array_equal(_bits(s_), _bits(want_s)), sgrid
+
+
 def test_fp16_rows_of_1024_above_1_1m_take_scan2r_by_default(vf, oracle):
     """The reference's own embedding width (bge-m3: 1024, config/example.yaml:3) as fp16 rows: above 1.1M rows the default is k_scan2r on the CU
     split (k_scan2's image does not fit this width; k_scan served it before): the rule's own path, no option set, against the oracle."""

@@ -1711,20 +1711,31 @@ __global__ __launch_bounds__(kScan2Waves * 64) void k_scan2r(ScanArgs a) {
         long long t0_, thi_, sb_;
         tile_rows(tile, t0_, thi_, sb_);
         TileSrc ts;
-        const long long base_row = t0_ > 0 ? t0_ : 0;
+        // the base row is clamped INTO the part: a sample tile of a range shorter than its sample part starts past the range's end (t0_ >
+        // thi_ - 1) -- past the corpus's for the last ranges (found by the fuzz as a memory fault: 21 845 rows in 2 048 ranges)
+        const long long last_row = thi_ - 1 > 0 ? thi_ - 1 : 0;
+        long long base_row = t0_ > 0 ? t0_ : 0;
+        base_row = base_row < last_row ? base_row : last_row;
         ts.ua = (unsigned long long)(a.rows + base_row * a.row_bytes);
         ts.ua = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ts.ua >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ts.ua);   // (wave-uniform by construction)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int row = 8 * m + drow;
             long long r = t0_ + row;
-            r = r < thi_ - 1 ? r : thi_ - 1;                           // rows past the part's end re-read its last row (masked in the epilogue)
+            r = r < last_row ? r : last_row;                           // rows past the part's end re-read its last row (masked in the epilogue)
             r = r > base_row ? r : base_row;
             ts.v[m] = (unsigned)((r - base_row) * a.row_bytes) + ((((lane & 7) ^ ((row >> 1) & 7))) << 4);
         }
         return ts;
     };
-    auto first_row = [&](int tile) { long long t0_, thi_, sb_; tile_rows(tile, t0_, thi_, sb_); return t0_; };
+    // first row of a tile for its epilogue operands (1 / norm of 32 rows from there; inv_scan is padded by 64 entries): clamped into the part like
+    // the rows' base -- a sample tile past its range's end has no row the epilogue looks at
+    auto first_row = [&](int tile) {
+        long long t0_, thi_, sb_;
+        tile_rows(tile, t0_, thi_, sb_);
+        const long long last_row = thi_ - 1 > 0 ? thi_ - 1 : 0;
+        return t0_ < last_row ? t0_ : last_row;
+    };
     auto issue_seg = [&](const TileSrc& src, int seg, int buf) {
         dma16x4(src.ua + (unsigned long long)seg * 128ull, src.v[0], src.v[1], src.v[2], src.v[3], ring_l + buf * kSegBytes);
     };
