@@ -1229,12 +1229,15 @@ __device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
 // configs[1] 0.289-0.294 -> 0.275-0.276, 10M x 1024 e4m3 1.79-1.81 -> 1.748.  (k_scan's register loads LOSE half their rate with nt --
 // a lane pair shares every line and four instructions walk it: round 3's measurement above stream_load -- which is why the hint had
 // been written off before the whole-line DMA existed.)
+#ifndef VF_ROW_POLICY
+#define VF_ROW_POLICY "nt"   // (A/B builds: -DVF_ROW_POLICY='"sc1 nt"' ...; the other policies measured: profiles/r06_row_policy_ab.log)
+#endif
 __device__ __forceinline__ void dma16x4(unsigned long long ua, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5 nt\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5 nt\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5 nt\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5 nt\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5 " VF_ROW_POLICY "\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5 " VF_ROW_POLICY "\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5 " VF_ROW_POLICY "\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5 " VF_ROW_POLICY "\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(ua), "s"(lds_base) : "memory", "scc");
 }
